@@ -1,0 +1,199 @@
+/* real3daug_hip.h -- C ABI of libreal3daug_hip.so (MI355X / gfx950).
+ *
+ * The hot path of Real3D-Aug (ctu-vras/pcl-augmentation): spherical projection, range-image
+ * min-reduce, 5x3 closing + hole fill, visibility mask, scene cull, sample select and concat.
+ * The reference has no FFI/plugin interface for this path -- it is a set of module-level Python
+ * functions called from the `__main__` block of Real3DAug/insertion.py -- so
+ * every entry point below cites the reference FUNCTION (or inline block) it replaces.  Paths are
+ * relative to the reference root; "SS" = semantic_segmentation/, the object_detection copies are
+ * byte-identical one line lower.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  Every data pointer is a DEVICE pointer (hipMalloc /
+ *     a PyTorch-ROCm tensor's data_ptr()) unless the comment says "host".
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All calls are
+ *     asynchronous and stream-ordered; none of them allocates, frees or synchronises, so a call
+ *     sequence can be captured into a hipGraph.
+ *   - The library owns no device memory and keeps no state besides a thread-local error string.
+ *     Scratch is a caller-provided workspace (size from the *_workspace_bytes queries).
+ *   - Return value: R3D_OK or a negative R3D_E_* (bad argument, HIP launch error).  Conditions the
+ *     reference reports with `assert` / exceptions while iterating over points are accumulated
+ *     as R3D_S_* bits in a caller-provided device word `status` (one per scene) which the host
+ *     reads when it chooses; no exception crosses the ABI.
+ *   - Layouts are the reference's: "pcl9" is the N x 9 float64 scratch record
+ *     [x y z r azimuth elevation intensity label pixel-id] of add_space_for_spherical
+ *     (SS Real3DAug/insertion.py:54-64); "pcl5" is N x 5 float64 [x y z intensity label]
+ *     (SS Real3DAug/tools/datasets.py:51-56); range images are row-major float64
+ *     [num_row][num_column] with 500 = empty depth and label +1 / -1 (insertion.py:98-99).
+ */
+#ifndef REAL3DAUG_HIP_H
+#define REAL3DAUG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R3D_VERSION 0x00010000
+
+#define R3D_NUMROW 112        /* insertion.py:22 */
+#define R3D_NUMCOLUMN 1440    /* insertion.py:23; the pixel id always multiplies by THIS (:116,:127) */
+
+/* return codes */
+#define R3D_OK 0
+#define R3D_E_ARG (-1)        /* null pointer, negative size, unsupported shape */
+#define R3D_E_HIP (-2)        /* a HIP runtime call failed; see r3d_last_error() */
+#define R3D_E_WORKSPACE (-3)  /* workspace smaller than the matching *_workspace_bytes() */
+
+/* device status bits (OR-ed into *status) */
+#define R3D_S_NONFINITE 1         /* NaN/Inf coordinate or a point at the origin (r = 0: z/r is NaN,
+                                     the reference's int() raises, insertion.py:104) */
+#define R3D_S_ROW_RANGE 2         /* scene row outside [0,num_row): assert insertion.py:110 */
+#define R3D_S_COL_RANGE 4         /* column outside [0,num_column): assert insertion.py:112 */
+#define R3D_S_SAMPLE_TOO_LARGE 8  /* batched path: sample exceeds R3D_MAX_SAMPLE points */
+#define R3D_S_CAPACITY 16         /* batched path: merged cloud / log would exceed its capacity */
+#define R3D_S_FAR_OVERFLOW 32     /* batched path: more than R3D_FAR_CAP pixels beyond 500 m */
+
+#define R3D_MAX_SAMPLE 8192       /* points per insert candidate in the batched path */
+#define R3D_FAR_CAP 1024
+
+int r3d_version(void);
+const char *r3d_last_error(void);   /* host string, thread-local, valid until the next failing call */
+
+/* ============================================================================================
+ * Level 1 -- one cloud at a time, the reference's functions one for one (float64 N x 9 layout).
+ * ============================================================================================ */
+
+/* a1  add_space_for_spherical(point_cloud)            SS Real3DAug/insertion.py:54-64
+ * pcl5 [n][5] -> pcl9 [n][9], every other column -1. */
+int r3d_add_space_for_spherical(const double *pcl5, int64_t n, double *pcl9, void *stream);
+
+/* a2  fill_spherical(point_cloud)                     SS Real3DAug/insertion.py:67-81
+ * In place on pcl9: col3 = sqrt(x*x+y*y+z*z) (no FMA contraction), col4 = atan2(y,x)+pi,
+ * col5 = acos(z/r).  bounds[0] = max elevation, bounds[1] = min elevation (the reference's return
+ * order, :81).  n == 0 is R3D_E_ARG (the reference raises on an empty reduction, :78). */
+int r3d_fill_spherical(double *pcl9, int64_t n, double *bounds, int32_t *status, void *stream);
+
+/* a3  geometrical_front_view(point_cloud, num_row, num_column, max_el, min_el, sample)
+ *                                                     SS Real3DAug/insertion.py:84-129
+ * Reads cols 3..5 of pcl9, writes col 8 = row*R3D_NUMCOLUMN+col for every binned point (skipped
+ * points keep their value, :107-108), and fills train/label [num_row][num_column].
+ * workspace: r3d_front_view_workspace_bytes(num_row, num_column). */
+size_t r3d_front_view_workspace_bytes(int32_t num_row, int32_t num_column);
+int r3d_geometrical_front_view(double *pcl9, int64_t n, int32_t num_row, int32_t num_column,
+                               double max_el, double min_el, int32_t sample,
+                               double *train, double *label,
+                               void *workspace, size_t workspace_bytes,
+                               int32_t *status, void *stream);
+
+/* a4  class_closing(original_label)                   SS Real3DAug/tools/closing.py:9-23
+ * closed [rows][cols] uint8 in {0,255}: grey closing of clip(label,0,1) with rectangle(5,3)
+ * (5 rows x 3 columns), windows clipped at the borders, no azimuth wrap. */
+int r3d_class_closing(const double *label, int32_t rows, int32_t cols, uint8_t *closed, void *stream);
+
+/* a5  smooth_out(original_train, original_label)      SS Real3DAug/tools/closing.py:26-62
+ * Closed-but-empty pixels get sum(original depth of occupied 5x3 neighbours, drow outer / dcolumn
+ * inner) / count and label 1; everything else is copied. */
+int r3d_smooth_out(const double *train, const double *label, int32_t rows, int32_t cols,
+                   double *train_out, double *label_out, void *stream);
+
+/* a6-a8  the inline visibility / cull / select block  SS Real3DAug/insertion.py:463-482
+ * (named occlusion_merge in the Python mirror).  scene9 [n][9], sample9 [m][9] with col 8 filled
+ * by a3; scene_train / sample_train are the smoothed range images [rows][cols], cols <=
+ * R3D_NUMCOLUMN.  Outputs, each [..][9] float64 with capacity n / m / n rows:
+ *   scene_out9 = scene rows whose pixel is not visible, original order       (:472-473)
+ *   visible9   = sample rows in visible pixels, by pixel id then sample order (:474-482)
+ *   covered9   = removed scene rows, by pixel id then scene order            (:470-471)
+ * counts (device int64[3]) = rows written to the three outputs. */
+size_t r3d_occlusion_merge_workspace_bytes(int64_t n, int64_t m, int32_t rows, int32_t cols);
+int r3d_occlusion_merge(const double *scene9, int64_t n, const double *sample9, int64_t m,
+                        const double *scene_train, const double *sample_train,
+                        int32_t rows, int32_t cols,
+                        double *scene_out9, double *visible9, double *covered9, int64_t *counts,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* a9  remove_space_for_spherical + the casts of save_data
+ *                         SS Real3DAug/tools/datasets.py:72-106, OD tools/datasets.py:76-109
+ * pcl9 -> xyzi float32 [n][4] (cols 0,1,2,6) and label uint32 [n] (col 7): the bytes of
+ * velodyne/{f}.bin and labels/{f}.label.  `check` (nullable) float32 [n][check_cols], check_cols
+ * 5 (SS: x y z i label) or 4 (OD: x y z i): the bytes of check/{f}.bin. */
+int r3d_remove_space_for_spherical(const double *pcl9, int64_t n, float *xyzi, uint32_t *label,
+                                   float *check, int32_t check_cols, void *stream);
+
+/* ============================================================================================
+ * Level 2 -- batched pipeline: B scenes advanced in lock step through K inserts
+ * (a10, the per-insert outer loop SS Real3DAug/insertion.py:371-381 with the candidate loop
+ * :449-545), everything resident in HBM.  See DESIGN.md for the incremental algorithm and the
+ * proof obligations (tests/test_incremental_model.py).
+ * ============================================================================================ */
+typedef struct r3d_batch {
+  int32_t B;             /* scenes in the batch */
+  int32_t rows, cols;    /* range image shape (reference: 112 x 1440) */
+  int32_t reserved;
+  int64_t cap;           /* point capacity per scene (original points + every insert) */
+  int64_t log_cap;       /* inserted-point capacity per scene */
+  /* the cloud of scene s lives at index s*cap .. s*cap + n_total[s] */
+  float *xyzi;           /* [B*cap][4]  x y z intensity as in velodyne .bin files (caller fills [0,n)) */
+  uint32_t *label;       /* [B*cap]     semantic label as in .label files, masked with 0xFFFF */
+  int32_t *pix;          /* [B*cap]     row*cols+col under the scene's current bounds */
+  int32_t *n_head;       /* [B] float32-exact points at the front of the cloud */
+  int32_t *n_total;      /* [B] n_head + live/dead inserted points */
+  int32_t *tail_ref;     /* [B*log_cap] log row of cloud point n_head + t */
+  /* append-only log of accepted visible points = all_visible_parts (insertion.py:534-545) */
+  double *log5;          /* [B*log_cap][5] x y z intensity label, float64 as the sample had them */
+  int32_t *log_birth;    /* [B*log_cap] step at which the row was inserted */
+  int32_t *n_log;        /* [B] */
+  /* per-scene range-image state */
+  uint64_t *grid;        /* [B*rows*cols] bits of min r, all-ones where empty */
+  uint64_t *sgrid;       /* [B*rows*cols] sample scratch image, all-ones between calls */
+  uint16_t *stamp;       /* [B*rows*cols] last step at which the pixel was visible (0 = never) */
+  uint32_t *ever;        /* [B*ceil(rows*cols/32)] bit set = stamp != 0 */
+  double *bounds;        /* [B][2] max elevation, min elevation */
+  int32_t *row_of_max;   /* [B] row of the max-elevation point */
+  int32_t *far_pix;      /* [B*R3D_FAR_CAP] occupied pixels deeper than 500 m */
+  int32_t *n_far;        /* [B] */
+  int32_t *rebase;       /* [B] set when the elevation bounds may have moved */
+  int32_t *status;       /* [B] R3D_S_* bits */
+  /* outputs of r3d_batch_finish (also scratch of a rebase) */
+  float *out_xyzi;       /* [B*cap][4] */
+  uint32_t *out_label;   /* [B*cap] */
+  int32_t *n_out;        /* [B] */
+  void *workspace;
+  size_t workspace_bytes;
+} r3d_batch_t;
+
+size_t r3d_batch_workspace_bytes(const r3d_batch_t *b);
+
+/* Step 0 (insertion.py:362, :373-375 for every scene): n_points (device int32[B]) points per
+ * scene are already in b->xyzi / b->label.  Computes the elevation bounds, projects every point,
+ * builds the range images and resets all per-scene state. */
+int r3d_batch_begin(const r3d_batch_t *b, const int32_t *n_points, void *stream);
+
+/* One placement candidate per scene (insertion.py:453-526).  samples5: rows of [x y z intensity
+ * label] float64, scene s owns rows sample_off[s] .. sample_off[s+1] (device int64[B+1]).
+ * Scenes with active[s] == 0 (nullable = all active) or an empty sample are skipped.
+ * n_visible[s] = len(visible_sample); accepted[s] = 1 iff n_visible >= max(1, min_points[s])
+ * (:511-517), in which case the scene is updated exactly as :526 would.  `step` is 1-based and
+ * must increase by one per call of an insert slot that may accept. */
+int r3d_batch_insert(const r3d_batch_t *b, const double *samples5, const int64_t *sample_off,
+                     const int32_t *min_points, const int32_t *active, int32_t step,
+                     int32_t *n_visible, int32_t *accepted, void *stream);
+
+/* Materialise the merged clouds: out_xyzi / out_label / n_out = bytes of velodyne/{f}.bin and
+ * labels/{f}.label (SS tools/datasets.py:72-84).  check (nullable) float32
+ * [B*log_cap][check_cols] = check/{f}.bin rows from the log. */
+int r3d_batch_finish(const r3d_batch_t *b, float *check, int32_t check_cols, void *stream);
+
+/* The two streaming passes of step 0 on their own (all scenes; state as left by r3d_batch_begin),
+ * exported for parity tests and for timing them in isolation:
+ *   elev_bounds = insertion.py:74-79 reduced to the two bounds per scene,
+ *   project     = insertion.py:74-76 + :104-127 fused (pixel ids + range-image min-reduce). */
+int r3d_batch_elev_bounds(const r3d_batch_t *b, void *stream);
+int r3d_batch_project(const r3d_batch_t *b, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REAL3DAUG_HIP_H */

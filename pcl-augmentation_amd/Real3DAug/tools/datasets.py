@@ -1,0 +1,91 @@
+"""The output-format half of the reference's ``Real3DAug/tools/datasets.py``.
+
+Only what the hot path's drop-in promise needs: reading a frame the way ``__getitem__`` does and
+writing ``velodyne/{f}.bin``, ``labels/{f}.label`` and ``check/{f}.bin`` byte for byte the way
+``save_data`` does (SS tools/datasets.py:45-60, 72-106; OD tools/datasets.py:56-109).  Directory
+creation prompts, pose handling and annotation synthesis stay with the reference's driver.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from ... import _lib
+from .._dev import ptr, to_device
+
+
+def remove_space_for_spherical(point_cloud):
+    """SS tools/datasets.py:93-106: (N x 4 xyz+intensity, N x 1 label), float64 like the reference."""
+    n = len(point_cloud)
+    labels = np.zeros((n, 1))
+    pcl = np.ones((n, 4)) * -1
+    if n:
+        pc = point_cloud.cpu().numpy() if hasattr(point_cloud, "cpu") else point_cloud
+        pcl[:, 0:3] = pc[:, 0:3]
+        pcl[:, 3] = pc[:, 6]
+        labels[:, 0] = pc[:, 7]
+    return pcl, labels
+
+
+def pack_for_save(point_cloud, check_cols=5):
+    """Device-side casts of save_data: (xyzi float32 [N,4], label uint32 [N], check float32)."""
+    torch = _lib.require_gpu()
+    lib = _lib.load()
+    dev, _ = to_device(point_cloud, torch.float64)
+    n = dev.shape[0]
+    xyzi = torch.empty((n, 4), dtype=torch.float32, device=dev.device)
+    label = torch.empty(n, dtype=torch.int32, device=dev.device)
+    check = torch.empty((n, check_cols), dtype=torch.float32, device=dev.device)
+    _lib.check(lib.r3d_remove_space_for_spherical(ptr(dev), n, ptr(xyzi), ptr(label), ptr(check), check_cols,
+                                                  _lib.stream_ptr()), "remove_space_for_spherical")
+    return xyzi.cpu().numpy(), label.cpu().numpy().view(np.uint32), check.cpu().numpy()
+
+
+def read_frame(velodyne_file, label_file):
+    """SS tools/datasets.py:51-56: float32 N x 4 + uint32 labels -> (xyzi, semantic label, instance)."""
+    xyzi = np.fromfile(velodyne_file, dtype=np.float32).reshape(-1, 4)
+    labels = np.fromfile(label_file, dtype=np.uint32)
+    return xyzi, labels & 0xFFFF, labels >> 16
+
+
+def write_frame(output_path, folder, name, xyzi, label, check, write_labels=True):
+    """Write the three files of save_data from packed arrays (SS :80-89; OD :86-93 has no labels)."""
+    base = os.path.join(output_path, folder)
+    for sub in ("velodyne", "check") + (("labels",) if write_labels else ()):
+        os.makedirs(os.path.join(base, sub), exist_ok=True)
+    np.ascontiguousarray(xyzi, dtype=np.float32).tofile(os.path.join(base, "velodyne", f"{name}.bin"))
+    if write_labels:
+        np.ascontiguousarray(label, dtype=np.uint32).tofile(os.path.join(base, "labels", f"{name}.label"))
+    np.ascontiguousarray(check, dtype=np.float32).tofile(os.path.join(base, "check", f"{name}.bin"))
+
+
+class SemanticKITTI:
+    """``save_data`` / ``remove_space_for_spherical`` of the reference's class (SS :72-106)."""
+
+    def __init__(self, config):
+        self.config = config
+
+    def remove_space_for_spherical(self, point_cloud):
+        return remove_space_for_spherical(point_cloud)
+
+    def save_data(self, point_cloud, added_points, folder, name, idx=None):
+        xyzi, label, _ = pack_for_save(point_cloud)
+        _, _, check = pack_for_save(added_points, 5)
+        write_frame(self.config["path"]["output_path"], folder, name, xyzi, label, check, True)
+
+
+class KITTI:
+    """Object-detection variant (OD tools/datasets.py:76-109): no label file, 4-column check."""
+
+    def __init__(self, config):
+        self.config = config
+        self.save_output_folder = config["path"]["output_path"]
+
+    def remove_space_for_spherical(self, point_cloud):
+        return remove_space_for_spherical(point_cloud)[0]
+
+    def save_data(self, point_cloud, added_points, folder, name, idx=None, additional_anno_lines=None):
+        xyzi, _, _ = pack_for_save(point_cloud)
+        _, _, check = pack_for_save(added_points, 4)
+        write_frame(self.save_output_folder, folder, name, xyzi, None, check, False)

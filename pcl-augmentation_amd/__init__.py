@@ -1,0 +1,18 @@
+"""Real3D-Aug occlusion handling + insertion merge on MI355X (gfx950).
+
+A drop-in for the per-frame hot path of ctu-vras/pcl-augmentation: the functions of
+``Real3DAug/insertion.py`` and ``Real3DAug/tools/closing.py`` keep their names, argument meaning
+and error behaviour (``Real3DAug`` sub-package), and ``SceneBatch`` runs many independent scenes
+through K inserts with everything resident in HBM.  All compute goes through the C ABI of
+``libreal3daug_hip.so`` (``include/real3daug_hip.h``); there is no CPU fallback.
+
+The directory name contains a hyphen, so import it with
+``importlib.import_module("pcl-augmentation_amd")`` (or through ``pcl_augmentation_amd.py`` at
+the repository root).
+"""
+from . import _lib, synth  # noqa: F401
+from ._lib import R3DError  # noqa: F401
+from .batch import SceneBatch, augment_batch, shard_indices  # noqa: F401
+from . import Real3DAug  # noqa: F401
+
+__all__ = ["SceneBatch", "augment_batch", "shard_indices", "Real3DAug", "synth", "R3DError"]

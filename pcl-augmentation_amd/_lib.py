@@ -1,0 +1,117 @@
+"""ctypes binding of libreal3daug_hip.so (the C ABI declared in include/real3daug_hip.h).
+
+There is no CPU fallback: if the shared library is missing this module raises at load time, and
+every operation raises when no GPU is visible.  PyTorch-ROCm is used for device memory, streams
+and nothing else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libreal3daug_hip.so")
+
+R3D_OK = 0
+S_NONFINITE, S_ROW_RANGE, S_COL_RANGE, S_SAMPLE_TOO_LARGE, S_CAPACITY, S_FAR_OVERFLOW = 1, 2, 4, 8, 16, 32
+STATUS_TEXT = {
+    S_NONFINITE: "NaN/Inf coordinate or a point at the origin (reference: int() raises, insertion.py:104)",
+    S_ROW_RANGE: "Rows in FoV went something wrong (assert insertion.py:110)",
+    S_COL_RANGE: "Column in FoV went something wrong (assert insertion.py:112)",
+    S_SAMPLE_TOO_LARGE: "sample has more than R3D_MAX_SAMPLE points",
+    S_CAPACITY: "merged cloud or insert log exceeds its capacity",
+    S_FAR_OVERFLOW: "more than R3D_FAR_CAP pixels deeper than 500 m",
+}
+NUMROW, NUMCOLUMN = 112, 1440
+MAX_SAMPLE = 8192
+FAR_CAP = 1024
+
+
+class R3DError(RuntimeError):
+    pass
+
+
+class BatchDesc(C.Structure):
+    """Mirror of r3d_batch_t."""
+    _fields_ = [
+        ("B", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("reserved", C.c_int32),
+        ("cap", C.c_int64), ("log_cap", C.c_int64),
+        ("xyzi", C.c_void_p), ("label", C.c_void_p), ("pix", C.c_void_p),
+        ("n_head", C.c_void_p), ("n_total", C.c_void_p), ("tail_ref", C.c_void_p),
+        ("log5", C.c_void_p), ("log_birth", C.c_void_p), ("n_log", C.c_void_p),
+        ("grid", C.c_void_p), ("sgrid", C.c_void_p), ("stamp", C.c_void_p), ("ever", C.c_void_p),
+        ("bounds", C.c_void_p), ("row_of_max", C.c_void_p), ("far_pix", C.c_void_p),
+        ("n_far", C.c_void_p), ("rebase", C.c_void_p), ("status", C.c_void_p),
+        ("out_xyzi", C.c_void_p), ("out_label", C.c_void_p), ("n_out", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "r3d_version": (C.c_int, []),
+    "r3d_last_error": (C.c_char_p, []),
+    "r3d_add_space_for_spherical": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "r3d_fill_spherical": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
+    "r3d_front_view_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "r3d_geometrical_front_view": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                             C.c_int32, _P, _P, _P, C.c_size_t, _P, _P]),
+    "r3d_class_closing": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
+    "r3d_smooth_out": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "r3d_occlusion_merge_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "r3d_occlusion_merge": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int32, C.c_int32,
+                                      _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "r3d_remove_space_for_spherical": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int32, _P]),
+    "r3d_batch_workspace_bytes": (C.c_size_t, [C.POINTER(BatchDesc)]),
+    "r3d_batch_begin": (C.c_int, [C.POINTER(BatchDesc), _P, _P]),
+    "r3d_batch_insert": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
+    "r3d_batch_finish": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int32, _P]),
+    "r3d_batch_elev_bounds": (C.c_int, [C.POINTER(BatchDesc), _P]),
+    "r3d_batch_project": (C.c_int, [C.POINTER(BatchDesc), _P]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises ImportError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != R3D_OK:
+        raise R3DError(f"{what or 'r3d call'} failed (code {rc}): {load().r3d_last_error().decode()}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise R3DError("no GPU visible: the Real3D-Aug HIP path has no CPU fallback")
+    return torch
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def raise_status(bits: int, where: str):
+    """Device status bits -> the exception the reference would have raised."""
+    if not bits:
+        return
+    msgs = [t for b, t in STATUS_TEXT.items() if bits & b]
+    if bits & (S_ROW_RANGE | S_COL_RANGE):
+        raise AssertionError(f"{where}: " + "; ".join(msgs))
+    raise ValueError(f"{where}: " + "; ".join(msgs))

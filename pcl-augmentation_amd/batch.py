@@ -1,0 +1,211 @@
+"""Batched, HBM-resident driver of the insert loop (SS Real3DAug/insertion.py:371-381, :449-545).
+
+``SceneBatch`` owns the device arrays of ``r3d_batch_t`` (as PyTorch-ROCm tensors) for B
+independent scenes and advances all of them in lock step: ``begin`` = the scene field of view of
+the first insert, ``insert`` = one placement candidate per scene, ``finish`` = the merged clouds in
+the byte layout of ``velodyne/*.bin`` / ``labels/*.label`` / ``check/*.bin``.  Scenes are
+independent, so several GPUs simply take disjoint scene shards (``shard_indices``); there is no
+collective on the data path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def shard_indices(n_scenes: int, rank: int, world_size: int):
+    """Scene i -> GPU i mod G: the indices rank ``rank`` processes."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank outside [0, world_size)")
+    return list(range(rank, n_scenes, world_size))
+
+
+class SceneBatch:
+    def __init__(self, B, cap, log_cap, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN, device="cuda:0"):
+        torch = _lib.require_gpu()
+        self.torch = torch
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.B, self.cap, self.log_cap, self.rows, self.cols = int(B), int(cap), int(log_cap), int(rows), int(cols)
+        npix = self.rows * self.cols
+        words = (npix + 31) // 32
+        dev = self.device
+
+        def z(shape, dt):
+            return torch.zeros(shape, dtype=dt, device=dev)
+
+        self.xyzi = z((B, cap, 4), torch.float32)
+        self.label = z((B, cap), torch.int32)            # uint32 bit patterns
+        self.pix = z((B, cap), torch.int32)
+        self.n_head = z((B,), torch.int32)
+        self.n_total = z((B,), torch.int32)
+        self.tail_ref = z((B, log_cap), torch.int32)
+        self.log5 = z((B, log_cap, 5), torch.float64)
+        self.log_birth = z((B, log_cap), torch.int32)
+        self.n_log = z((B,), torch.int32)
+        self.grid = z((B, npix), torch.int64)
+        self.sgrid = z((B, npix), torch.int64)
+        self.stamp = z((B, npix), torch.int16)
+        self.ever = z((B, words), torch.int32)
+        self.bounds = z((B, 2), torch.float64)
+        self.row_of_max = z((B,), torch.int32)
+        self.far_pix = z((B, _lib.FAR_CAP), torch.int32)
+        self.n_far = z((B,), torch.int32)
+        self.rebase = z((B,), torch.int32)
+        self.status = z((B,), torch.int32)
+        self.out_xyzi = z((B, cap, 4), torch.float32)
+        self.out_label = z((B, cap), torch.int32)
+        self.n_out = z((B,), torch.int32)
+        self.n_points = z((B,), torch.int32)
+        self.n_visible = z((B,), torch.int32)
+        self.accepted = z((B,), torch.int32)
+        self.check = None
+        self.step = 0
+
+        d = _lib.BatchDesc()
+        d.B, d.rows, d.cols, d.reserved, d.cap, d.log_cap = B, rows, cols, 0, cap, log_cap
+        for name in ("xyzi", "label", "pix", "n_head", "n_total", "tail_ref", "log5", "log_birth", "n_log",
+                     "grid", "sgrid", "stamp", "ever", "bounds", "row_of_max", "far_pix", "n_far", "rebase",
+                     "status", "out_xyzi", "out_label", "n_out"):
+            setattr(d, name, getattr(self, name).data_ptr())
+        d.workspace, d.workspace_bytes = 0, 0
+        ws_bytes = self.lib.r3d_batch_workspace_bytes(C.byref(d))
+        if ws_bytes == 0:
+            raise _lib.R3DError("r3d_batch_workspace_bytes rejected the batch shape")
+        self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        d.workspace, d.workspace_bytes = self.ws.data_ptr(), ws_bytes
+        self.desc = d
+
+    # -- loading --------------------------------------------------------------------------------
+    def load(self, scenes):
+        """scenes: list of (xyzi float32 [n,4], label uint32 [n]) host arrays, one per scene."""
+        torch = self.torch
+        assert len(scenes) == self.B
+        n_host = np.zeros(self.B, dtype=np.int32)
+        hx = np.zeros((self.B, self.cap, 4), dtype=np.float32)
+        hl = np.zeros((self.B, self.cap), dtype=np.uint32)
+        for s, (xyzi, label) in enumerate(scenes):
+            n = len(xyzi)
+            if n > self.cap:
+                raise ValueError(f"scene {s}: {n} points exceed capacity {self.cap}")
+            n_host[s] = n
+            hx[s, :n] = xyzi
+            hl[s, :n] = np.asarray(label, dtype=np.uint32) & 0xFFFF
+        self.xyzi.copy_(torch.from_numpy(hx))
+        self.label.copy_(torch.from_numpy(hl.view(np.int32)))
+        self.n_points.copy_(torch.from_numpy(n_host))
+
+    def load_device(self, xyzi, label, n_points):
+        """Same from tensors already on the device (copied into the batch slabs)."""
+        self.xyzi.copy_(xyzi)
+        self.label.copy_(label)
+        self.n_points.copy_(n_points)
+
+    # -- the three phases -----------------------------------------------------------------------
+    def begin(self):
+        self.step = 0
+        _lib.check(self.lib.r3d_batch_begin(C.byref(self.desc), C.c_void_p(self.n_points.data_ptr()),
+                                            _lib.stream_ptr()), "r3d_batch_begin")
+
+    def insert_device(self, samples5, sample_off, min_points, active=None, new_slot=True):
+        """One candidate per scene from device tensors; returns (n_visible, accepted) tensors.
+
+        ``new_slot`` starts a new insert slot (a new step number); further candidates of the same
+        slot pass ``new_slot=False`` together with ``active`` = scenes still without an accept.
+        """
+        if new_slot:
+            self.step += 1
+        _lib.check(self.lib.r3d_batch_insert(
+            C.byref(self.desc), C.c_void_p(samples5.data_ptr()), C.c_void_p(sample_off.data_ptr()),
+            C.c_void_p(min_points.data_ptr()), C.c_void_p(active.data_ptr() if active is not None else 0),
+            self.step, C.c_void_p(self.n_visible.data_ptr()), C.c_void_p(self.accepted.data_ptr()),
+            _lib.stream_ptr()), "r3d_batch_insert")
+        return self.n_visible, self.accepted
+
+    def pack_samples(self, samples):
+        """list of (M x 5 float64 | None) per scene -> (samples5, sample_off) device tensors."""
+        torch = self.torch
+        assert len(samples) == self.B
+        sizes = [0 if smp is None else len(smp) for smp in samples]
+        off = np.zeros(self.B + 1, dtype=np.int64)
+        off[1:] = np.cumsum(sizes)
+        rows = np.zeros((max(int(off[-1]), 1), 5), dtype=np.float64)
+        for s, smp in enumerate(samples):
+            if sizes[s]:
+                rows[off[s]:off[s + 1]] = smp
+        return (torch.from_numpy(rows).to(self.device), torch.from_numpy(off).to(self.device))
+
+    def insert(self, samples, min_points, active=None, new_slot=True):
+        torch = self.torch
+        s5, off = self.pack_samples(samples)
+        mp = torch.from_numpy(np.asarray(min_points, dtype=np.int32)).to(self.device)
+        act = None if active is None else torch.from_numpy(np.asarray(active, dtype=np.int32)).to(self.device)
+        nv, acc = self.insert_device(s5, off, mp, act, new_slot)
+        self._keep = (s5, off, mp, act)          # keep the inputs alive until the stream has run
+        return nv.cpu().numpy().copy(), acc.cpu().numpy().copy()
+
+    def finish(self, check_cols=5):
+        torch = self.torch
+        if check_cols:
+            self.check = torch.zeros((self.B, self.log_cap, check_cols), dtype=torch.float32, device=self.device)
+            cp = C.c_void_p(self.check.data_ptr())
+        else:
+            self.check, cp = None, C.c_void_p(0)
+        _lib.check(self.lib.r3d_batch_finish(C.byref(self.desc), cp, int(check_cols or 5), _lib.stream_ptr()),
+                   "r3d_batch_finish")
+
+    # -- results --------------------------------------------------------------------------------
+    def raise_on_status(self):
+        st = self.status.cpu().numpy()
+        for s in np.nonzero(st)[0]:
+            _lib.raise_status(int(st[s]), f"scene {s}")
+
+    def results(self):
+        """Per scene: (xyzi float32 [n,4], label uint32 [n], check float32 [m,cols])."""
+        self.raise_on_status()
+        n_out = self.n_out.cpu().numpy()
+        n_log = self.n_log.cpu().numpy()
+        ox = self.out_xyzi.cpu().numpy()
+        ol = self.out_label.cpu().numpy().view(np.uint32)
+        ck = self.check.cpu().numpy() if self.check is not None else None
+        out = []
+        for s in range(self.B):
+            out.append((ox[s, :n_out[s]].copy(), ol[s, :n_out[s]].copy(),
+                        ck[s, :n_log[s]].copy() if ck is not None else None))
+        return out
+
+
+def augment_batch(scenes, candidates, min_points, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN, device="cuda:0",
+                  check_cols=5):
+    """Run whole frames through the insert loop on one GPU.
+
+    scenes[s] = (xyzi float32 [n,4], label uint32 [n]); candidates[s][k] = ordered list of M x 5
+    float64 placement candidates tried for insert k of scene s (the first one whose visible part
+    reaches min_points[s][k] points is merged, insertion.py:449-526).  Returns
+    (results, accepted) with results as ``SceneBatch.results`` and accepted[s][k] = index of the
+    accepted candidate or -1.
+    """
+    B = len(scenes)
+    k_max = max(len(c) for c in candidates)
+    grow = max(sum(max((len(x) for x in slot), default=0) for slot in c) for c in candidates)
+    cap = max(len(x) for x, _ in scenes) + grow
+    batch = SceneBatch(B, cap, max(grow, 1), rows, cols, device)
+    batch.load(scenes)
+    batch.begin()
+    accepted = [[-1] * len(c) for c in candidates]
+    for k in range(k_max):
+        n_cand = max(len(c[k]) if k < len(c) else 0 for c in candidates)
+        need = [min_points[s][k] if k < len(candidates[s]) else 0 for s in range(B)]
+        for ci in range(n_cand):
+            smp = [candidates[s][k][ci] if k < len(candidates[s]) and ci < len(candidates[s][k])
+                   and accepted[s][k] < 0 else None for s in range(B)]
+            active = [0 if x is None else 1 for x in smp]
+            _, acc = batch.insert(smp, need, active, new_slot=(ci == 0))
+            for s in range(B):
+                if active[s] and acc[s]:
+                    accepted[s][k] = ci
+    batch.finish(check_cols)
+    return batch.results(), accepted

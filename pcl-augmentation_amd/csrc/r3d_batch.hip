@@ -1,0 +1,803 @@
+// Level 2: B scenes advanced in lock step through K inserts, everything resident in HBM.
+//
+// The algorithm is the incremental one stated in tests/incremental_model.py and DESIGN.md par.3:
+// project every scene once (step 0), then per insert evaluate the sample only on its candidate
+// pixels, patch the scene's range image at the visible pixels, stamp them, append the visible
+// points; dead points are dropped once, in r3d_batch_finish (or earlier by a "rebase" when the
+// elevation bounds may have moved, after which the scene is re-projected like step 0).
+//
+// Kernels that walk scenes take a (list, count) pair: block row `blockIdx.y` handles scenes
+// list[blockIdx.y], list[blockIdx.y + gridDim.y], ... below *count.  With the identity list this
+// is "all scenes"; with the rebase list (normally empty) the blocks return at once.
+#include "r3d_device.hpp"
+#include "r3d_host.hpp"
+
+namespace r3d {
+
+constexpr int kPT = 256;             // threads of the streaming kernels
+constexpr int kPerThread = 8;
+constexpr int kTile = kPT * kPerThread;   // points per block tile
+constexpr int kST = 512;             // threads of the per-scene insert kernel
+constexpr int kKeyCap = R3D_MAX_SAMPLE;
+constexpr int kIdxBits = 13;         // kKeyCap == 1 << kIdxBits
+constexpr int kRebaseRows = 16;      // block rows of the (normally idle) rebase launches
+
+struct BatchWs {
+  unsigned long long *qkeys;    // [B][2] ordered keys of min / max of z/r
+  int32_t *tile_alive;          // [B*tiles]
+  int32_t *tile_head;           // [B*tiles]
+  int32_t *new_head;            // [B]
+  int32_t *tail_tmp;            // [B*log_cap]
+  uint32_t *cand;               // [B*npix] candidate pixel lists of the insert kernel
+  int32_t *all_list;            // [B] identity
+  int32_t *all_count;           // [1] = B
+  int32_t *rebase_list;         // [B]
+  int32_t *n_rebase;            // [1]
+  size_t total;
+};
+
+static int tiles_of(const r3d_batch_t &b) { return (int)((b.cap + kTile - 1) / kTile); }
+static int mask_words(const r3d_batch_t &b) { return (int)(((int64_t)b.rows * b.cols + 31) / 32); }
+
+static BatchWs carve_batch(const r3d_batch_t &b, void *base) {
+  BatchWs w;
+  Carver c(base);
+  int64_t npix = (int64_t)b.rows * b.cols;
+  int tiles = tiles_of(b);
+  w.qkeys = c.take<unsigned long long>((size_t)b.B * 2);
+  w.tile_alive = c.take<int32_t>((size_t)b.B * tiles);
+  w.tile_head = c.take<int32_t>((size_t)b.B * tiles);
+  w.new_head = c.take<int32_t>((size_t)b.B);
+  w.tail_tmp = c.take<int32_t>((size_t)b.B * b.log_cap);
+  w.cand = c.take<uint32_t>((size_t)b.B * npix);
+  w.all_list = c.take<int32_t>((size_t)b.B);
+  w.all_count = c.take<int32_t>(1);
+  w.rebase_list = c.take<int32_t>((size_t)b.B);
+  w.n_rebase = c.take<int32_t>(1);
+  w.total = c.off;
+  return w;
+}
+
+// ---- cloud access ---------------------------------------------------------------------------
+// A cloud point is float32-exact (head, from velodyne .bin) or a float64 inserted point (tail)
+// whose exact coordinates live in the log; xyzi holds the float32 rounding of tail points so the
+// output .bin bytes are a plain copy.
+__device__ __forceinline__ void load_point(const r3d_batch_t &b, int s, int i, int n_head, double &x,
+                                           double &y, double &z) {
+  if (i < n_head) {
+    float4 p = reinterpret_cast<const float4 *>(b.xyzi)[(int64_t)s * b.cap + i];
+    x = (double)p.x;
+    y = (double)p.y;
+    z = (double)p.z;
+  } else {
+    int lr = b.tail_ref[(int64_t)s * b.log_cap + (i - n_head)];
+    const double *q = b.log5 + ((int64_t)s * b.log_cap + lr) * 5;
+    x = q[0];
+    y = q[1];
+    z = q[2];
+  }
+}
+
+__device__ __forceinline__ bool point_alive(const r3d_batch_t &b, int s, int i, int n_head, int npix,
+                                            int words) {
+  int p = b.pix[(int64_t)s * b.cap + i];
+  if (i < n_head) return !((b.ever[(int64_t)s * words + (p >> 5)] >> (p & 31)) & 1u);
+  int lr = b.tail_ref[(int64_t)s * b.log_cap + (i - n_head)];
+  return (int)b.stamp[(int64_t)s * npix + p] <= b.log_birth[(int64_t)s * b.log_cap + lr];
+}
+
+// ---- step 0 / rebase: bounds ------------------------------------------------------------------
+__global__ void k_begin_init(r3d_batch_t b, const int32_t *n_points, BatchWs w) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s == 0) {
+    *w.all_count = b.B;
+    *w.n_rebase = 0;
+  }
+  if (s >= b.B) return;
+  int n = n_points[s];
+  int st = 0;
+  if (n < 0 || n > b.cap) {
+    n = 0;
+    st = R3D_S_CAPACITY;
+  }
+  b.n_head[s] = n;
+  b.n_total[s] = n;
+  b.n_log[s] = 0;
+  b.n_far[s] = 0;
+  b.rebase[s] = 0;
+  b.status[s] = st;
+  b.n_out[s] = 0;
+  w.all_list[s] = s;
+}
+
+__global__ void k_bounds_init(const int32_t *list, const int32_t *count, BatchWs w) {
+  int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= *count) return;
+  int s = list[li];
+  w.qkeys[2 * s + 0] = ~0ull;   // running min of z/r
+  w.qkeys[2 * s + 1] = 0ull;    // running max of z/r
+}
+
+// elevation = acos(z/r) is monotone in q = z/r, so the bounds of insertion.py:78-79 are acos of
+// the extreme q: reduce q here (sqrt + divide per point), take acos twice per scene afterwards.
+__global__ void __launch_bounds__(kPT)
+k_bounds(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
+  __shared__ unsigned long long s_min[kPT / 64], s_max[kPT / 64];
+  int cnt = *count;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    int s = list[li];
+    int n = b.n_total[s], n_head = b.n_head[s];
+    int t0 = blockIdx.x * kTile;
+    if (t0 >= n) continue;
+    unsigned long long lmin = ~0ull, lmax = 0ull;
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+      int i = t0 + k * kPT + threadIdx.x;
+      if (i < n) {
+        double x, y, z;
+        load_point(b, s, i, n_head, x, y, z);
+        double r = sqrt(x * x + y * y + z * z);
+        double q = z / r;
+        if (!(q >= -1.0 && q <= 1.0) || !isfinite(x) || !isfinite(y)) {
+          bad = 1;
+        } else {
+          unsigned long long kq = ordered_key(q);
+          lmin = kq < lmin ? kq : lmin;
+          lmax = kq > lmax ? kq : lmax;
+        }
+      }
+    }
+    lmin = wave_min_u64(lmin);
+    lmax = wave_max_u64(lmax);
+    bad = wave_or_i32(bad);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+      s_min[wave] = lmin;
+      s_max[wave] = lmax;
+      if (bad) atomicOr(&b.status[s], R3D_S_NONFINITE);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int v = 1; v < kPT / 64; ++v) {
+        lmin = s_min[v] < lmin ? s_min[v] : lmin;
+        lmax = s_max[v] > lmax ? s_max[v] : lmax;
+      }
+      atomicMin(&w.qkeys[2 * s + 0], lmin);
+      atomicMax(&w.qkeys[2 * s + 1], lmax);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void k_bounds_finish(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
+  int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= *count) return;
+  int s = list[li];
+  unsigned long long kmin = w.qkeys[2 * s + 0], kmax = w.qkeys[2 * s + 1];
+  if (kmin == ~0ull) {                    // no valid point: the reference raises (insertion.py:78)
+    b.bounds[2 * s + 0] = b.bounds[2 * s + 1] = 0.0;
+    b.row_of_max[s] = 0;
+    atomicOr(&b.status[s], R3D_S_NONFINITE);
+    return;
+  }
+  double max_el = acos(ordered_key_inv(kmin));   // insertion.py:79
+  double min_el = acos(ordered_key_inv(kmax));   // insertion.py:78
+  b.bounds[2 * s + 0] = max_el;
+  b.bounds[2 * s + 1] = min_el;
+  double d_el = (max_el - min_el) / (double)b.rows;
+  double t = trunc((max_el - min_el - 0.00001) / d_el);
+  b.row_of_max[s] = (t >= 0.0 && t < (double)b.rows) ? (int)t : 0;
+}
+
+// ---- step 0 / rebase: reset the per-scene images ----------------------------------------------
+__global__ void __launch_bounds__(kPT)
+k_reset(r3d_batch_t b, const int32_t *list, const int32_t *count) {
+  int cnt = *count;
+  int64_t npix = (int64_t)b.rows * b.cols;
+  int words = (int)((npix + 31) / 32);
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    int s = list[li];
+    unsigned long long *g = (unsigned long long *)b.grid + (int64_t)s * npix;
+    uint16_t *st = b.stamp + (int64_t)s * npix;
+    uint32_t *ev = b.ever + (int64_t)s * words;
+    for (int64_t p = blockIdx.x * (int64_t)kPT + threadIdx.x; p < npix; p += (int64_t)gridDim.x * kPT) {
+      g[p] = R3D_SENT;
+      st[p] = 0;
+      if (p < words) ev[p] = 0u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) b.n_far[s] = 0;
+  }
+}
+
+// ---- step 0 / rebase: spherical projection + range-image min-reduce ----------------------------
+// insertion.py:74-76 and :104-127 fused: r/az/el are never stored, only the pixel id.
+__global__ void __launch_bounds__(kPT)
+k_project(r3d_batch_t b, const int32_t *list, const int32_t *count) {
+  int cnt = *count;
+  int64_t npix = (int64_t)b.rows * b.cols;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    int s = list[li];
+    int n = b.n_total[s], n_head = b.n_head[s];
+    int t0 = blockIdx.x * kTile;
+    if (t0 >= n) continue;
+    Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
+    unsigned long long *g = (unsigned long long *)b.grid + (int64_t)s * npix;
+    int flags = 0;
+#pragma unroll 2
+    for (int k = 0; k < kPerThread; ++k) {
+      int i = t0 + k * kPT + threadIdx.x;
+      if (i >= n) continue;
+      double x, y, z;
+      load_point(b, s, i, n_head, x, y, z);
+      Sph sp = spherical(x, y, z);
+      int row, col;
+      int ok = bin_point(bn, sp.az, sp.el, row, col);
+      int p = 0;
+      if (!(ok & 1)) flags |= isfinite(sp.el) ? R3D_S_ROW_RANGE : R3D_S_NONFINITE;
+      else if (!(ok & 2)) flags |= R3D_S_COL_RANGE;
+      else {
+        p = row * b.cols + col;
+        atomicMin(&g[p], depth_key(sp.r));
+        if (sp.r > R3D_EMPTY_DEPTH) {         // "first hit overwrites the 500": insertion.py:122-125
+          int f = atomicAdd(&b.n_far[s], 1);
+          if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
+          else flags |= R3D_S_FAR_OVERFLOW;
+        }
+      }
+      b.pix[(int64_t)s * b.cap + i] = p;
+    }
+    flags = wave_or_i32(flags);
+    if ((threadIdx.x & 63) == 0 && flags) atomicOr(&b.status[s], flags);
+  }
+}
+
+// ---- one insert candidate per scene ------------------------------------------------------------
+struct BitMask {
+  uint32_t *w;
+  __device__ __forceinline__ bool get(int p) const { return (w[p >> 5] >> (p & 31)) & 1u; }
+  __device__ __forceinline__ bool test_and_set(int p) {
+    uint32_t bit = 1u << (p & 31);
+    return atomicOr(&w[p >> 5], bit) & bit;
+  }
+};
+
+// Marks the 5 x 3 neighbourhood of pixel p as candidates (closing is a subset of dilation, so a
+// pixel outside every such neighbourhood has sample depth 500 and cannot become visible unless
+// the scene is deeper than 500 m there -- the far list covers that).
+__device__ __forceinline__ void mark_candidates(int p, int rows, int cols, BitMask seen, uint32_t *list,
+                                                int *n_list) {
+  int r = p / cols, c = p - r * cols;
+  for (int dr = -2; dr <= 2; ++dr) {
+    int rr = r + dr;
+    if (rr < 0 || rr >= rows) continue;
+    for (int dc = -1; dc <= 1; ++dc) {
+      int cc = c + dc;
+      if (cc < 0 || cc >= cols) continue;
+      int q = rr * cols + cc;
+      if (!seen.test_and_set(q)) list[atomicAdd(n_list, 1)] = (uint32_t)q;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kST)
+k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__restrict__ sample_off,
+         const int32_t *__restrict__ min_points, const int32_t *__restrict__ active, int step,
+         int32_t *__restrict__ n_visible, int32_t *__restrict__ accepted, BatchWs w) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int s = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int npix = b.rows * b.cols;
+  const int words = (npix + 31) / 32;
+  uint32_t *s_keys = reinterpret_cast<uint32_t *>(smem);          // [kKeyCap]
+  uint32_t *s_seen = s_keys + kKeyCap;                            // [words] candidate seen
+  uint32_t *s_vis = s_seen + words;                               // [words] visible pixels
+  uint32_t *s_occ = s_vis + words;                                // [words] sample occupancy
+  uint32_t *s_oob = s_occ + words;                                // [kKeyCap/32] el outside bounds
+  int *s_misc = reinterpret_cast<int *>(s_oob + kKeyCap / 32);    // counters + scan scratch
+  int *s_nvalid = s_misc + 0, *s_ncand = s_misc + 1, *s_rebase = s_misc + 2, *s_flags = s_misc + 3;
+  int *s_scan = s_misc + 4;                                       // [kST/64 + 1]
+
+  const int64_t off = sample_off[s];
+  const int64_t m64 = sample_off[s + 1] - off;
+  const bool on = (!active || active[s]) && m64 > 0 && m64 <= kKeyCap;
+  if (!on) {
+    if (tid == 0) {
+      n_visible[s] = 0;
+      accepted[s] = 0;
+      if (m64 > kKeyCap && (!active || active[s])) atomicOr(&b.status[s], R3D_S_SAMPLE_TOO_LARGE);
+    }
+    return;
+  }
+  const int m = (int)m64;
+  int pw = 64;
+  while (pw < m) pw <<= 1;
+
+  for (int i = tid; i < 3 * words + kKeyCap / 32; i += kST) s_seen[i] = 0u;   // seen, vis, occ, oob
+  if (tid < 4) s_misc[tid] = 0;
+  __syncthreads();
+
+  const Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
+  unsigned long long *grid = (unsigned long long *)b.grid + (int64_t)s * npix;
+  unsigned long long *sgrid = (unsigned long long *)b.sgrid + (int64_t)s * npix;
+  const double *rows5 = samples5 + off * 5;
+
+  // -- 1. project the sample with the scene's bounds, sample=True (insertion.py:455-459) ---------
+  for (int j = tid; j < pw; j += kST) {
+    uint32_t key = 0xFFFFFFFFu;
+    if (j < m) {
+      const double *q = rows5 + (int64_t)j * 5;
+      Sph sp = spherical(q[0], q[1], q[2]);
+      int row, col;
+      int ok = bin_point(bn, sp.az, sp.el, row, col);
+      if (!isfinite(sp.el) || !isfinite(sp.az)) {
+        atomicOr(s_flags, R3D_S_NONFINITE);
+      } else if (ok & 1) {                           // rows outside [0, rows) are skipped (:107-108)
+        if (!(ok & 2)) {
+          atomicOr(s_flags, R3D_S_COL_RANGE);        // assert :112
+        } else {
+          int p = row * b.cols + col;
+          key = ((uint32_t)p << kIdxBits) | (uint32_t)j;
+          atomicMin(&sgrid[p], depth_key(sp.r));
+          atomicAdd(s_nvalid, 1);
+          if (sp.el < bn.min_el || sp.el > bn.max_el) atomicOr(&s_oob[j >> 5], 1u << (j & 31));
+        }
+      }
+    }
+    s_keys[j] = key;
+  }
+  __syncthreads();
+
+  // -- 2. sort (pixel, sample index): the order of visible_sample (insertion.py:474-482) ---------
+  for (int k = 2; k <= pw; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < pw; i += kST) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          uint32_t a = s_keys[i], c = s_keys[ixj];
+          bool up = (i & k) == 0;
+          if ((a > c) == up) {
+            s_keys[i] = c;
+            s_keys[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int nvalid = *s_nvalid;
+
+  // -- 3. occupied sample pixels and the candidate pixel list -----------------------------------
+  BitMask seen{s_seen}, vis{s_vis}, occ{s_occ};
+  uint32_t *cand = w.cand + (int64_t)s * npix;
+  for (int k = tid; k < nvalid; k += kST) {
+    int p = (int)(s_keys[k] >> kIdxBits);
+    if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != p) {
+      atomicOr(&s_occ[p >> 5], 1u << (p & 31));
+      mark_candidates(p, b.rows, b.cols, seen, cand, s_ncand);
+    }
+  }
+  {
+    int nf = b.n_far[s];
+    nf = nf < R3D_FAR_CAP ? nf : R3D_FAR_CAP;
+    for (int f = tid; f < nf; f += kST)
+      mark_candidates(b.far_pix[(int64_t)s * R3D_FAR_CAP + f], b.rows, b.cols, seen, cand, s_ncand);
+  }
+  __syncthreads();
+  const int ncand = *s_ncand;
+
+  // -- 4. visibility on the candidates: smoothed sample depth < smoothed scene depth (:461-467) --
+  auto g_scene = [&](int r, int c) { return grid[r * b.cols + c]; };
+  auto g_sample = [&](int r, int c) {
+    return __hip_atomic_load(&sgrid[r * b.cols + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto o_sample = [&](int r, int c) { return occ.get(r * b.cols + c); };
+  for (int ci = tid; ci < ncand; ci += kST) {
+    int q = (int)cand[ci];
+    int r = q / b.cols, c = q - r * b.cols;
+    double sd = R3D_EMPTY_DEPTH;
+    if (occ.get(q)) {
+      sd = key_depth(g_sample(r, c));
+    } else if (closed_at(o_sample, r, c, b.rows, b.cols)) {
+      double mval;
+      if (hole_mean(g_sample, r, c, b.rows, b.cols, mval)) sd = mval;
+    }
+    double cd = smoothed_depth(g_scene, r, c, b.rows, b.cols);
+    if (sd < cd) atomicOr(&s_vis[q >> 5], 1u << (q & 31));
+  }
+  __syncthreads();
+
+  // -- 5. count the visible sample points, accept test (insertion.py:511-517) --------------------
+  int mine = 0;
+  for (int k = tid; k < nvalid; k += kST) mine += vis.get((int)(s_keys[k] >> kIdxBits)) ? 1 : 0;
+  int nvis;
+  (void)block_escan_i32(mine, s_scan, nvis);
+  const int n_total = b.n_total[s], n_head = b.n_head[s], n_log = b.n_log[s];
+  int need = min_points[s];
+  bool accept = nvis > 0 && nvis >= need;
+  if (accept && ((int64_t)n_total + nvis > b.cap || (int64_t)n_log + nvis > b.log_cap)) {
+    accept = false;
+    if (tid == 0) atomicOr(&b.status[s], R3D_S_CAPACITY);
+  }
+
+  // -- 6. commit: append (insertion.py:526), patch the range image, stamp ------------------------
+  if (accept) {
+    int base = 0;
+    for (int k0 = 0; k0 < nvalid; k0 += kST) {
+      int k = k0 + tid;
+      uint32_t key = k < nvalid ? s_keys[k] : 0u;
+      int p = (int)(key >> kIdxBits);
+      int flag = (k < nvalid && vis.get(p)) ? 1 : 0;
+      int tot;
+      int ex = block_escan_i32(flag, s_scan, tot);
+      if (flag) {
+        int j = (int)(key & (kKeyCap - 1));
+        const double *q = rows5 + (int64_t)j * 5;
+        int dst = n_total + base + ex, lr = n_log + base + ex;
+        float4 f;
+        f.x = (float)q[0];
+        f.y = (float)q[1];
+        f.z = (float)q[2];
+        f.w = (float)q[3];
+        reinterpret_cast<float4 *>(b.xyzi)[(int64_t)s * b.cap + dst] = f;
+        b.label[(int64_t)s * b.cap + dst] = (uint32_t)(int64_t)q[4];
+        b.pix[(int64_t)s * b.cap + dst] = p;
+        b.tail_ref[(int64_t)s * b.log_cap + (dst - n_head)] = lr;
+        double *l = b.log5 + ((int64_t)s * b.log_cap + lr) * 5;
+        l[0] = q[0];
+        l[1] = q[1];
+        l[2] = q[2];
+        l[3] = q[3];
+        l[4] = q[4];
+        b.log_birth[(int64_t)s * b.log_cap + lr] = step;
+        if ((s_oob[j >> 5] >> (j & 31)) & 1u) *s_rebase = 1;   // bounds move: new extreme elevation
+      }
+      base += tot;
+    }
+    const int row_of_max = b.row_of_max[s];
+    uint16_t *stamp = b.stamp + (int64_t)s * npix;
+    uint32_t *ever = b.ever + (int64_t)s * words;
+    for (int ci = tid; ci < ncand; ci += kST) {
+      int q = (int)cand[ci];
+      if (!vis.get(q)) continue;
+      int r = q / b.cols;
+      if (grid[q] != R3D_SENT && (r == 0 || r == row_of_max)) *s_rebase = 1;   // an extreme may be culled
+      unsigned long long nv = occ.get(q) ? g_sample(r, q - r * b.cols) : R3D_SENT;
+      grid[q] = nv;
+      if (nv != R3D_SENT && key_depth(nv) > R3D_EMPTY_DEPTH) {
+        int f = atomicAdd(&b.n_far[s], 1);
+        if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = q;
+        else atomicOr(s_flags, R3D_S_FAR_OVERFLOW);
+      }
+      stamp[q] = (uint16_t)step;
+      atomicOr(&ever[q >> 5], 1u << (q & 31));
+    }
+  }
+  __syncthreads();
+
+  // -- 7. leave the sample scratch image clean, publish -----------------------------------------
+  for (int k = tid; k < nvalid; k += kST) {
+    int p = (int)(s_keys[k] >> kIdxBits);
+    if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != p) sgrid[p] = R3D_SENT;
+  }
+  if (tid == 0) {
+    n_visible[s] = nvis;
+    accepted[s] = accept ? 1 : 0;
+    if (*s_flags) atomicOr(&b.status[s], *s_flags);
+    if (accept) {
+      b.n_total[s] = n_total + nvis;
+      b.n_log[s] = n_log + nvis;
+      if (*s_rebase) {
+        b.rebase[s] = 1;
+        w.rebase_list[atomicAdd(w.n_rebase, 1)] = s;
+      }
+    }
+  }
+}
+
+// ---- compaction: drop dead points (finish, or rebase) ------------------------------------------
+__global__ void __launch_bounds__(kPT)
+k_alive_count(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles) {
+  __shared__ int s_a[kPT / 64], s_h[kPT / 64];
+  int cnt = *count;
+  int npix = b.rows * b.cols, words = (npix + 31) / 32;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    int s = list[li];
+    int n = b.n_total[s], n_head = b.n_head[s];
+    int t0 = blockIdx.x * kTile;
+    int alive = 0, head = 0;
+    if (t0 < n) {
+#pragma unroll
+      for (int k = 0; k < kPerThread; ++k) {
+        int i = t0 + k * kPT + threadIdx.x;
+        if (i < n && point_alive(b, s, i, n_head, npix, words)) {
+          ++alive;
+          head += i < n_head ? 1 : 0;
+        }
+      }
+    }
+    alive = wave_sum_i32(alive);
+    head = wave_sum_i32(head);
+    if ((threadIdx.x & 63) == 0) {
+      s_a[threadIdx.x >> 6] = alive;
+      s_h[threadIdx.x >> 6] = head;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int a = 0, h = 0;
+      for (int v = 0; v < kPT / 64; ++v) {
+        a += s_a[v];
+        h += s_h[v];
+      }
+      w.tile_alive[(int64_t)s * tiles + blockIdx.x] = a;
+      w.tile_head[(int64_t)s * tiles + blockIdx.x] = h;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+k_alive_scan(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles) {
+  __shared__ int sm[1024 / 64 + 1];
+  __shared__ int s_carry, s_head;
+  int cnt = *count;
+  for (int li = blockIdx.x; li < cnt; li += gridDim.x) {
+    int s = list[li];
+    if (threadIdx.x == 0) s_carry = s_head = 0;
+    __syncthreads();
+    for (int base = 0; base < tiles; base += 1024) {
+      int t = base + threadIdx.x;
+      int a = t < tiles ? w.tile_alive[(int64_t)s * tiles + t] : 0;
+      int h = t < tiles ? w.tile_head[(int64_t)s * tiles + t] : 0;
+      int tot, htot;
+      int ex = block_escan_i32(a, sm, tot);
+      (void)block_escan_i32(h, sm, htot);
+      int carry = s_carry;
+      if (t < tiles) w.tile_alive[(int64_t)s * tiles + t] = carry + ex;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        s_carry = carry + tot;
+        s_head += htot;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      b.n_out[s] = s_carry;
+      w.new_head[s] = s_head;
+    }
+    __syncthreads();
+  }
+}
+
+// Survivors in original order (insertion.py:472-473 applied once for all steps), float4 + label
+// straight into the output arrays; tail references follow into tail_tmp for a rebase.
+__global__ void __launch_bounds__(kPT)
+k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles) {
+  __shared__ int sm[kPT / 64 + 1];
+  int cnt = *count;
+  int npix = b.rows * b.cols, words = (npix + 31) / 32;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    int s = list[li];
+    int n = b.n_total[s], n_head = b.n_head[s];
+    int t0 = blockIdx.x * kTile;
+    if (t0 >= n) continue;
+    int base = w.tile_alive[(int64_t)s * tiles + blockIdx.x];
+    int new_head = w.new_head[s];
+    const float4 *src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
+    float4 *dst = reinterpret_cast<float4 *>(b.out_xyzi) + (int64_t)s * b.cap;
+    for (int k = 0; k < kPerThread; ++k) {
+      int i = t0 + k * kPT + threadIdx.x;
+      int flag = (i < n && point_alive(b, s, i, n_head, npix, words)) ? 1 : 0;
+      int tot;
+      int ex = block_escan_i32(flag, sm, tot);
+      if (flag) {
+        int o = base + ex;
+        dst[o] = src[i];
+        b.out_label[(int64_t)s * b.cap + o] = b.label[(int64_t)s * b.cap + i];
+        if (i >= n_head)
+          w.tail_tmp[(int64_t)s * b.log_cap + (o - new_head)] =
+              b.tail_ref[(int64_t)s * b.log_cap + (i - n_head)];
+      }
+      base += tot;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kPT)
+k_rebase_copyback(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
+  int cnt = *count;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    int s = list[li];
+    int n = b.n_out[s], nh = w.new_head[s];
+    const float4 *src = reinterpret_cast<const float4 *>(b.out_xyzi) + (int64_t)s * b.cap;
+    float4 *dst = reinterpret_cast<float4 *>(b.xyzi) + (int64_t)s * b.cap;
+    for (int i = blockIdx.x * kPT + threadIdx.x; i < n; i += gridDim.x * kPT) {
+      dst[i] = src[i];
+      b.label[(int64_t)s * b.cap + i] = b.out_label[(int64_t)s * b.cap + i];
+      if (i >= nh)
+        b.tail_ref[(int64_t)s * b.log_cap + (i - nh)] = w.tail_tmp[(int64_t)s * b.log_cap + (i - nh)];
+    }
+  }
+}
+
+__global__ void k_rebase_counts(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
+  int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= *count) return;
+  int s = list[li];
+  b.n_total[s] = b.n_out[s];
+  b.n_head[s] = w.new_head[s];
+}
+
+__global__ void k_rebase_done(r3d_batch_t b, BatchWs w) {   // single block
+  int cnt = *w.n_rebase;
+  for (int li = threadIdx.x; li < cnt; li += blockDim.x) b.rebase[w.rebase_list[li]] = 0;
+  __syncthreads();
+  // every thread has read the count before it is cleared
+  if (threadIdx.x == 0) *w.n_rebase = 0;
+}
+
+// check/{f}.bin rows from the log (SS tools/datasets.py:73-75, :86-88; OD :77, :91-93).
+__global__ void k_pack_log(r3d_batch_t b, float *__restrict__ check, int check_cols) {
+  int s = blockIdx.y;
+  int n = b.n_log[s];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double *l = b.log5 + ((int64_t)s * b.log_cap + i) * 5;
+    float *c = check + ((int64_t)s * b.log_cap + i) * check_cols;
+    c[0] = (float)l[0];
+    c[1] = (float)l[1];
+    c[2] = (float)l[2];
+    c[3] = (float)l[3];
+    if (check_cols == 5) c[4] = (float)l[4];
+  }
+}
+
+static int check_batch(const r3d_batch_t *b) {
+  if (!b) return fail(R3D_E_ARG, "batch: null descriptor");
+  if (b->B <= 0 || b->rows <= 0 || b->cols <= 0 || b->cap <= 0 || b->log_cap <= 0)
+    return fail(R3D_E_ARG, "batch: non-positive shape");
+  if (b->cap > (int64_t)1 << 30 || (int64_t)b->rows * b->cols > (int64_t)1 << (32 - kIdxBits))
+    return fail(R3D_E_ARG, "batch: cap or range image too large for 32-bit point / pixel ids");
+  if (!b->xyzi || !b->label || !b->pix || !b->n_head || !b->n_total || !b->tail_ref || !b->log5 ||
+      !b->log_birth || !b->n_log || !b->grid || !b->sgrid || !b->stamp || !b->ever || !b->bounds ||
+      !b->row_of_max || !b->far_pix || !b->n_far || !b->rebase || !b->status || !b->out_xyzi ||
+      !b->out_label || !b->n_out || !b->workspace)
+    return fail(R3D_E_ARG, "batch: null array");
+  size_t lds = (size_t)kKeyCap * 4 + 3 * (size_t)mask_words(*b) * 4 + kKeyCap / 8 + 64 * 4;
+  if (lds > 160 * 1024)
+    return fail(R3D_E_ARG, "batch: range image too large for the LDS-resident masks of k_insert");
+  if (b->workspace_bytes < carve_batch(*b, nullptr).total)
+    return fail(R3D_E_WORKSPACE, "batch: workspace smaller than r3d_batch_workspace_bytes()");
+  return R3D_OK;
+}
+
+static size_t insert_lds_bytes(const r3d_batch_t &b) {
+  return (size_t)kKeyCap * 4 + 3 * (size_t)mask_words(b) * 4 + kKeyCap / 8 + 64 * 4;
+}
+
+// bounds -> reset -> project for the scenes of (list, count); rows = block rows of the launches.
+static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_t *list,
+                            const int32_t *count, int rows, hipStream_t st) {
+  int tiles = tiles_of(b);
+  int lb = (b.B + 255) / 256;
+  hipLaunchKernelGGL(k_bounds_init, dim3(lb), dim3(256), 0, st, list, count, w);
+  hipLaunchKernelGGL(k_bounds, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w);
+  hipLaunchKernelGGL(k_bounds_finish, dim3(lb), dim3(256), 0, st, b, list, count, w);
+  int64_t npix = (int64_t)b.rows * b.cols;
+  int rb = (int)((npix + kPT * 4 - 1) / (kPT * 4));
+  hipLaunchKernelGGL(k_reset, dim3(rb, rows), dim3(kPT), 0, st, b, list, count);
+  hipLaunchKernelGGL(k_project, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count);
+  R3D_LAUNCHED("reproject kernels");
+  return R3D_OK;
+}
+
+static int launch_compact(const r3d_batch_t &b, const BatchWs &w, const int32_t *list,
+                          const int32_t *count, int rows, hipStream_t st) {
+  int tiles = tiles_of(b);
+  hipLaunchKernelGGL(k_alive_count, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, tiles);
+  hipLaunchKernelGGL(k_alive_scan, dim3(rows), dim3(1024), 0, st, b, list, count, w, tiles);
+  hipLaunchKernelGGL(k_alive_write, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, tiles);
+  R3D_LAUNCHED("compaction kernels");
+  return R3D_OK;
+}
+
+}  // namespace r3d
+
+using namespace r3d;
+
+extern "C" {
+
+size_t r3d_batch_workspace_bytes(const r3d_batch_t *b) {
+  if (!b || b->B <= 0 || b->rows <= 0 || b->cols <= 0 || b->cap <= 0 || b->log_cap <= 0) return 0;
+  return carve_batch(*b, nullptr).total;
+}
+
+int r3d_batch_begin(const r3d_batch_t *b, const int32_t *n_points, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  if (!n_points) return fail(R3D_E_ARG, "batch_begin: null n_points");
+  hipStream_t st = (hipStream_t)stream;
+  BatchWs w = carve_batch(*b, b->workspace);
+  int64_t npix = (int64_t)b->rows * b->cols;
+  hipLaunchKernelGGL(k_begin_init, dim3((b->B + 255) / 256), dim3(256), 0, st, *b, n_points, w);
+  R3D_HIP(hipMemsetAsync(b->sgrid, 0xFF, (size_t)b->B * npix * sizeof(unsigned long long), st));
+  return launch_reproject(*b, w, w.all_list, w.all_count, b->B, st);
+}
+
+int r3d_batch_elev_bounds(const r3d_batch_t *b, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  BatchWs w = carve_batch(*b, b->workspace);
+  int tiles = tiles_of(*b), lb = (b->B + 255) / 256;
+  hipLaunchKernelGGL(k_bounds_init, dim3(lb), dim3(256), 0, st, w.all_list, w.all_count, w);
+  hipLaunchKernelGGL(k_bounds, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w);
+  hipLaunchKernelGGL(k_bounds_finish, dim3(lb), dim3(256), 0, st, *b, w.all_list, w.all_count, w);
+  R3D_LAUNCHED("bounds kernels");
+  return R3D_OK;
+}
+
+int r3d_batch_project(const r3d_batch_t *b, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  BatchWs w = carve_batch(*b, b->workspace);
+  int64_t npix = (int64_t)b->rows * b->cols;
+  int rb = (int)((npix + kPT * 4 - 1) / (kPT * 4));
+  hipLaunchKernelGGL(k_reset, dim3(rb, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count);
+  hipLaunchKernelGGL(k_project, dim3(tiles_of(*b), b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count);
+  R3D_LAUNCHED("project kernels");
+  return R3D_OK;
+}
+
+int r3d_batch_insert(const r3d_batch_t *b, const double *samples5, const int64_t *sample_off,
+                     const int32_t *min_points, const int32_t *active, int32_t step,
+                     int32_t *n_visible, int32_t *accepted, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  if (!samples5 || !sample_off || !min_points || !n_visible || !accepted || step < 1 || step > 65535)
+    return fail(R3D_E_ARG, "batch_insert: null pointer or step outside [1, 65535]");
+  hipStream_t st = (hipStream_t)stream;
+  BatchWs w = carve_batch(*b, b->workspace);
+  size_t lds = insert_lds_bytes(*b);
+  static thread_local size_t lds_opted = 0;
+  if (lds > lds_opted) {
+    R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_opted = lds;
+  }
+  hipLaunchKernelGGL(k_insert, dim3(b->B), dim3(kST), lds, st, *b, samples5, sample_off, min_points,
+                     active, (int)step, n_visible, accepted, w);
+  R3D_LAUNCHED("k_insert");
+  // rebase chain: idle unless k_insert flagged a scene (then: compact, re-project like step 0)
+  int rows = b->B < kRebaseRows ? b->B : kRebaseRows;
+  rc = launch_compact(*b, w, w.rebase_list, w.n_rebase, rows, st);
+  if (rc != R3D_OK) return rc;
+  hipLaunchKernelGGL(k_rebase_copyback, dim3(tiles_of(*b), rows), dim3(kPT), 0, st, *b, w.rebase_list,
+                     w.n_rebase, w);
+  hipLaunchKernelGGL(k_rebase_counts, dim3((b->B + 255) / 256), dim3(256), 0, st, *b, w.rebase_list,
+                     w.n_rebase, w);
+  rc = launch_reproject(*b, w, w.rebase_list, w.n_rebase, rows, st);
+  if (rc != R3D_OK) return rc;
+  hipLaunchKernelGGL(k_rebase_done, dim3(1), dim3(1024), 0, st, *b, w);
+  R3D_LAUNCHED("rebase kernels");
+  return R3D_OK;
+}
+
+int r3d_batch_finish(const r3d_batch_t *b, float *check, int32_t check_cols, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  if (check && check_cols != 4 && check_cols != 5) return fail(R3D_E_ARG, "batch_finish: check_cols");
+  hipStream_t st = (hipStream_t)stream;
+  BatchWs w = carve_batch(*b, b->workspace);
+  rc = launch_compact(*b, w, w.all_list, w.all_count, b->B, st);
+  if (rc != R3D_OK) return rc;
+  if (check) {
+    int gx = (int)((b->log_cap + 255) / 256);
+    gx = gx > 64 ? 64 : gx;
+    hipLaunchKernelGGL(k_pack_log, dim3(gx, b->B), dim3(256), 0, st, *b, check, (int)check_cols);
+    R3D_LAUNCHED("k_pack_log");
+  }
+  return R3D_OK;
+}
+
+}  // extern "C"

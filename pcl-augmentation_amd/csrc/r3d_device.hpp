@@ -1,0 +1,217 @@
+// Device-side building blocks shared by the Level-1 and batched kernels (gfx950, wave64).
+//
+// Everything that decides a pixel id or a depth is IEEE float64 with FMA contraction off
+// (the library is built with -ffp-contract=off): the reference bins in float64 and binning in
+// float32 moves 11 of 120 000 pixel ids.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/real3daug_hip.h"
+
+#define R3D_SENT 0xFFFFFFFFFFFFFFFFull   // empty pixel: above the bits of every finite double
+#define R3D_EMPTY_DEPTH 500.0             // insertion.py:99
+#define R3D_WAVE 64
+
+namespace r3d {
+
+constexpr double kPi = 3.14159265358979323846;      // == math.pi == np.pi
+constexpr double kTwoPi = 2.0 * 3.14159265358979323846;
+
+struct Sph {
+  double r, az, el;
+};
+
+// insertion.py:74-76.  x*x + y*y + z*z left to right, no contraction; sqrt and / are the
+// correctly rounded IEEE operations; atan2/acos come from the ROCm device library (<= 1-2 ULP,
+// as NumPy's own SVML/libm kernels are).
+__device__ __forceinline__ Sph spherical(double x, double y, double z) {
+  Sph s;
+  s.r = sqrt(x * x + y * y + z * z);
+  s.az = atan2(y, x) + kPi;
+  s.el = acos(z / s.r);
+  return s;
+}
+
+struct Binning {
+  double min_el, max_el, d_el, d_az;
+  int rows, cols;
+};
+
+__device__ __forceinline__ Binning make_binning(double max_el, double min_el, int rows, int cols) {
+  Binning b;
+  b.min_el = min_el;
+  b.max_el = max_el;
+  b.d_el = (max_el - min_el) / (double)rows;   // insertion.py:96
+  b.d_az = kTwoPi / (double)cols;              // insertion.py:97
+  b.rows = rows;
+  b.cols = cols;
+  return b;
+}
+
+// Python's float % for a positive divisor.
+__device__ __forceinline__ double pymod(double a, double m) {
+  if (a >= 0.0 && a < m) return a;
+  double f = fmod(a, m);
+  if (f != 0.0 && f < 0.0) f += m;
+  return f;
+}
+
+// insertion.py:104-112.  Returns a bit set: 1 = row in range, 2 = column in range.  int()
+// truncates toward zero, so (-1, 0) lands in row 0; NaN fails both tests.
+__device__ __forceinline__ int bin_point(const Binning &b, double az, double el, int &row, int &col) {
+  double tr = trunc((el - b.min_el - 0.00001) / b.d_el);
+  double tc = trunc(pymod(az, kTwoPi) / b.d_az);
+  int ok = 0;
+  row = col = 0;
+  if (tr >= 0.0 && tr < (double)b.rows) {
+    ok |= 1;
+    row = (int)tr;
+  }
+  if (tc >= 0.0 && tc < (double)b.cols) {
+    ok |= 2;
+    col = (int)tc;
+  }
+  return ok;
+}
+
+__device__ __forceinline__ unsigned long long depth_key(double r) {
+  return (unsigned long long)__double_as_longlong(r);
+}
+__device__ __forceinline__ double key_depth(unsigned long long k) {
+  return __longlong_as_double((long long)k);
+}
+
+// Order-preserving map double -> u64 for values of either sign (used for z/r reductions).
+__device__ __forceinline__ unsigned long long ordered_key(double v) {
+  unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ordered_key_inv(unsigned long long k) {
+  unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  return __longlong_as_double((long long)u);
+}
+
+// ---- wave / block reductions and scans (wave = 64 lanes) ------------------------------------
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long w = __shfl_xor(v, o, 64);
+    v = w < v ? w : v;
+  }
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long w = __shfl_xor(v, o, 64);
+    v = w > v ? w : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_or_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Inclusive wave scan of ints.
+__device__ __forceinline__ int wave_iscan_i32(int v) {
+  int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int w = __shfl_up(v, o, 64);
+    if (lane >= o) v += w;
+  }
+  return v;
+}
+
+// Exclusive block scan; `sm` needs blockDim.x/64 + 1 ints.  Returns the exclusive prefix of v and
+// the block total in `total`.  Contains two barriers; every thread of the block must call it.
+__device__ __forceinline__ int block_escan_i32(int v, int *sm, int &total) {
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  int inc = wave_iscan_i32(v);
+  if (lane == 63) sm[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    int t = lane < nw ? sm[lane] : 0;
+    int ti = wave_iscan_i32(t);
+    if (lane < nw) sm[lane] = ti - t;
+    if (lane == nw - 1) sm[nw] = ti;
+  }
+  __syncthreads();
+  int base = sm[wave];
+  total = sm[nw];
+  __syncthreads();
+  return base + inc - v;
+}
+
+// ---- 5 x 3 closing / hole fill on a u64 range image (SENT = empty) ---------------------------
+// Accessor: unsigned long long operator()(int row, int col) for in-range coordinates.
+
+// closing.py:20-21: closed = erode(dilate(occ)), window 5 rows x 3 columns clipped at the borders.
+template <class Occ>
+__device__ __forceinline__ bool closed_at(const Occ &occ, int r, int c, int rows, int cols) {
+  for (int er = r - 2; er <= r + 2; ++er) {
+    if (er < 0 || er >= rows) continue;
+    for (int ec = c - 1; ec <= c + 1; ++ec) {
+      if (ec < 0 || ec >= cols) continue;
+      bool any = false;
+      for (int dr = er - 2; dr <= er + 2 && !any; ++dr) {
+        if (dr < 0 || dr >= rows) continue;
+        for (int dc = ec - 1; dc <= ec + 1; ++dc) {
+          if (dc < 0 || dc >= cols) continue;
+          if (occ(dr, dc)) {
+            any = true;
+            break;
+          }
+        }
+      }
+      if (!any) return false;
+    }
+  }
+  return true;
+}
+
+// closing.py:44-57: sum of ORIGINAL depths of occupied neighbours, drow outer, dcolumn inner,
+// divided by the neighbour count.  Returns false when there is no occupied neighbour.
+template <class Grid>
+__device__ __forceinline__ bool hole_mean(const Grid &g, int r, int c, int rows, int cols, double &out) {
+  double sum = 0.0;
+  int cnt = 0;
+  for (int dr = -2; dr <= 2; ++dr) {
+    int rr = r + dr;
+    if (rr < 0 || rr >= rows) continue;
+    for (int dc = -1; dc <= 1; ++dc) {
+      int cc = c + dc;
+      if (cc < 0 || cc >= cols) continue;
+      unsigned long long k = g(rr, cc);
+      if (k != R3D_SENT) {
+        ++cnt;
+        sum += key_depth(k);
+      }
+    }
+  }
+  if (cnt == 0) return false;
+  out = sum / (double)cnt;
+  return true;
+}
+
+// Smoothed depth (closing.py:26-62) of one pixel of a u64 image, evaluated on demand.
+template <class Grid>
+__device__ __forceinline__ double smoothed_depth(const Grid &g, int r, int c, int rows, int cols) {
+  unsigned long long k = g(r, c);
+  if (k != R3D_SENT) return key_depth(k);
+  auto occ = [&](int rr, int cc) { return g(rr, cc) != R3D_SENT; };
+  if (!closed_at(occ, r, c, rows, cols)) return R3D_EMPTY_DEPTH;
+  double m;
+  return hole_mean(g, r, c, rows, cols, m) ? m : R3D_EMPTY_DEPTH;
+}
+
+}  // namespace r3d

@@ -1,0 +1,66 @@
+"""The C-ABI library loads and exports every symbol include/real3daug_hip.h declares (not gpu)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "real3daug_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(r3d_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(pkg):
+    names = _declared()
+    assert len(names) >= 17
+    assert sorted(pkg._lib.EXPORTS) == names
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg._lib.load()
+    for name in _declared():
+        assert hasattr(lib, name), name
+    assert lib.r3d_version() == 0x00010000
+    assert isinstance(lib.r3d_last_error(), bytes)
+
+
+def test_batch_descriptor_matches_header(pkg):
+    text = open(os.path.join(ROOT, "include", "real3daug_hip.h")).read()
+    body = re.search(r"typedef struct r3d_batch \{(.*?)\} r3d_batch_t;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.replace("*", " ").split()
+        first = names.index(next(n for n in names if n not in
+                                 ("int32_t", "int64_t", "uint32_t", "uint16_t", "uint64_t", "float", "double",
+                                  "void", "size_t")))
+        fields += [n.strip(",") for n in names[first:]]
+    assert [f for f, _ in pkg._lib.BatchDesc._fields_] == fields
+    assert ctypes.sizeof(pkg._lib.BatchDesc) == 4 * 4 + 2 * 8 + 22 * 8 + 2 * 8
+
+
+def test_bad_arguments_are_reported_without_a_gpu(pkg):
+    lib = pkg._lib.load()
+    assert lib.r3d_add_space_for_spherical(None, -1, None, None) == -1
+    assert b"add_space" in lib.r3d_last_error()
+    assert lib.r3d_fill_spherical(None, 0, None, None, None) == -1
+    assert lib.r3d_front_view_workspace_bytes(112, 1440) >= 112 * 1440 * 8
+    assert lib.r3d_batch_workspace_bytes(None) == 0
+
+
+def test_no_cpu_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import numpy as np
+    with pytest.raises(pkg.R3DError):
+        pkg.Real3DAug.insertion.add_space_for_spherical(np.zeros((4, 5)))
+    with pytest.raises(pkg.R3DError):
+        pkg.SceneBatch(1, 16, 16)

