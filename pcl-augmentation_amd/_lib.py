@@ -82,6 +82,11 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
                 "(or `python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7; importing torch
+        # first makes the loader bind this library's NEEDED libamdhip64.so.7 to that same copy, so
+        # tensors, streams and our kernels share one runtime (loaded the other way round, two
+        # runtimes coexist and ours reports "no ROCm-capable device").
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
