@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark: augmented scenes/s on BASELINE.json config C2 -- a batch of 256 synthetic
+64-beam ~120k-point scenes, 5 inserts each -- with inputs resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" is one pass of the hot path over one batch: r3d_batch_begin (elevation bounds,
+spherical projection + range-image min-reduce), five r3d_batch_insert calls (sample projection,
+closing / hole fill on the candidate pixels, visibility mask, cull, append) and r3d_batch_finish
+(compaction into the velodyne/.bin + labels/.label + check/.bin byte layout).  With N > 1 the
+driver starts one process per GPU (torchrun); every rank runs its own batch of 256 scenes (weak
+scaling, scenes are independent, no collective on the data path), the timed region is bracketed
+by a barrier + synchronize and the maximum over ranks is reported.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, measured with HIP events on
+the launch stream after the timed region; `cpu_baseline` is the NumPy oracle (a port of the
+reference's algorithm, single core) timed on a bounded sample of the same workload.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+B_SCENES = 256
+KINDS = ["pedestrian", "cyclist", "car", "pedestrian", "cyclist"]      # config C2
+MIN_POINTS = 20
+
+
+def build_inputs(pkg, rank, B):
+    synth = pkg.synth
+    scenes = [synth.make_scene(1000 * rank + s) for s in range(B)]
+    inserts = [synth.make_inserts(1000 * rank + s, KINDS) for s in range(B)]
+    return scenes, inserts
+
+
+def event_time_ms(torch, fn, reps=5):
+    """Average duration of fn() in ms, HIP events on the current (launch) stream."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def cpu_baseline(pkg, budget_s=20.0, max_scenes=16):
+    """The oracle's literal K-insert chain on scenes of the same workload, one core.  The synthetic
+    generator is outside the timed region."""
+    from oracle import real3d_oracle as O
+    synth = pkg.synth
+    done, spent = 0, 0.0
+    while done < max_scenes:
+        xyzi, label = synth.make_scene(5000 + done)
+        ins = synth.make_inserts(5000 + done, KINDS)
+        s5 = synth.scene5_from_packed(xyzi, label)
+        t1 = time.perf_counter()
+        O.augment_scene(s5, [[x] for x in ins], [MIN_POINTS] * len(ins))
+        per = time.perf_counter() - t1
+        spent += per
+        done += 1
+        if spent + per > budget_s:
+            break
+    return done, spent
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scenes", type=int, default=B_SCENES, help="scenes per GPU batch (256 = config C2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torchrun with WORLD_SIZE={args.gpus} (got {world})")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    pkg = importlib.import_module("pcl-augmentation_amd")
+    B = args.scenes
+    scenes, inserts = build_inputs(pkg, rank, B)
+    n_max = max(len(x) for x, _ in scenes)
+    grow = sum(max(len(inserts[s][k]) for s in range(B)) for k in range(len(KINDS)))
+    batch = pkg.SceneBatch(B, n_max + grow, grow, device=f"cuda:{local_rank}")
+    batch.load(scenes)                                    # inputs resident in HBM from here on
+    packed = [batch.pack_samples([inserts[s][k] for s in range(B)]) for k in range(len(KINDS))]
+    need = torch.full((B,), MIN_POINTS, dtype=torch.int32, device=batch.device)
+    n_pts = float(sum(len(x) for x, _ in scenes))
+    m_pts = float(sum(len(i) for ins in inserts for i in ins))
+
+    def one_step():
+        batch.begin()
+        for s5, off in packed:
+            batch.insert_device(s5, off, need)
+        batch.finish(check_cols=0)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=batch.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    batch.raise_on_status()
+    n_out = batch.n_out.cpu().numpy()
+    accepted_all = bool(batch.accepted.cpu().numpy().all())
+
+    if rank == 0:
+        import ctypes as C
+        lib, desc = batch.lib, batch.desc
+        st = pkg._lib.stream_ptr
+        # per-kernel timing after the timed region (state: a finished batch; begin() resets it)
+        batch.begin()
+        t_bounds = event_time_ms(torch, lambda: lib.r3d_batch_elev_bounds(C.byref(desc), st()))
+        t_project = event_time_ms(torch, lambda: lib.r3d_batch_project(C.byref(desc), st()))
+        t_begin = event_time_ms(torch, batch.begin)
+        t_insert = []
+        batch.begin()
+        for s5, off in packed:                      # each insert once, in order (they mutate state)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            batch.insert_device(s5, off, need)
+            e1.record()
+            torch.cuda.synchronize()
+            t_insert.append(e0.elapsed_time(e1))
+        t_finish = event_time_ms(torch, lambda: batch.finish(check_cols=0))
+        n_out_pts = float(batch.n_out.sum().item())
+        # algorithmic bytes per launch: project reads xyzi once; finish reads
+        # xyzi + label and writes the survivors; insert reads the sample rows twice.
+        kernels = {
+            "elev_bounds": {"ms": t_bounds, "alg_bytes": 16.0 * n_pts},
+            "project": {"ms": t_project, "alg_bytes": 16.0 * n_pts},
+            "insert_x5": {"ms": float(sum(t_insert)), "alg_bytes": 40.0 * m_pts * 2},
+            "finish_compact": {"ms": t_finish, "alg_bytes": 20.0 * n_pts + 20.0 * n_out_pts},
+        }
+        for k in kernels.values():
+            k["GBps"] = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9
+        dominant = max(("elev_bounds", "project", "finish_compact", "insert_x5"), key=lambda k: kernels[k]["ms"])
+        dk = kernels[dominant]
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(dk["GBps"], 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(dk["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "alg_bytes_per_launch": dk["alg_bytes"], "ms_per_launch": round(dk["ms"], 4),
+                    "all_kernels": {k: {"ms": round(v["ms"], 4), "GBps": round(v["GBps"], 1)} for k, v in kernels.items()},
+                    "begin_ms": round(t_begin, 4)}
+        scenes_per_s = B * world * args.steps / elapsed
+        # whole-step algorithmic bytes actually needed by this pipeline (conservative rule of
+        # passes that are not made are not claimed)
+        step_bytes = 16.0 * n_pts * 2 + 20.0 * n_pts + 20.0 * n_out_pts + 80.0 * m_pts
+        out = {
+            "metric": "augmented scenes/sec (120k-pt, 64-beam)", "value": round(scenes_per_s, 1),
+            "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: batch of 256 synthetic 64-beam 120k-pt scenes, 5 inserts each "
+                                   "(2 pedestrians, 2 cyclists, 1 car), per GPU",
+                       "scenes_per_gpu": B, "points_per_scene": int(n_pts / B), "inserts_per_scene": len(KINDS),
+                       "range_image": [batch.rows, batch.cols], "all_inserts_accepted": accepted_all,
+                       "mean_points_out": float(n_out.mean())},
+            "roofline": roofline,
+            "pipeline_alg_GBps_per_gpu": round(step_bytes * args.steps / elapsed / 1e9, 1),
+        }
+        if not args.no_cpu_baseline:
+            done, secs = cpu_baseline(pkg)
+            out["cpu_baseline"] = {"value": round(done / secs, 3), "unit": "scenes/s", "cores": 1, "kind": "port",
+                                   "sample": f"{done} scenes of the same workload (120k points, 5 inserts) through "
+                                             "oracle.augment_scene (NumPy port of the reference), one core"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
