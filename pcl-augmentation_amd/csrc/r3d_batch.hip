@@ -33,6 +33,7 @@ struct BatchWs {
   int32_t *all_count;           // [1] = B
   int32_t *rebase_list;         // [B]
   int32_t *n_rebase;            // [1]
+  int32_t *rebase_ticket;       // [1]
   size_t total;
 };
 
@@ -54,6 +55,7 @@ static BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.all_count = c.take<int32_t>(1);
   w.rebase_list = c.take<int32_t>((size_t)b.B);
   w.n_rebase = c.take<int32_t>(1);
+  w.rebase_ticket = c.take<int32_t>(1);
   w.total = c.off;
   return w;
 }
@@ -92,6 +94,7 @@ __global__ void k_begin_init(r3d_batch_t b, const int32_t *n_points, BatchWs w) 
   if (s == 0) {
     *w.all_count = b.B;
     *w.n_rebase = 0;
+    *w.rebase_ticket = 0;
   }
   if (s >= b.B) return;
   int n = n_points[s];
@@ -253,31 +256,70 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count) {
 }
 
 // ---- one insert candidate per scene ------------------------------------------------------------
-struct BitMask {
+// Row-aligned bit images (cols % 32 == 0, wpr = cols / 32 words per row) live in LDS; dilation and
+// erosion with the 5-row x 3-column element of closing.py:20 are word-parallel shifts and ORs/ANDs,
+// windows clipped at the image border exactly like the reference's (no azimuth wrap).
+struct BitImage {
   uint32_t *w;
+  int wpr, rows;
   __device__ __forceinline__ bool get(int p) const { return (w[p >> 5] >> (p & 31)) & 1u; }
-  __device__ __forceinline__ bool test_and_set(int p) {
-    uint32_t bit = 1u << (p & 31);
-    return atomicOr(&w[p >> 5], bit) & bit;
-  }
+  __device__ __forceinline__ void set(int p) { atomicOr(&w[p >> 5], 1u << (p & 31)); }
+  __device__ __forceinline__ uint32_t word(int r, int j) const { return w[r * wpr + j]; }
 };
 
-// Marks the 5 x 3 neighbourhood of pixel p as candidates (closing is a subset of dilation, so a
-// pixel outside every such neighbourhood has sample depth 500 and cannot become visible unless
-// the scene is deeper than 500 m there -- the far list covers that).
-__device__ __forceinline__ void mark_candidates(int p, int rows, int cols, BitMask seen, uint32_t *list,
-                                                int *n_list) {
-  int r = p / cols, c = p - r * cols;
-  for (int dr = -2; dr <= 2; ++dr) {
+// OR of a word with its two horizontal neighbours' bits (columns c-1, c, c+1), clipped at the row ends.
+__device__ __forceinline__ uint32_t hor3(const BitImage &m, int r, int j) {
+  uint32_t c = m.word(r, j);
+  uint32_t l = j > 0 ? m.word(r, j - 1) : 0u;
+  uint32_t rr = j < m.wpr - 1 ? m.word(r, j + 1) : 0u;
+  return c | (c << 1) | (l >> 31) | (c >> 1) | (rr << 31);
+}
+// AND of the same three columns; a neighbour outside the image does not constrain (erosion border).
+__device__ __forceinline__ uint32_t hand3(const BitImage &m, int r, int j) {
+  uint32_t c = m.word(r, j);
+  uint32_t l = j > 0 ? (m.word(r, j - 1) >> 31) : 1u;
+  uint32_t rr = j < m.wpr - 1 ? (m.word(r, j + 1) << 31) : 0x80000000u;
+  return c & ((c << 1) | l) & ((c >> 1) | rr);
+}
+
+// dst = dilate(src) on rows [r0, r1], words [j0, j1]; then (ERODE) dst = erode(src) likewise.
+template <bool ERODE>
+__device__ __forceinline__ void morph_rows(const BitImage &src, BitImage &dst, int r0, int r1, int j0, int j1,
+                                           int tid, int nthreads) {
+  int nj = j1 - j0 + 1, total = (r1 - r0 + 1) * nj;
+  for (int e = tid; e < total; e += nthreads) {
+    int r = r0 + e / nj, j = j0 + e % nj;
+    uint32_t acc = ERODE ? 0xFFFFFFFFu : 0u;
+    for (int dr = -2; dr <= 2; ++dr) {
+      int rr = r + dr;
+      if (rr < 0 || rr >= src.rows) continue;
+      if (ERODE) acc &= hand3(src, rr, j);
+      else acc |= hor3(src, rr, j);
+    }
+    dst.w[r * dst.wpr + j] = acc;
+  }
+}
+
+// closing.py:44-57 with the occupancy known from a bit image: the up-to-15 loads are independent.
+template <class Load>
+__device__ __forceinline__ double mean_of_occupied(const BitImage &occ, const Load &load, int r, int c,
+                                                   int rows, int cols) {
+  double sum = 0.0;
+  int cnt = 0;
+  for (int dr = -2; dr <= 2; ++dr) {                   // drow outer (closing.py:46)
     int rr = r + dr;
     if (rr < 0 || rr >= rows) continue;
-    for (int dc = -1; dc <= 1; ++dc) {
+    for (int dc = -1; dc <= 1; ++dc) {                 // dcolumn inner (closing.py:47)
       int cc = c + dc;
       if (cc < 0 || cc >= cols) continue;
       int q = rr * cols + cc;
-      if (!seen.test_and_set(q)) list[atomicAdd(n_list, 1)] = (uint32_t)q;
+      if (occ.get(q)) {
+        ++cnt;
+        sum += key_depth(load(q));
+      }
     }
   }
+  return cnt ? sum / (double)cnt : R3D_EMPTY_DEPTH;
 }
 
 __global__ void __launch_bounds__(kST)
@@ -287,16 +329,21 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   extern __shared__ __align__(16) unsigned char smem[];
   const int s = blockIdx.x;
   const int tid = threadIdx.x;
-  const int npix = b.rows * b.cols;
-  const int words = (npix + 31) / 32;
-  uint32_t *s_keys = reinterpret_cast<uint32_t *>(smem);          // [kKeyCap]
-  uint32_t *s_seen = s_keys + kKeyCap;                            // [words] candidate seen
-  uint32_t *s_vis = s_seen + words;                               // [words] visible pixels
-  uint32_t *s_occ = s_vis + words;                                // [words] sample occupancy
-  uint32_t *s_oob = s_occ + words;                                // [kKeyCap/32] el outside bounds
-  int *s_misc = reinterpret_cast<int *>(s_oob + kKeyCap / 32);    // counters + scan scratch
+  const int rows = b.rows, cols = b.cols;
+  const int npix = rows * cols;
+  const int words = npix >> 5, wpr = cols >> 5;
+  uint32_t *s_keys = reinterpret_cast<uint32_t *>(smem);          // [kKeyCap] sorted (pixel, index)
+  uint32_t *s_img = s_keys + kKeyCap;                             // 5 bit images of `words` words
+  uint32_t *s_oob = s_img + 5 * words;                            // [kKeyCap/32] el outside bounds
+  int *s_misc = reinterpret_cast<int *>(s_oob + kKeyCap / 32);
   int *s_nvalid = s_misc + 0, *s_ncand = s_misc + 1, *s_rebase = s_misc + 2, *s_flags = s_misc + 3;
-  int *s_scan = s_misc + 4;                                       // [kST/64 + 1]
+  int *s_rmin = s_misc + 4, *s_rmax = s_misc + 5, *s_cmin = s_misc + 6, *s_cmax = s_misc + 7;
+  int *s_scan = s_misc + 8;                                       // [kST/64 + 1]
+  BitImage A{s_img, wpr, rows};                // sample occupancy
+  BitImage T{s_img + words, wpr, rows};        // scratch: dilations, candidate mask, then visible pixels
+  BitImage Cs{s_img + 2 * words, wpr, rows};   // sample closed
+  BitImage D{s_img + 3 * words, wpr, rows};    // scene occupancy (window only)
+  BitImage E{s_img + 4 * words, wpr, rows};    // scene closed (window only)
 
   const int64_t off = sample_off[s];
   const int64_t m64 = sample_off[s + 1] - off;
@@ -313,38 +360,67 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   int pw = 64;
   while (pw < m) pw <<= 1;
 
-  for (int i = tid; i < 3 * words + kKeyCap / 32; i += kST) s_seen[i] = 0u;   // seen, vis, occ, oob
-  if (tid < 4) s_misc[tid] = 0;
+  for (int i = tid; i < 5 * words + kKeyCap / 32; i += kST) s_img[i] = 0u;
+  if (tid < 8) s_misc[tid] = (tid == 4 || tid == 6) ? 0x7FFFFFFF : (tid == 5 || tid == 7) ? -1 : 0;
   __syncthreads();
 
-  const Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
+  const Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], rows, cols);
   unsigned long long *grid = (unsigned long long *)b.grid + (int64_t)s * npix;
   unsigned long long *sgrid = (unsigned long long *)b.sgrid + (int64_t)s * npix;
   const double *rows5 = samples5 + off * 5;
+  auto ld_scene = [&](int q) { return grid[q]; };
+  auto ld_sample = [&](int q) {
+    return __hip_atomic_load(&sgrid[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
 
   // -- 1. project the sample with the scene's bounds, sample=True (insertion.py:455-459) ---------
-  for (int j = tid; j < pw; j += kST) {
-    uint32_t key = 0xFFFFFFFFu;
-    if (j < m) {
-      const double *q = rows5 + (int64_t)j * 5;
-      Sph sp = spherical(q[0], q[1], q[2]);
-      int row, col;
-      int ok = bin_point(bn, sp.az, sp.el, row, col);
-      if (!isfinite(sp.el) || !isfinite(sp.az)) {
-        atomicOr(s_flags, R3D_S_NONFINITE);
-      } else if (ok & 1) {                           // rows outside [0, rows) are skipped (:107-108)
-        if (!(ok & 2)) {
-          atomicOr(s_flags, R3D_S_COL_RANGE);        // assert :112
-        } else {
-          int p = row * b.cols + col;
-          key = ((uint32_t)p << kIdxBits) | (uint32_t)j;
-          atomicMin(&sgrid[p], depth_key(sp.r));
-          atomicAdd(s_nvalid, 1);
-          if (sp.el < bn.min_el || sp.el > bn.max_el) atomicOr(&s_oob[j >> 5], 1u << (j & 31));
+  {
+    int rmin = 0x7FFFFFFF, rmax = -1, cmin = 0x7FFFFFFF, cmax = -1, nval = 0, flags = 0;
+    for (int j = tid; j < pw; j += kST) {
+      uint32_t key = 0xFFFFFFFFu;
+      if (j < m) {
+        const double *q = rows5 + (int64_t)j * 5;
+        Sph sp = spherical(q[0], q[1], q[2]);
+        int row, col;
+        int ok = bin_point(bn, sp.az, sp.el, row, col);
+        if (!isfinite(sp.el) || !isfinite(sp.az)) {
+          flags |= R3D_S_NONFINITE;
+        } else if (ok & 1) {                         // rows outside [0, rows) are skipped (:107-108)
+          if (!(ok & 2)) {
+            flags |= R3D_S_COL_RANGE;                // assert :112
+          } else {
+            int p = row * cols + col;
+            key = ((uint32_t)p << kIdxBits) | (uint32_t)j;
+            atomicMin(&sgrid[p], depth_key(sp.r));
+            ++nval;
+            rmin = row < rmin ? row : rmin;
+            rmax = row > rmax ? row : rmax;
+            cmin = col < cmin ? col : cmin;
+            cmax = col > cmax ? col : cmax;
+            if (sp.el < bn.min_el || sp.el > bn.max_el) atomicOr(&s_oob[j >> 5], 1u << (j & 31));
+          }
         }
       }
+      s_keys[j] = key;
     }
-    s_keys[j] = key;
+    nval = wave_sum_i32(nval);
+    flags = wave_or_i32(flags);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      int t;
+      t = __shfl_xor(rmin, o, 64); rmin = t < rmin ? t : rmin;
+      t = __shfl_xor(rmax, o, 64); rmax = t > rmax ? t : rmax;
+      t = __shfl_xor(cmin, o, 64); cmin = t < cmin ? t : cmin;
+      t = __shfl_xor(cmax, o, 64); cmax = t > cmax ? t : cmax;
+    }
+    if ((tid & 63) == 0) {
+      atomicAdd(s_nvalid, nval);
+      if (flags) atomicOr(s_flags, flags);
+      atomicMin(s_rmin, rmin);
+      atomicMax(s_rmax, rmax);
+      atomicMin(s_cmin, cmin);
+      atomicMax(s_cmax, cmax);
+    }
   }
   __syncthreads();
 
@@ -366,48 +442,102 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
     }
   }
   const int nvalid = *s_nvalid;
+  const int n_far = b.n_far[s] < R3D_FAR_CAP ? b.n_far[s] : R3D_FAR_CAP;
 
-  // -- 3. occupied sample pixels and the candidate pixel list -----------------------------------
-  BitMask seen{s_seen}, vis{s_vis}, occ{s_occ};
-  uint32_t *cand = w.cand + (int64_t)s * npix;
+  // -- 3. bit images: sample occupancy, scene occupancy in the window around the sample ----------
+  // candidates lie within 2 rows / 1 column of a sample pixel; their closing looks 4 rows / 2
+  // columns further.  Pixels deeper than 500 m (far list) can be visible anywhere: whole image.
+  int r_lo = 0, r_hi = rows - 1, c_lo = 0, c_hi = cols - 1;
+  if (n_far == 0 && nvalid > 0) {
+    r_lo = *s_rmin - 6 < 0 ? 0 : *s_rmin - 6;
+    r_hi = *s_rmax + 6 > rows - 1 ? rows - 1 : *s_rmax + 6;
+    c_lo = *s_cmin - 3 < 0 ? 0 : *s_cmin - 3;
+    c_hi = *s_cmax + 3 > cols - 1 ? cols - 1 : *s_cmax + 3;
+  }
   for (int k = tid; k < nvalid; k += kST) {
     int p = (int)(s_keys[k] >> kIdxBits);
-    if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != p) {
-      atomicOr(&s_occ[p >> 5], 1u << (p & 31));
-      mark_candidates(p, b.rows, b.cols, seen, cand, s_ncand);
+    if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != p) A.set(p);
+  }
+  if (nvalid > 0 || n_far > 0) {
+    int wc = c_hi - c_lo + 1, total = (r_hi - r_lo + 1) * wc;
+    for (int e = tid; e < total; e += kST) {
+      int q = (r_lo + e / wc) * cols + c_lo + e % wc;
+      if (grid[q] != R3D_SENT) D.set(q);
     }
   }
+  __syncthreads();
+
+  // -- 4. closing of both occupancies (closing.py:9-23) by word-parallel dilate / erode ----------
+  const int j_lo = c_lo >> 5, j_hi = c_hi >> 5;
+  const int dr_lo = r_lo, dr_hi = r_hi;                     // dilation rows (clipped window)
+  morph_rows<false>(A, T, dr_lo, dr_hi, j_lo, j_hi, tid, kST);
+  __syncthreads();
+  morph_rows<true>(T, Cs, dr_lo, dr_hi, j_lo, j_hi, tid, kST);
+  __syncthreads();
+  morph_rows<false>(D, T, dr_lo, dr_hi, j_lo, j_hi, tid, kST);
+  __syncthreads();
+  morph_rows<true>(T, E, dr_lo, dr_hi, j_lo, j_hi, tid, kST);
+  __syncthreads();
+  // Rows at the clipped window edge used fewer dilation rows than the image has: only rows at
+  // least 2 inside the window (or at the image border) are exact, and candidates lie there.
+
+  // -- 5. candidate pixels: where the sample is closed, plus the far neighbourhoods --------------
   {
-    int nf = b.n_far[s];
-    nf = nf < R3D_FAR_CAP ? nf : R3D_FAR_CAP;
-    for (int f = tid; f < nf; f += kST)
-      mark_candidates(b.far_pix[(int64_t)s * R3D_FAR_CAP + f], b.rows, b.cols, seen, cand, s_ncand);
+    int nj = j_hi - j_lo + 1, total = (r_hi - r_lo + 1) * nj;
+    for (int e = tid; e < total; e += kST) {
+      int idx = (r_lo + e / nj) * wpr + j_lo + e % nj;
+      T.w[idx] = Cs.w[idx];
+    }
+  }
+  __syncthreads();
+  for (int f = tid; f < n_far; f += kST) {
+    int p = b.far_pix[(int64_t)s * R3D_FAR_CAP + f];
+    int r = p / cols, c = p - r * cols;
+    for (int dr = -2; dr <= 2; ++dr)
+      for (int dc = -1; dc <= 1; ++dc) {
+        int rr = r + dr, cc = c + dc;
+        if (rr >= 0 && rr < rows && cc >= 0 && cc < cols) T.set(rr * cols + cc);
+      }
+  }
+  __syncthreads();
+  uint32_t *cand = w.cand + (int64_t)s * npix;
+  {
+    int nj = j_hi - j_lo + 1, total = (r_hi - r_lo + 1) * nj;
+    for (int e = tid; e < total; e += kST) {
+      int r = r_lo + e / nj, j = j_lo + e % nj;
+      uint32_t bits = T.w[r * wpr + j];
+      if (!bits) continue;
+      int pos = atomicAdd(s_ncand, __popc(bits));
+      while (bits) {
+        int bit = __ffs(bits) - 1;
+        bits &= bits - 1;
+        cand[pos++] = (uint32_t)(r * cols + (j << 5) + bit);
+      }
+    }
   }
   __syncthreads();
   const int ncand = *s_ncand;
+  {
+    int nj = j_hi - j_lo + 1, total = (r_hi - r_lo + 1) * nj;
+    for (int e = tid; e < total; e += kST) T.w[(r_lo + e / nj) * wpr + j_lo + e % nj] = 0u;
+  }
+  __syncthreads();
+  BitImage &vis = T;
 
-  // -- 4. visibility on the candidates: smoothed sample depth < smoothed scene depth (:461-467) --
-  auto g_scene = [&](int r, int c) { return grid[r * b.cols + c]; };
-  auto g_sample = [&](int r, int c) {
-    return __hip_atomic_load(&sgrid[r * b.cols + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  auto o_sample = [&](int r, int c) { return occ.get(r * b.cols + c); };
+  // -- 6. visibility on the candidates: smoothed sample depth < smoothed scene depth (:461-467) --
   for (int ci = tid; ci < ncand; ci += kST) {
     int q = (int)cand[ci];
-    int r = q / b.cols, c = q - r * b.cols;
-    double sd = R3D_EMPTY_DEPTH;
-    if (occ.get(q)) {
-      sd = key_depth(g_sample(r, c));
-    } else if (closed_at(o_sample, r, c, b.rows, b.cols)) {
-      double mval;
-      if (hole_mean(g_sample, r, c, b.rows, b.cols, mval)) sd = mval;
-    }
-    double cd = smoothed_depth(g_scene, r, c, b.rows, b.cols);
-    if (sd < cd) atomicOr(&s_vis[q >> 5], 1u << (q & 31));
+    int r = q / cols, c = q - r * cols;
+    double sd = R3D_EMPTY_DEPTH, cd = R3D_EMPTY_DEPTH;
+    if (A.get(q)) sd = key_depth(ld_sample(q));
+    else if (Cs.get(q)) sd = mean_of_occupied(A, ld_sample, r, c, rows, cols);
+    if (D.get(q)) cd = key_depth(ld_scene(q));
+    else if (E.get(q)) cd = mean_of_occupied(D, ld_scene, r, c, rows, cols);
+    if (sd < cd) vis.set(q);
   }
   __syncthreads();
 
-  // -- 5. count the visible sample points, accept test (insertion.py:511-517) --------------------
+  // -- 7. count the visible sample points, accept test (insertion.py:511-517) --------------------
   int mine = 0;
   for (int k = tid; k < nvalid; k += kST) mine += vis.get((int)(s_keys[k] >> kIdxBits)) ? 1 : 0;
   int nvis;
@@ -420,7 +550,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
     if (tid == 0) atomicOr(&b.status[s], R3D_S_CAPACITY);
   }
 
-  // -- 6. commit: append (insertion.py:526), patch the range image, stamp ------------------------
+  // -- 8. commit: append (insertion.py:526), patch the range image, stamp ------------------------
   if (accept) {
     int base = 0;
     for (int k0 = 0; k0 < nvalid; k0 += kST) {
@@ -460,9 +590,9 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
     for (int ci = tid; ci < ncand; ci += kST) {
       int q = (int)cand[ci];
       if (!vis.get(q)) continue;
-      int r = q / b.cols;
-      if (grid[q] != R3D_SENT && (r == 0 || r == row_of_max)) *s_rebase = 1;   // an extreme may be culled
-      unsigned long long nv = occ.get(q) ? g_sample(r, q - r * b.cols) : R3D_SENT;
+      int r = q / cols;
+      if (D.get(q) && (r == 0 || r == row_of_max)) *s_rebase = 1;   // an extreme point may be culled
+      unsigned long long nv = A.get(q) ? ld_sample(q) : R3D_SENT;
       grid[q] = nv;
       if (nv != R3D_SENT && key_depth(nv) > R3D_EMPTY_DEPTH) {
         int f = atomicAdd(&b.n_far[s], 1);
@@ -475,7 +605,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   }
   __syncthreads();
 
-  // -- 7. leave the sample scratch image clean, publish -----------------------------------------
+  // -- 9. leave the sample scratch image clean, publish -----------------------------------------
   for (int k = tid; k < nvalid; k += kST) {
     int p = (int)(s_keys[k] >> kIdxBits);
     if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != p) sgrid[p] = R3D_SENT;
@@ -603,37 +733,144 @@ k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
   }
 }
 
-__global__ void __launch_bounds__(kPT)
-k_rebase_copyback(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
-  int cnt = *count;
-  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
-    int s = list[li];
-    int n = b.n_out[s], nh = w.new_head[s];
-    const float4 *src = reinterpret_cast<const float4 *>(b.out_xyzi) + (int64_t)s * b.cap;
-    float4 *dst = reinterpret_cast<float4 *>(b.xyzi) + (int64_t)s * b.cap;
-    for (int i = blockIdx.x * kPT + threadIdx.x; i < n; i += gridDim.x * kPT) {
-      dst[i] = src[i];
-      b.label[(int64_t)s * b.cap + i] = b.out_label[(int64_t)s * b.cap + i];
-      if (i >= nh)
-        b.tail_ref[(int64_t)s * b.log_cap + (i - nh)] = w.tail_tmp[(int64_t)s * b.log_cap + (i - nh)];
+// ---- rebase: one workgroup re-bases one flagged scene (rare path) --------------------------------
+// Triggered when an accepted insert may have moved the elevation bounds (k_insert, step 8).  Does,
+// for that scene only, what the reference does for every insert (insertion.py:373-375): drop the
+// culled points, recompute the bounds, re-project every point.  All phases run inside one block so
+// the idle case costs one empty launch; phases are separated by a device-scope fence + barrier
+// because later phases re-read what earlier ones wrote.
+constexpr int kRB = 1024;
+
+__device__ __forceinline__ void phase_sync() {
+  __threadfence();
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(kRB)
+k_rebase(r3d_batch_t b, BatchWs w) {
+  __shared__ int sm[kRB / 64 + 1];
+  __shared__ unsigned long long s_min[kRB / 64], s_max[kRB / 64];
+  const int tid = threadIdx.x;
+  const int npix = b.rows * b.cols, words = (npix + 31) / 32;
+  const int cnt = *w.n_rebase;
+  for (int li = blockIdx.x; li < cnt; li += gridDim.x) {
+    const int s = w.rebase_list[li];
+    const int n = b.n_total[s], n_head = b.n_head[s];
+    float4 *xyzi = reinterpret_cast<float4 *>(b.xyzi) + (int64_t)s * b.cap;
+    uint32_t *label = b.label + (int64_t)s * b.cap;
+    int32_t *tref = b.tail_ref + (int64_t)s * b.log_cap;
+    // (a) alive head points: the new n_head
+    int mine = 0;
+    for (int i = tid; i < n_head; i += kRB) mine += point_alive(b, s, i, n_head, npix, words) ? 1 : 0;
+    int new_head;
+    (void)block_escan_i32(mine, sm, new_head);
+    // (b) in-place stable compaction, tile by tile (write index <= read index)
+    int base = 0;
+    for (int t0 = 0; t0 < n; t0 += kRB) {
+      int i = t0 + tid;
+      int flag = (i < n && point_alive(b, s, i, n_head, npix, words)) ? 1 : 0;
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint32_t lab = 0;
+      int tr = 0;
+      if (flag) {
+        p = xyzi[i];
+        lab = label[i];
+        if (i >= n_head) tr = tref[i - n_head];
+      }
+      int tot;
+      int ex = block_escan_i32(flag, sm, tot);      // barriers: every read of the tile is done
+      if (flag) {
+        int o = base + ex;
+        xyzi[o] = p;
+        label[o] = lab;
+        if (i >= n_head) tref[o - new_head] = tr;
+      }
+      base += tot;
+      phase_sync();
+    }
+    const int n_new = base;
+    if (tid == 0) {
+      b.n_head[s] = new_head;
+      b.n_total[s] = n_new;
+    }
+    phase_sync();
+    // (c) bounds (insertion.py:78-79) via the extreme z/r
+    unsigned long long lmin = ~0ull, lmax = 0ull;
+    int bad = 0;
+    for (int i = tid; i < n_new; i += kRB) {
+      double x, y, z;
+      load_point(b, s, i, new_head, x, y, z);
+      double q = z / sqrt(x * x + y * y + z * z);
+      if (!(q >= -1.0 && q <= 1.0)) bad = 1;
+      else {
+        unsigned long long kq = ordered_key(q);
+        lmin = kq < lmin ? kq : lmin;
+        lmax = kq > lmax ? kq : lmax;
+      }
+    }
+    lmin = wave_min_u64(lmin);
+    lmax = wave_max_u64(lmax);
+    if ((tid & 63) == 0) {
+      s_min[tid >> 6] = lmin;
+      s_max[tid >> 6] = lmax;
+    }
+    if (bad) atomicOr(&b.status[s], R3D_S_NONFINITE);
+    __syncthreads();
+    if (tid == 0) {
+      for (int v = 1; v < kRB / 64; ++v) {
+        lmin = s_min[v] < lmin ? s_min[v] : lmin;
+        lmax = s_max[v] > lmax ? s_max[v] : lmax;
+      }
+      double max_el = acos(ordered_key_inv(lmin)), min_el = acos(ordered_key_inv(lmax));
+      b.bounds[2 * s + 0] = max_el;
+      b.bounds[2 * s + 1] = min_el;
+      double t = trunc((max_el - min_el - 0.00001) / ((max_el - min_el) / (double)b.rows));
+      b.row_of_max[s] = (t >= 0.0 && t < (double)b.rows) ? (int)t : 0;
+      b.n_far[s] = 0;
+      b.rebase[s] = 0;
+    }
+    // (d) reset the images
+    unsigned long long *g = (unsigned long long *)b.grid + (int64_t)s * npix;
+    for (int p = tid; p < npix; p += kRB) {
+      g[p] = R3D_SENT;
+      b.stamp[(int64_t)s * npix + p] = 0;
+      if (p < words) b.ever[(int64_t)s * words + p] = 0u;
+    }
+    phase_sync();
+    // (e) re-project (insertion.py:74-76, :104-127)
+    Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
+    int flags = 0;
+    for (int i = tid; i < n_new; i += kRB) {
+      double x, y, z;
+      load_point(b, s, i, new_head, x, y, z);
+      Sph sp = spherical(x, y, z);
+      int row, col, p = 0;
+      int ok = bin_point(bn, sp.az, sp.el, row, col);
+      if (!(ok & 1)) flags |= isfinite(sp.el) ? R3D_S_ROW_RANGE : R3D_S_NONFINITE;
+      else if (!(ok & 2)) flags |= R3D_S_COL_RANGE;
+      else {
+        p = row * b.cols + col;
+        atomicMin(&g[p], depth_key(sp.r));
+        if (sp.r > R3D_EMPTY_DEPTH) {
+          int f = atomicAdd(&b.n_far[s], 1);
+          if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
+          else flags |= R3D_S_FAR_OVERFLOW;
+        }
+      }
+      b.pix[(int64_t)s * b.cap + i] = p;
+    }
+    if (flags) atomicOr(&b.status[s], flags);
+    phase_sync();
+  }
+  // the last block to leave clears the list for the next insert call
+  if (tid == 0) {
+    __threadfence();
+    int t = atomicAdd(w.rebase_ticket, 1);
+    if (t == (int)gridDim.x - 1) {
+      *w.rebase_ticket = 0;
+      *w.n_rebase = 0;
     }
   }
-}
-
-__global__ void k_rebase_counts(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
-  int li = blockIdx.x * blockDim.x + threadIdx.x;
-  if (li >= *count) return;
-  int s = list[li];
-  b.n_total[s] = b.n_out[s];
-  b.n_head[s] = w.new_head[s];
-}
-
-__global__ void k_rebase_done(r3d_batch_t b, BatchWs w) {   // single block
-  int cnt = *w.n_rebase;
-  for (int li = threadIdx.x; li < cnt; li += blockDim.x) b.rebase[w.rebase_list[li]] = 0;
-  __syncthreads();
-  // every thread has read the count before it is cleared
-  if (threadIdx.x == 0) *w.n_rebase = 0;
 }
 
 // check/{f}.bin rows from the log (SS tools/datasets.py:73-75, :86-88; OD :77, :91-93).
@@ -662,7 +899,9 @@ static int check_batch(const r3d_batch_t *b) {
       !b->row_of_max || !b->far_pix || !b->n_far || !b->rebase || !b->status || !b->out_xyzi ||
       !b->out_label || !b->n_out || !b->workspace)
     return fail(R3D_E_ARG, "batch: null array");
-  size_t lds = (size_t)kKeyCap * 4 + 3 * (size_t)mask_words(*b) * 4 + kKeyCap / 8 + 64 * 4;
+  if (b->cols % 32 != 0)
+    return fail(R3D_E_ARG, "batch: cols must be a multiple of 32 (row-aligned bit images)");
+  size_t lds = (size_t)kKeyCap * 4 + 5 * (size_t)mask_words(*b) * 4 + kKeyCap / 8 + 64 * 4;
   if (lds > 160 * 1024)
     return fail(R3D_E_ARG, "batch: range image too large for the LDS-resident masks of k_insert");
   if (b->workspace_bytes < carve_batch(*b, nullptr).total)
@@ -671,7 +910,7 @@ static int check_batch(const r3d_batch_t *b) {
 }
 
 static size_t insert_lds_bytes(const r3d_batch_t &b) {
-  return (size_t)kKeyCap * 4 + 3 * (size_t)mask_words(b) * 4 + kKeyCap / 8 + 64 * 4;
+  return (size_t)kKeyCap * 4 + 5 * (size_t)mask_words(b) * 4 + kKeyCap / 8 + 64 * 4;
 }
 
 // bounds -> reset -> project for the scenes of (list, count); rows = block rows of the launches.
@@ -768,18 +1007,10 @@ int r3d_batch_insert(const r3d_batch_t *b, const double *samples5, const int64_t
   hipLaunchKernelGGL(k_insert, dim3(b->B), dim3(kST), lds, st, *b, samples5, sample_off, min_points,
                      active, (int)step, n_visible, accepted, w);
   R3D_LAUNCHED("k_insert");
-  // rebase chain: idle unless k_insert flagged a scene (then: compact, re-project like step 0)
-  int rows = b->B < kRebaseRows ? b->B : kRebaseRows;
-  rc = launch_compact(*b, w, w.rebase_list, w.n_rebase, rows, st);
-  if (rc != R3D_OK) return rc;
-  hipLaunchKernelGGL(k_rebase_copyback, dim3(tiles_of(*b), rows), dim3(kPT), 0, st, *b, w.rebase_list,
-                     w.n_rebase, w);
-  hipLaunchKernelGGL(k_rebase_counts, dim3((b->B + 255) / 256), dim3(256), 0, st, *b, w.rebase_list,
-                     w.n_rebase, w);
-  rc = launch_reproject(*b, w, w.rebase_list, w.n_rebase, rows, st);
-  if (rc != R3D_OK) return rc;
-  hipLaunchKernelGGL(k_rebase_done, dim3(1), dim3(1024), 0, st, *b, w);
-  R3D_LAUNCHED("rebase kernels");
+  // idle unless k_insert flagged a scene: then that scene is compacted and re-projected like step 0
+  int rb = b->B < kRebaseRows ? b->B : kRebaseRows;
+  hipLaunchKernelGGL(k_rebase, dim3(rb), dim3(kRB), 0, st, *b, w);
+  R3D_LAUNCHED("k_rebase");
   return R3D_OK;
 }
 
