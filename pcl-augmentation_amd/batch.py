@@ -24,6 +24,8 @@ def shard_indices(n_scenes: int, rank: int, world_size: int):
 
 
 class SceneBatch:
+    last_rebases = 0      # rebases counted by the most recent augment_batch (diagnostics / tests)
+
     def __init__(self, B, cap, log_cap, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN, device="cuda:0"):
         torch = _lib.require_gpu()
         self.torch = torch
@@ -51,7 +53,7 @@ class SceneBatch:
         self.stamp = z((B, npix), torch.int16)
         self.ever = z((B, words), torch.int32)
         self.bounds = z((B, 2), torch.float64)
-        self.row_of_max = z((B,), torch.int32)
+        self.extreme_pix = z((B, 2), torch.int32)
         self.far_pix = z((B, _lib.FAR_CAP), torch.int32)
         self.n_far = z((B,), torch.int32)
         self.rebase = z((B,), torch.int32)
@@ -68,7 +70,7 @@ class SceneBatch:
         d = _lib.BatchDesc()
         d.B, d.rows, d.cols, d.reserved, d.cap, d.log_cap = B, rows, cols, 0, cap, log_cap
         for name in ("xyzi", "label", "pix", "n_head", "n_total", "tail_ref", "log5", "log_birth", "n_log",
-                     "grid", "sgrid", "stamp", "ever", "bounds", "row_of_max", "far_pix", "n_far", "rebase",
+                     "grid", "sgrid", "stamp", "ever", "bounds", "extreme_pix", "far_pix", "n_far", "rebase",
                      "status", "out_xyzi", "out_label", "n_out"):
             setattr(d, name, getattr(self, name).data_ptr())
         d.workspace, d.workspace_bytes = 0, 0
@@ -208,4 +210,5 @@ def augment_batch(scenes, candidates, min_points, rows=_lib.NUMROW, cols=_lib.NU
                 if active[s] and acc[s]:
                     accepted[s][k] = ci
     batch.finish(check_cols)
+    SceneBatch.last_rebases = int(batch.rebase.sum().item())
     return batch.results(), accepted

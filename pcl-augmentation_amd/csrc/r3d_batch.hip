@@ -180,7 +180,7 @@ __global__ void k_bounds_finish(r3d_batch_t b, const int32_t *list, const int32_
   unsigned long long kmin = w.qkeys[2 * s + 0], kmax = w.qkeys[2 * s + 1];
   if (kmin == ~0ull) {                    // no valid point: the reference raises (insertion.py:78)
     b.bounds[2 * s + 0] = b.bounds[2 * s + 1] = 0.0;
-    b.row_of_max[s] = 0;
+    b.extreme_pix[2 * s + 0] = b.extreme_pix[2 * s + 1] = -1;
     atomicOr(&b.status[s], R3D_S_NONFINITE);
     return;
   }
@@ -188,9 +188,7 @@ __global__ void k_bounds_finish(r3d_batch_t b, const int32_t *list, const int32_
   double min_el = acos(ordered_key_inv(kmax));   // insertion.py:78
   b.bounds[2 * s + 0] = max_el;
   b.bounds[2 * s + 1] = min_el;
-  double d_el = (max_el - min_el) / (double)b.rows;
-  double t = trunc((max_el - min_el - 0.00001) / d_el);
-  b.row_of_max[s] = (t >= 0.0 && t < (double)b.rows) ? (int)t : 0;
+  b.extreme_pix[2 * s + 0] = b.extreme_pix[2 * s + 1] = -1;   // recorded by the projection pass
 }
 
 // ---- step 0 / rebase: reset the per-scene images ----------------------------------------------
@@ -242,6 +240,8 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count) {
       else {
         p = row * b.cols + col;
         atomicMin(&g[p], depth_key(sp.r));
+        if (sp.el == bn.max_el) b.extreme_pix[2 * s + 0] = p;   // any holder will do
+        if (sp.el == bn.min_el) b.extreme_pix[2 * s + 1] = p;
         if (sp.r > R3D_EMPTY_DEPTH) {         // "first hit overwrites the 500": insertion.py:122-125
           int f = atomicAdd(&b.n_far[s], 1);
           if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
@@ -282,43 +282,28 @@ __device__ __forceinline__ uint32_t hand3(const BitImage &m, int r, int j) {
   return c & ((c << 1) | l) & ((c >> 1) | rr);
 }
 
-// dst = dilate(src) on rows [r0, r1], words [j0, j1]; then (ERODE) dst = erode(src) likewise.
-template <bool ERODE>
-__device__ __forceinline__ void morph_rows(const BitImage &src, BitImage &dst, int r0, int r1, int j0, int j1,
-                                           int tid, int nthreads) {
-  int nj = j1 - j0 + 1, total = (r1 - r0 + 1) * nj;
-  for (int e = tid; e < total; e += nthreads) {
-    int r = r0 + e / nj, j = j0 + e % nj;
-    uint32_t acc = ERODE ? 0xFFFFFFFFu : 0u;
-    for (int dr = -2; dr <= 2; ++dr) {
-      int rr = r + dr;
-      if (rr < 0 || rr >= src.rows) continue;
-      if (ERODE) acc &= hand3(src, rr, j);
-      else acc |= hor3(src, rr, j);
-    }
-    dst.w[r * dst.wpr + j] = acc;
-  }
-}
-
-// closing.py:44-57 with the occupancy known from a bit image: the up-to-15 loads are independent.
+// closing.py:44-57: all (up to 15) neighbour loads are issued first and are independent; an empty
+// pixel holds R3D_SENT, so occupancy is read off the value.  The sum then runs drow outer,
+// dcolumn inner over the occupied ones, as the reference's does.
 template <class Load>
-__device__ __forceinline__ double mean_of_occupied(const BitImage &occ, const Load &load, int r, int c,
-                                                   int rows, int cols) {
+__device__ __forceinline__ double mean_of_occupied(const Load &load, int r, int c, int rows, int cols) {
+  unsigned long long v[15];
+#pragma unroll
+  for (int dr = -2; dr <= 2; ++dr)
+#pragma unroll
+    for (int dc = -1; dc <= 1; ++dc) {
+      int rr = r + dr, cc = c + dc;
+      bool in = rr >= 0 && rr < rows && cc >= 0 && cc < cols;
+      v[(dr + 2) * 3 + (dc + 1)] = in ? load(rr * cols + cc) : R3D_SENT;
+    }
   double sum = 0.0;
   int cnt = 0;
-  for (int dr = -2; dr <= 2; ++dr) {                   // drow outer (closing.py:46)
-    int rr = r + dr;
-    if (rr < 0 || rr >= rows) continue;
-    for (int dc = -1; dc <= 1; ++dc) {                 // dcolumn inner (closing.py:47)
-      int cc = c + dc;
-      if (cc < 0 || cc >= cols) continue;
-      int q = rr * cols + cc;
-      if (occ.get(q)) {
-        ++cnt;
-        sum += key_depth(load(q));
-      }
+#pragma unroll
+  for (int k = 0; k < 15; ++k)
+    if (v[k] != R3D_SENT) {
+      ++cnt;
+      sum += key_depth(v[k]);
     }
-  }
   return cnt ? sum / (double)cnt : R3D_EMPTY_DEPTH;
 }
 
@@ -337,8 +322,9 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   uint32_t *s_oob = s_img + 5 * words;                            // [kKeyCap/32] el outside bounds
   int *s_misc = reinterpret_cast<int *>(s_oob + kKeyCap / 32);
   int *s_nvalid = s_misc + 0, *s_ncand = s_misc + 1, *s_rebase = s_misc + 2, *s_flags = s_misc + 3;
-  int *s_rmin = s_misc + 4, *s_rmax = s_misc + 5, *s_cmin = s_misc + 6, *s_cmax = s_misc + 7;
-  int *s_scan = s_misc + 8;                                       // [kST/64 + 1]
+  int *s_rmin = s_misc + 4, *s_rmax = s_misc + 5;                 // sample row range
+  int *s_cmin = s_misc + 6, *s_cmax = s_misc + 8;                 // [2] column range per image half
+  int *s_scan = s_misc + 10;                                      // [kST/64 + 1]
   BitImage A{s_img, wpr, rows};                // sample occupancy
   BitImage T{s_img + words, wpr, rows};        // scratch: dilations, candidate mask, then visible pixels
   BitImage Cs{s_img + 2 * words, wpr, rows};   // sample closed
@@ -361,7 +347,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   while (pw < m) pw <<= 1;
 
   for (int i = tid; i < 5 * words + kKeyCap / 32; i += kST) s_img[i] = 0u;
-  if (tid < 8) s_misc[tid] = (tid == 4 || tid == 6) ? 0x7FFFFFFF : (tid == 5 || tid == 7) ? -1 : 0;
+  if (tid < 10) s_misc[tid] = (tid == 4 || tid == 6 || tid == 7) ? 0x7FFFFFFF : (tid == 5 || tid >= 8) ? -1 : 0;
   __syncthreads();
 
   const Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], rows, cols);
@@ -375,7 +361,11 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
 
   // -- 1. project the sample with the scene's bounds, sample=True (insertion.py:455-459) ---------
   {
-    int rmin = 0x7FFFFFFF, rmax = -1, cmin = 0x7FFFFFFF, cmax = -1, nval = 0, flags = 0;
+    // column ranges are kept per image half so that an object across the azimuth seam (columns
+    // 0 and cols-1) yields two narrow windows instead of one full-width window
+    const int half = cols >> 1;
+    int rmin = 0x7FFFFFFF, rmax = -1, cmin0 = 0x7FFFFFFF, cmax0 = -1, cmin1 = 0x7FFFFFFF, cmax1 = -1;
+    int nval = 0, flags = 0;
     for (int j = tid; j < pw; j += kST) {
       uint32_t key = 0xFFFFFFFFu;
       if (j < m) {
@@ -395,8 +385,13 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
             ++nval;
             rmin = row < rmin ? row : rmin;
             rmax = row > rmax ? row : rmax;
-            cmin = col < cmin ? col : cmin;
-            cmax = col > cmax ? col : cmax;
+            if (col < half) {
+              cmin0 = col < cmin0 ? col : cmin0;
+              cmax0 = col > cmax0 ? col : cmax0;
+            } else {
+              cmin1 = col < cmin1 ? col : cmin1;
+              cmax1 = col > cmax1 ? col : cmax1;
+            }
             if (sp.el < bn.min_el || sp.el > bn.max_el) atomicOr(&s_oob[j >> 5], 1u << (j & 31));
           }
         }
@@ -410,16 +405,20 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
       int t;
       t = __shfl_xor(rmin, o, 64); rmin = t < rmin ? t : rmin;
       t = __shfl_xor(rmax, o, 64); rmax = t > rmax ? t : rmax;
-      t = __shfl_xor(cmin, o, 64); cmin = t < cmin ? t : cmin;
-      t = __shfl_xor(cmax, o, 64); cmax = t > cmax ? t : cmax;
+      t = __shfl_xor(cmin0, o, 64); cmin0 = t < cmin0 ? t : cmin0;
+      t = __shfl_xor(cmax0, o, 64); cmax0 = t > cmax0 ? t : cmax0;
+      t = __shfl_xor(cmin1, o, 64); cmin1 = t < cmin1 ? t : cmin1;
+      t = __shfl_xor(cmax1, o, 64); cmax1 = t > cmax1 ? t : cmax1;
     }
     if ((tid & 63) == 0) {
       atomicAdd(s_nvalid, nval);
       if (flags) atomicOr(s_flags, flags);
       atomicMin(s_rmin, rmin);
       atomicMax(s_rmax, rmax);
-      atomicMin(s_cmin, cmin);
-      atomicMax(s_cmax, cmax);
+      atomicMin(s_cmin + 0, cmin0);
+      atomicMax(s_cmax + 0, cmax0);
+      atomicMin(s_cmin + 1, cmin1);
+      atomicMax(s_cmax + 1, cmax1);
     }
   }
   __syncthreads();
@@ -446,48 +445,90 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
 
   // -- 3. bit images: sample occupancy, scene occupancy in the window around the sample ----------
   // candidates lie within 2 rows / 1 column of a sample pixel; their closing looks 4 rows / 2
-  // columns further.  Pixels deeper than 500 m (far list) can be visible anywhere: whole image.
-  int r_lo = 0, r_hi = rows - 1, c_lo = 0, c_hi = cols - 1;
-  if (n_far == 0 && nvalid > 0) {
+  // columns further.  The window is rows [r_lo, r_hi] x one or two column intervals (whole words
+  // jl[k]..jh[k]).  Pixels deeper than 500 m (far list) can be visible anywhere: whole image.
+  int r_lo = 0, r_hi = rows - 1, n_iv = 1;
+  int jl[2] = {0, 0}, jh[2] = {wpr - 1, 0};
+  if (n_far == 0 && nvalid == 0) {
+    r_hi = -1;                                           // nothing can be visible: empty window
+  } else if (n_far == 0) {
     r_lo = *s_rmin - 6 < 0 ? 0 : *s_rmin - 6;
     r_hi = *s_rmax + 6 > rows - 1 ? rows - 1 : *s_rmax + 6;
-    c_lo = *s_cmin - 3 < 0 ? 0 : *s_cmin - 3;
-    c_hi = *s_cmax + 3 > cols - 1 ? cols - 1 : *s_cmax + 3;
+    n_iv = 0;
+    for (int h = 0; h < 2; ++h) {
+      if (s_cmax[h] < 0) continue;
+      int lo = s_cmin[h] - 3 < 0 ? 0 : s_cmin[h] - 3;
+      int hi = s_cmax[h] + 3 > cols - 1 ? cols - 1 : s_cmax[h] + 3;
+      int a = lo >> 5, z = hi >> 5;
+      if (n_iv == 1 && a <= jh[0] + 1) jh[0] = z > jh[0] ? z : jh[0];   // touches the first: merge
+      else {
+        jl[n_iv] = a;
+        jh[n_iv] = z;
+        ++n_iv;
+      }
+    }
   }
+  const int nj0 = jh[0] - jl[0] + 1, nj1 = n_iv > 1 ? jh[1] - jl[1] + 1 : 0, njw = nj0 + nj1;
+  const int nrw = r_hi - r_lo + 1;
+  // window word index e in [0, nrw * njw) -> (row, word-in-row)
+  auto win_row = [&](int e) { return r_lo + e / njw; };
+  auto win_word = [&](int e) {
+    int k = e % njw;
+    return k < nj0 ? jl[0] + k : jl[1] + (k - nj0);
+  };
   for (int k = tid; k < nvalid; k += kST) {
     int p = (int)(s_keys[k] >> kIdxBits);
     if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != p) A.set(p);
   }
   if (nvalid > 0 || n_far > 0) {
-    int wc = c_hi - c_lo + 1, total = (r_hi - r_lo + 1) * wc;
-    for (int e = tid; e < total; e += kST) {
-      int q = (r_lo + e / wc) * cols + c_lo + e % wc;
-      if (grid[q] != R3D_SENT) D.set(q);
+    // scene occupancy: each lane loads the 4 pixels of one nibble of a window word (32-byte loads),
+    // 8 lanes assemble a word by shuffles -> plain LDS store, no LDS atomics
+    const int total = nrw * njw * 8;
+    for (int e0 = 0; e0 < total; e0 += kST) {
+      int e = e0 + tid;
+      uint32_t nib = 0;
+      int r = 0, j = 0;
+      if (e < total) {
+        r = win_row(e >> 3);
+        j = win_word(e >> 3);
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(grid + r * cols + (j << 5) + ((e & 7) << 2));
+        ulonglong2 v0 = src[0], v1 = src[1];
+        nib = (v0.x != R3D_SENT ? 1u : 0u) | (v0.y != R3D_SENT ? 2u : 0u) | (v1.x != R3D_SENT ? 4u : 0u) |
+              (v1.y != R3D_SENT ? 8u : 0u);
+        nib <<= (e & 7) << 2;
+      }
+      nib |= __shfl_xor(nib, 1, 64);
+      nib |= __shfl_xor(nib, 2, 64);
+      nib |= __shfl_xor(nib, 4, 64);
+      if (e < total && (e & 7) == 0) D.w[r * wpr + j] = nib;
     }
   }
   __syncthreads();
 
   // -- 4. closing of both occupancies (closing.py:9-23) by word-parallel dilate / erode ----------
-  const int j_lo = c_lo >> 5, j_hi = c_hi >> 5;
-  const int dr_lo = r_lo, dr_hi = r_hi;                     // dilation rows (clipped window)
-  morph_rows<false>(A, T, dr_lo, dr_hi, j_lo, j_hi, tid, kST);
-  __syncthreads();
-  morph_rows<true>(T, Cs, dr_lo, dr_hi, j_lo, j_hi, tid, kST);
-  __syncthreads();
-  morph_rows<false>(D, T, dr_lo, dr_hi, j_lo, j_hi, tid, kST);
-  __syncthreads();
-  morph_rows<true>(T, E, dr_lo, dr_hi, j_lo, j_hi, tid, kST);
-  __syncthreads();
-  // Rows at the clipped window edge used fewer dilation rows than the image has: only rows at
-  // least 2 inside the window (or at the image border) are exact, and candidates lie there.
+  // Exact on every row at least 2 inside the window (or at the image border): candidates are.
+  for (int pass = 0; pass < 4; ++pass) {
+    const BitImage &src = pass == 0 ? A : pass == 2 ? D : T;
+    BitImage &dst = pass == 0 ? T : pass == 1 ? Cs : pass == 2 ? T : E;
+    const bool erode = pass & 1;
+    for (int e = tid; e < nrw * njw; e += kST) {
+      int r = win_row(e), j = win_word(e);
+      uint32_t acc = erode ? 0xFFFFFFFFu : 0u;
+      for (int dr = -2; dr <= 2; ++dr) {
+        int rr = r + dr;
+        if (rr < 0 || rr >= rows) continue;
+        if (erode) acc &= hand3(src, rr, j);
+        else acc |= hor3(src, rr, j);
+      }
+      dst.w[r * wpr + j] = acc;
+    }
+    __syncthreads();
+  }
 
   // -- 5. candidate pixels: where the sample is closed, plus the far neighbourhoods --------------
-  {
-    int nj = j_hi - j_lo + 1, total = (r_hi - r_lo + 1) * nj;
-    for (int e = tid; e < total; e += kST) {
-      int idx = (r_lo + e / nj) * wpr + j_lo + e % nj;
-      T.w[idx] = Cs.w[idx];
-    }
+  for (int e = tid; e < nrw * njw; e += kST) {
+    int idx = win_row(e) * wpr + win_word(e);
+    T.w[idx] = Cs.w[idx];
   }
   __syncthreads();
   for (int f = tid; f < n_far; f += kST) {
@@ -501,26 +542,20 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   }
   __syncthreads();
   uint32_t *cand = w.cand + (int64_t)s * npix;
-  {
-    int nj = j_hi - j_lo + 1, total = (r_hi - r_lo + 1) * nj;
-    for (int e = tid; e < total; e += kST) {
-      int r = r_lo + e / nj, j = j_lo + e % nj;
-      uint32_t bits = T.w[r * wpr + j];
-      if (!bits) continue;
-      int pos = atomicAdd(s_ncand, __popc(bits));
-      while (bits) {
-        int bit = __ffs(bits) - 1;
-        bits &= bits - 1;
-        cand[pos++] = (uint32_t)(r * cols + (j << 5) + bit);
-      }
+  for (int e = tid; e < nrw * njw; e += kST) {
+    int r = win_row(e), j = win_word(e);
+    uint32_t bits = T.w[r * wpr + j];
+    if (!bits) continue;
+    int pos = atomicAdd(s_ncand, __popc(bits));
+    while (bits) {
+      int bit = __ffs(bits) - 1;
+      bits &= bits - 1;
+      cand[pos++] = (uint32_t)(r * cols + (j << 5) + bit);
     }
   }
   __syncthreads();
   const int ncand = *s_ncand;
-  {
-    int nj = j_hi - j_lo + 1, total = (r_hi - r_lo + 1) * nj;
-    for (int e = tid; e < total; e += kST) T.w[(r_lo + e / nj) * wpr + j_lo + e % nj] = 0u;
-  }
+  for (int e = tid; e < nrw * njw; e += kST) T.w[win_row(e) * wpr + win_word(e)] = 0u;
   __syncthreads();
   BitImage &vis = T;
 
@@ -530,9 +565,9 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
     int r = q / cols, c = q - r * cols;
     double sd = R3D_EMPTY_DEPTH, cd = R3D_EMPTY_DEPTH;
     if (A.get(q)) sd = key_depth(ld_sample(q));
-    else if (Cs.get(q)) sd = mean_of_occupied(A, ld_sample, r, c, rows, cols);
+    else if (Cs.get(q)) sd = mean_of_occupied(ld_sample, r, c, rows, cols);
     if (D.get(q)) cd = key_depth(ld_scene(q));
-    else if (E.get(q)) cd = mean_of_occupied(D, ld_scene, r, c, rows, cols);
+    else if (E.get(q)) cd = mean_of_occupied(ld_scene, r, c, rows, cols);
     if (sd < cd) vis.set(q);
   }
   __syncthreads();
@@ -584,14 +619,13 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
       }
       base += tot;
     }
-    const int row_of_max = b.row_of_max[s];
+    const int pix_of_max = b.extreme_pix[2 * s + 0], pix_of_min = b.extreme_pix[2 * s + 1];
     uint16_t *stamp = b.stamp + (int64_t)s * npix;
     uint32_t *ever = b.ever + (int64_t)s * words;
     for (int ci = tid; ci < ncand; ci += kST) {
       int q = (int)cand[ci];
       if (!vis.get(q)) continue;
-      int r = q / cols;
-      if (D.get(q) && (r == 0 || r == row_of_max)) *s_rebase = 1;   // an extreme point may be culled
+      if (q == pix_of_max || q == pix_of_min) *s_rebase = 1;   // the recorded extreme point is culled
       unsigned long long nv = A.get(q) ? ld_sample(q) : R3D_SENT;
       grid[q] = nv;
       if (nv != R3D_SENT && key_depth(nv) > R3D_EMPTY_DEPTH) {
@@ -618,7 +652,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
       b.n_total[s] = n_total + nvis;
       b.n_log[s] = n_log + nvis;
       if (*s_rebase) {
-        b.rebase[s] = 1;
+        b.rebase[s] += 1;                                       // single writer per scene
         w.rebase_list[atomicAdd(w.n_rebase, 1)] = s;
       }
     }
@@ -824,10 +858,8 @@ k_rebase(r3d_batch_t b, BatchWs w) {
       double max_el = acos(ordered_key_inv(lmin)), min_el = acos(ordered_key_inv(lmax));
       b.bounds[2 * s + 0] = max_el;
       b.bounds[2 * s + 1] = min_el;
-      double t = trunc((max_el - min_el - 0.00001) / ((max_el - min_el) / (double)b.rows));
-      b.row_of_max[s] = (t >= 0.0 && t < (double)b.rows) ? (int)t : 0;
+      b.extreme_pix[2 * s + 0] = b.extreme_pix[2 * s + 1] = -1;
       b.n_far[s] = 0;
-      b.rebase[s] = 0;
     }
     // (d) reset the images
     unsigned long long *g = (unsigned long long *)b.grid + (int64_t)s * npix;
@@ -851,6 +883,8 @@ k_rebase(r3d_batch_t b, BatchWs w) {
       else {
         p = row * b.cols + col;
         atomicMin(&g[p], depth_key(sp.r));
+        if (sp.el == bn.max_el) b.extreme_pix[2 * s + 0] = p;
+        if (sp.el == bn.min_el) b.extreme_pix[2 * s + 1] = p;
         if (sp.r > R3D_EMPTY_DEPTH) {
           int f = atomicAdd(&b.n_far[s], 1);
           if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
@@ -896,7 +930,7 @@ static int check_batch(const r3d_batch_t *b) {
     return fail(R3D_E_ARG, "batch: cap or range image too large for 32-bit point / pixel ids");
   if (!b->xyzi || !b->label || !b->pix || !b->n_head || !b->n_total || !b->tail_ref || !b->log5 ||
       !b->log_birth || !b->n_log || !b->grid || !b->sgrid || !b->stamp || !b->ever || !b->bounds ||
-      !b->row_of_max || !b->far_pix || !b->n_far || !b->rebase || !b->status || !b->out_xyzi ||
+      !b->extreme_pix || !b->far_pix || !b->n_far || !b->rebase || !b->status || !b->out_xyzi ||
       !b->out_label || !b->n_out || !b->workspace)
     return fail(R3D_E_ARG, "batch: null array");
   if (b->cols % 32 != 0)

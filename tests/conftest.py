@@ -29,3 +29,15 @@ def pkg():
 @pytest.fixture(scope="session")
 def synth():
     return importlib.import_module("pcl-augmentation_amd.synth")
+
+
+def blob_in_front_of_extreme(xyzi, which="max", n=200, seed=0):
+    """A small float64 blob half way to the scene's max- (or min-) elevation point: it covers that
+    point's pixel, so the point is culled and the elevation bounds move (forces a rebase)."""
+    xyz = xyzi[:, :3].astype(np.float64)
+    r = np.sqrt((xyz * xyz).sum(1))
+    el = np.arccos(xyz[:, 2] / r)
+    i = int(np.argmax(el) if which == "max" else np.argmin(el))
+    rng = np.random.default_rng(seed)
+    pts = xyz[i] * 0.5 + rng.normal(0.0, 0.01, size=(n, 3))
+    return np.column_stack([pts, rng.random(n), np.full(n, 30.0)])

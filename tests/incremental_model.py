@@ -12,8 +12,8 @@ point keeps its pixel id, so one insert step only has to
 * append the visible points to the tail log.
 
 The cloud is compacted (dead points dropped) once at the end, or earlier when the bounds may
-have moved ("rebase": a culled point sat in the first or last occupied row, or a visible point
-lies outside the old bounds); after a rebase everything is re-projected like step 0.
+have moved ("rebase": the pixel holding the recorded max- or min-elevation point was culled, or
+a visible point lies outside the old bounds); after a rebase everything is re-projected like step 0.
 
 This file states that algorithm in plain NumPy so that ``tests/test_incremental_model.py`` can
 prove it equal to the oracle's literal K-insert chain on the CPU, before any kernel runs; the
@@ -49,8 +49,9 @@ class IncrementalScene:
         self.pix = pc[:, 8].astype(np.int64)
         self.grid = np.where(lab == 1, train, SENT)          # raw min depth, SENT where empty
         self.stamp = np.zeros((self.R, self.C), dtype=np.int64)
-        d_el = (self.max_el - self.min_el) / self.R
-        self.row_of_max = int((self.max_el - self.min_el - 0.00001) / d_el)
+        # pixel of one max-elevation point and of one min-elevation point: while those two pixels
+        # stay uncovered their points survive and the bounds cannot shrink
+        self.extreme_pix = (int(self.pix[np.argmax(pc[:, 5])]), int(self.pix[np.argmin(pc[:, 5])]))
 
     def _alive(self):
         st = self.stamp.reshape(-1)[(self.pix // O.NUMCOLUMN) * self.C + self.pix % O.NUMCOLUMN]
@@ -83,8 +84,8 @@ class IncrementalScene:
             return 0
         # commit ---------------------------------------------------------------------------
         rr, cc = np.nonzero(vis)
-        culled_rows = rr[self.grid[rr, cc] != SENT]
-        rebase = bool(np.any((culled_rows == 0) | (culled_rows == self.row_of_max)))
+        culled = (rr * self.C + cc)[self.grid[rr, cc] != SENT]
+        rebase = bool(np.isin(np.array(self.extreme_pix), culled).any())
         rebase |= bool(np.any(visible[:, 5] < self.min_el) or np.any(visible[:, 5] > self.max_el))
         self.grid[rr, cc] = np.where(s_lab[rr, cc] == 1, s_train[rr, cc], SENT)
         self.stamp[rr, cc] = self.step_no

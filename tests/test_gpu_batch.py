@@ -5,7 +5,7 @@ seeded inputs, including the rebase paths, multi-candidate slots, ragged batches
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import blob_in_front_of_extreme, load_golden
 from oracle import real3d_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -94,7 +94,9 @@ def test_rebase_paths_vs_oracle(P, synth):
     tall[:, 2] = tall[:, 2] * 3.0 + 2.0
     low = synth.make_insert(6, "car", centre_range=2.5)
     low[:, 2] -= 1.0
-    slots = [[synth.make_insert(3, "cyclist", centre_range=9.0)], [tall],
+    slots = [[blob_in_front_of_extreme(xyzi, "max")], [synth.make_insert(10, "cyclist", centre_range=7.0) * [1, -1, 1, 1, 1]],
+             [blob_in_front_of_extreme(xyzi, "min")], [synth.make_insert(12, "car", centre_range=8.0)],
+             [synth.make_insert(3, "cyclist", centre_range=9.0)], [tall],
              [synth.make_insert(10, "cyclist", centre_range=7.0)], [low],
              [synth.make_insert(8, "car", centre_range=3.2, centre_az=1.0)],
              [synth.make_insert(11, "pedestrian", centre_range=5.0, centre_az=1.0)]]
@@ -102,6 +104,7 @@ def test_rebase_paths_vs_oracle(P, synth):
     # second scene in the same batch never rebases: the conditional kernels must leave it alone
     x2, l2, s2, n2 = _random_case(synth, 4)
     res, acc = P.augment_batch([(xyzi, label), (x2, l2)], [slots, s2[:6]], [need, n2[:6]])
+    assert P.batch.SceneBatch.last_rebases >= 3          # the rebase kernel really ran
     vb, lb, cb, oacc = _oracle_chain(xyzi, label, slots, need)
     assert acc[0] == oacc
     _check_scene(res[0], vb, lb, cb)

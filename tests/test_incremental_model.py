@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import blob_in_front_of_extreme, load_golden
 from incremental_model import IncrementalScene
 from oracle import real3d_oracle as O
 
@@ -40,10 +40,12 @@ def test_rebase_paths(synth):
     low[:, 2] -= 1.0                                 # reaches below the lowest beam: max_el moves
     cover_bottom = synth.make_insert(8, "car", centre_range=3.2, centre_az=1.0)   # culls last-row points
     later = synth.make_insert(10, "cyclist", centre_range=7.0)
-    samples = [synth.make_insert(3, "cyclist", centre_range=9.0), tall, later, low, cover_bottom,
+    samples = [blob_in_front_of_extreme(xyzi, "max"), later * [1, -1, 1, 1, 1],
+               blob_in_front_of_extreme(xyzi, "min"), synth.make_insert(12, "car", centre_range=8.0),
+               synth.make_insert(3, "cyclist", centre_range=9.0), tall, later, low, cover_bottom,
                synth.make_insert(11, "pedestrian", centre_range=5.0, centre_az=1.0)]
     inc = _run_both(xyzi, label, samples, [10] * len(samples))
-    assert inc.rebases >= 2
+    assert inc.rebases >= 3
 
 
 @pytest.mark.parametrize("name", ["chain_c20k.npz", "chain_c8k_od.npz"])
