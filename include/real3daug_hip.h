@@ -146,8 +146,9 @@ typedef struct r3d_batch {
   int32_t *log_birth;    /* [B*log_cap] step at which the row was inserted */
   int32_t *n_log;        /* [B] */
   /* per-scene range-image state */
-  uint64_t *grid;        /* [B*rows*cols] bits of min r, all-ones where empty */
-  uint64_t *sgrid;       /* [B*rows*cols] sample scratch image, all-ones between calls */
+  uint64_t *grid;        /* [B*rows*cols] scratch: scene range image (bits of min r) inside the window
+                            of the insert being evaluated; all-ones (= empty) between calls */
+  uint64_t *sgrid;       /* [B*rows*cols] scratch: sample range image, all-ones between calls */
   uint16_t *stamp;       /* [B*rows*cols] last step at which the pixel was visible (0 = never) */
   uint32_t *ever;        /* [B*ceil(rows*cols/32)] bit set = stamp != 0 */
   double *bounds;        /* [B][2] max elevation, min elevation */
@@ -166,9 +167,14 @@ typedef struct r3d_batch {
 
 size_t r3d_batch_workspace_bytes(const r3d_batch_t *b);
 
+/* Once per descriptor, before the first r3d_batch_begin: marks the two scratch range images
+ * (grid, sgrid) all-empty.  Every later call leaves them all-empty again. */
+int r3d_batch_create(const r3d_batch_t *b, void *stream);
+
 /* Step 0 (insertion.py:362, :373-375 for every scene): n_points (device int32[B]) points per
- * scene are already in b->xyzi / b->label.  Computes the elevation bounds, projects every point,
- * builds the range images and resets all per-scene state. */
+ * scene are already in b->xyzi / b->label.  Computes the elevation bounds, the pixel id of every
+ * point and resets all per-scene state.  (The min-reduce of :118-125 is done per insert, on the
+ * window of the range image that the insert can see -- DESIGN.md par.3.) */
 int r3d_batch_begin(const r3d_batch_t *b, const int32_t *n_points, void *stream);
 
 /* One placement candidate per scene (insertion.py:453-526).  samples5: rows of [x y z intensity
@@ -189,7 +195,7 @@ int r3d_batch_finish(const r3d_batch_t *b, float *check, int32_t check_cols, voi
 /* The two streaming passes of step 0 on their own (all scenes; state as left by r3d_batch_begin),
  * exported for parity tests and for timing them in isolation:
  *   elev_bounds = insertion.py:74-79 reduced to the two bounds per scene,
- *   project     = insertion.py:74-76 + :104-127 fused (pixel ids + range-image min-reduce). */
+ *   project     = insertion.py:74-76 + :104-116 fused (spherical coordinates -> pixel ids). */
 int r3d_batch_elev_bounds(const r3d_batch_t *b, void *stream);
 int r3d_batch_project(const r3d_batch_t *b, void *stream);
 

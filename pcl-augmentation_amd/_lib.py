@@ -63,6 +63,7 @@ _SIGNATURES = {
                                       _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "r3d_remove_space_for_spherical": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int32, _P]),
     "r3d_batch_workspace_bytes": (C.c_size_t, [C.POINTER(BatchDesc)]),
+    "r3d_batch_create": (C.c_int, [C.POINTER(BatchDesc), _P]),
     "r3d_batch_begin": (C.c_int, [C.POINTER(BatchDesc), _P, _P]),
     "r3d_batch_insert": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "r3d_batch_finish": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int32, _P]),

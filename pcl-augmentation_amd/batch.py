@@ -80,6 +80,7 @@ class SceneBatch:
         self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         d.workspace, d.workspace_bytes = self.ws.data_ptr(), ws_bytes
         self.desc = d
+        _lib.check(self.lib.r3d_batch_create(C.byref(d), _lib.stream_ptr()), "r3d_batch_create")
 
     # -- loading --------------------------------------------------------------------------------
     def load(self, scenes):

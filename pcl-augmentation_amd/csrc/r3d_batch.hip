@@ -34,10 +34,13 @@ struct BatchWs {
   int32_t *rebase_list;         // [B]
   int32_t *n_rebase;            // [1]
   int32_t *rebase_ticket;       // [1]
+  unsigned long long *chunk_box; // [B*chunks] rows/cols bounding box of 64 consecutive points
+  int32_t *n_proj;              // [B] points covered by the chunk boxes
   size_t total;
 };
 
 static int tiles_of(const r3d_batch_t &b) { return (int)((b.cap + kTile - 1) / kTile); }
+static int chunks_of(const r3d_batch_t &b) { return (int)((b.cap + 63) / 64); }
 static int mask_words(const r3d_batch_t &b) { return (int)(((int64_t)b.rows * b.cols + 31) / 32); }
 
 static BatchWs carve_batch(const r3d_batch_t &b, void *base) {
@@ -56,6 +59,8 @@ static BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.rebase_list = c.take<int32_t>((size_t)b.B);
   w.n_rebase = c.take<int32_t>(1);
   w.rebase_ticket = c.take<int32_t>(1);
+  w.chunk_box = c.take<unsigned long long>((size_t)b.B * chunks_of(b));
+  w.n_proj = c.take<int32_t>((size_t)b.B);
   w.total = c.off;
   return w;
 }
@@ -191,7 +196,7 @@ __global__ void k_bounds_finish(r3d_batch_t b, const int32_t *list, const int32_
   b.extreme_pix[2 * s + 0] = b.extreme_pix[2 * s + 1] = -1;   // recorded by the projection pass
 }
 
-// ---- step 0 / rebase: reset the per-scene images ----------------------------------------------
+// ---- step 0 / rebase: reset the per-scene visibility stamps -------------------------------------
 __global__ void __launch_bounds__(kPT)
 k_reset(r3d_batch_t b, const int32_t *list, const int32_t *count) {
   int cnt = *count;
@@ -199,56 +204,94 @@ k_reset(r3d_batch_t b, const int32_t *list, const int32_t *count) {
   int words = (int)((npix + 31) / 32);
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
-    unsigned long long *g = (unsigned long long *)b.grid + (int64_t)s * npix;
-    uint16_t *st = b.stamp + (int64_t)s * npix;
+    uint32_t *st = reinterpret_cast<uint32_t *>(b.stamp + (int64_t)s * npix);   // npix is even
     uint32_t *ev = b.ever + (int64_t)s * words;
-    for (int64_t p = blockIdx.x * (int64_t)kPT + threadIdx.x; p < npix; p += (int64_t)gridDim.x * kPT) {
-      g[p] = R3D_SENT;
-      st[p] = 0;
+    for (int64_t p = blockIdx.x * (int64_t)kPT + threadIdx.x; p < npix / 2; p += (int64_t)gridDim.x * kPT) {
+      st[p] = 0u;
       if (p < words) ev[p] = 0u;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) b.n_far[s] = 0;
   }
 }
 
-// ---- step 0 / rebase: spherical projection + range-image min-reduce ----------------------------
-// insertion.py:74-76 and :104-127 fused: r/az/el are never stored, only the pixel id.
+// ---- step 0 / rebase: spherical projection -> pixel ids ------------------------------------------
+// insertion.py:74-76 and :104-116 fused: r/az/el are never stored, only the pixel id of every
+// point.  The min-reduce of :118-125 is NOT done here for the whole image: a scene's range image
+// is only ever read in the window around an inserted object, so k_insert builds exactly that
+// window from the points.  To find those points without scanning the cloud,
+// every 64 consecutive points (one wave) leave their row / column bounding box; LiDAR files are
+// ring-ordered, so a box is about one row by 50 columns.
+__device__ __forceinline__ unsigned long long pack_box(int rmin, int rmax, int cmin, int cmax) {
+  return (unsigned long long)(rmin & 0xFFFF) | ((unsigned long long)(rmax & 0xFFFF) << 16) |
+         ((unsigned long long)(cmin & 0xFFFF) << 32) | ((unsigned long long)(cmax & 0xFFFF) << 48);
+}
+
+// Projects point i of scene s (if valid) and returns its pixel; accumulates the wave's box.
+struct BoxAcc {
+  int rmin = 0xFFFF, rmax = 0, cmin = 0xFFFF, cmax = 0;
+  __device__ __forceinline__ void add(int row, int col) {
+    rmin = row < rmin ? row : rmin;
+    rmax = row > rmax ? row : rmax;
+    cmin = col < cmin ? col : cmin;
+    cmax = col > cmax ? col : cmax;
+  }
+  __device__ __forceinline__ unsigned long long wave_pack() {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      int t;
+      t = __shfl_xor(rmin, o, 64); rmin = t < rmin ? t : rmin;
+      t = __shfl_xor(rmax, o, 64); rmax = t > rmax ? t : rmax;
+      t = __shfl_xor(cmin, o, 64); cmin = t < cmin ? t : cmin;
+      t = __shfl_xor(cmax, o, 64); cmax = t > cmax ? t : cmax;
+    }
+    return pack_box(rmin, rmax, cmin, cmax);   // rmin > rmax: empty box
+  }
+};
+
+__device__ __forceinline__ int project_point(const r3d_batch_t &b, int s, const Binning &bn, double x,
+                                             double y, double z, int &flags, BoxAcc &box) {
+  Sph sp = spherical(x, y, z);
+  int row, col, p = 0;
+  int ok = bin_point(bn, sp.az, sp.el, row, col);
+  if (!(ok & 1)) flags |= isfinite(sp.el) ? R3D_S_ROW_RANGE : R3D_S_NONFINITE;   // assert :110
+  else if (!(ok & 2)) flags |= R3D_S_COL_RANGE;                                   // assert :112
+  else {
+    p = row * b.cols + col;
+    box.add(row, col);
+    if (sp.el == bn.max_el) b.extreme_pix[2 * s + 0] = p;   // any holder will do
+    if (sp.el == bn.min_el) b.extreme_pix[2 * s + 1] = p;
+    if (sp.r > R3D_EMPTY_DEPTH) {           // "first hit overwrites the 500": insertion.py:122-125
+      int f = atomicAdd(&b.n_far[s], 1);
+      if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
+      else flags |= R3D_S_FAR_OVERFLOW;
+    }
+  }
+  return p;
+}
+
 __global__ void __launch_bounds__(kPT)
-k_project(r3d_batch_t b, const int32_t *list, const int32_t *count) {
+k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int chunks) {
   int cnt = *count;
-  int64_t npix = (int64_t)b.rows * b.cols;
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
     int n = b.n_total[s], n_head = b.n_head[s];
     int t0 = blockIdx.x * kTile;
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.n_proj[s] = n;
     if (t0 >= n) continue;
     Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
-    unsigned long long *g = (unsigned long long *)b.grid + (int64_t)s * npix;
     int flags = 0;
 #pragma unroll 2
     for (int k = 0; k < kPerThread; ++k) {
       int i = t0 + k * kPT + threadIdx.x;
-      if (i >= n) continue;
-      double x, y, z;
-      load_point(b, s, i, n_head, x, y, z);
-      Sph sp = spherical(x, y, z);
-      int row, col;
-      int ok = bin_point(bn, sp.az, sp.el, row, col);
-      int p = 0;
-      if (!(ok & 1)) flags |= isfinite(sp.el) ? R3D_S_ROW_RANGE : R3D_S_NONFINITE;
-      else if (!(ok & 2)) flags |= R3D_S_COL_RANGE;
-      else {
-        p = row * b.cols + col;
-        atomicMin(&g[p], depth_key(sp.r));
-        if (sp.el == bn.max_el) b.extreme_pix[2 * s + 0] = p;   // any holder will do
-        if (sp.el == bn.min_el) b.extreme_pix[2 * s + 1] = p;
-        if (sp.r > R3D_EMPTY_DEPTH) {         // "first hit overwrites the 500": insertion.py:122-125
-          int f = atomicAdd(&b.n_far[s], 1);
-          if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
-          else flags |= R3D_S_FAR_OVERFLOW;
-        }
+      BoxAcc box;
+      if (i < n) {
+        double x, y, z;
+        load_point(b, s, i, n_head, x, y, z);
+        b.pix[(int64_t)s * b.cap + i] = project_point(b, s, bn, x, y, z, flags, box);
       }
-      b.pix[(int64_t)s * b.cap + i] = p;
+      unsigned long long packed = box.wave_pack();
+      int i0 = t0 + k * kPT + (threadIdx.x & ~63);
+      if ((threadIdx.x & 63) == 0 && i0 < n) w.chunk_box[(int64_t)s * chunks + (i0 >> 6)] = packed;
     }
     flags = wave_or_i32(flags);
     if ((threadIdx.x & 63) == 0 && flags) atomicOr(&b.status[s], flags);
@@ -310,7 +353,7 @@ __device__ __forceinline__ double mean_of_occupied(const Load &load, int r, int 
 __global__ void __launch_bounds__(kST)
 k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__restrict__ sample_off,
          const int32_t *__restrict__ min_points, const int32_t *__restrict__ active, int step,
-         int32_t *__restrict__ n_visible, int32_t *__restrict__ accepted, BatchWs w) {
+         int32_t *__restrict__ n_visible, int32_t *__restrict__ accepted, BatchWs w, int chunks) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int s = blockIdx.x;
   const int tid = threadIdx.x;
@@ -324,7 +367,8 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   int *s_nvalid = s_misc + 0, *s_ncand = s_misc + 1, *s_rebase = s_misc + 2, *s_flags = s_misc + 3;
   int *s_rmin = s_misc + 4, *s_rmax = s_misc + 5;                 // sample row range
   int *s_cmin = s_misc + 6, *s_cmax = s_misc + 8;                 // [2] column range per image half
-  int *s_scan = s_misc + 10;                                      // [kST/64 + 1]
+  int *s_nlist = s_misc + 10;                                     // chunks that touch the window
+  int *s_scan = s_misc + 11;                                      // [kST/64 + 1]
   BitImage A{s_img, wpr, rows};                // sample occupancy
   BitImage T{s_img + words, wpr, rows};        // scratch: dilations, candidate mask, then visible pixels
   BitImage Cs{s_img + 2 * words, wpr, rows};   // sample closed
@@ -347,14 +391,16 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   while (pw < m) pw <<= 1;
 
   for (int i = tid; i < 5 * words + kKeyCap / 32; i += kST) s_img[i] = 0u;
-  if (tid < 10) s_misc[tid] = (tid == 4 || tid == 6 || tid == 7) ? 0x7FFFFFFF : (tid == 5 || tid >= 8) ? -1 : 0;
+  if (tid < 11) s_misc[tid] = (tid == 4 || tid == 6 || tid == 7) ? 0x7FFFFFFF : (tid == 5 || tid == 8 || tid == 9) ? -1 : 0;
   __syncthreads();
 
   const Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], rows, cols);
   unsigned long long *grid = (unsigned long long *)b.grid + (int64_t)s * npix;
   unsigned long long *sgrid = (unsigned long long *)b.sgrid + (int64_t)s * npix;
   const double *rows5 = samples5 + off * 5;
-  auto ld_scene = [&](int q) { return grid[q]; };
+  auto ld_scene = [&](int q) {
+    return __hip_atomic_load(&grid[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   auto ld_sample = [&](int q) {
     return __hip_atomic_load(&sgrid[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
@@ -480,9 +526,49 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
     int p = (int)(s_keys[k] >> kIdxBits);
     if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != p) A.set(p);
   }
-  if (nvalid > 0 || n_far > 0) {
-    // scene occupancy: each lane loads the 4 pixels of one nibble of a window word (32-byte loads),
-    // 8 lanes assemble a word by shuffles -> plain LDS store, no LDS atomics
+  // -- 3b. the scene's range image inside the window, built from the points (insertion.py:118-125)
+  // Alive points whose pixel lies in the window min-reduce into the (all-empty) scratch image:
+  // first the 64-point chunks whose bounding box touches the window, then the points appended
+  // since the last projection.  Dead points (their pixel was visible at a later step) are skipped,
+  // which is what culling them (:472-473) does to the image.
+  uint32_t *cand = w.cand + (int64_t)s * npix;
+  const int n_total = b.n_total[s], n_head = b.n_head[s], n_log = b.n_log[s];
+  auto in_window = [&](int p) {
+    int r = p / cols, j = (p - r * cols) >> 5;
+    return r >= r_lo && r <= r_hi && ((j >= jl[0] && j <= jh[0]) || (n_iv > 1 && j >= jl[1] && j <= jh[1]));
+  };
+  auto reduce_point = [&](int i) {
+    int p = b.pix[(int64_t)s * b.cap + i];
+    if (!in_window(p) || !point_alive(b, s, i, n_head, npix, words)) return;
+    double x, y, z;
+    load_point(b, s, i, n_head, x, y, z);
+    atomicMin(&grid[p], depth_key(sqrt(x * x + y * y + z * z)));
+  };
+  if (nrw > 0) {
+    const int n_proj = w.n_proj[s] < n_total ? w.n_proj[s] : n_total;
+    const int n_chunks = (n_proj + 63) >> 6;
+    const unsigned long long *boxes = w.chunk_box + (int64_t)s * chunks;
+    for (int c = tid; c < n_chunks; c += kST) {
+      unsigned long long bx = boxes[c];
+      int rmin = (int)(bx & 0xFFFF), rmax = (int)((bx >> 16) & 0xFFFF);
+      int jmin = (int)((bx >> 32) & 0xFFFF) >> 5, jmax = (int)((bx >> 48) & 0xFFFF) >> 5;
+      bool hit = rmin <= r_hi && rmax >= r_lo &&
+                 ((jmin <= jh[0] && jmax >= jl[0]) || (n_iv > 1 && jmin <= jh[1] && jmax >= jl[1]));
+      if (hit) cand[atomicAdd(s_nlist, 1)] = (uint32_t)c;
+    }
+    __syncthreads();
+    const int nlist = *s_nlist;
+    for (int e = tid; e < nlist * 64; e += kST) {
+      int i = (int)(cand[e >> 6] << 6) + (e & 63);
+      if (i < n_proj) reduce_point(i);
+    }
+    for (int i = n_proj + tid; i < n_total; i += kST) reduce_point(i);
+  }
+  __syncthreads();     // every atomic of the block has been performed (vmcnt(0) at the barrier)
+
+  if (nrw > 0) {
+    // scene occupancy: each lane loads the 4 pixels of one nibble of a window word, 8 lanes
+    // assemble a word by shuffles -> plain LDS store, no LDS atomics
     const int total = nrw * njw * 8;
     for (int e0 = 0; e0 < total; e0 += kST) {
       int e = e0 + tid;
@@ -491,10 +577,9 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
       if (e < total) {
         r = win_row(e >> 3);
         j = win_word(e >> 3);
-        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(grid + r * cols + (j << 5) + ((e & 7) << 2));
-        ulonglong2 v0 = src[0], v1 = src[1];
-        nib = (v0.x != R3D_SENT ? 1u : 0u) | (v0.y != R3D_SENT ? 2u : 0u) | (v1.x != R3D_SENT ? 4u : 0u) |
-              (v1.y != R3D_SENT ? 8u : 0u);
+        int q0 = r * cols + (j << 5) + ((e & 7) << 2);
+        nib = (ld_scene(q0) != R3D_SENT ? 1u : 0u) | (ld_scene(q0 + 1) != R3D_SENT ? 2u : 0u) |
+              (ld_scene(q0 + 2) != R3D_SENT ? 4u : 0u) | (ld_scene(q0 + 3) != R3D_SENT ? 8u : 0u);
         nib <<= (e & 7) << 2;
       }
       nib |= __shfl_xor(nib, 1, 64);
@@ -541,7 +626,6 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
       }
   }
   __syncthreads();
-  uint32_t *cand = w.cand + (int64_t)s * npix;
   for (int e = tid; e < nrw * njw; e += kST) {
     int r = win_row(e), j = win_word(e);
     uint32_t bits = T.w[r * wpr + j];
@@ -577,7 +661,6 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   for (int k = tid; k < nvalid; k += kST) mine += vis.get((int)(s_keys[k] >> kIdxBits)) ? 1 : 0;
   int nvis;
   (void)block_escan_i32(mine, s_scan, nvis);
-  const int n_total = b.n_total[s], n_head = b.n_head[s], n_log = b.n_log[s];
   int need = min_points[s];
   bool accept = nvis > 0 && nvis >= need;
   if (accept && ((int64_t)n_total + nvis > b.cap || (int64_t)n_log + nvis > b.log_cap)) {
@@ -627,7 +710,6 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
       if (!vis.get(q)) continue;
       if (q == pix_of_max || q == pix_of_min) *s_rebase = 1;   // the recorded extreme point is culled
       unsigned long long nv = A.get(q) ? ld_sample(q) : R3D_SENT;
-      grid[q] = nv;
       if (nv != R3D_SENT && key_depth(nv) > R3D_EMPTY_DEPTH) {
         int f = atomicAdd(&b.n_far[s], 1);
         if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = q;
@@ -639,7 +721,13 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   }
   __syncthreads();
 
-  // -- 9. leave the sample scratch image clean, publish -----------------------------------------
+  // -- 9. leave both scratch images clean (all-empty), publish ----------------------------------
+  for (int e = tid; e < nrw * njw * 8; e += kST) {
+    int q0 = win_row(e >> 3) * cols + (win_word(e >> 3) << 5) + ((e & 7) << 2);
+    ulonglong2 sent = make_ulonglong2(R3D_SENT, R3D_SENT);
+    reinterpret_cast<ulonglong2 *>(grid + q0)[0] = sent;
+    reinterpret_cast<ulonglong2 *>(grid + q0)[1] = sent;
+  }
   for (int k = tid; k < nvalid; k += kST) {
     int p = (int)(s_keys[k] >> kIdxBits);
     if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != p) sgrid[p] = R3D_SENT;
@@ -781,7 +869,7 @@ __device__ __forceinline__ void phase_sync() {
 }
 
 __global__ void __launch_bounds__(kRB)
-k_rebase(r3d_batch_t b, BatchWs w) {
+k_rebase(r3d_batch_t b, BatchWs w, int chunks) {
   __shared__ int sm[kRB / 64 + 1];
   __shared__ unsigned long long s_min[kRB / 64], s_max[kRB / 64];
   const int tid = threadIdx.x;
@@ -861,38 +949,28 @@ k_rebase(r3d_batch_t b, BatchWs w) {
       b.extreme_pix[2 * s + 0] = b.extreme_pix[2 * s + 1] = -1;
       b.n_far[s] = 0;
     }
-    // (d) reset the images
-    unsigned long long *g = (unsigned long long *)b.grid + (int64_t)s * npix;
+    // (d) reset the visibility stamps
     for (int p = tid; p < npix; p += kRB) {
-      g[p] = R3D_SENT;
       b.stamp[(int64_t)s * npix + p] = 0;
       if (p < words) b.ever[(int64_t)s * words + p] = 0u;
     }
     phase_sync();
-    // (e) re-project (insertion.py:74-76, :104-127)
+    // (e) re-project (insertion.py:74-76, :104-116): pixel ids and chunk boxes
     Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
     int flags = 0;
-    for (int i = tid; i < n_new; i += kRB) {
-      double x, y, z;
-      load_point(b, s, i, new_head, x, y, z);
-      Sph sp = spherical(x, y, z);
-      int row, col, p = 0;
-      int ok = bin_point(bn, sp.az, sp.el, row, col);
-      if (!(ok & 1)) flags |= isfinite(sp.el) ? R3D_S_ROW_RANGE : R3D_S_NONFINITE;
-      else if (!(ok & 2)) flags |= R3D_S_COL_RANGE;
-      else {
-        p = row * b.cols + col;
-        atomicMin(&g[p], depth_key(sp.r));
-        if (sp.el == bn.max_el) b.extreme_pix[2 * s + 0] = p;
-        if (sp.el == bn.min_el) b.extreme_pix[2 * s + 1] = p;
-        if (sp.r > R3D_EMPTY_DEPTH) {
-          int f = atomicAdd(&b.n_far[s], 1);
-          if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
-          else flags |= R3D_S_FAR_OVERFLOW;
-        }
+    for (int i0 = 0; i0 < n_new; i0 += kRB) {
+      int i = i0 + tid;
+      BoxAcc box;
+      if (i < n_new) {
+        double x, y, z;
+        load_point(b, s, i, new_head, x, y, z);
+        b.pix[(int64_t)s * b.cap + i] = project_point(b, s, bn, x, y, z, flags, box);
       }
-      b.pix[(int64_t)s * b.cap + i] = p;
+      unsigned long long packed = box.wave_pack();
+      int c0 = i0 + (tid & ~63);
+      if ((tid & 63) == 0 && c0 < n_new) w.chunk_box[(int64_t)s * chunks + (c0 >> 6)] = packed;
     }
+    if (tid == 0) w.n_proj[s] = n_new;
     if (flags) atomicOr(&b.status[s], flags);
     phase_sync();
   }
@@ -958,7 +1036,7 @@ static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_
   int64_t npix = (int64_t)b.rows * b.cols;
   int rb = (int)((npix + kPT * 4 - 1) / (kPT * 4));
   hipLaunchKernelGGL(k_reset, dim3(rb, rows), dim3(kPT), 0, st, b, list, count);
-  hipLaunchKernelGGL(k_project, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count);
+  hipLaunchKernelGGL(k_project, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, chunks_of(b));
   R3D_LAUNCHED("reproject kernels");
   return R3D_OK;
 }
@@ -984,6 +1062,17 @@ size_t r3d_batch_workspace_bytes(const r3d_batch_t *b) {
   return carve_batch(*b, nullptr).total;
 }
 
+int r3d_batch_create(const r3d_batch_t *b, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  size_t bytes = (size_t)b->B * b->rows * b->cols * sizeof(unsigned long long);
+  // the two scratch range images are all-empty between calls; every kernel leaves them so
+  R3D_HIP(hipMemsetAsync(b->grid, 0xFF, bytes, st));
+  R3D_HIP(hipMemsetAsync(b->sgrid, 0xFF, bytes, st));
+  return R3D_OK;
+}
+
 int r3d_batch_begin(const r3d_batch_t *b, const int32_t *n_points, void *stream) {
   int rc = check_batch(b);
   if (rc != R3D_OK) return rc;
@@ -991,8 +1080,8 @@ int r3d_batch_begin(const r3d_batch_t *b, const int32_t *n_points, void *stream)
   hipStream_t st = (hipStream_t)stream;
   BatchWs w = carve_batch(*b, b->workspace);
   int64_t npix = (int64_t)b->rows * b->cols;
+  (void)npix;
   hipLaunchKernelGGL(k_begin_init, dim3((b->B + 255) / 256), dim3(256), 0, st, *b, n_points, w);
-  R3D_HIP(hipMemsetAsync(b->sgrid, 0xFF, (size_t)b->B * npix * sizeof(unsigned long long), st));
   return launch_reproject(*b, w, w.all_list, w.all_count, b->B, st);
 }
 
@@ -1017,7 +1106,8 @@ int r3d_batch_project(const r3d_batch_t *b, void *stream) {
   int64_t npix = (int64_t)b->rows * b->cols;
   int rb = (int)((npix + kPT * 4 - 1) / (kPT * 4));
   hipLaunchKernelGGL(k_reset, dim3(rb, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count);
-  hipLaunchKernelGGL(k_project, dim3(tiles_of(*b), b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count);
+  hipLaunchKernelGGL(k_project, dim3(tiles_of(*b), b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w,
+                     chunks_of(*b));
   R3D_LAUNCHED("project kernels");
   return R3D_OK;
 }
@@ -1039,11 +1129,11 @@ int r3d_batch_insert(const r3d_batch_t *b, const double *samples5, const int64_t
     lds_opted = lds;
   }
   hipLaunchKernelGGL(k_insert, dim3(b->B), dim3(kST), lds, st, *b, samples5, sample_off, min_points,
-                     active, (int)step, n_visible, accepted, w);
+                     active, (int)step, n_visible, accepted, w, chunks_of(*b));
   R3D_LAUNCHED("k_insert");
   // idle unless k_insert flagged a scene: then that scene is compacted and re-projected like step 0
   int rb = b->B < kRebaseRows ? b->B : kRebaseRows;
-  hipLaunchKernelGGL(k_rebase, dim3(rb), dim3(kRB), 0, st, *b, w);
+  hipLaunchKernelGGL(k_rebase, dim3(rb), dim3(kRB), 0, st, *b, w, chunks_of(*b));
   R3D_LAUNCHED("k_rebase");
   return R3D_OK;
 }

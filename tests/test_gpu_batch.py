@@ -56,11 +56,11 @@ def test_begin_matches_golden_pixels_and_bounds(P, synth):
     b.begin()
     assert np.array_equal(b.pix[0, :len(xyzi)].cpu().numpy(), g["scene_pix"])
     assert np.abs(b.bounds[0].cpu().numpy() - g["bounds"]).max() <= 1e-12
-    grid = b.grid[0].cpu().numpy().view(np.uint64)
-    raw = np.where(grid == np.uint64(0xFFFFFFFFFFFFFFFF), 500.0, grid.view(np.float64)).reshape(112, 1440)
-    assert np.array_equal(raw, g["scene_train_raw"])
+    # the scratch range images are all-empty between calls (the window min-reduce happens per insert)
+    assert bool((b.grid[0] == -1).all()) and bool((b.sgrid[0] == -1).all())
     nv, acc = b.insert([g["sample5"]], [20])
     assert nv[0] == len(g["visible_idx"]) and acc[0] == 1
+    assert bool((b.grid[0] == -1).all()) and bool((b.sgrid[0] == -1).all())
     b.finish()
     out_xyzi, out_label, check = b.results()[0]
     assert np.array_equal(out_xyzi[:len(g["keep_idx"])], xyzi[g["keep_idx"]])
