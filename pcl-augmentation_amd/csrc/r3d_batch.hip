@@ -17,7 +17,7 @@ namespace r3d {
 constexpr int kPT = 256;             // threads of the streaming kernels
 constexpr int kPerThread = 8;
 constexpr int kTile = kPT * kPerThread;   // points per block tile
-constexpr int kST = 512;             // threads of the per-scene insert kernel
+constexpr int kST = 1024;            // threads of the per-scene insert kernel
 constexpr int kKeyCap = R3D_MAX_SAMPLE;
 constexpr int kIdxBits = 13;         // kKeyCap == 1 << kIdxBits
 constexpr int kRebaseRows = 16;      // block rows of the (normally idle) rebase launches
@@ -28,7 +28,7 @@ struct BatchWs {
   int32_t *tile_head;           // [B*tiles]
   int32_t *new_head;            // [B]
   int32_t *tail_tmp;            // [B*log_cap]
-  uint32_t *cand;               // [B*npix] candidate pixel lists of the insert kernel
+  uint32_t *cand;               // [B*2*npix] chunk / candidate pixel lists of the insert kernel
   int32_t *all_list;            // [B] identity
   int32_t *all_count;           // [1] = B
   int32_t *rebase_list;         // [B]
@@ -36,6 +36,7 @@ struct BatchWs {
   int32_t *rebase_ticket;       // [1]
   unsigned long long *chunk_box; // [B*chunks] rows/cols bounding box of 64 consecutive points
   int32_t *n_proj;              // [B] points covered by the chunk boxes
+  double *smp_r;                // [B*R3D_MAX_SAMPLE] range of every sample point (k_insert scratch)
   size_t total;
 };
 
@@ -53,7 +54,7 @@ static BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.tile_head = c.take<int32_t>((size_t)b.B * tiles);
   w.new_head = c.take<int32_t>((size_t)b.B);
   w.tail_tmp = c.take<int32_t>((size_t)b.B * b.log_cap);
-  w.cand = c.take<uint32_t>((size_t)b.B * npix);
+  w.cand = c.take<uint32_t>((size_t)b.B * npix * 2);
   w.all_list = c.take<int32_t>((size_t)b.B);
   w.all_count = c.take<int32_t>(1);
   w.rebase_list = c.take<int32_t>((size_t)b.B);
@@ -61,6 +62,7 @@ static BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.rebase_ticket = c.take<int32_t>(1);
   w.chunk_box = c.take<unsigned long long>((size_t)b.B * chunks_of(b));
   w.n_proj = c.take<int32_t>((size_t)b.B);
+  w.smp_r = c.take<double>((size_t)b.B * kKeyCap);
   w.total = c.off;
   return w;
 }
@@ -83,6 +85,13 @@ __device__ __forceinline__ void load_point(const r3d_batch_t &b, int s, int i, i
     y = q[1];
     z = q[2];
   }
+}
+
+__device__ __forceinline__ bool point_alive_at(const r3d_batch_t &b, int s, int i, int p, int n_head,
+                                               int npix, int words) {
+  if (i < n_head) return !((b.ever[(int64_t)s * words + (p >> 5)] >> (p & 31)) & 1u);
+  int lr = b.tail_ref[(int64_t)s * b.log_cap + (i - n_head)];
+  return (int)b.stamp[(int64_t)s * npix + p] <= b.log_birth[(int64_t)s * b.log_cap + lr];
 }
 
 __device__ __forceinline__ bool point_alive(const r3d_batch_t &b, int s, int i, int n_head, int npix,
@@ -299,46 +308,128 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
 }
 
 // ---- one insert candidate per scene ------------------------------------------------------------
-// Row-aligned bit images (cols % 32 == 0, wpr = cols / 32 words per row) live in LDS; dilation and
-// erosion with the 5-row x 3-column element of closing.py:20 are word-parallel shifts and ORs/ANDs,
-// windows clipped at the image border exactly like the reference's (no azimuth wrap).
-struct BitImage {
-  uint32_t *w;
-  int wpr, rows;
-  __device__ __forceinline__ bool get(int p) const { return (w[p >> 5] >> (p & 31)) & 1u; }
-  __device__ __forceinline__ void set(int p) { atomicOr(&w[p >> 5], 1u << (p & 31)); }
-  __device__ __forceinline__ uint32_t word(int r, int j) const { return w[r * wpr + j]; }
+// One workgroup evaluates one placement candidate against one scene (insertion.py:455-526).
+// Everything it needs lives in a WINDOW of the range image around the sample: rows
+// [r_lo, r_hi] x one or two column intervals of whole 32-pixel words (two when the object
+// straddles the azimuth seam).  Inside the window:
+//   * bit images (sample / scene occupancy, their closings, candidates, visible pixels) are
+//     window-local words in LDS; the 5-row x 3-column closing of closing.py:20 is word-parallel
+//     shifts with ORs / ANDs, windows clipped at the image border like the reference's;
+//   * the scene's depths are min-reduced from the alive points into an LDS tile (or, when the
+//     window is too large for LDS, into the global scratch image `grid`);
+//   * the sample's depths live in an LDS array indexed by the rank of the pixel among the
+//     sample's occupied pixels (or in the global scratch image `sgrid`).
+// Sorts keys[0, pw) ascending; pw is a power of two, pw <= E * blockDim.x, pw >= 64.
+template <int E>
+__device__ __forceinline__ void block_bitonic_sort(uint32_t *keys, int pw, int tid) {
+  const int active = pw / E;                  // threads that own elements
+  uint32_t v[E];
+  const bool own = tid < active;
+#pragma unroll
+  for (int e = 0; e < E; ++e) v[e] = own ? keys[tid * E + e] : 0xFFFFFFFFu;
+  for (int k = 2; k <= pw; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64 * E) {                       // partner lives in another wave: exchange through LDS
+        __syncthreads();
+        if (own) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) keys[tid * E + e] = v[e];
+        }
+        __syncthreads();
+        if (own) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            int i = tid * E + e;
+            uint32_t o = keys[i ^ j];
+            bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+            v[e] = keep_min ? (o < v[e] ? o : v[e]) : (o > v[e] ? o : v[e]);
+          }
+        }
+      } else if (j >= E) {                     // partner is another lane of this wave
+        const int lane_mask = j / E;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          int i = tid * E + e;
+          uint32_t o = (uint32_t)__shfl_xor((int)v[e], lane_mask, 64);
+          bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+          v[e] = keep_min ? (o < v[e] ? o : v[e]) : (o > v[e] ? o : v[e]);
+        }
+      } else {                                 // partner is another register of this thread
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          int e2 = e ^ j;
+          if (e2 > e) {
+            int i = tid * E + e;
+            bool up = (i & k) == 0;
+            uint32_t a = v[e], c = v[e2];
+            bool swap = (a > c) == up;
+            v[e] = swap ? c : a;
+            v[e2] = swap ? a : c;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (own) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) keys[tid * E + e] = v[e];
+  }
+  __syncthreads();
+}
+
+struct Window {
+  int r_lo, r_hi, n_iv, jl[2], jh[2], nj0, njw, nrw, cols;
+  // window-local word index of image word (row r, word j), -1 outside the window
+  __device__ __forceinline__ int lword(int r, int j) const {
+    if (r < r_lo || r > r_hi) return -1;
+    int k;
+    if (j >= jl[0] && j <= jh[0]) k = j - jl[0];
+    else if (n_iv > 1 && j >= jl[1] && j <= jh[1]) k = nj0 + j - jl[1];
+    else return -1;
+    return (r - r_lo) * njw + k;
+  }
+  __device__ __forceinline__ int row_of(int e) const { return r_lo + e / njw; }      // e: local word
+  __device__ __forceinline__ int word_of(int e) const {
+    int k = e % njw;
+    return k < nj0 ? jl[0] + k : jl[1] + (k - nj0);
+  }
+  __device__ __forceinline__ int lpix_rc(int r, int c) const {  // window-local pixel, -1 outside
+    int lw = lword(r, c >> 5);
+    return lw < 0 ? -1 : (lw << 5) + (c & 31);
+  }
+  __device__ __forceinline__ int lpix(int q) const {
+    int r = q / cols;
+    return lpix_rc(r, q - r * cols);
+  }
 };
 
-// OR of a word with its two horizontal neighbours' bits (columns c-1, c, c+1), clipped at the row ends.
-__device__ __forceinline__ uint32_t hor3(const BitImage &m, int r, int j) {
-  uint32_t c = m.word(r, j);
-  uint32_t l = j > 0 ? m.word(r, j - 1) : 0u;
-  uint32_t rr = j < m.wpr - 1 ? m.word(r, j + 1) : 0u;
+struct WinImage {
+  uint32_t *w;
+  __device__ __forceinline__ bool get_local(int lp) const { return (w[lp >> 5] >> (lp & 31)) & 1u; }
+  __device__ __forceinline__ void set_local(int lp) { atomicOr(&w[lp >> 5], 1u << (lp & 31)); }
+  __device__ __forceinline__ uint32_t word(const Window &win, int r, int j) const {
+    int lw = win.lword(r, j);
+    return lw < 0 ? 0u : w[lw];
+  }
+};
+
+// OR of a word with its horizontal neighbours' bits (columns c-1, c, c+1), clipped at the row ends.
+__device__ __forceinline__ uint32_t hor3(const WinImage &m, const Window &win, int r, int j) {
+  uint32_t c = m.word(win, r, j), l = m.word(win, r, j - 1), rr = m.word(win, r, j + 1);
   return c | (c << 1) | (l >> 31) | (c >> 1) | (rr << 31);
 }
-// AND of the same three columns; a neighbour outside the image does not constrain (erosion border).
-__device__ __forceinline__ uint32_t hand3(const BitImage &m, int r, int j) {
-  uint32_t c = m.word(r, j);
-  uint32_t l = j > 0 ? (m.word(r, j - 1) >> 31) : 1u;
-  uint32_t rr = j < m.wpr - 1 ? (m.word(r, j + 1) << 31) : 0x80000000u;
+// AND of the same three columns; a neighbour outside the IMAGE does not constrain (erosion border).
+__device__ __forceinline__ uint32_t hand3(const WinImage &m, const Window &win, int r, int j, int wpr) {
+  uint32_t c = m.word(win, r, j);
+  uint32_t l = j > 0 ? (m.word(win, r, j - 1) >> 31) : 1u;
+  uint32_t rr = j < wpr - 1 ? (m.word(win, r, j + 1) << 31) : 0x80000000u;
   return c & ((c << 1) | l) & ((c >> 1) | rr);
 }
 
-// closing.py:44-57: all (up to 15) neighbour loads are issued first and are independent; an empty
-// pixel holds R3D_SENT, so occupancy is read off the value.  The sum then runs drow outer,
-// dcolumn inner over the occupied ones, as the reference's does.
-template <class Load>
-__device__ __forceinline__ double mean_of_occupied(const Load &load, int r, int c, int rows, int cols) {
-  unsigned long long v[15];
-#pragma unroll
-  for (int dr = -2; dr <= 2; ++dr)
-#pragma unroll
-    for (int dc = -1; dc <= 1; ++dc) {
-      int rr = r + dr, cc = c + dc;
-      bool in = rr >= 0 && rr < rows && cc >= 0 && cc < cols;
-      v[(dr + 2) * 3 + (dc + 1)] = in ? load(rr * cols + cc) : R3D_SENT;
-    }
+// closing.py:44-57 on up to 15 already loaded keys (R3D_SENT = empty): sum over the occupied ones,
+// drow outer / dcolumn inner, divided by their count.
+__device__ __forceinline__ double mean_of_keys(const unsigned long long (&v)[15]) {
   double sum = 0.0;
   int cnt = 0;
 #pragma unroll
@@ -350,6 +441,20 @@ __device__ __forceinline__ double mean_of_occupied(const Load &load, int r, int 
   return cnt ? sum / (double)cnt : R3D_EMPTY_DEPTH;
 }
 
+// Diagnostic builds (make STAMPS=1) record a 100 MHz wall-clock stamp per phase in the first bytes
+// of the scene's out_xyzi slab (scratch until r3d_batch_finish); tools/stamps_insert.py reads them.
+#ifdef R3D_STAMPS
+#define STAMP(i)                                                                                   \
+  do {                                                                                             \
+    __syncthreads();                                                                               \
+    if (tid == 0) reinterpret_cast<long long *>(b.out_xyzi + (int64_t)s * b.cap * 4)[i] = wall_clock64(); \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+constexpr int kLdsBytes = 160 * 1024;
+constexpr int kLdsFixed = 256 + kKeyCap / 8;      // counters + out-of-bounds bits
+
 __global__ void __launch_bounds__(kST)
 k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__restrict__ sample_off,
          const int32_t *__restrict__ min_points, const int32_t *__restrict__ active, int step,
@@ -360,20 +465,14 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   const int rows = b.rows, cols = b.cols;
   const int npix = rows * cols;
   const int words = npix >> 5, wpr = cols >> 5;
-  uint32_t *s_keys = reinterpret_cast<uint32_t *>(smem);          // [kKeyCap] sorted (pixel, index)
-  uint32_t *s_img = s_keys + kKeyCap;                             // 5 bit images of `words` words
-  uint32_t *s_oob = s_img + 5 * words;                            // [kKeyCap/32] el outside bounds
-  int *s_misc = reinterpret_cast<int *>(s_oob + kKeyCap / 32);
+  int *s_misc = reinterpret_cast<int *>(smem);
   int *s_nvalid = s_misc + 0, *s_ncand = s_misc + 1, *s_rebase = s_misc + 2, *s_flags = s_misc + 3;
   int *s_rmin = s_misc + 4, *s_rmax = s_misc + 5;                 // sample row range
   int *s_cmin = s_misc + 6, *s_cmax = s_misc + 8;                 // [2] column range per image half
-  int *s_nlist = s_misc + 10;                                     // chunks that touch the window
-  int *s_scan = s_misc + 11;                                      // [kST/64 + 1]
-  BitImage A{s_img, wpr, rows};                // sample occupancy
-  BitImage T{s_img + words, wpr, rows};        // scratch: dilations, candidate mask, then visible pixels
-  BitImage Cs{s_img + 2 * words, wpr, rows};   // sample closed
-  BitImage D{s_img + 3 * words, wpr, rows};    // scene occupancy (window only)
-  BitImage E{s_img + 4 * words, wpr, rows};    // scene closed (window only)
+  int *s_nlist = s_misc + 10, *s_carry = s_misc + 11;
+  int *s_scan = s_misc + 12;                                      // [kST/64 + 1]
+  uint32_t *s_oob = reinterpret_cast<uint32_t *>(smem + 256);     // [kKeyCap/32] el outside bounds
+  uint32_t *s_keys = reinterpret_cast<uint32_t *>(smem + kLdsFixed);   // [pw] sorted (pixel, index)
 
   const int64_t off = sample_off[s];
   const int64_t m64 = sample_off[s + 1] - off;
@@ -390,21 +489,17 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   int pw = 64;
   while (pw < m) pw <<= 1;
 
-  for (int i = tid; i < 5 * words + kKeyCap / 32; i += kST) s_img[i] = 0u;
-  if (tid < 11) s_misc[tid] = (tid == 4 || tid == 6 || tid == 7) ? 0x7FFFFFFF : (tid == 5 || tid == 8 || tid == 9) ? -1 : 0;
+  for (int i = tid; i < kKeyCap / 32; i += kST) s_oob[i] = 0u;
+  if (tid < 12) s_misc[tid] = (tid == 4 || tid == 6 || tid == 7) ? 0x7FFFFFFF : (tid == 5 || tid == 8 || tid == 9) ? -1 : 0;
   __syncthreads();
 
   const Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], rows, cols);
   unsigned long long *grid = (unsigned long long *)b.grid + (int64_t)s * npix;
   unsigned long long *sgrid = (unsigned long long *)b.sgrid + (int64_t)s * npix;
+  double *smp_r = w.smp_r + (int64_t)s * kKeyCap;
   const double *rows5 = samples5 + off * 5;
-  auto ld_scene = [&](int q) {
-    return __hip_atomic_load(&grid[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  auto ld_sample = [&](int q) {
-    return __hip_atomic_load(&sgrid[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
 
+  STAMP(0);
   // -- 1. project the sample with the scene's bounds, sample=True (insertion.py:455-459) ---------
   {
     // column ranges are kept per image half so that an object across the azimuth seam (columns
@@ -425,9 +520,8 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
           if (!(ok & 2)) {
             flags |= R3D_S_COL_RANGE;                // assert :112
           } else {
-            int p = row * cols + col;
-            key = ((uint32_t)p << kIdxBits) | (uint32_t)j;
-            atomicMin(&sgrid[p], depth_key(sp.r));
+            key = ((uint32_t)(row * cols + col) << kIdxBits) | (uint32_t)j;
+            smp_r[j] = sp.r;
             ++nval;
             rmin = row < rmin ? row : rmin;
             rmax = row > rmax ? row : rmax;
@@ -469,82 +563,155 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   }
   __syncthreads();
 
+  STAMP(1);
   // -- 2. sort (pixel, sample index): the order of visible_sample (insertion.py:474-482) ---------
-  for (int k = 2; k <= pw; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < pw; i += kST) {
-        int ixj = i ^ j;
-        if (ixj > i) {
-          uint32_t a = s_keys[i], c = s_keys[ixj];
-          bool up = (i & k) == 0;
-          if ((a > c) == up) {
-            s_keys[i] = c;
-            s_keys[ixj] = a;
-          }
-        }
-      }
-      __syncthreads();
-    }
+  // Bitonic network; thread t owns elements t*E .. t*E+E-1.  Strides below E swap registers,
+  // strides below 64*E are wave shuffles, only the strides that cross waves go through LDS.
+  switch (pw <= kST ? 1 : pw / kST) {
+    case 1: block_bitonic_sort<1>(s_keys, pw, tid); break;
+    case 2: block_bitonic_sort<2>(s_keys, pw, tid); break;
+    case 4: block_bitonic_sort<4>(s_keys, pw, tid); break;
+    default: block_bitonic_sort<8>(s_keys, pw, tid); break;
   }
   const int nvalid = *s_nvalid;
   const int n_far = b.n_far[s] < R3D_FAR_CAP ? b.n_far[s] : R3D_FAR_CAP;
+  const int n_total = b.n_total[s], n_head = b.n_head[s], n_log = b.n_log[s];
 
-  // -- 3. bit images: sample occupancy, scene occupancy in the window around the sample ----------
-  // candidates lie within 2 rows / 1 column of a sample pixel; their closing looks 4 rows / 2
-  // columns further.  The window is rows [r_lo, r_hi] x one or two column intervals (whole words
-  // jl[k]..jh[k]).  Pixels deeper than 500 m (far list) can be visible anywhere: whole image.
-  int r_lo = 0, r_hi = rows - 1, n_iv = 1;
-  int jl[2] = {0, 0}, jh[2] = {wpr - 1, 0};
+  STAMP(2);
+  // -- 3. the window: candidates lie within 2 rows / 1 column of a sample pixel, their closing
+  // looks 4 rows / 2 columns further.  Pixels deeper than 500 m (far list) can be visible
+  // anywhere: whole image.
+  Window win;
+  win.cols = cols;
+  win.r_lo = 0;
+  win.r_hi = rows - 1;
+  win.n_iv = 1;
+  win.jl[0] = 0;
+  win.jh[0] = wpr - 1;
+  win.jl[1] = win.jh[1] = 0;
   if (n_far == 0 && nvalid == 0) {
-    r_hi = -1;                                           // nothing can be visible: empty window
+    win.r_hi = -1;                                       // nothing can be visible: empty window
   } else if (n_far == 0) {
-    r_lo = *s_rmin - 6 < 0 ? 0 : *s_rmin - 6;
-    r_hi = *s_rmax + 6 > rows - 1 ? rows - 1 : *s_rmax + 6;
-    n_iv = 0;
+    win.r_lo = *s_rmin - 6 < 0 ? 0 : *s_rmin - 6;
+    win.r_hi = *s_rmax + 6 > rows - 1 ? rows - 1 : *s_rmax + 6;
+    win.n_iv = 0;
     for (int h = 0; h < 2; ++h) {
       if (s_cmax[h] < 0) continue;
       int lo = s_cmin[h] - 3 < 0 ? 0 : s_cmin[h] - 3;
       int hi = s_cmax[h] + 3 > cols - 1 ? cols - 1 : s_cmax[h] + 3;
       int a = lo >> 5, z = hi >> 5;
-      if (n_iv == 1 && a <= jh[0] + 1) jh[0] = z > jh[0] ? z : jh[0];   // touches the first: merge
+      if (win.n_iv == 1 && a <= win.jh[0] + 1) win.jh[0] = z > win.jh[0] ? z : win.jh[0];   // merge
       else {
-        jl[n_iv] = a;
-        jh[n_iv] = z;
-        ++n_iv;
+        win.jl[win.n_iv] = a;
+        win.jh[win.n_iv] = z;
+        ++win.n_iv;
       }
     }
   }
-  const int nj0 = jh[0] - jl[0] + 1, nj1 = n_iv > 1 ? jh[1] - jl[1] + 1 : 0, njw = nj0 + nj1;
-  const int nrw = r_hi - r_lo + 1;
-  // window word index e in [0, nrw * njw) -> (row, word-in-row)
-  auto win_row = [&](int e) { return r_lo + e / njw; };
-  auto win_word = [&](int e) {
-    int k = e % njw;
-    return k < nj0 ? jl[0] + k : jl[1] + (k - nj0);
-  };
+  win.nj0 = win.jh[0] - win.jl[0] + 1;
+  win.njw = win.nj0 + (win.n_iv > 1 ? win.jh[1] - win.jl[1] + 1 : 0);
+  win.nrw = win.r_hi - win.r_lo + 1;
+  const int ww = win.nrw * win.njw;                       // window words
+  const int wpx = ww << 5;                                // window pixels
+
+  // LDS carve: keys | 5 bit images + rank | sample depths | scene depth tile
+  int carve = (kLdsFixed + pw * 4 + 7) & ~7;
+  uint32_t *s_img = reinterpret_cast<uint32_t *>(smem + carve);
+  carve = (carve + 6 * ww * 4 + 7) & ~7;
+  WinImage A{s_img};                 // sample occupancy
+  WinImage T{s_img + ww};            // scratch: dilations, candidate mask, then visible pixels
+  WinImage Cs{s_img + 2 * ww};       // sample closed
+  WinImage D{s_img + 3 * ww};        // scene occupancy
+  WinImage E{s_img + 4 * ww};        // scene closed
+  uint32_t *s_rank = s_img + 5 * ww; // occupied sample pixels before each window word
+  const bool s_lds = carve + nvalid * 8 <= kLdsBytes;
+  unsigned long long *s_sdepth = reinterpret_cast<unsigned long long *>(smem + carve);
+  if (s_lds) carve += nvalid * 8;
+  const bool c_lds = carve + (int64_t)wpx * 8 <= kLdsBytes;
+  unsigned long long *s_ctile = reinterpret_cast<unsigned long long *>(smem + carve);
+
+  for (int i = tid; i < 6 * ww; i += kST) s_img[i] = 0u;
+  if (s_lds)
+    for (int i = tid; i < nvalid; i += kST) s_sdepth[i] = R3D_SENT;
+  if (c_lds)
+    for (int i = tid; i < wpx; i += kST) s_ctile[i] = R3D_SENT;
+  __syncthreads();
+
+  STAMP(3);
+  // -- 3a. sample occupancy, rank of every occupied sample pixel -----------------------------------
   for (int k = tid; k < nvalid; k += kST) {
     int p = (int)(s_keys[k] >> kIdxBits);
-    if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != p) A.set(p);
+    if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != p) A.set_local(win.lpix(p));
   }
+  __syncthreads();
+  for (int base = 0; base < ww; base += kST) {           // exclusive prefix popcount over the words
+    int e = base + tid;
+    int c = e < ww ? __popc(A.w[e]) : 0;
+    int tot;
+    int ex = block_escan_i32(c, s_scan, tot);
+    int carry0 = *s_carry;
+    if (e < ww) s_rank[e] = (uint32_t)(carry0 + ex);
+    __syncthreads();
+    if (tid == 0) *s_carry = carry0 + tot;
+    __syncthreads();
+  }
+  auto sample_rank = [&](int lp) {
+    return (int)s_rank[lp >> 5] + __popc(A.w[lp >> 5] & ((1u << (lp & 31)) - 1u));
+  };
+  // sample depth per occupied pixel = min r over its points (insertion.py:118-125); runs are short
+  for (int k = tid; k < nvalid; k += kST) {
+    uint32_t key = s_keys[k];
+    int p = (int)(key >> kIdxBits);
+    if (k != 0 && (int)(s_keys[k - 1] >> kIdxBits) == p) continue;
+    double best = smp_r[key & (kKeyCap - 1)];
+    for (int k2 = k + 1; k2 < nvalid && (int)(s_keys[k2] >> kIdxBits) == p; ++k2) {
+      double r2 = smp_r[s_keys[k2] & (kKeyCap - 1)];
+      best = r2 < best ? r2 : best;
+    }
+    if (s_lds) s_sdepth[sample_rank(win.lpix(p))] = depth_key(best);
+    else sgrid[p] = depth_key(best);
+  }
+  auto sample_key = [&](int q, int lp) -> unsigned long long {   // lp = window-local pixel of q
+    if (!A.get_local(lp)) return R3D_SENT;
+    return s_lds ? s_sdepth[sample_rank(lp)]
+                 : __hip_atomic_load(&sgrid[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+  STAMP(4);
   // -- 3b. the scene's range image inside the window, built from the points (insertion.py:118-125)
-  // Alive points whose pixel lies in the window min-reduce into the (all-empty) scratch image:
-  // first the 64-point chunks whose bounding box touches the window, then the points appended
-  // since the last projection.  Dead points (their pixel was visible at a later step) are skipped,
-  // which is what culling them (:472-473) does to the image.
-  uint32_t *cand = w.cand + (int64_t)s * npix;
-  const int n_total = b.n_total[s], n_head = b.n_head[s], n_log = b.n_log[s];
-  auto in_window = [&](int p) {
-    int r = p / cols, j = (p - r * cols) >> 5;
-    return r >= r_lo && r <= r_hi && ((j >= jl[0] && j <= jh[0]) || (n_iv > 1 && j >= jl[1] && j <= jh[1]));
+  // Alive points whose pixel lies in the window min-reduce into the tile: first the 64-point
+  // chunks whose bounding box touches the window, then the points appended since the last
+  // projection.  Dead points (their pixel was visible at a later step) are skipped, which is what
+  // culling them (:472-473) does to the image.
+  uint32_t *cand = w.cand + (int64_t)s * 2 * npix;      // [npix] window-local pixel, then [npix] (row, col)
+  uint32_t *cand_rc = cand + npix;
+  // 4 points per thread are taken through the dependent loads (pixel -> alive -> coordinates)
+  // stage by stage, so that the loads of one stage are in flight together.
+  auto reduce_points = [&](const int (&idx)[4]) {
+    int p[4], lp[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p[u] = idx[u] >= 0 ? b.pix[(int64_t)s * b.cap + idx[u]] : 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) lp[u] = idx[u] >= 0 ? win.lpix(p[u]) : -1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ok[u] = lp[u] >= 0 && point_alive_at(b, s, idx[u], p[u], n_head, npix, words);
+    double x[4], y[4], z[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      x[u] = 1.0;
+      y[u] = z[u] = 0.0;
+      if (ok[u]) load_point(b, s, idx[u], n_head, x[u], y[u], z[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      unsigned long long key = depth_key(sqrt(x[u] * x[u] + y[u] * y[u] + z[u] * z[u]));
+      if (c_lds) atomicMin(&s_ctile[lp[u]], key);
+      else atomicMin(&grid[p[u]], key);
+    }
   };
-  auto reduce_point = [&](int i) {
-    int p = b.pix[(int64_t)s * b.cap + i];
-    if (!in_window(p) || !point_alive(b, s, i, n_head, npix, words)) return;
-    double x, y, z;
-    load_point(b, s, i, n_head, x, y, z);
-    atomicMin(&grid[p], depth_key(sqrt(x * x + y * y + z * z)));
-  };
-  if (nrw > 0) {
+  if (ww > 0) {
     const int n_proj = w.n_proj[s] < n_total ? w.n_proj[s] : n_total;
     const int n_chunks = (n_proj + 63) >> 6;
     const unsigned long long *boxes = w.chunk_box + (int64_t)s * chunks;
@@ -552,69 +719,69 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
       unsigned long long bx = boxes[c];
       int rmin = (int)(bx & 0xFFFF), rmax = (int)((bx >> 16) & 0xFFFF);
       int jmin = (int)((bx >> 32) & 0xFFFF) >> 5, jmax = (int)((bx >> 48) & 0xFFFF) >> 5;
-      bool hit = rmin <= r_hi && rmax >= r_lo &&
-                 ((jmin <= jh[0] && jmax >= jl[0]) || (n_iv > 1 && jmin <= jh[1] && jmax >= jl[1]));
+      bool hit = rmin <= win.r_hi && rmax >= win.r_lo &&
+                 ((jmin <= win.jh[0] && jmax >= win.jl[0]) ||
+                  (win.n_iv > 1 && jmin <= win.jh[1] && jmax >= win.jl[1]));
       if (hit) cand[atomicAdd(s_nlist, 1)] = (uint32_t)c;
     }
     __syncthreads();
-    const int nlist = *s_nlist;
-    for (int e = tid; e < nlist * 64; e += kST) {
-      int i = (int)(cand[e >> 6] << 6) + (e & 63);
-      if (i < n_proj) reduce_point(i);
-    }
-    for (int i = n_proj + tid; i < n_total; i += kST) reduce_point(i);
-  }
-  __syncthreads();     // every atomic of the block has been performed (vmcnt(0) at the barrier)
-
-  if (nrw > 0) {
-    // scene occupancy: each lane loads the 4 pixels of one nibble of a window word, 8 lanes
-    // assemble a word by shuffles -> plain LDS store, no LDS atomics
-    const int total = nrw * njw * 8;
-    for (int e0 = 0; e0 < total; e0 += kST) {
-      int e = e0 + tid;
-      uint32_t nib = 0;
-      int r = 0, j = 0;
-      if (e < total) {
-        r = win_row(e >> 3);
-        j = win_word(e >> 3);
-        int q0 = r * cols + (j << 5) + ((e & 7) << 2);
-        nib = (ld_scene(q0) != R3D_SENT ? 1u : 0u) | (ld_scene(q0 + 1) != R3D_SENT ? 2u : 0u) |
-              (ld_scene(q0 + 2) != R3D_SENT ? 4u : 0u) | (ld_scene(q0 + 3) != R3D_SENT ? 8u : 0u);
-        nib <<= (e & 7) << 2;
+    const int npts = *s_nlist * 64;
+    for (int e0 = tid; e0 < npts; e0 += 4 * kST) {
+      int idx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int e = e0 + u * kST;
+        int i = e < npts ? (int)(cand[e >> 6] << 6) + (e & 63) : -1;
+        idx[u] = i < n_proj ? i : -1;
       }
-      nib |= __shfl_xor(nib, 1, 64);
-      nib |= __shfl_xor(nib, 2, 64);
-      nib |= __shfl_xor(nib, 4, 64);
-      if (e < total && (e & 7) == 0) D.w[r * wpr + j] = nib;
+      reduce_points(idx);
     }
+    for (int i0 = n_proj + tid; i0 < n_total; i0 += 4 * kST) {
+      int idx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) idx[u] = i0 + u * kST < n_total ? i0 + u * kST : -1;
+      reduce_points(idx);
+    }
+  }
+  __syncthreads();     // LDS tile complete / every global atomic performed (vmcnt(0) at the barrier)
+  auto scene_key = [&](int q, int lp) -> unsigned long long {
+    return c_lds ? s_ctile[lp] : __hip_atomic_load(&grid[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+  STAMP(5);
+  // scene occupancy bits: one window word per thread
+  for (int e = tid; e < ww; e += kST) {
+    int q0 = win.row_of(e) * cols + (win.word_of(e) << 5);
+    uint32_t bits = 0;
+    for (int bit = 0; bit < 32; ++bit) bits |= (scene_key(q0 + bit, (e << 5) + bit) != R3D_SENT ? 1u : 0u) << bit;
+    D.w[e] = bits;
   }
   __syncthreads();
 
+  STAMP(6);
   // -- 4. closing of both occupancies (closing.py:9-23) by word-parallel dilate / erode ----------
   // Exact on every row at least 2 inside the window (or at the image border): candidates are.
   for (int pass = 0; pass < 4; ++pass) {
-    const BitImage &src = pass == 0 ? A : pass == 2 ? D : T;
-    BitImage &dst = pass == 0 ? T : pass == 1 ? Cs : pass == 2 ? T : E;
+    const WinImage &src = pass == 0 ? A : pass == 2 ? D : T;
+    WinImage &dst = pass == 0 ? T : pass == 1 ? Cs : pass == 2 ? T : E;
     const bool erode = pass & 1;
-    for (int e = tid; e < nrw * njw; e += kST) {
-      int r = win_row(e), j = win_word(e);
+    for (int e = tid; e < ww; e += kST) {
+      int r = win.row_of(e), j = win.word_of(e);
       uint32_t acc = erode ? 0xFFFFFFFFu : 0u;
       for (int dr = -2; dr <= 2; ++dr) {
         int rr = r + dr;
         if (rr < 0 || rr >= rows) continue;
-        if (erode) acc &= hand3(src, rr, j);
-        else acc |= hor3(src, rr, j);
+        if (erode) acc &= hand3(src, win, rr, j, wpr);
+        else acc |= hor3(src, win, rr, j);
       }
-      dst.w[r * wpr + j] = acc;
+      dst.w[e] = acc;
     }
     __syncthreads();
   }
 
+  STAMP(7);
   // -- 5. candidate pixels: where the sample is closed, plus the far neighbourhoods --------------
-  for (int e = tid; e < nrw * njw; e += kST) {
-    int idx = win_row(e) * wpr + win_word(e);
-    T.w[idx] = Cs.w[idx];
-  }
+  for (int e = tid; e < ww; e += kST) T.w[e] = Cs.w[e];
   __syncthreads();
   for (int f = tid; f < n_far; f += kST) {
     int p = b.far_pix[(int64_t)s * R3D_FAR_CAP + f];
@@ -622,43 +789,64 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
     for (int dr = -2; dr <= 2; ++dr)
       for (int dc = -1; dc <= 1; ++dc) {
         int rr = r + dr, cc = c + dc;
-        if (rr >= 0 && rr < rows && cc >= 0 && cc < cols) T.set(rr * cols + cc);
+        if (rr >= 0 && rr < rows && cc >= 0 && cc < cols) T.set_local(win.lpix(rr * cols + cc));
       }
   }
   __syncthreads();
-  for (int e = tid; e < nrw * njw; e += kST) {
-    int r = win_row(e), j = win_word(e);
-    uint32_t bits = T.w[r * wpr + j];
+  for (int e = tid; e < ww; e += kST) {
+    uint32_t bits = T.w[e];
     if (!bits) continue;
     int pos = atomicAdd(s_ncand, __popc(bits));
+    const uint32_t rc0 = ((uint32_t)win.row_of(e) << 16) | (uint32_t)(win.word_of(e) << 5);
     while (bits) {
       int bit = __ffs(bits) - 1;
       bits &= bits - 1;
-      cand[pos++] = (uint32_t)(r * cols + (j << 5) + bit);
+      cand[pos] = (uint32_t)((e << 5) + bit);            // window-local pixel
+      cand_rc[pos++] = rc0 + (uint32_t)bit;              // (row << 16) | column
     }
   }
   __syncthreads();
   const int ncand = *s_ncand;
-  for (int e = tid; e < nrw * njw; e += kST) T.w[win_row(e) * wpr + win_word(e)] = 0u;
+  for (int e = tid; e < ww; e += kST) T.w[e] = 0u;
   __syncthreads();
-  BitImage &vis = T;
+  WinImage &vis = T;
 
+  STAMP(8);
   // -- 6. visibility on the candidates: smoothed sample depth < smoothed scene depth (:461-467) --
   for (int ci = tid; ci < ncand; ci += kST) {
-    int q = (int)cand[ci];
-    int r = q / cols, c = q - r * cols;
+    int lp = (int)cand[ci];
+    int r = (int)(cand_rc[ci] >> 16), c = (int)(cand_rc[ci] & 0xFFFF);
+    int q = r * cols + c;
     double sd = R3D_EMPTY_DEPTH, cd = R3D_EMPTY_DEPTH;
-    if (A.get(q)) sd = key_depth(ld_sample(q));
-    else if (Cs.get(q)) sd = mean_of_occupied(ld_sample, r, c, rows, cols);
-    if (D.get(q)) cd = key_depth(ld_scene(q));
-    else if (E.get(q)) cd = mean_of_occupied(ld_scene, r, c, rows, cols);
-    if (sd < cd) vis.set(q);
+    bool s_hole = !A.get_local(lp) && Cs.get_local(lp);
+    bool c_hole = !D.get_local(lp) && E.get_local(lp);
+    if (A.get_local(lp)) sd = key_depth(sample_key(q, lp));
+    if (D.get_local(lp)) cd = key_depth(scene_key(q, lp));
+    if (s_hole || c_hole) {
+      unsigned long long vs[15], vc[15];
+#pragma unroll
+      for (int dr = -2; dr <= 2; ++dr)
+#pragma unroll
+        for (int dc = -1; dc <= 1; ++dc) {
+          int rr = r + dr, cc = c + dc, k = (dr + 2) * 3 + (dc + 1);
+          vs[k] = vc[k] = R3D_SENT;
+          if (rr < 0 || rr >= rows || cc < 0 || cc >= cols) continue;
+          int q2 = rr * cols + cc, lp2 = win.lpix_rc(rr, cc);   // inside the window: holes are >= 2 rows in
+          if (lp2 < 0) continue;
+          if (s_hole) vs[k] = sample_key(q2, lp2);
+          if (c_hole) vc[k] = scene_key(q2, lp2);
+        }
+      if (s_hole) sd = mean_of_keys(vs);
+      if (c_hole) cd = mean_of_keys(vc);
+    }
+    if (sd < cd) vis.set_local(lp);
   }
   __syncthreads();
 
+  STAMP(9);
   // -- 7. count the visible sample points, accept test (insertion.py:511-517) --------------------
   int mine = 0;
-  for (int k = tid; k < nvalid; k += kST) mine += vis.get((int)(s_keys[k] >> kIdxBits)) ? 1 : 0;
+  for (int k = tid; k < nvalid; k += kST) mine += vis.get_local(win.lpix((int)(s_keys[k] >> kIdxBits))) ? 1 : 0;
   int nvis;
   (void)block_escan_i32(mine, s_scan, nvis);
   int need = min_points[s];
@@ -668,14 +856,15 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
     if (tid == 0) atomicOr(&b.status[s], R3D_S_CAPACITY);
   }
 
-  // -- 8. commit: append (insertion.py:526), patch the range image, stamp ------------------------
+  STAMP(10);
+  // -- 8. commit: append (insertion.py:526), stamp the visible pixels ------------------------------
   if (accept) {
     int base = 0;
     for (int k0 = 0; k0 < nvalid; k0 += kST) {
       int k = k0 + tid;
       uint32_t key = k < nvalid ? s_keys[k] : 0u;
       int p = (int)(key >> kIdxBits);
-      int flag = (k < nvalid && vis.get(p)) ? 1 : 0;
+      int flag = (k < nvalid && vis.get_local(win.lpix(p))) ? 1 : 0;
       int tot;
       int ex = block_escan_i32(flag, s_scan, tot);
       if (flag) {
@@ -706,11 +895,12 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
     uint16_t *stamp = b.stamp + (int64_t)s * npix;
     uint32_t *ever = b.ever + (int64_t)s * words;
     for (int ci = tid; ci < ncand; ci += kST) {
-      int q = (int)cand[ci];
-      if (!vis.get(q)) continue;
+      int lp = (int)cand[ci];
+      if (!vis.get_local(lp)) continue;
+      int q = (int)(cand_rc[ci] >> 16) * cols + (int)(cand_rc[ci] & 0xFFFF);
       if (q == pix_of_max || q == pix_of_min) *s_rebase = 1;   // the recorded extreme point is culled
-      unsigned long long nv = A.get(q) ? ld_sample(q) : R3D_SENT;
-      if (nv != R3D_SENT && key_depth(nv) > R3D_EMPTY_DEPTH) {
+      unsigned long long nv = sample_key(q, lp);
+      if (nv != R3D_SENT && key_depth(nv) > R3D_EMPTY_DEPTH) {  // the pixel now holds a far return
         int f = atomicAdd(&b.n_far[s], 1);
         if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = q;
         else atomicOr(s_flags, R3D_S_FAR_OVERFLOW);
@@ -721,17 +911,28 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   }
   __syncthreads();
 
-  // -- 9. leave both scratch images clean (all-empty), publish ----------------------------------
-  for (int e = tid; e < nrw * njw * 8; e += kST) {
-    int q0 = win_row(e >> 3) * cols + (win_word(e >> 3) << 5) + ((e & 7) << 2);
-    ulonglong2 sent = make_ulonglong2(R3D_SENT, R3D_SENT);
-    reinterpret_cast<ulonglong2 *>(grid + q0)[0] = sent;
-    reinterpret_cast<ulonglong2 *>(grid + q0)[1] = sent;
+  STAMP(11);
+  // -- 9. leave the global scratch images all-empty (only touched when LDS was too small), publish
+  if (!c_lds)
+    for (int e = tid; e < ww * 8; e += kST) {
+      int q0 = win.row_of(e >> 3) * cols + (win.word_of(e >> 3) << 5) + ((e & 7) << 2);
+      ulonglong2 sent = make_ulonglong2(R3D_SENT, R3D_SENT);
+      reinterpret_cast<ulonglong2 *>(grid + q0)[0] = sent;
+      reinterpret_cast<ulonglong2 *>(grid + q0)[1] = sent;
+    }
+  if (!s_lds)
+    for (int k = tid; k < nvalid; k += kST) {
+      int p = (int)(s_keys[k] >> kIdxBits);
+      if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != p) sgrid[p] = R3D_SENT;
+    }
+  STAMP(12);
+#ifdef R3D_STAMPS
+  if (tid == 0) {
+    long long *dbg = reinterpret_cast<long long *>(b.out_xyzi + (int64_t)s * b.cap * 4);
+    dbg[13] = ((long long)ww << 32) | (unsigned)ncand;
+    dbg[14] = ((long long)*s_nlist << 32) | (unsigned)nvalid;
   }
-  for (int k = tid; k < nvalid; k += kST) {
-    int p = (int)(s_keys[k] >> kIdxBits);
-    if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != p) sgrid[p] = R3D_SENT;
-  }
+#endif
   if (tid == 0) {
     n_visible[s] = nvis;
     accepted[s] = accept ? 1 : 0;
@@ -1013,8 +1214,8 @@ static int check_batch(const r3d_batch_t *b) {
     return fail(R3D_E_ARG, "batch: null array");
   if (b->cols % 32 != 0)
     return fail(R3D_E_ARG, "batch: cols must be a multiple of 32 (row-aligned bit images)");
-  size_t lds = (size_t)kKeyCap * 4 + 5 * (size_t)mask_words(*b) * 4 + kKeyCap / 8 + 64 * 4;
-  if (lds > 160 * 1024)
+  size_t lds = (size_t)kLdsFixed + (size_t)kKeyCap * 4 + 6 * (size_t)mask_words(*b) * 4 + 16;
+  if (lds > (size_t)kLdsBytes)
     return fail(R3D_E_ARG, "batch: range image too large for the LDS-resident masks of k_insert");
   if (b->workspace_bytes < carve_batch(*b, nullptr).total)
     return fail(R3D_E_WORKSPACE, "batch: workspace smaller than r3d_batch_workspace_bytes()");
@@ -1022,7 +1223,8 @@ static int check_batch(const r3d_batch_t *b) {
 }
 
 static size_t insert_lds_bytes(const r3d_batch_t &b) {
-  return (size_t)kKeyCap * 4 + 5 * (size_t)mask_words(b) * 4 + kKeyCap / 8 + 64 * 4;
+  (void)b;
+  return (size_t)kLdsBytes;      // carved at run time: keys | bit images | sample depths | scene tile
 }
 
 // bounds -> reset -> project for the scenes of (list, count); rows = block rows of the launches.
