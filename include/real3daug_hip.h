@@ -131,7 +131,7 @@ int r3d_remove_space_for_spherical(const double *pcl9, int64_t n, float *xyzi, u
 typedef struct r3d_batch {
   int32_t B;             /* scenes in the batch */
   int32_t rows, cols;    /* range image shape (reference: 112 x 1440) */
-  int32_t reserved;
+  int32_t reserved;      /* bit 0: diagnostic, project with the reference formula only (no float32 guess) */
   int64_t cap;           /* point capacity per scene (original points + every insert) */
   int64_t log_cap;       /* inserted-point capacity per scene */
   /* the cloud of scene s lives at index s*cap .. s*cap + n_total[s] */

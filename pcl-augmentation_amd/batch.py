@@ -26,7 +26,8 @@ def shard_indices(n_scenes: int, rank: int, world_size: int):
 class SceneBatch:
     last_rebases = 0      # rebases counted by the most recent augment_batch (diagnostics / tests)
 
-    def __init__(self, B, cap, log_cap, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN, device="cuda:0"):
+    def __init__(self, B, cap, log_cap, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN, device="cuda:0",
+                 exact_projection=False):
         torch = _lib.require_gpu()
         self.torch = torch
         self.lib = _lib.load()
@@ -68,7 +69,9 @@ class SceneBatch:
         self.step = 0
 
         d = _lib.BatchDesc()
-        d.B, d.rows, d.cols, d.reserved, d.cap, d.log_cap = B, rows, cols, 0, cap, log_cap
+        # reserved bit 0: evaluate the reference's float64 formula for every point instead of the
+        # verified float32 guess (diagnostic; results are identical, tests/test_gpu_batch.py)
+        d.B, d.rows, d.cols, d.reserved, d.cap, d.log_cap = B, rows, cols, 1 if exact_projection else 0, cap, log_cap
         for name in ("xyzi", "label", "pix", "n_head", "n_total", "tail_ref", "log5", "log_birth", "n_log",
                      "grid", "sgrid", "stamp", "ever", "bounds", "extreme_pix", "far_pix", "n_far", "rebase",
                      "status", "out_xyzi", "out_label", "n_out"):

@@ -37,6 +37,11 @@ struct BatchWs {
   unsigned long long *chunk_box; // [B*chunks] rows/cols bounding box of 64 consecutive points
   int32_t *n_proj;              // [B] points covered by the chunk boxes
   double *smp_r;                // [B*R3D_MAX_SAMPLE] range of every sample point (k_insert scratch)
+  double *row_q;                // [B*(rows+2)] cos of the row edges: row k <=> row_q[k+1] >= z/r > row_q[k+2]
+  double *col_dir;              // [(cols+1)*2] unit vector of every column edge
+  double *q_ext;                // [B*2] min and max of z/r (the points that hold the elevation bounds)
+  int32_t *n_slow;              // [B] points queued for k_project_slow
+  int64_t cand_stride;          // uint32 entries of `cand` per scene: max(2*npix, cap)
   size_t total;
 };
 
@@ -54,7 +59,8 @@ static BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.tile_head = c.take<int32_t>((size_t)b.B * tiles);
   w.new_head = c.take<int32_t>((size_t)b.B);
   w.tail_tmp = c.take<int32_t>((size_t)b.B * b.log_cap);
-  w.cand = c.take<uint32_t>((size_t)b.B * npix * 2);
+  w.cand_stride = 2 * npix > b.cap ? 2 * npix : b.cap;
+  w.cand = c.take<uint32_t>((size_t)b.B * w.cand_stride);
   w.all_list = c.take<int32_t>((size_t)b.B);
   w.all_count = c.take<int32_t>(1);
   w.rebase_list = c.take<int32_t>((size_t)b.B);
@@ -63,6 +69,10 @@ static BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.chunk_box = c.take<unsigned long long>((size_t)b.B * chunks_of(b));
   w.n_proj = c.take<int32_t>((size_t)b.B);
   w.smp_r = c.take<double>((size_t)b.B * kKeyCap);
+  w.row_q = c.take<double>((size_t)b.B * (b.rows + 2));
+  w.col_dir = c.take<double>((size_t)(b.cols + 1) * 2);
+  w.q_ext = c.take<double>((size_t)b.B * 2);
+  w.n_slow = c.take<int32_t>((size_t)b.B);
   w.total = c.off;
   return w;
 }
@@ -203,11 +213,39 @@ __global__ void k_bounds_finish(r3d_batch_t b, const int32_t *list, const int32_
   b.bounds[2 * s + 0] = max_el;
   b.bounds[2 * s + 1] = min_el;
   b.extreme_pix[2 * s + 0] = b.extreme_pix[2 * s + 1] = -1;   // recorded by the projection pass
+  w.q_ext[2 * s + 0] = ordered_key_inv(kmin);
+  w.q_ext[2 * s + 1] = ordered_key_inv(kmax);
+}
+
+// Tables of the verified fast projection (k_project): a bin guessed in float32 is accepted only if
+// the point lies strictly inside that bin's edges, tested in float64 on monotone images of the
+// edges -- cos of the row edges against z/r, and the sign of the cross product with the unit
+// vector of the column edges -- with a margin far above the rounding of either side.
+__global__ void k_row_table(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
+  int li = blockIdx.y;
+  if (li >= *count) return;
+  int s = list[li];
+  int k = blockIdx.x * blockDim.x + threadIdx.x;           // entry k holds edge k-1
+  if (k >= b.rows + 2) return;
+  double max_el = b.bounds[2 * s + 0], min_el = b.bounds[2 * s + 1];
+  double d_el = (max_el - min_el) / (double)b.rows;
+  double edge = min_el + 0.00001 + (double)(k - 1) * d_el;
+  // outside [0, pi] the cosine stops being monotone: clamp (such rows can hold no point anyway)
+  edge = edge < 0.0 ? 0.0 : (edge > kPi ? kPi : edge);
+  w.row_q[(int64_t)s * (b.rows + 2) + k] = cos(edge);
+}
+
+__global__ void k_col_table(r3d_batch_t b, BatchWs w) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > b.cols) return;
+  double alpha = (double)c * (kTwoPi / (double)b.cols) - kPi;   // direction angle of column edge c
+  w.col_dir[2 * c + 0] = cos(alpha);
+  w.col_dir[2 * c + 1] = sin(alpha);
 }
 
 // ---- step 0 / rebase: reset the per-scene visibility stamps -------------------------------------
 __global__ void __launch_bounds__(kPT)
-k_reset(r3d_batch_t b, const int32_t *list, const int32_t *count) {
+k_reset(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
   int cnt = *count;
   int64_t npix = (int64_t)b.rows * b.cols;
   int words = (int)((npix + 31) / 32);
@@ -219,7 +257,10 @@ k_reset(r3d_batch_t b, const int32_t *list, const int32_t *count) {
       st[p] = 0u;
       if (p < words) ev[p] = 0u;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) b.n_far[s] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      b.n_far[s] = 0;
+      w.n_slow[s] = 0;
+    }
   }
 }
 
@@ -236,24 +277,24 @@ __device__ __forceinline__ unsigned long long pack_box(int rmin, int rmax, int c
 }
 
 // Projects point i of scene s (if valid) and returns its pixel; accumulates the wave's box.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
 struct BoxAcc {
-  int rmin = 0xFFFF, rmax = 0, cmin = 0xFFFF, cmax = 0;
+  u16x2 lo = {0xFFFF, 0xFFFF}, hi = {0, 0};        // (row, col) minima and maxima
   __device__ __forceinline__ void add(int row, int col) {
-    rmin = row < rmin ? row : rmin;
-    rmax = row > rmax ? row : rmax;
-    cmin = col < cmin ? col : cmin;
-    cmax = col > cmax ? col : cmax;
+    u16x2 v = {(unsigned short)row, (unsigned short)col};
+    lo = __builtin_elementwise_min(lo, v);
+    hi = __builtin_elementwise_max(hi, v);
   }
   __device__ __forceinline__ unsigned long long wave_pack() {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      int t;
-      t = __shfl_xor(rmin, o, 64); rmin = t < rmin ? t : rmin;
-      t = __shfl_xor(rmax, o, 64); rmax = t > rmax ? t : rmax;
-      t = __shfl_xor(cmin, o, 64); cmin = t < cmin ? t : cmin;
-      t = __shfl_xor(cmax, o, 64); cmax = t > cmax ? t : cmax;
+    for (int o = 32; o > 0; o >>= 1) {                 // two packed 16-bit reductions per step
+      int tl = __shfl_xor(__builtin_bit_cast(int, lo), o, 64);
+      int th = __shfl_xor(__builtin_bit_cast(int, hi), o, 64);
+      lo = __builtin_elementwise_min(lo, __builtin_bit_cast(u16x2, tl));
+      hi = __builtin_elementwise_max(hi, __builtin_bit_cast(u16x2, th));
     }
-    return pack_box(rmin, rmax, cmin, cmax);   // rmin > rmax: empty box
+    return pack_box(lo.x, hi.x, lo.y, hi.y);           // rmin > rmax: empty box
   }
 };
 
@@ -278,17 +319,55 @@ __device__ __forceinline__ int project_point(const r3d_batch_t &b, int s, const 
   return p;
 }
 
+// Verified float32 guess of (row, col); returns false when the float64 check cannot confirm the
+// guessed bin (the caller then queues the point for the reference formula).
+constexpr double kEdgeMargin = 1e-12;
+
+__device__ __forceinline__ bool fast_bin(const Binning &bn, const double *__restrict__ row_q,
+                                         const double *__restrict__ col_dir, float inv_del, float inv_daz,
+                                         float elo, double x, double y, double z, double r, double q,
+                                         int &row, int &col) {
+  float xf = (float)x, yf = (float)y, zf = (float)z;
+  float qf = zf * __frsqrt_rn(xf * xf + yf * yf + zf * zf);
+  qf = qf < -1.f ? -1.f : (qf > 1.f ? 1.f : qf);
+  int rg = (int)floorf((acosf(qf) - elo) * inv_del);
+  int cg = (int)((atan2f(yf, xf) + 3.14159274f) * inv_daz);
+  rg = rg < 0 ? 0 : (rg > bn.rows - 1 ? bn.rows - 1 : rg);
+  cg = cg < 0 ? 0 : (cg > bn.cols - 1 ? bn.cols - 1 : cg);
+  if (!(fabs(q) < 0.999999)) return false;                    // acos is ill-conditioned there
+  // rows: elevation in [edge_k, edge_k+1)  <=>  cos(edge_k+1) < q <= cos(edge_k); row 0 also takes
+  // the truncated interval below edge_0 (int() rounds toward zero)
+  double hi = row_q[rg == 0 ? 0 : rg + 1], lo = row_q[rg + 2];
+  double ax = col_dir[2 * cg], ay = col_dir[2 * cg + 1], bx = col_dir[2 * cg + 2], by = col_dir[2 * cg + 3];
+  const double m2 = kEdgeMargin * r;
+  row = rg;
+  col = cg;
+  return q < hi - kEdgeMargin && q > lo + kEdgeMargin && ax * y - ay * x > m2 && bx * y - by * x < -m2;
+}
+
 __global__ void __launch_bounds__(kPT)
 k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int chunks) {
+  extern __shared__ __align__(16) double s_tab[];          // [(cols+1)*2] column edges, [rows+2] row edges
+  double *s_col = s_tab, *s_row = s_tab + (b.cols + 1) * 2;
+  for (int e = threadIdx.x; e < (b.cols + 1) * 2; e += kPT) s_col[e] = w.col_dir[e];
   int cnt = *count;
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
     int n = b.n_total[s], n_head = b.n_head[s];
     int t0 = blockIdx.x * kTile;
     if (blockIdx.x == 0 && threadIdx.x == 0) w.n_proj[s] = n;
+    __syncthreads();                                       // previous scene's row table is no longer read
+    for (int e = threadIdx.x; e < b.rows + 2; e += kPT) s_row[e] = w.row_q[(int64_t)s * (b.rows + 2) + e];
+    __syncthreads();
     if (t0 >= n) continue;
     Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
+    const bool exact = b.reserved & 1;                       // diagnostic: reference formula only
+    const float inv_del = (float)(1.0 / bn.d_el), inv_daz = (float)(1.0 / bn.d_az);
+    const float elo = (float)(bn.min_el + 0.00001);
+    const double q_min = w.q_ext[2 * s + 0], q_max = w.q_ext[2 * s + 1];
+    uint32_t *queue = w.cand + (int64_t)s * w.cand_stride;  // k_insert scratch, free during step 0
     int flags = 0;
+    // verified float32 guess, 8 points per thread; unconfirmed points are queued for k_project_slow
 #pragma unroll 2
     for (int k = 0; k < kPerThread; ++k) {
       int i = t0 + k * kPT + threadIdx.x;
@@ -296,7 +375,25 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
       if (i < n) {
         double x, y, z;
         load_point(b, s, i, n_head, x, y, z);
-        b.pix[(int64_t)s * b.cap + i] = project_point(b, s, bn, x, y, z, flags, box);
+        double r = sqrt(x * x + y * y + z * z);
+        double q = z / r;
+        int row, col;
+        if (!exact && fast_bin(bn, s_row, s_col, inv_del, inv_daz, elo, x, y, z, r, q, row, col)) {
+          int p = row * b.cols + col;
+          box.add(row, col);
+          if (q == q_min) b.extreme_pix[2 * s + 0] = p;      // max elevation = acos(min z/r)
+          if (q == q_max) b.extreme_pix[2 * s + 1] = p;
+          if (r > R3D_EMPTY_DEPTH) {
+            int f = atomicAdd(&b.n_far[s], 1);
+            if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
+            else flags |= R3D_S_FAR_OVERFLOW;
+          }
+          b.pix[(int64_t)s * b.cap + i] = p;
+        } else {
+          queue[atomicAdd(&w.n_slow[s], 1)] = (uint32_t)i;
+          box.add(0, 0);                                     // unknown pixel: the chunk's box covers
+          box.add(b.rows - 1, b.cols - 1);                   // the whole image
+        }
       }
       unsigned long long packed = box.wave_pack();
       int i0 = t0 + k * kPT + (threadIdx.x & ~63);
@@ -304,6 +401,29 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
     }
     flags = wave_or_i32(flags);
     if ((threadIdx.x & 63) == 0 && flags) atomicOr(&b.status[s], flags);
+  }
+}
+
+// The reference formula (insertion.py:74-76, :104-116) for the points k_project could not confirm:
+// none to a handful per scan (points within 1e-12 of a bin edge, or a float32 guess one bin off).
+__global__ void __launch_bounds__(kPT)
+k_project_slow(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
+  int cnt = *count;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    int s = list[li];
+    int n_slow = w.n_slow[s], n_head = b.n_head[s];
+    if (blockIdx.x * kPT >= n_slow) continue;
+    Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
+    const uint32_t *queue = w.cand + (int64_t)s * w.cand_stride;
+    int flags = 0;
+    for (int e = blockIdx.x * kPT + threadIdx.x; e < n_slow; e += gridDim.x * kPT) {
+      int i = (int)queue[e];
+      double x, y, z;
+      load_point(b, s, i, n_head, x, y, z);
+      BoxAcc unused;
+      b.pix[(int64_t)s * b.cap + i] = project_point(b, s, bn, x, y, z, flags, unused);
+    }
+    if (flags) atomicOr(&b.status[s], flags);
   }
 }
 
@@ -683,7 +803,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   // chunks whose bounding box touches the window, then the points appended since the last
   // projection.  Dead points (their pixel was visible at a later step) are skipped, which is what
   // culling them (:472-473) does to the image.
-  uint32_t *cand = w.cand + (int64_t)s * 2 * npix;      // [npix] window-local pixel, then [npix] (row, col)
+  uint32_t *cand = w.cand + (int64_t)s * w.cand_stride;  // [npix] window-local pixel, then [npix] (row, col)
   uint32_t *cand_rc = cand + npix;
   // 4 points per thread are taken through the dependent loads (pixel -> alive -> coordinates)
   // stage by stage, so that the loads of one stage are in flight together.
@@ -1222,6 +1342,10 @@ static int check_batch(const r3d_batch_t *b) {
   return R3D_OK;
 }
 
+static size_t project_lds_bytes(const r3d_batch_t &b) {
+  return ((size_t)(b.cols + 1) * 2 + b.rows + 2) * sizeof(double);
+}
+
 static size_t insert_lds_bytes(const r3d_batch_t &b) {
   (void)b;
   return (size_t)kLdsBytes;      // carved at run time: keys | bit images | sample depths | scene tile
@@ -1235,10 +1359,13 @@ static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_
   hipLaunchKernelGGL(k_bounds_init, dim3(lb), dim3(256), 0, st, list, count, w);
   hipLaunchKernelGGL(k_bounds, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_bounds_finish, dim3(lb), dim3(256), 0, st, b, list, count, w);
+  hipLaunchKernelGGL(k_row_table, dim3((b.rows + 2 + 127) / 128, rows), dim3(128), 0, st, b, list, count, w);
   int64_t npix = (int64_t)b.rows * b.cols;
   int rb = (int)((npix + kPT * 4 - 1) / (kPT * 4));
-  hipLaunchKernelGGL(k_reset, dim3(rb, rows), dim3(kPT), 0, st, b, list, count);
-  hipLaunchKernelGGL(k_project, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, chunks_of(b));
+  hipLaunchKernelGGL(k_reset, dim3(rb, rows), dim3(kPT), 0, st, b, list, count, w);
+  hipLaunchKernelGGL(k_project, dim3(tiles, rows), dim3(kPT), project_lds_bytes(b), st, b, list, count, w,
+                     chunks_of(b));
+  hipLaunchKernelGGL(k_project_slow, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w);
   R3D_LAUNCHED("reproject kernels");
   return R3D_OK;
 }
@@ -1272,6 +1399,9 @@ int r3d_batch_create(const r3d_batch_t *b, void *stream) {
   // the two scratch range images are all-empty between calls; every kernel leaves them so
   R3D_HIP(hipMemsetAsync(b->grid, 0xFF, bytes, st));
   R3D_HIP(hipMemsetAsync(b->sgrid, 0xFF, bytes, st));
+  BatchWs w = carve_batch(*b, b->workspace);
+  hipLaunchKernelGGL(k_col_table, dim3((b->cols + 1 + 255) / 256), dim3(256), 0, st, *b, w);
+  R3D_LAUNCHED("k_col_table");
   return R3D_OK;
 }
 
@@ -1296,6 +1426,8 @@ int r3d_batch_elev_bounds(const r3d_batch_t *b, void *stream) {
   hipLaunchKernelGGL(k_bounds_init, dim3(lb), dim3(256), 0, st, w.all_list, w.all_count, w);
   hipLaunchKernelGGL(k_bounds, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w);
   hipLaunchKernelGGL(k_bounds_finish, dim3(lb), dim3(256), 0, st, *b, w.all_list, w.all_count, w);
+  hipLaunchKernelGGL(k_row_table, dim3((b->rows + 2 + 127) / 128, b->B), dim3(128), 0, st, *b, w.all_list,
+                     w.all_count, w);
   R3D_LAUNCHED("bounds kernels");
   return R3D_OK;
 }
@@ -1307,9 +1439,10 @@ int r3d_batch_project(const r3d_batch_t *b, void *stream) {
   BatchWs w = carve_batch(*b, b->workspace);
   int64_t npix = (int64_t)b->rows * b->cols;
   int rb = (int)((npix + kPT * 4 - 1) / (kPT * 4));
-  hipLaunchKernelGGL(k_reset, dim3(rb, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count);
-  hipLaunchKernelGGL(k_project, dim3(tiles_of(*b), b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w,
-                     chunks_of(*b));
+  hipLaunchKernelGGL(k_reset, dim3(rb, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w);
+  hipLaunchKernelGGL(k_project, dim3(tiles_of(*b), b->B), dim3(kPT), project_lds_bytes(*b), st, *b, w.all_list,
+                     w.all_count, w, chunks_of(*b));
+  hipLaunchKernelGGL(k_project_slow, dim3(tiles_of(*b), b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w);
   R3D_LAUNCHED("project kernels");
   return R3D_OK;
 }

@@ -188,3 +188,43 @@ def test_full_size_properties(P, synth):
     assert acc2[0] == [-1]
     assert np.array_equal(res2[0][0], scenes[0][0]) and np.array_equal(res2[0][1], scenes[0][1])
     assert len(res2[0][2]) == 0
+
+
+def test_fast_projection_equals_reference_formula(P, synth):
+    """The verified float32 guess of k_project gives exactly the pixel ids of the float64 formula,
+    on ordinary scans and on points laid on / next to bin edges, the seam and the poles."""
+    rng = np.random.default_rng(3)
+    scenes = [synth.make_scene(70), synth.make_scene(71, shuffle=True)]
+    # adversarial cloud: azimuths and elevations on bin edges +- tiny offsets, then rounded to float32
+    base, label = synth.make_scene(72, 64, 1500)
+    xyz = base[:, :3].astype(np.float64)
+    r = np.sqrt((xyz * xyz).sum(1))
+    el = np.arccos(xyz[:, 2] / r)
+    mn, mx = el.min(), el.max()
+    n = 60000
+    k_row = rng.integers(0, 113, n)
+    k_col = rng.integers(0, 1441, n)
+    off = rng.choice([0.0, 1e-15, -1e-15, 1e-12, -1e-12, 1e-9, -1e-9, 1e-7, -1e-7, 1e-5, -1e-5, 3e-4], n)
+    e2 = np.clip(mn + 1e-5 + k_row * (mx - mn) / 112 + off, mn, mx)
+    a2 = (k_col * (2 * np.pi / 1440) + rng.permutation(off)) % (2 * np.pi) - np.pi
+    rad = rng.uniform(2.0, 80.0, n)
+    adv = np.stack([rad * np.sin(e2) * np.cos(a2), rad * np.sin(e2) * np.sin(a2), rad * np.cos(e2),
+                    np.zeros(n)], axis=1).astype(np.float32)
+    extra = np.array([[-6.0, 0.0, -0.5, 0], [-6.0, -0.0, -0.4, 0], [0.0, 5.0, 0.1, 0], [3.0, 3.0, -1.0, 0],
+                      [1e-3, 0.0, 9.0, 0], [0.0, -1e-4, -7.0, 0], [5.0, 0.0, 0.0, 0], [0.0, 0.0, 4.0, 0]], dtype=np.float32)
+    scenes.append((np.vstack([base, adv, extra]), np.concatenate([label, np.full(n + len(extra), 7, np.uint32)])))
+    cap = max(len(x) for x, _ in scenes) + 64
+    pix = []
+    for exact in (True, False):
+        b = P.SceneBatch(len(scenes), cap, 64, exact_projection=exact)
+        b.load(scenes)
+        b.begin()
+        pix.append((b.pix.cpu().numpy(), b.status.cpu().numpy(), b.bounds.cpu().numpy(), b.extreme_pix.cpu().numpy(),
+                    b.n_far.cpu().numpy()))
+    for a, c in zip(pix[0], pix[1]):
+        assert np.array_equal(a, c)
+    assert (pix[0][1] == 0).all()
+    # and against the oracle for the ordinary scan
+    sc = O.add_space_for_spherical(synth.scene5_from_packed(*scenes[0]))
+    sc, _, _, _, _ = O.scene_field_of_view(sc)
+    assert np.array_equal(pix[1][0][0, :len(sc)], sc[:, 8].astype(np.int32))
