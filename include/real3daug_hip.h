@@ -152,7 +152,6 @@ typedef struct r3d_batch {
   uint16_t *stamp;       /* [B*rows*cols] last step at which the pixel was visible (0 = never) */
   uint32_t *ever;        /* [B*ceil(rows*cols/32)] bit set = stamp != 0 */
   double *bounds;        /* [B][2] max elevation, min elevation */
-  int32_t *extreme_pix;  /* [B][2] pixel of a max-elevation point, of a min-elevation point */
   int32_t *far_pix;      /* [B*R3D_FAR_CAP] occupied pixels deeper than 500 m */
   int32_t *n_far;        /* [B] */
   int32_t *rebase;       /* [B] re-projections forced so far because the elevation bounds may have moved */

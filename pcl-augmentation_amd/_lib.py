@@ -40,7 +40,7 @@ class BatchDesc(C.Structure):
         ("n_head", C.c_void_p), ("n_total", C.c_void_p), ("tail_ref", C.c_void_p),
         ("log5", C.c_void_p), ("log_birth", C.c_void_p), ("n_log", C.c_void_p),
         ("grid", C.c_void_p), ("sgrid", C.c_void_p), ("stamp", C.c_void_p), ("ever", C.c_void_p),
-        ("bounds", C.c_void_p), ("extreme_pix", C.c_void_p), ("far_pix", C.c_void_p),
+        ("bounds", C.c_void_p), ("far_pix", C.c_void_p),
         ("n_far", C.c_void_p), ("rebase", C.c_void_p), ("status", C.c_void_p),
         ("out_xyzi", C.c_void_p), ("out_label", C.c_void_p), ("n_out", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),

@@ -54,7 +54,6 @@ class SceneBatch:
         self.stamp = z((B, npix), torch.int16)
         self.ever = z((B, words), torch.int32)
         self.bounds = z((B, 2), torch.float64)
-        self.extreme_pix = z((B, 2), torch.int32)
         self.far_pix = z((B, _lib.FAR_CAP), torch.int32)
         self.n_far = z((B,), torch.int32)
         self.rebase = z((B,), torch.int32)
@@ -73,7 +72,7 @@ class SceneBatch:
         # verified float32 guess (diagnostic; results are identical, tests/test_gpu_batch.py)
         d.B, d.rows, d.cols, d.reserved, d.cap, d.log_cap = B, rows, cols, 1 if exact_projection else 0, cap, log_cap
         for name in ("xyzi", "label", "pix", "n_head", "n_total", "tail_ref", "log5", "log_birth", "n_log",
-                     "grid", "sgrid", "stamp", "ever", "bounds", "extreme_pix", "far_pix", "n_far", "rebase",
+                     "grid", "sgrid", "stamp", "ever", "bounds", "far_pix", "n_far", "rebase",
                      "status", "out_xyzi", "out_label", "n_out"):
             setattr(d, name, getattr(self, name).data_ptr())
         d.workspace, d.workspace_bytes = 0, 0

@@ -37,7 +37,7 @@ struct BatchWs {
   unsigned long long *chunk_box; // [B*chunks] rows/cols bounding box of 64 consecutive points
   int32_t *n_proj;              // [B] points covered by the chunk boxes
   double *smp_r;                // [B*R3D_MAX_SAMPLE] range of every sample point (k_insert scratch)
-  double *row_q;                // [B*(rows+2)] cos of the row edges: row k <=> row_q[k+1] >= z/r > row_q[k+2]
+  double *row_q;                // [B*(rows+2)] c*|c|, c = cos of the row edges (entry k: edge k-1)
   double *col_dir;              // [(cols+1)*2] unit vector of every column edge
   double *q_ext;                // [B*2] min and max of z/r (the points that hold the elevation bounds)
   int32_t *n_slow;              // [B] points queued for k_project_slow
@@ -204,7 +204,6 @@ __global__ void k_bounds_finish(r3d_batch_t b, const int32_t *list, const int32_
   unsigned long long kmin = w.qkeys[2 * s + 0], kmax = w.qkeys[2 * s + 1];
   if (kmin == ~0ull) {                    // no valid point: the reference raises (insertion.py:78)
     b.bounds[2 * s + 0] = b.bounds[2 * s + 1] = 0.0;
-    b.extreme_pix[2 * s + 0] = b.extreme_pix[2 * s + 1] = -1;
     atomicOr(&b.status[s], R3D_S_NONFINITE);
     return;
   }
@@ -212,7 +211,6 @@ __global__ void k_bounds_finish(r3d_batch_t b, const int32_t *list, const int32_
   double min_el = acos(ordered_key_inv(kmax));   // insertion.py:78
   b.bounds[2 * s + 0] = max_el;
   b.bounds[2 * s + 1] = min_el;
-  b.extreme_pix[2 * s + 0] = b.extreme_pix[2 * s + 1] = -1;   // recorded by the projection pass
   w.q_ext[2 * s + 0] = ordered_key_inv(kmin);
   w.q_ext[2 * s + 1] = ordered_key_inv(kmax);
 }
@@ -232,7 +230,8 @@ __global__ void k_row_table(r3d_batch_t b, const int32_t *list, const int32_t *c
   double edge = min_el + 0.00001 + (double)(k - 1) * d_el;
   // outside [0, pi] the cosine stops being monotone: clamp (such rows can hold no point anyway)
   edge = edge < 0.0 ? 0.0 : (edge > kPi ? kPi : edge);
-  w.row_q[(int64_t)s * (b.rows + 2) + k] = cos(edge);
+  double c = cos(edge);
+  w.row_q[(int64_t)s * (b.rows + 2) + k] = c * fabs(c);     // compared with z*|z| / (x*x+y*y+z*z)
 }
 
 __global__ void k_col_table(r3d_batch_t b, BatchWs w) {
@@ -308,8 +307,6 @@ __device__ __forceinline__ int project_point(const r3d_batch_t &b, int s, const 
   else {
     p = row * b.cols + col;
     box.add(row, col);
-    if (sp.el == bn.max_el) b.extreme_pix[2 * s + 0] = p;   // any holder will do
-    if (sp.el == bn.min_el) b.extreme_pix[2 * s + 1] = p;
     if (sp.r > R3D_EMPTY_DEPTH) {           // "first hit overwrites the 500": insertion.py:122-125
       int f = atomicAdd(&b.n_far[s], 1);
       if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
@@ -321,28 +318,32 @@ __device__ __forceinline__ int project_point(const r3d_batch_t &b, int s, const 
 
 // Verified float32 guess of (row, col); returns false when the float64 check cannot confirm the
 // guessed bin (the caller then queues the point for the reference formula).
-constexpr double kEdgeMargin = 1e-12;
-
-__device__ __forceinline__ bool fast_bin(const Binning &bn, const double *__restrict__ row_q,
+//   rows: elevation in [edge_k, edge_k+1)  <=>  cos(edge_k+1) < z/r <= cos(edge_k); both sides are
+//         mapped through t -> t*|t| (strictly increasing) and multiplied by r*r = ss, which needs
+//         neither the square root nor the division: z*|z| against c*|c| * ss.  Row 0 also takes
+//         the truncated interval below edge_0 (int() rounds toward zero).
+//   cols: the point lies counter-clockwise of column edge k and clockwise of edge k+1 (sign of
+//         the cross product with the edges' unit vectors).
+// Margins are relative 4e-12 resp. 1e-12 (the L1 norm bounds r from above), three orders of
+// magnitude above the rounding of the products and of the reference's own float64 evaluation.
+__device__ __forceinline__ bool fast_bin(const Binning &bn, const double *__restrict__ row_cc,
                                          const double *__restrict__ col_dir, float inv_del, float inv_daz,
-                                         float elo, double x, double y, double z, double r, double q,
-                                         int &row, int &col) {
-  float xf = (float)x, yf = (float)y, zf = (float)z;
+                                         float elo, float xf, float yf, float zf, double x, double y, double z,
+                                         double ss, int &row, int &col) {
   float qf = zf * __frsqrt_rn(xf * xf + yf * yf + zf * zf);
   qf = qf < -1.f ? -1.f : (qf > 1.f ? 1.f : qf);
   int rg = (int)floorf((acosf(qf) - elo) * inv_del);
   int cg = (int)((atan2f(yf, xf) + 3.14159274f) * inv_daz);
   rg = rg < 0 ? 0 : (rg > bn.rows - 1 ? bn.rows - 1 : rg);
   cg = cg < 0 ? 0 : (cg > bn.cols - 1 ? bn.cols - 1 : cg);
-  if (!(fabs(q) < 0.999999)) return false;                    // acos is ill-conditioned there
-  // rows: elevation in [edge_k, edge_k+1)  <=>  cos(edge_k+1) < q <= cos(edge_k); row 0 also takes
-  // the truncated interval below edge_0 (int() rounds toward zero)
-  double hi = row_q[rg == 0 ? 0 : rg + 1], lo = row_q[rg + 2];
-  double ax = col_dir[2 * cg], ay = col_dir[2 * cg + 1], bx = col_dir[2 * cg + 2], by = col_dir[2 * cg + 3];
-  const double m2 = kEdgeMargin * r;
   row = rg;
   col = cg;
-  return q < hi - kEdgeMargin && q > lo + kEdgeMargin && ax * y - ay * x > m2 && bx * y - by * x < -m2;
+  const double zz = z * fabs(z);
+  const double hi = row_cc[rg == 0 ? 0 : rg + 1], lo = row_cc[rg + 2];
+  const double ax = col_dir[2 * cg], ay = col_dir[2 * cg + 1], bx = col_dir[2 * cg + 2], by = col_dir[2 * cg + 3];
+  const double mr = 4e-12 * ss, mc = 1e-12 * (fabs(x) + fabs(y) + fabs(z));
+  return fabs(zz) < 0.999998 * ss &&                          // acos is ill-conditioned at the poles
+         zz < hi * ss - mr && zz > lo * ss + mr && ax * y - ay * x > mc && bx * y - by * x < -mc;
 }
 
 __global__ void __launch_bounds__(kPT)
@@ -364,7 +365,6 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
     const bool exact = b.reserved & 1;                       // diagnostic: reference formula only
     const float inv_del = (float)(1.0 / bn.d_el), inv_daz = (float)(1.0 / bn.d_az);
     const float elo = (float)(bn.min_el + 0.00001);
-    const double q_min = w.q_ext[2 * s + 0], q_max = w.q_ext[2 * s + 1];
     uint32_t *queue = w.cand + (int64_t)s * w.cand_stride;  // k_insert scratch, free during step 0
     int flags = 0;
     // verified float32 guess, 8 points per thread; unconfirmed points are queued for k_project_slow
@@ -375,15 +375,13 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
       if (i < n) {
         double x, y, z;
         load_point(b, s, i, n_head, x, y, z);
-        double r = sqrt(x * x + y * y + z * z);
-        double q = z / r;
+        double ss = x * x + y * y + z * z;
         int row, col;
-        if (!exact && fast_bin(bn, s_row, s_col, inv_del, inv_daz, elo, x, y, z, r, q, row, col)) {
+        if (!exact && fast_bin(bn, s_row, s_col, inv_del, inv_daz, elo, (float)x, (float)y, (float)z, x, y, z, ss,
+                               row, col)) {
           int p = row * b.cols + col;
           box.add(row, col);
-          if (q == q_min) b.extreme_pix[2 * s + 0] = p;      // max elevation = acos(min z/r)
-          if (q == q_max) b.extreme_pix[2 * s + 1] = p;
-          if (r > R3D_EMPTY_DEPTH) {
+          if (ss > R3D_EMPTY_DEPTH * R3D_EMPTY_DEPTH) {      // r > 500 (or rounds to it): far list
             int f = atomicAdd(&b.n_far[s], 1);
             if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
             else flags |= R3D_S_FAR_OVERFLOW;
@@ -590,7 +588,8 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   int *s_rmin = s_misc + 4, *s_rmax = s_misc + 5;                 // sample row range
   int *s_cmin = s_misc + 6, *s_cmax = s_misc + 8;                 // [2] column range per image half
   int *s_nlist = s_misc + 10, *s_carry = s_misc + 11;
-  int *s_scan = s_misc + 12;                                      // [kST/64 + 1]
+  int *s_ext = s_misc + 12;                                       // [2] window pixel of a max / min elevation point
+  int *s_scan = s_misc + 14;                                      // [kST/64 + 1]
   uint32_t *s_oob = reinterpret_cast<uint32_t *>(smem + 256);     // [kKeyCap/32] el outside bounds
   uint32_t *s_keys = reinterpret_cast<uint32_t *>(smem + kLdsFixed);   // [pw] sorted (pixel, index)
 
@@ -610,7 +609,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   while (pw < m) pw <<= 1;
 
   for (int i = tid; i < kKeyCap / 32; i += kST) s_oob[i] = 0u;
-  if (tid < 12) s_misc[tid] = (tid == 4 || tid == 6 || tid == 7) ? 0x7FFFFFFF : (tid == 5 || tid == 8 || tid == 9) ? -1 : 0;
+  if (tid < 14) s_misc[tid] = (tid == 4 || tid == 6 || tid == 7) ? 0x7FFFFFFF : (tid == 5 || tid == 8 || tid == 9 || tid >= 12) ? -1 : 0;
   __syncthreads();
 
   const Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], rows, cols);
@@ -803,6 +802,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   // chunks whose bounding box touches the window, then the points appended since the last
   // projection.  Dead points (their pixel was visible at a later step) are skipped, which is what
   // culling them (:472-473) does to the image.
+  const double q_min = w.q_ext[2 * s + 0], q_max = w.q_ext[2 * s + 1];
   uint32_t *cand = w.cand + (int64_t)s * w.cand_stride;  // [npix] window-local pixel, then [npix] (row, col)
   uint32_t *cand_rc = cand + npix;
   // 4 points per thread are taken through the dependent loads (pixel -> alive -> coordinates)
@@ -826,9 +826,15 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (!ok[u]) continue;
-      unsigned long long key = depth_key(sqrt(x[u] * x[u] + y[u] * y[u] + z[u] * z[u]));
+      double r = sqrt(x[u] * x[u] + y[u] * y[u] + z[u] * z[u]);
+      unsigned long long key = depth_key(r);
       if (c_lds) atomicMin(&s_ctile[lp[u]], key);
       else atomicMin(&grid[p[u]], key);
+      // the points that hold the elevation bounds (max elevation = acos(min z/r)): if the pixel of
+      // one of them turns out visible it is culled and the bounds may move (any holder will do)
+      double q = z[u] / r;
+      if (q == q_min) s_ext[0] = lp[u];
+      if (q == q_max) s_ext[1] = lp[u];
     }
   };
   if (ww > 0) {
@@ -1011,14 +1017,14 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
       }
       base += tot;
     }
-    const int pix_of_max = b.extreme_pix[2 * s + 0], pix_of_min = b.extreme_pix[2 * s + 1];
+    if (tid == 0 && ((s_ext[0] >= 0 && vis.get_local(s_ext[0])) || (s_ext[1] >= 0 && vis.get_local(s_ext[1]))))
+      *s_rebase = 1;                                         // a point that holds a bound is culled
     uint16_t *stamp = b.stamp + (int64_t)s * npix;
     uint32_t *ever = b.ever + (int64_t)s * words;
     for (int ci = tid; ci < ncand; ci += kST) {
       int lp = (int)cand[ci];
       if (!vis.get_local(lp)) continue;
       int q = (int)(cand_rc[ci] >> 16) * cols + (int)(cand_rc[ci] & 0xFFFF);
-      if (q == pix_of_max || q == pix_of_min) *s_rebase = 1;   // the recorded extreme point is culled
       unsigned long long nv = sample_key(q, lp);
       if (nv != R3D_SENT && key_depth(nv) > R3D_EMPTY_DEPTH) {  // the pixel now holds a far return
         int f = atomicAdd(&b.n_far[s], 1);
@@ -1267,7 +1273,8 @@ k_rebase(r3d_batch_t b, BatchWs w, int chunks) {
       double max_el = acos(ordered_key_inv(lmin)), min_el = acos(ordered_key_inv(lmax));
       b.bounds[2 * s + 0] = max_el;
       b.bounds[2 * s + 1] = min_el;
-      b.extreme_pix[2 * s + 0] = b.extreme_pix[2 * s + 1] = -1;
+      w.q_ext[2 * s + 0] = ordered_key_inv(lmin);
+      w.q_ext[2 * s + 1] = ordered_key_inv(lmax);
       b.n_far[s] = 0;
     }
     // (d) reset the visibility stamps
@@ -1329,7 +1336,7 @@ static int check_batch(const r3d_batch_t *b) {
     return fail(R3D_E_ARG, "batch: cap or range image too large for 32-bit point / pixel ids");
   if (!b->xyzi || !b->label || !b->pix || !b->n_head || !b->n_total || !b->tail_ref || !b->log5 ||
       !b->log_birth || !b->n_log || !b->grid || !b->sgrid || !b->stamp || !b->ever || !b->bounds ||
-      !b->extreme_pix || !b->far_pix || !b->n_far || !b->rebase || !b->status || !b->out_xyzi ||
+       !b->far_pix || !b->n_far || !b->rebase || !b->status || !b->out_xyzi ||
       !b->out_label || !b->n_out || !b->workspace)
     return fail(R3D_E_ARG, "batch: null array");
   if (b->cols % 32 != 0)

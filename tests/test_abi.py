@@ -43,7 +43,7 @@ def test_batch_descriptor_matches_header(pkg):
                                   "void", "size_t")))
         fields += [n.strip(",") for n in names[first:]]
     assert [f for f, _ in pkg._lib.BatchDesc._fields_] == fields
-    assert ctypes.sizeof(pkg._lib.BatchDesc) == 4 * 4 + 2 * 8 + 22 * 8 + 2 * 8
+    assert ctypes.sizeof(pkg._lib.BatchDesc) == 4 * 4 + 2 * 8 + 21 * 8 + 2 * 8
 
 
 def test_bad_arguments_are_reported_without_a_gpu(pkg):

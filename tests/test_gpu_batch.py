@@ -219,7 +219,7 @@ def test_fast_projection_equals_reference_formula(P, synth):
         b = P.SceneBatch(len(scenes), cap, 64, exact_projection=exact)
         b.load(scenes)
         b.begin()
-        pix.append((b.pix.cpu().numpy(), b.status.cpu().numpy(), b.bounds.cpu().numpy(), b.extreme_pix.cpu().numpy(),
+        pix.append((b.pix.cpu().numpy(), b.status.cpu().numpy(), b.bounds.cpu().numpy(),
                     b.n_far.cpu().numpy()))
     for a, c in zip(pix[0], pix[1]):
         assert np.array_equal(a, c)
