@@ -355,19 +355,19 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
     int n = b.n_total[s], n_head = b.n_head[s];
-    int t0 = blockIdx.x * kTile;
     if (blockIdx.x == 0 && threadIdx.x == 0) w.n_proj[s] = n;
     __syncthreads();                                       // previous scene's row table is no longer read
     for (int e = threadIdx.x; e < b.rows + 2; e += kPT) s_row[e] = w.row_q[(int64_t)s * (b.rows + 2) + e];
     __syncthreads();
-    if (t0 >= n) continue;
     Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
     const bool exact = b.reserved & 1;                       // diagnostic: reference formula only
     const float inv_del = (float)(1.0 / bn.d_el), inv_daz = (float)(1.0 / bn.d_az);
     const float elo = (float)(bn.min_el + 0.00001);
     uint32_t *queue = w.cand + (int64_t)s * w.cand_stride;  // k_insert scratch, free during step 0
     int flags = 0;
-    // verified float32 guess, 8 points per thread; unconfirmed points are queued for k_project_slow
+    // verified float32 guess, 8 points per thread and tile; unconfirmed points are queued for
+    // k_project_slow.  A block walks several tiles so that the tables are staged once.
+    for (int t0 = blockIdx.x * kTile; t0 < n; t0 += gridDim.x * kTile)
 #pragma unroll 2
     for (int k = 0; k < kPerThread; ++k) {
       int i = t0 + k * kPT + threadIdx.x;
@@ -410,7 +410,6 @@ k_project_slow(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
     int n_slow = w.n_slow[s], n_head = b.n_head[s];
-    if (blockIdx.x * kPT >= n_slow) continue;
     Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
     const uint32_t *queue = w.cand + (int64_t)s * w.cand_stride;
     int flags = 0;
@@ -1349,6 +1348,13 @@ static int check_batch(const r3d_batch_t *b) {
   return R3D_OK;
 }
 
+// blocks per scene of k_project: each walks ~4 tiles, at least ~2048 blocks in a 256-scene launch
+static int project_blocks(const r3d_batch_t &b) {
+  int t = tiles_of(b);
+  int per = (t + 3) / 4;
+  return per < 1 ? 1 : per;
+}
+
 static size_t project_lds_bytes(const r3d_batch_t &b) {
   return ((size_t)(b.cols + 1) * 2 + b.rows + 2) * sizeof(double);
 }
@@ -1370,9 +1376,9 @@ static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_
   int64_t npix = (int64_t)b.rows * b.cols;
   int rb = (int)((npix + kPT * 4 - 1) / (kPT * 4));
   hipLaunchKernelGGL(k_reset, dim3(rb, rows), dim3(kPT), 0, st, b, list, count, w);
-  hipLaunchKernelGGL(k_project, dim3(tiles, rows), dim3(kPT), project_lds_bytes(b), st, b, list, count, w,
-                     chunks_of(b));
-  hipLaunchKernelGGL(k_project_slow, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w);
+  hipLaunchKernelGGL(k_project, dim3(project_blocks(b), rows), dim3(kPT), project_lds_bytes(b), st, b, list,
+                     count, w, chunks_of(b));
+  hipLaunchKernelGGL(k_project_slow, dim3(4, rows), dim3(kPT), 0, st, b, list, count, w);
   R3D_LAUNCHED("reproject kernels");
   return R3D_OK;
 }
@@ -1447,9 +1453,9 @@ int r3d_batch_project(const r3d_batch_t *b, void *stream) {
   int64_t npix = (int64_t)b->rows * b->cols;
   int rb = (int)((npix + kPT * 4 - 1) / (kPT * 4));
   hipLaunchKernelGGL(k_reset, dim3(rb, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w);
-  hipLaunchKernelGGL(k_project, dim3(tiles_of(*b), b->B), dim3(kPT), project_lds_bytes(*b), st, *b, w.all_list,
-                     w.all_count, w, chunks_of(*b));
-  hipLaunchKernelGGL(k_project_slow, dim3(tiles_of(*b), b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w);
+  hipLaunchKernelGGL(k_project, dim3(project_blocks(*b), b->B), dim3(kPT), project_lds_bytes(*b), st, *b,
+                     w.all_list, w.all_count, w, chunks_of(*b));
+  hipLaunchKernelGGL(k_project_slow, dim3(4, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w);
   R3D_LAUNCHED("project kernels");
   return R3D_OK;
 }
