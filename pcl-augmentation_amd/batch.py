@@ -215,3 +215,32 @@ def augment_batch(scenes, candidates, min_points, rows=_lib.NUMROW, cols=_lib.NU
     batch.finish(check_cols)
     SceneBatch.last_rebases = int(batch.rebase.sum().item())
     return batch.results(), accepted
+
+
+def run_sharded(n_scenes, process_shard, rank=None, world_size=None, group=None):
+    """Scene-sharded execution across the GPUs of a node: rank r processes
+    scenes r, r+G, r+2G, ... with ``process_shard(indices) -> list of per-scene results`` and the
+    per-rank results are gathered on every rank in scene order.  No collective touches the data
+    path; the single ``all_gather_object`` at the end only returns results to the caller (a
+    production driver writes its own files instead and skips it with ``group=False``).
+
+    ``process_shard`` is the GPU pipeline in production (``augment_batch`` on the rank's device);
+    the CPU tests inject the oracle to prove that the union of shards equals the unsharded run.
+    """
+    import torch.distributed as dist
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    mine = shard_indices(n_scenes, rank, world_size)
+    local = process_shard(mine)
+    if len(local) != len(mine):
+        raise ValueError("process_shard must return one result per scene index")
+    if world_size == 1 or group is False:
+        return dict(zip(mine, local))
+    gathered = [None] * world_size
+    dist.all_gather_object(gathered, list(zip(mine, local)), group=group)
+    merged = {}
+    for part in gathered:
+        merged.update(dict(part))
+    return merged
