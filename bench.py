@@ -180,41 +180,77 @@ def main():
 
     if rank == 0:
         import ctypes as C
+        L = pkg._lib
         lib, desc = batch.lib, batch.desc
-        st = pkg._lib.stream_ptr
-        # per-kernel timing after the timed region (state: a finished batch; begin() resets it)
+
+        def one(which):
+            return lambda: L.check(lib.r3d_batch_launch_one(C.byref(desc), which, L.stream_ptr()), "launch_one")
+
+        # per-kernel timing after the timed region, HIP events on the launch stream
         batch.begin()
-        t_bounds = event_time_ms(torch, lambda: lib.r3d_batch_elev_bounds(C.byref(desc), st()))
-        t_project = event_time_ms(torch, lambda: lib.r3d_batch_project(C.byref(desc), st()))
+        t_bounds = event_time_ms(torch, one(L.K_BOUNDS))
+        t_reset = event_time_ms(torch, one(L.K_RESET))
+        t_project = event_time_ms(torch, one(L.K_PROJECT))
         t_begin = event_time_ms(torch, batch.begin)
+
         def five_inserts():                         # begin() restores the state the inserts mutate
             batch.begin()
             for s5, off in packed:
                 batch.insert_device(s5, off, need)
 
-        t_insert = [event_time_ms(torch, five_inserts) - t_begin]
+        t_insert_all = event_time_ms(torch, five_inserts) - t_begin      # 5 x (k_insert + idle k_rebase)
+        batch.finish(check_cols=0)
+        t_count = event_time_ms(torch, one(L.K_ALIVE_COUNT))
+        t_write = event_time_ms(torch, one(L.K_ALIVE_WRITE))
         t_finish = event_time_ms(torch, lambda: batch.finish(check_cols=0))
         n_out_pts = float(batch.n_out.sum().item())
-        # algorithmic bytes per launch: project reads xyzi once; finish reads
-        # xyzi + label and writes the survivors; insert reads the sample rows twice.
+        # Algorithmic bytes per launch (SURVEY.md par.8d with the conservative rule:
+        # a pass that is not made is not claimed).  bounds / project read xyzi once (16 B per point);
+        # the compaction reads xyzi + label and writes the survivors (20 B + 20 B per point); an
+        # insert launch reads every sample row twice (2 x 40 B per sample point).
         kernels = {
-            "elev_bounds": {"ms": t_bounds, "alg_bytes": 16.0 * n_pts},
-            "project": {"ms": t_project, "alg_bytes": 16.0 * n_pts},
-            "insert_x5": {"ms": float(sum(t_insert)), "alg_bytes": 40.0 * m_pts * 2},
-            "finish_compact": {"ms": t_finish, "alg_bytes": 20.0 * n_pts + 20.0 * n_out_pts},
+            "k_bounds": {"ms": t_bounds, "launches_per_step": 1, "alg_bytes": 16.0 * n_pts},
+            "k_project": {"ms": t_project, "launches_per_step": 1, "alg_bytes": 16.0 * n_pts},
+            "k_insert": {"ms": t_insert_all / len(KINDS), "launches_per_step": len(KINDS),
+                         "alg_bytes": 80.0 * m_pts / len(KINDS)},
+            "k_alive_count": {"ms": t_count, "launches_per_step": 1, "alg_bytes": 4.0 * n_pts},
+            "k_alive_write": {"ms": t_write, "launches_per_step": 1, "alg_bytes": 20.0 * n_pts + 20.0 * n_out_pts},
+            "k_reset": {"ms": t_reset, "launches_per_step": 1, "alg_bytes": 2.0 * B * batch.rows * batch.cols},
         }
-        for k in kernels.values():
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))["kernels"]
+        except Exception:
+            pass
+        for name, k in kernels.items():
             k["GBps"] = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9
-        dominant = max(("elev_bounds", "project", "finish_compact", "insert_x5"), key=lambda k: kernels[k]["ms"])
+            k["frac"] = k["GBps"] / HBM_PEAK_GBS
+            k["share_of_step"] = k["ms"] * k["launches_per_step"] / (1e3 * elapsed / args.steps)
+        dominant = max(kernels, key=lambda k: kernels[k]["ms"] * kernels[k]["launches_per_step"])
         dk = kernels[dominant]
-        roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(dk["GBps"], 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(dk["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
-                    "alg_bytes_per_launch": dk["alg_bytes"], "ms_per_launch": round(dk["ms"], 4),
-                    "all_kernels": {k: {"ms": round(v["ms"], 4), "GBps": round(v["GBps"], 1)} for k, v in kernels.items()},
-                    "begin_ms": round(t_begin, 4)}
+        roofline = {
+            "bound": "hbm", "kernel": dominant, "achieved": round(dk["GBps"], 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(dk["frac"], 4),
+            "traffic": pmc.get(dominant, {}).get("hbm_bytes_corrected"),
+            "traffic_source": "profiles/r01_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                              "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch" if dominant in pmc else None,
+            "alg_bytes_per_launch": dk["alg_bytes"], "ms_per_launch": round(dk["ms"], 4),
+            "launches_per_step": dk["launches_per_step"],
+            "note": "k_insert is one workgroup per scene working in LDS on the window of the range image around the "
+                    "inserted object; it is latency-bound by design and moves almost no HBM bytes (the incremental "
+                    "pipeline removed the per-insert streaming passes), so its HBM fraction is low by construction. "
+                    "The HBM-bound streaming kernels are listed in all_kernels."
+                    if dominant == "k_insert" else "",
+            "all_kernels": {n: {"ms_per_launch": round(k["ms"], 4), "launches_per_step": k["launches_per_step"],
+                                "alg_GBps": round(k["GBps"], 1), "frac_of_hbm_peak": round(k["frac"], 4),
+                                "share_of_step": round(k["share_of_step"], 3),
+                                "pmc_hbm_bytes_per_launch": pmc.get(n, {}).get("hbm_bytes_corrected")}
+                            for n, k in kernels.items()},
+            "api_calls_ms": {"r3d_batch_begin": round(t_begin, 4), "r3d_batch_insert_x5": round(t_insert_all, 4),
+                             "r3d_batch_finish": round(t_finish, 4)},
+        }
         scenes_per_s = B * world * args.steps / elapsed
-        # whole-step algorithmic bytes actually needed by this pipeline (conservative rule of
-        # passes that are not made are not claimed)
+        # whole-step algorithmic bytes actually needed by this pipeline
         step_bytes = 16.0 * n_pts * 2 + 20.0 * n_pts + 20.0 * n_out_pts + 80.0 * m_pts
         out = {
             "metric": "augmented scenes/sec (120k-pt, 64-beam)", "value": round(scenes_per_s, 1),

@@ -191,12 +191,16 @@ int r3d_batch_insert(const r3d_batch_t *b, const double *samples5, const int64_t
  * [B*log_cap][check_cols] = check/{f}.bin rows from the log. */
 int r3d_batch_finish(const r3d_batch_t *b, float *check, int32_t check_cols, void *stream);
 
-/* The two streaming passes of step 0 on their own (all scenes; state as left by r3d_batch_begin),
- * exported for parity tests and for timing them in isolation:
- *   elev_bounds = insertion.py:74-79 reduced to the two bounds per scene,
- *   project     = insertion.py:74-76 + :104-116 fused (spherical coordinates -> pixel ids). */
-int r3d_batch_elev_bounds(const r3d_batch_t *b, void *stream);
-int r3d_batch_project(const r3d_batch_t *b, void *stream);
+/* One streaming kernel of the batched path on its own, all scenes, for timing it in isolation
+ * with HIP events (bench.py) and for rocprofv3: the state must be the one r3d_batch_begin
+ * (BOUNDS, RESET, PROJECT) or r3d_batch_finish (ALIVE_COUNT, ALIVE_WRITE) leaves; every one of
+ * them is idempotent on that state. */
+#define R3D_K_BOUNDS 1        /* k_bounds: min / max of z/r per scene (insertion.py:74-79) */
+#define R3D_K_RESET 2         /* k_reset: visibility stamps back to zero */
+#define R3D_K_PROJECT 3       /* k_project: pixel id of every point (insertion.py:74-76, :104-116) */
+#define R3D_K_ALIVE_COUNT 4   /* k_alive_count: survivors per tile (insertion.py:472-473), + the tile scan */
+#define R3D_K_ALIVE_WRITE 5   /* k_alive_write: survivors, original order, into out_xyzi / out_label */
+int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream);
 
 #ifdef __cplusplus
 }

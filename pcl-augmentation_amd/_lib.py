@@ -22,6 +22,7 @@ STATUS_TEXT = {
     S_CAPACITY: "merged cloud or insert log exceeds its capacity",
     S_FAR_OVERFLOW: "more than R3D_FAR_CAP pixels deeper than 500 m",
 }
+K_BOUNDS, K_RESET, K_PROJECT, K_ALIVE_COUNT, K_ALIVE_WRITE = 1, 2, 3, 4, 5
 NUMROW, NUMCOLUMN = 112, 1440
 MAX_SAMPLE = 8192
 FAR_CAP = 1024
@@ -67,8 +68,7 @@ _SIGNATURES = {
     "r3d_batch_begin": (C.c_int, [C.POINTER(BatchDesc), _P, _P]),
     "r3d_batch_insert": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "r3d_batch_finish": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int32, _P]),
-    "r3d_batch_elev_bounds": (C.c_int, [C.POINTER(BatchDesc), _P]),
-    "r3d_batch_project": (C.c_int, [C.POINTER(BatchDesc), _P]),
+    "r3d_batch_launch_one": (C.c_int, [C.POINTER(BatchDesc), C.c_int32, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -1430,33 +1430,37 @@ int r3d_batch_begin(const r3d_batch_t *b, const int32_t *n_points, void *stream)
   return launch_reproject(*b, w, w.all_list, w.all_count, b->B, st);
 }
 
-int r3d_batch_elev_bounds(const r3d_batch_t *b, void *stream) {
+int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream) {
   int rc = check_batch(b);
   if (rc != R3D_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   BatchWs w = carve_batch(*b, b->workspace);
-  int tiles = tiles_of(*b), lb = (b->B + 255) / 256;
-  hipLaunchKernelGGL(k_bounds_init, dim3(lb), dim3(256), 0, st, w.all_list, w.all_count, w);
-  hipLaunchKernelGGL(k_bounds, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w);
-  hipLaunchKernelGGL(k_bounds_finish, dim3(lb), dim3(256), 0, st, *b, w.all_list, w.all_count, w);
-  hipLaunchKernelGGL(k_row_table, dim3((b->rows + 2 + 127) / 128, b->B), dim3(128), 0, st, *b, w.all_list,
-                     w.all_count, w);
-  R3D_LAUNCHED("bounds kernels");
-  return R3D_OK;
-}
-
-int r3d_batch_project(const r3d_batch_t *b, void *stream) {
-  int rc = check_batch(b);
-  if (rc != R3D_OK) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  BatchWs w = carve_batch(*b, b->workspace);
+  int tiles = tiles_of(*b);
   int64_t npix = (int64_t)b->rows * b->cols;
-  int rb = (int)((npix + kPT * 4 - 1) / (kPT * 4));
-  hipLaunchKernelGGL(k_reset, dim3(rb, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w);
-  hipLaunchKernelGGL(k_project, dim3(project_blocks(*b), b->B), dim3(kPT), project_lds_bytes(*b), st, *b,
-                     w.all_list, w.all_count, w, chunks_of(*b));
-  hipLaunchKernelGGL(k_project_slow, dim3(4, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w);
-  R3D_LAUNCHED("project kernels");
+  switch (which) {
+    case R3D_K_BOUNDS:
+      hipLaunchKernelGGL(k_bounds, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w);
+      break;
+    case R3D_K_RESET:
+      hipLaunchKernelGGL(k_reset, dim3((int)((npix + kPT * 4 - 1) / (kPT * 4)), b->B), dim3(kPT), 0, st, *b,
+                         w.all_list, w.all_count, w);
+      break;
+    case R3D_K_PROJECT:
+      hipLaunchKernelGGL(k_project, dim3(project_blocks(*b), b->B), dim3(kPT), project_lds_bytes(*b), st, *b,
+                         w.all_list, w.all_count, w, chunks_of(*b));
+      break;
+    case R3D_K_ALIVE_COUNT:
+      hipLaunchKernelGGL(k_alive_count, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w, tiles);
+      // the counts overwrite the tile offsets k_alive_write relies on: re-run the (tiny) scan with it
+      hipLaunchKernelGGL(k_alive_scan, dim3(b->B), dim3(1024), 0, st, *b, w.all_list, w.all_count, w, tiles);
+      break;
+    case R3D_K_ALIVE_WRITE:
+      hipLaunchKernelGGL(k_alive_write, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w, tiles);
+      break;
+    default:
+      return fail(R3D_E_ARG, "batch_launch_one: unknown kernel id");
+  }
+  R3D_LAUNCHED("batch_launch_one");
   return R3D_OK;
 }
 
