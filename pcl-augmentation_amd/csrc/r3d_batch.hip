@@ -27,7 +27,6 @@ struct BatchWs {
   int32_t *tile_alive;          // [B*tiles]
   int32_t *tile_head;           // [B*tiles]
   int32_t *new_head;            // [B]
-  int32_t *tail_tmp;            // [B*log_cap]
   uint32_t *cand;               // [B*2*npix] chunk / candidate pixel lists of the insert kernel
   int32_t *all_list;            // [B] identity
   int32_t *all_count;           // [1] = B
@@ -58,7 +57,6 @@ static BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.tile_alive = c.take<int32_t>((size_t)b.B * tiles);
   w.tile_head = c.take<int32_t>((size_t)b.B * tiles);
   w.new_head = c.take<int32_t>((size_t)b.B);
-  w.tail_tmp = c.take<int32_t>((size_t)b.B * b.log_cap);
   w.cand_stride = 2 * npix > b.cap ? 2 * npix : b.cap;
   w.cand = c.take<uint32_t>((size_t)b.B * w.cand_stride);
   w.all_list = c.take<int32_t>((size_t)b.B);
@@ -1148,36 +1146,52 @@ k_alive_scan(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w
 }
 
 // Survivors in original order (insertion.py:472-473 applied once for all steps), float4 + label
-// straight into the output arrays; tail references follow into tail_tmp for a rebase.
+// straight into the output arrays.  The 8 alive tests of a thread are issued together, ranks come
+// from wave ballots and one small LDS table: a single barrier per tile.
 __global__ void __launch_bounds__(kPT)
 k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles) {
-  __shared__ int sm[kPT / 64 + 1];
+  __shared__ int s_cnt[kPerThread][kPT / 64];           // survivors of (row k, wave)
   int cnt = *count;
   int npix = b.rows * b.cols, words = (npix + 31) / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
     int n = b.n_total[s], n_head = b.n_head[s];
     int t0 = blockIdx.x * kTile;
     if (t0 >= n) continue;
-    int base = w.tile_alive[(int64_t)s * tiles + blockIdx.x];
-    int new_head = w.new_head[s];
+    const int tile_base = w.tile_alive[(int64_t)s * tiles + blockIdx.x];
     const float4 *src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
     float4 *dst = reinterpret_cast<float4 *>(b.out_xyzi) + (int64_t)s * b.cap;
+    bool flag[kPerThread];
+#pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
       int i = t0 + k * kPT + threadIdx.x;
-      int flag = (i < n && point_alive(b, s, i, n_head, npix, words)) ? 1 : 0;
-      int tot;
-      int ex = block_escan_i32(flag, sm, tot);
-      if (flag) {
-        int o = base + ex;
+      flag[k] = i < n && point_alive(b, s, i, n_head, npix, words);
+    }
+    int rank[kPerThread];
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+      unsigned long long m = __ballot(flag[k]);
+      rank[k] = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) s_cnt[k][wave] = __popcll(m);
+    }
+    __syncthreads();
+    int run = tile_base;
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+      int mine = 0;
+#pragma unroll
+      for (int v = 0; v < kPT / 64; ++v) {
+        if (v == wave) mine = run;
+        run += s_cnt[k][v];
+      }
+      if (flag[k]) {
+        int i = t0 + k * kPT + threadIdx.x, o = mine + rank[k];
         dst[o] = src[i];
         b.out_label[(int64_t)s * b.cap + o] = b.label[(int64_t)s * b.cap + i];
-        if (i >= n_head)
-          w.tail_tmp[(int64_t)s * b.log_cap + (o - new_head)] =
-              b.tail_ref[(int64_t)s * b.log_cap + (i - n_head)];
       }
-      base += tot;
     }
+    __syncthreads();                                      // s_cnt is reused by the next scene
   }
 }
 
