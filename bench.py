@@ -96,10 +96,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torchrun with WORLD_SIZE={args.gpus} (got {world})")
+    # R3D_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a
+    # one-GPU box); the driver's runs use RCCL ("nccl") with one rank per GPU.
+    backend = os.environ.get("R3D_DIST_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
 
     pkg = importlib.import_module("pcl-augmentation_amd")
     B = args.scenes
@@ -165,7 +173,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=batch.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=batch.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     for bt, _, _ in subs:
