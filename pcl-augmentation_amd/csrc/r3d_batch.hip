@@ -40,6 +40,7 @@ struct BatchWs {
   double *col_dir;              // [(cols+1)*2] unit vector of every column edge
   double *q_ext;                // [B*2] min and max of z/r (the points that hold the elevation bounds)
   int32_t *n_slow;              // [B] points queued for k_project_slow
+  unsigned long long *alive_bits; // [B*chunks] survivor bit of every point (k_alive_count -> k_alive_write)
   int64_t cand_stride;          // uint32 entries of `cand` per scene: max(2*npix, cap)
   size_t total;
 };
@@ -71,6 +72,7 @@ static BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.col_dir = c.take<double>((size_t)(b.cols + 1) * 2);
   w.q_ext = c.take<double>((size_t)b.B * 2);
   w.n_slow = c.take<int32_t>((size_t)b.B);
+  w.alive_bits = c.take<unsigned long long>((size_t)b.B * chunks_of(b));
   w.total = c.off;
   return w;
 }
@@ -1073,7 +1075,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
 
 // ---- compaction: drop dead points (finish, or rebase) ------------------------------------------
 __global__ void __launch_bounds__(kPT)
-k_alive_count(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles) {
+k_alive_count(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles, int chunks) {
   __shared__ int s_a[kPT / 64], s_h[kPT / 64];
   int cnt = *count;
   int npix = b.rows * b.cols, words = (npix + 31) / 32;
@@ -1083,17 +1085,26 @@ k_alive_count(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
     int t0 = blockIdx.x * kTile;
     int alive = 0, head = 0;
     if (t0 < n) {
+      bool flag[kPerThread];
 #pragma unroll
       for (int k = 0; k < kPerThread; ++k) {
         int i = t0 + k * kPT + threadIdx.x;
-        if (i < n && point_alive(b, s, i, n_head, npix, words)) {
-          ++alive;
-          head += i < n_head ? 1 : 0;
+        flag[k] = i < n && point_alive(b, s, i, n_head, npix, words);
+      }
+      // one bit per point (a 64-bit word per wave and row) so that k_alive_write need not repeat the
+      // pixel-id load and the stamp lookups
+#pragma unroll
+      for (int k = 0; k < kPerThread; ++k) {
+        int i0 = t0 + k * kPT + (threadIdx.x & ~63);
+        unsigned long long m = __ballot(flag[k]);
+        if ((threadIdx.x & 63) == 0 && i0 < n) {
+          w.alive_bits[(int64_t)s * chunks + (i0 >> 6)] = m;
+          alive += __popcll(m);
+          int nh = n_head - i0;                             // points of this word that are head points
+          head += nh >= 64 ? __popcll(m) : (nh > 0 ? __popcll(m & ((1ull << nh) - 1ull)) : 0);
         }
       }
     }
-    alive = wave_sum_i32(alive);
-    head = wave_sum_i32(head);
     if ((threadIdx.x & 63) == 0) {
       s_a[threadIdx.x >> 6] = alive;
       s_h[threadIdx.x >> 6] = head;
@@ -1149,29 +1160,25 @@ k_alive_scan(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w
 // straight into the output arrays.  The 8 alive tests of a thread are issued together, ranks come
 // from wave ballots and one small LDS table: a single barrier per tile.
 __global__ void __launch_bounds__(kPT)
-k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles) {
+k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles, int chunks) {
   __shared__ int s_cnt[kPerThread][kPT / 64];           // survivors of (row k, wave)
   int cnt = *count;
-  int npix = b.rows * b.cols, words = (npix + 31) / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
-    int n = b.n_total[s], n_head = b.n_head[s];
+    int n = b.n_total[s];
     int t0 = blockIdx.x * kTile;
     if (t0 >= n) continue;
     const int tile_base = w.tile_alive[(int64_t)s * tiles + blockIdx.x];
     const float4 *src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
     float4 *dst = reinterpret_cast<float4 *>(b.out_xyzi) + (int64_t)s * b.cap;
     bool flag[kPerThread];
-#pragma unroll
-    for (int k = 0; k < kPerThread; ++k) {
-      int i = t0 + k * kPT + threadIdx.x;
-      flag[k] = i < n && point_alive(b, s, i, n_head, npix, words);
-    }
     int rank[kPerThread];
 #pragma unroll
-    for (int k = 0; k < kPerThread; ++k) {
-      unsigned long long m = __ballot(flag[k]);
+    for (int k = 0; k < kPerThread; ++k) {                  // the alive bits k_alive_count left
+      int i0 = t0 + k * kPT + (threadIdx.x & ~63);
+      unsigned long long m = i0 < n ? w.alive_bits[(int64_t)s * chunks + (i0 >> 6)] : 0ull;
+      flag[k] = (m >> lane) & 1ull;
       rank[k] = __popcll(m & ((1ull << lane) - 1ull));
       if (lane == 0) s_cnt[k][wave] = __popcll(m);
     }
@@ -1400,9 +1407,9 @@ static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_
 static int launch_compact(const r3d_batch_t &b, const BatchWs &w, const int32_t *list,
                           const int32_t *count, int rows, hipStream_t st) {
   int tiles = tiles_of(b);
-  hipLaunchKernelGGL(k_alive_count, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, tiles);
+  hipLaunchKernelGGL(k_alive_count, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, tiles, chunks_of(b));
   hipLaunchKernelGGL(k_alive_scan, dim3(rows), dim3(1024), 0, st, b, list, count, w, tiles);
-  hipLaunchKernelGGL(k_alive_write, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, tiles);
+  hipLaunchKernelGGL(k_alive_write, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, tiles, chunks_of(b));
   R3D_LAUNCHED("compaction kernels");
   return R3D_OK;
 }
@@ -1464,12 +1471,14 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream) {
                          w.all_list, w.all_count, w, chunks_of(*b));
       break;
     case R3D_K_ALIVE_COUNT:
-      hipLaunchKernelGGL(k_alive_count, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w, tiles);
+      hipLaunchKernelGGL(k_alive_count, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w, tiles,
+                         chunks_of(*b));
       // the counts overwrite the tile offsets k_alive_write relies on: re-run the (tiny) scan with it
       hipLaunchKernelGGL(k_alive_scan, dim3(b->B), dim3(1024), 0, st, *b, w.all_list, w.all_count, w, tiles);
       break;
     case R3D_K_ALIVE_WRITE:
-      hipLaunchKernelGGL(k_alive_write, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w, tiles);
+      hipLaunchKernelGGL(k_alive_write, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w, tiles,
+                         chunks_of(*b));
       break;
     default:
       return fail(R3D_E_ARG, "batch_launch_one: unknown kernel id");
