@@ -14,5 +14,6 @@ from . import _lib, synth  # noqa: F401
 from ._lib import R3DError  # noqa: F401
 from .batch import SceneBatch, augment_batch, run_sharded, shard_indices  # noqa: F401
 from . import Real3DAug  # noqa: F401
+from .pipeline import AugmentPipeline, Frame  # noqa: F401
 
-__all__ = ["SceneBatch", "augment_batch", "run_sharded", "shard_indices", "Real3DAug", "synth", "R3DError"]
+__all__ = ["SceneBatch", "augment_batch", "run_sharded", "shard_indices", "AugmentPipeline", "Frame", "Real3DAug", "synth", "R3DError"]

@@ -184,20 +184,28 @@ class SceneBatch:
 
 
 def augment_batch(scenes, candidates, min_points, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN, device="cuda:0",
-                  check_cols=5):
+                  check_cols=5, reuse=None):
     """Run whole frames through the insert loop on one GPU.
 
     scenes[s] = (xyzi float32 [n,4], label uint32 [n]); candidates[s][k] = ordered list of M x 5
     float64 placement candidates tried for insert k of scene s (the first one whose visible part
     reaches min_points[s][k] points is merged, insertion.py:449-526).  Returns
     (results, accepted) with results as ``SceneBatch.results`` and accepted[s][k] = index of the
-    accepted candidate or -1.
+    accepted candidate or -1.  ``reuse``: optional dict in which the ``SceneBatch`` is kept between
+    calls (keyed by B) instead of being allocated every time.
     """
     B = len(scenes)
     k_max = max(len(c) for c in candidates)
     grow = max(sum(max((len(x) for x in slot), default=0) for slot in c) for c in candidates)
     cap = max(len(x) for x, _ in scenes) + grow
-    batch = SceneBatch(B, cap, max(grow, 1), rows, cols, device)
+    batch = reuse.get(B) if reuse is not None else None
+    if batch is None or batch.cap < cap or batch.log_cap < max(grow, 1) or (batch.rows, batch.cols) != (rows, cols):
+        # a descriptor is re-usable for any later call that fits (a rebase rewrites only the slabs
+        # that load() overwrites anyway); `reuse` is the caller's {B: SceneBatch} cache
+        batch = SceneBatch(B, int(cap * 1.05) + 64 if reuse is not None else cap, max(grow, 1) * (2 if reuse is not None else 1),
+                           rows, cols, device)
+        if reuse is not None:
+            reuse[B] = batch
     batch.load(scenes)
     batch.begin()
     accepted = [[-1] * len(c) for c in candidates]

@@ -1,0 +1,145 @@
+"""File-to-file driver around the batched hot path.
+
+Reads frames the way the reference's dataset classes do (``velodyne/*.bin`` float32 N x 4 +
+``labels/*.label`` uint32, SS tools/datasets.py:51-56; OD tools/datasets.py:56-62), runs
+``SceneBatch`` on batches of them, and writes ``velodyne/{f}.bin``, ``labels/{f}.label`` (not for
+KITTI object detection) and ``check/{f}.bin`` byte for byte like ``save_data``
+(SS tools/datasets.py:72-91, OD :76-95).  What the reference's driver decides on the host stays
+with the caller: ``candidates_for(i)`` returns, for frame i, the ordered placement candidates of
+every insert (``find_possible_places`` output, find_spot.py:192) and the ``min_points`` of their
+classes.
+
+Reading, computing and writing overlap: a reader thread parses the files of batch i+1 and a
+writer thread stores the results of batch i-1 while batch i is on the GPU; the device descriptor
+(``SceneBatch``) is allocated once and re-used.  Upload and download are not yet overlapped with
+the kernels (one stream).  ``process`` can be injected (the CPU tests pass the oracle there;
+production uses the HIP path and has no fallback).
+"""
+from __future__ import annotations
+
+import os
+import queue
+import threading
+import time
+
+import numpy as np
+
+from .Real3DAug.tools.datasets import read_frame, write_frame
+
+
+class Frame:
+    """One input frame: where its scan and labels are, and the name the outputs get."""
+
+    def __init__(self, velodyne_file, label_file, name=None):
+        self.velodyne_file, self.label_file = velodyne_file, label_file
+        self.name = name or os.path.splitext(os.path.basename(velodyne_file))[0]
+
+
+def _outputs_exist(output_path, folder, name, write_labels):
+    subs = ("velodyne", "check") + (("labels",) if write_labels else ())
+    ext = {"velodyne": "bin", "check": "bin", "labels": "label"}
+    return all(os.path.exists(os.path.join(output_path, folder, sub, f"{name}.{ext[sub]}")) for sub in subs)
+
+
+class AugmentPipeline:
+    def __init__(self, output_path, folder, dataset="semantic", batch_size=64, device="cuda:0",
+                 collapse_labels_to_road=None, resume=True, process=None):
+        """dataset: "semantic" (SemanticKITTI: labels written, 5-column check file) or "kitti"
+        (object detection: labels collapsed to {Road, 1} before use, OD insertion.py:353-355,
+        no label file, 4-column check file)."""
+        assert dataset in ("semantic", "kitti")
+        self.output_path, self.folder, self.dataset = output_path, folder, dataset
+        self.batch_size, self.device, self.resume = int(batch_size), device, resume
+        self.check_cols = 5 if dataset == "semantic" else 4
+        self.write_labels = dataset == "semantic"
+        self.road_label = 40 if collapse_labels_to_road is None and dataset == "kitti" else collapse_labels_to_road
+        self.process = process or self._process_hip
+        self._batches = {}
+
+    # -- the GPU leg ------------------------------------------------------------------------------
+    def _process_hip(self, scenes, candidates, min_points):
+        from .batch import augment_batch
+        return augment_batch(scenes, candidates, min_points, device=self.device, check_cols=self.check_cols,
+                             reuse=self._batches)
+
+    # -- reading / writing -------------------------------------------------------------------------
+    def _read(self, frame):
+        xyzi, label, _ = read_frame(frame.velodyne_file, frame.label_file)
+        if self.road_label is not None:                       # OD insertion.py:353-355
+            label = np.where(label == self.road_label, self.road_label, 1).astype(np.uint32)
+        return np.ascontiguousarray(xyzi), np.ascontiguousarray(label.astype(np.uint32))
+
+    def run(self, frames, candidates_for):
+        """Process every frame; returns a dict of counters and timings.
+
+        candidates_for(i) -> (slots, min_points): slots[k] = ordered list of M x 5 float64
+        candidates of insert k of frame i, min_points[k] its acceptance threshold."""
+        todo = [i for i, f in enumerate(frames)
+                if not (self.resume and _outputs_exist(self.output_path, self.folder, f.name, self.write_labels))]
+        stats = {"frames": len(frames), "skipped_existing": len(frames) - len(todo), "written": 0,
+                 "inserted": 0, "t_read": 0.0, "t_process": 0.0, "t_write": 0.0}
+        t_start = time.perf_counter()
+        chunks = [todo[i:i + self.batch_size] for i in range(0, len(todo), self.batch_size)]
+        read_q, write_q = queue.Queue(maxsize=2), queue.Queue(maxsize=2)
+        errors = []
+
+        def reader():
+            try:
+                for chunk in chunks:
+                    t0 = time.perf_counter()
+                    scenes = [self._read(frames[i]) for i in chunk]
+                    cands = [candidates_for(i) for i in chunk]
+                    stats["t_read"] += time.perf_counter() - t0
+                    read_q.put((chunk, scenes, cands))
+            except Exception as e:                              # surface in the main thread
+                errors.append(e)
+            finally:
+                read_q.put(None)
+
+        def writer():
+            try:
+                while True:
+                    item = write_q.get()
+                    if item is None:
+                        return
+                    chunk, results = item
+                    t0 = time.perf_counter()
+                    for i, (xyzi, label, check) in zip(chunk, results):
+                        write_frame(self.output_path, self.folder, frames[i].name, xyzi, label, check,
+                                    self.write_labels)
+                        stats["written"] += 1
+                    stats["t_write"] += time.perf_counter() - t0
+            except Exception as e:
+                errors.append(e)
+
+        threads = [threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)]
+        for t in threads:
+            t.start()
+        while True:
+            item = read_q.get()
+            if item is None or errors:
+                break
+            chunk, scenes, cands = item
+            t0 = time.perf_counter()
+            results, accepted = self.process(scenes, [c[0] for c in cands], [c[1] for c in cands])
+            stats["t_process"] += time.perf_counter() - t0
+            stats["inserted"] += sum(1 for a in accepted for x in a if x >= 0)
+            while not errors:                                   # do not block on a dead writer
+                try:
+                    write_q.put((chunk, results), timeout=0.5)
+                    break
+                except queue.Full:
+                    pass
+        while threads[1].is_alive():
+            try:
+                write_q.put(None, timeout=0.5)
+                break
+            except queue.Full:
+                if errors:
+                    break
+        threads[1].join(timeout=60)
+        if errors:
+            raise errors[0]
+        stats["t_total"] = time.perf_counter() - t_start
+        stats["frames_per_s"] = stats["written"] / stats["t_total"] if stats["t_total"] > 0 else 0.0
+        return stats

@@ -228,3 +228,38 @@ def test_fast_projection_equals_reference_formula(P, synth):
     sc = O.add_space_for_spherical(synth.scene5_from_packed(*scenes[0]))
     sc, _, _, _, _ = O.scene_field_of_view(sc)
     assert np.array_equal(pix[1][0][0, :len(sc)], sc[:, 8].astype(np.int32))
+
+
+def test_baseline_config_shapes(P, synth):
+    """BASELINE.json configs as parity cases (full size, few scenes): C3 = object-detection path
+    (labels collapsed to {40, 1}, 10 mixed inserts, 4-column check file), C4 = 8 inserts per frame,
+    C5 = a 256-beam ~1M-point scan (reference range image 112 x 1440) with a long insert chain."""
+    # C3
+    scenes = [synth.make_scene(300 + s, collapse_labels_to_road=True) for s in range(2)]
+    slots = [[[x] for x in synth.make_inserts(300 + s, synth.CONFIG_INSERTS["C3"])] for s in range(2)]
+    need = [[20] * 10] * 2
+    res, acc = P.augment_batch(scenes, slots, need, check_cols=4)
+    for (xyzi, label), sl, nd, r, a in zip(scenes, slots, need, res, acc):
+        s5 = synth.scene5_from_packed(xyzi, label)
+        merged, allvis, oacc = O.augment_scene(s5, sl, nd)
+        vb, cb = O.save_bytes_kitti(merged, allvis)
+        assert a == oacc and r[0].tobytes() == vb and r[2].tobytes() == cb
+    # C4
+    scenes = [synth.make_scene(400 + s) for s in range(2)]
+    slots = [[[x] for x in synth.make_inserts(400 + s, synth.CONFIG_INSERTS["C4"])] for s in range(2)]
+    need = [[20] * 8] * 2
+    res, acc = P.augment_batch(scenes, slots, need)
+    for (xyzi, label), sl, nd, r, a in zip(scenes, slots, need, res, acc):
+        vb, lb, cb, oacc = _oracle_chain(xyzi, label, sl, nd)
+        assert a == oacc
+        _check_scene(r, vb, lb, cb)
+    # C5 (one scan, 12 of the 50 inserts to keep the oracle's share of the test short)
+    xyzi, label = synth.make_scene(500, n_beams=256, n_az=3906)
+    assert len(xyzi) == 999936
+    kinds = (["car", "pedestrian", "cyclist"] * 4)
+    sl = [[x] for x in synth.make_inserts(500, kinds)]
+    nd = [20] * len(sl)
+    res, acc = P.augment_batch([(xyzi, label)], [sl], [nd])
+    vb, lb, cb, oacc = _oracle_chain(xyzi, label, sl, nd)
+    assert acc[0] == oacc
+    _check_scene(res[0], vb, lb, cb)
