@@ -947,22 +947,30 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
     bool c_hole = !D.get_local(lp) && E.get_local(lp);
     if (A.get_local(lp)) sd = key_depth(sample_key(q, lp));
     if (D.get_local(lp)) cd = key_depth(scene_key(q, lp));
-    if (s_hole || c_hole) {
-      unsigned long long vs[15], vc[15];
+    // hole means (closing.py:44-57): the 15 neighbour keys are gathered first, one image at a time
+    // (one register array), then summed in the reference's order
+    auto gather15 = [&](bool scene, unsigned long long (&v)[15]) {
 #pragma unroll
       for (int dr = -2; dr <= 2; ++dr)
 #pragma unroll
         for (int dc = -1; dc <= 1; ++dc) {
           int rr = r + dr, cc = c + dc, k = (dr + 2) * 3 + (dc + 1);
-          vs[k] = vc[k] = R3D_SENT;
+          v[k] = R3D_SENT;
           if (rr < 0 || rr >= rows || cc < 0 || cc >= cols) continue;
           int q2 = rr * cols + cc, lp2 = win.lpix_rc(rr, cc);   // inside the window: holes are >= 2 rows in
           if (lp2 < 0) continue;
-          if (s_hole) vs[k] = sample_key(q2, lp2);
-          if (c_hole) vc[k] = scene_key(q2, lp2);
+          v[k] = scene ? scene_key(q2, lp2) : sample_key(q2, lp2);
         }
-      if (s_hole) sd = mean_of_keys(vs);
-      if (c_hole) cd = mean_of_keys(vc);
+    };
+    if (s_hole) {
+      unsigned long long v[15];
+      gather15(false, v);
+      sd = mean_of_keys(v);
+    }
+    if (c_hole) {
+      unsigned long long v[15];
+      gather15(true, v);
+      cd = mean_of_keys(v);
     }
     if (sd < cd) vis.set_local(lp);
   }
