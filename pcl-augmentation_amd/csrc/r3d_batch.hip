@@ -342,8 +342,10 @@ __device__ __forceinline__ bool fast_bin(const Binning &bn, const double *__rest
   const double hi = row_cc[rg == 0 ? 0 : rg + 1], lo = row_cc[rg + 2];
   const double ax = col_dir[2 * cg], ay = col_dir[2 * cg + 1], bx = col_dir[2 * cg + 2], by = col_dir[2 * cg + 3];
   const double mr = 4e-12 * ss, mc = 1e-12 * (fabs(x) + fabs(y) + fabs(z));
-  return fabs(zz) < 0.999998 * ss &&                          // acos is ill-conditioned at the poles
-         zz < hi * ss - mr && zz > lo * ss + mr && ax * y - ay * x > mc && bx * y - by * x < -mc;
+  // (non-short-circuit on purpose: six compares and five ANDs instead of five branches)
+  return (int)(fabs(zz) < 0.999998 * ss) &                    // acos is ill-conditioned at the poles
+         (int)(zz < hi * ss - mr) & (int)(zz > lo * ss + mr) & (int)(ax * y - ay * x > mc) &
+         (int)(bx * y - by * x < -mc);
 }
 
 __global__ void __launch_bounds__(kPT)
@@ -373,12 +375,15 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
       int i = t0 + k * kPT + threadIdx.x;
       BoxAcc box;
       if (i < n) {
-        double x, y, z;
-        load_point(b, s, i, n_head, x, y, z);
+        // float32 points straight from the slab; inserted (float64) points, which only exist when a
+        // re-based scene is projected by this kernel, take the queue
+        float4 pt = i < n_head ? reinterpret_cast<const float4 *>(b.xyzi)[(int64_t)s * b.cap + i]
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        double x = (double)pt.x, y = (double)pt.y, z = (double)pt.z;
         double ss = x * x + y * y + z * z;
         int row, col;
-        if (!exact && fast_bin(bn, s_row, s_col, inv_del, inv_daz, elo, (float)x, (float)y, (float)z, x, y, z, ss,
-                               row, col)) {
+        if ((int)(!exact) & (int)(i < n_head) &
+            (int)fast_bin(bn, s_row, s_col, inv_del, inv_daz, elo, pt.x, pt.y, pt.z, x, y, z, ss, row, col)) {
           int p = row * b.cols + col;
           box.add(row, col);
           if (ss > R3D_EMPTY_DEPTH * R3D_EMPTY_DEPTH) {      // r > 500 (or rounds to it): far list
