@@ -223,7 +223,7 @@ def main():
                          "alg_bytes": 80.0 * m_pts / len(KINDS)},
             "k_alive_count": {"ms": t_count, "launches_per_step": 1, "alg_bytes": 4.0 * n_pts},
             "k_alive_write": {"ms": t_write, "launches_per_step": 1, "alg_bytes": 20.0 * n_pts + 20.0 * n_out_pts},
-            "k_reset": {"ms": t_reset, "launches_per_step": 1, "alg_bytes": 2.0 * B * batch.rows * batch.cols},
+            "k_reset": {"ms": t_reset, "launches_per_step": 1, "alg_bytes": B * batch.rows * batch.cols / 8.0},
         }
         pmc = {}
         try:
