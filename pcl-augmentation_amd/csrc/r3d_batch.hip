@@ -25,8 +25,6 @@ constexpr int kRebaseRows = 16;      // block rows of the (normally idle) rebase
 struct BatchWs {
   unsigned long long *qkeys;    // [B][2] ordered keys of min / max of z/r
   int32_t *tile_alive;          // [B*tiles]
-  int32_t *tile_head;           // [B*tiles]
-  int32_t *new_head;            // [B]
   uint32_t *cand;               // [B*2*npix] chunk / candidate pixel lists of the insert kernel
   int32_t *all_list;            // [B] identity
   int32_t *all_count;           // [1] = B
@@ -56,8 +54,6 @@ static BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   int tiles = tiles_of(b);
   w.qkeys = c.take<unsigned long long>((size_t)b.B * 2);
   w.tile_alive = c.take<int32_t>((size_t)b.B * tiles);
-  w.tile_head = c.take<int32_t>((size_t)b.B * tiles);
-  w.new_head = c.take<int32_t>((size_t)b.B);
   w.cand_stride = 2 * npix > b.cap ? 2 * npix : b.cap;
   w.cand = c.take<uint32_t>((size_t)b.B * w.cand_stride);
   w.all_list = c.take<int32_t>((size_t)b.B);
@@ -1097,14 +1093,14 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
 // ---- compaction: drop dead points (finish, or rebase) ------------------------------------------
 __global__ void __launch_bounds__(kPT)
 k_alive_count(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles, int chunks) {
-  __shared__ int s_a[kPT / 64], s_h[kPT / 64];
+  __shared__ int s_a[kPT / 64];
   int cnt = *count;
   int npix = b.rows * b.cols, words = (npix + 31) / 32;
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
     int n = b.n_total[s], n_head = b.n_head[s];
     int t0 = blockIdx.x * kTile;
-    int alive = 0, head = 0;
+    int alive = 0;
     if (t0 < n) {
       // one bit per point (a 64-bit word per wave and row) so that k_alive_write need not repeat the
       // pixel-id load and the stamp lookups.  (Skipping whole chunks whose bounding box holds no
@@ -1123,57 +1119,15 @@ k_alive_count(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
         if ((threadIdx.x & 63) == 0 && i0 < n) {
           w.alive_bits[(int64_t)s * chunks + (i0 >> 6)] = m;
           alive += __popcll(m);
-          int nh = n_head - i0;                             // points of this word that are head points
-          head += nh >= 64 ? __popcll(m) : (nh > 0 ? __popcll(m & ((1ull << nh) - 1ull)) : 0);
         }
       }
     }
-    if ((threadIdx.x & 63) == 0) {
-      s_a[threadIdx.x >> 6] = alive;
-      s_h[threadIdx.x >> 6] = head;
-    }
+    if ((threadIdx.x & 63) == 0) s_a[threadIdx.x >> 6] = alive;
     __syncthreads();
     if (threadIdx.x == 0) {
-      int a = 0, h = 0;
-      for (int v = 0; v < kPT / 64; ++v) {
-        a += s_a[v];
-        h += s_h[v];
-      }
-      w.tile_alive[(int64_t)s * tiles + blockIdx.x] = a;
-      w.tile_head[(int64_t)s * tiles + blockIdx.x] = h;
-    }
-    __syncthreads();
-  }
-}
-
-__global__ void __launch_bounds__(1024)
-k_alive_scan(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles) {
-  __shared__ int sm[1024 / 64 + 1];
-  __shared__ int s_carry, s_head;
-  int cnt = *count;
-  for (int li = blockIdx.x; li < cnt; li += gridDim.x) {
-    int s = list[li];
-    if (threadIdx.x == 0) s_carry = s_head = 0;
-    __syncthreads();
-    for (int base = 0; base < tiles; base += 1024) {
-      int t = base + threadIdx.x;
-      int a = t < tiles ? w.tile_alive[(int64_t)s * tiles + t] : 0;
-      int h = t < tiles ? w.tile_head[(int64_t)s * tiles + t] : 0;
-      int tot, htot;
-      int ex = block_escan_i32(a, sm, tot);
-      (void)block_escan_i32(h, sm, htot);
-      int carry = s_carry;
-      if (t < tiles) w.tile_alive[(int64_t)s * tiles + t] = carry + ex;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        s_carry = carry + tot;
-        s_head += htot;
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      b.n_out[s] = s_carry;
-      w.new_head[s] = s_head;
+      int a = 0;
+      for (int v = 0; v < kPT / 64; ++v) a += s_a[v];
+      w.tile_alive[(int64_t)s * tiles + blockIdx.x] = a;          // 0 for tiles beyond the cloud
     }
     __syncthreads();
   }
@@ -1185,6 +1139,7 @@ k_alive_scan(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w
 __global__ void __launch_bounds__(kPT)
 k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles, int chunks) {
   __shared__ int s_cnt[kPerThread][kPT / 64];           // survivors of (row k, wave)
+  __shared__ int s_pre[kPT / 64];
   int cnt = *count;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
@@ -1192,7 +1147,17 @@ k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
     int n = b.n_total[s];
     int t0 = blockIdx.x * kTile;
     if (t0 >= n) continue;
-    const int tile_base = w.tile_alive[(int64_t)s * tiles + blockIdx.x];
+    // survivors of the preceding tiles of this scene (at most a few dozen counts): the tile's offset
+    int pre = 0;
+    for (int t = threadIdx.x; t < (int)blockIdx.x; t += kPT) pre += w.tile_alive[(int64_t)s * tiles + t];
+    pre = wave_sum_i32(pre);
+    if (lane == 0) s_pre[wave] = pre;
+    __syncthreads();
+    int tile_base = 0;
+#pragma unroll
+    for (int v = 0; v < kPT / 64; ++v) tile_base += s_pre[v];
+    if (threadIdx.x == 0 && t0 + kTile >= n)                   // the scene's last tile publishes the total
+      b.n_out[s] = tile_base + w.tile_alive[(int64_t)s * tiles + blockIdx.x];
     const float4 *src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
     float4 *dst = reinterpret_cast<float4 *>(b.out_xyzi) + (int64_t)s * b.cap;
     bool flag[kPerThread];
@@ -1431,7 +1396,6 @@ static int launch_compact(const r3d_batch_t &b, const BatchWs &w, const int32_t 
                           const int32_t *count, int rows, hipStream_t st) {
   int tiles = tiles_of(b);
   hipLaunchKernelGGL(k_alive_count, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, tiles, chunks_of(b));
-  hipLaunchKernelGGL(k_alive_scan, dim3(rows), dim3(1024), 0, st, b, list, count, w, tiles);
   hipLaunchKernelGGL(k_alive_write, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, tiles, chunks_of(b));
   R3D_LAUNCHED("compaction kernels");
   return R3D_OK;
@@ -1496,8 +1460,6 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream) {
     case R3D_K_ALIVE_COUNT:
       hipLaunchKernelGGL(k_alive_count, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w, tiles,
                          chunks_of(*b));
-      // the counts overwrite the tile offsets k_alive_write relies on: re-run the (tiny) scan with it
-      hipLaunchKernelGGL(k_alive_scan, dim3(b->B), dim3(1024), 0, st, *b, w.all_list, w.all_count, w, tiles);
       break;
     case R3D_K_ALIVE_WRITE:
       hipLaunchKernelGGL(k_alive_write, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w, tiles,
