@@ -197,7 +197,7 @@ def main():
         # per-kernel timing after the timed region, HIP events on the launch stream
         batch.begin()
         t_bounds = event_time_ms(torch, one(L.K_BOUNDS))
-        t_reset = event_time_ms(torch, one(L.K_RESET))
+        t_reset = event_time_ms(torch, one(L.K_PREPARE))
         t_project = event_time_ms(torch, one(L.K_PROJECT))
         t_begin = event_time_ms(torch, batch.begin)
 
@@ -223,7 +223,7 @@ def main():
                          "alg_bytes": 80.0 * m_pts / len(KINDS)},
             "k_alive_count": {"ms": t_count, "launches_per_step": 1, "alg_bytes": 4.0 * n_pts},
             "k_alive_write": {"ms": t_write, "launches_per_step": 1, "alg_bytes": 20.0 * n_pts + 20.0 * n_out_pts},
-            "k_reset": {"ms": t_reset, "launches_per_step": 1, "alg_bytes": B * batch.rows * batch.cols / 8.0},
+            "k_prepare": {"ms": t_reset, "launches_per_step": 1, "alg_bytes": B * batch.rows * batch.cols / 8.0},
         }
         pmc = {}
         try:

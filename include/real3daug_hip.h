@@ -196,7 +196,7 @@ int r3d_batch_finish(const r3d_batch_t *b, float *check, int32_t check_cols, voi
  * (BOUNDS, RESET, PROJECT) or r3d_batch_finish (ALIVE_COUNT, ALIVE_WRITE) leaves; every one of
  * them is idempotent on that state. */
 #define R3D_K_BOUNDS 1        /* k_bounds: min / max of z/r per scene (insertion.py:74-79) */
-#define R3D_K_RESET 2         /* k_reset: visibility stamps back to zero */
+#define R3D_K_PREPARE 2       /* k_prepare: bounds from the extremes, row-edge table, visibility stamps to zero */
 #define R3D_K_PROJECT 3       /* k_project: pixel id of every point (insertion.py:74-76, :104-116) */
 #define R3D_K_ALIVE_COUNT 4   /* k_alive_count: survivor bits and per-tile counts (insertion.py:472-473) */
 #define R3D_K_ALIVE_WRITE 5   /* k_alive_write: survivors, original order, into out_xyzi / out_label */

@@ -22,7 +22,7 @@ STATUS_TEXT = {
     S_CAPACITY: "merged cloud or insert log exceeds its capacity",
     S_FAR_OVERFLOW: "more than R3D_FAR_CAP pixels deeper than 500 m",
 }
-K_BOUNDS, K_RESET, K_PROJECT, K_ALIVE_COUNT, K_ALIVE_WRITE = 1, 2, 3, 4, 5
+K_BOUNDS, K_PREPARE, K_PROJECT, K_ALIVE_COUNT, K_ALIVE_WRITE = 1, 2, 3, 4, 5
 NUMROW, NUMCOLUMN = 112, 1440
 MAX_SAMPLE = 8192
 FAR_CAP = 1024

@@ -131,12 +131,6 @@ __global__ void k_begin_init(r3d_batch_t b, const int32_t *n_points, BatchWs w) 
   b.status[s] = st;
   b.n_out[s] = 0;
   w.all_list[s] = s;
-}
-
-__global__ void k_bounds_init(const int32_t *list, const int32_t *count, BatchWs w) {
-  int li = blockIdx.x * blockDim.x + threadIdx.x;
-  if (li >= *count) return;
-  int s = list[li];
   w.qkeys[2 * s + 0] = ~0ull;   // running min of z/r
   w.qkeys[2 * s + 1] = 0ull;    // running max of z/r
 }
@@ -193,61 +187,53 @@ k_bounds(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
   }
 }
 
-__global__ void k_bounds_finish(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
-  int li = blockIdx.x * blockDim.x + threadIdx.x;
-  if (li >= *count) return;
-  int s = list[li];
-  unsigned long long kmin = w.qkeys[2 * s + 0], kmax = w.qkeys[2 * s + 1];
-  if (kmin == ~0ull) {                    // no valid point: the reference raises (insertion.py:78)
-    b.bounds[2 * s + 0] = b.bounds[2 * s + 1] = 0.0;
-    atomicOr(&b.status[s], R3D_S_NONFINITE);
-    return;
-  }
-  double max_el = acos(ordered_key_inv(kmin));   // insertion.py:79
-  double min_el = acos(ordered_key_inv(kmax));   // insertion.py:78
-  b.bounds[2 * s + 0] = max_el;
-  b.bounds[2 * s + 1] = min_el;
-  w.q_ext[2 * s + 0] = ordered_key_inv(kmin);
-  w.q_ext[2 * s + 1] = ordered_key_inv(kmax);
-}
-
-// Tables of the verified fast projection (k_project): a bin guessed in float32 is accepted only if
-// the point lies strictly inside that bin's edges, tested in float64 on monotone images of the
-// edges -- cos of the row edges against z/r, and the sign of the cross product with the unit
-// vector of the column edges -- with a margin far above the rounding of either side.
-__global__ void k_row_table(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
-  int li = blockIdx.y;
-  if (li >= *count) return;
-  int s = list[li];
-  int k = blockIdx.x * blockDim.x + threadIdx.x;           // entry k holds edge k-1
-  if (k >= b.rows + 2) return;
-  double max_el = b.bounds[2 * s + 0], min_el = b.bounds[2 * s + 1];
-  double d_el = (max_el - min_el) / (double)b.rows;
-  double edge = min_el + 0.00001 + (double)(k - 1) * d_el;
-  // outside [0, pi] the cosine stops being monotone: clamp (such rows can hold no point anyway)
-  edge = edge < 0.0 ? 0.0 : (edge > kPi ? kPi : edge);
-  double c = cos(edge);
-  w.row_q[(int64_t)s * (b.rows + 2) + k] = c * fabs(c);     // compared with z*|z| / (x*x+y*y+z*z)
-}
-
-__global__ void k_col_table(r3d_batch_t b, BatchWs w) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c > b.cols) return;
-  double alpha = (double)c * (kTwoPi / (double)b.cols) - kPi;   // direction angle of column edge c
-  w.col_dir[2 * c + 0] = cos(alpha);
-  w.col_dir[2 * c + 1] = sin(alpha);
-}
-
-// ---- step 0: reset the per-scene visibility stamps ------------------------------------------------
-// Only pixels whose `ever` bit is set carry a stamp, so the reset walks the bit image (20 KB per
-// scene) instead of the stamp image (322 KB per scene).
+// After k_bounds: the elevation bounds (insertion.py:78-79) = acos of the extreme z/r, the row-edge
+// table of the verified fast projection (k_project), and the reset of the visibility stamps, in one
+// launch.  Only pixels whose `ever` bit is set carry a stamp, so the reset walks the bit image
+// (20 KB per scene) instead of the stamp image (322 KB per scene).
+//
+// Tables of the fast projection: a bin guessed in float32 is accepted only if the point lies
+// strictly inside that bin's edges, tested in float64 on monotone images of the edges -- cos of
+// the row edges against z/r, and the sign of the cross product with the unit vector of the column
+// edges -- with a margin far above the rounding of either side.
 __global__ void __launch_bounds__(kPT)
-k_reset(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
+k_prepare(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
+  __shared__ double s_b[2];
+  __shared__ int s_ok;
   int cnt = *count;
   int64_t npix = (int64_t)b.rows * b.cols;
   int words = (int)((npix + 31) / 32);
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
+    if (blockIdx.x == 0) {
+      if (threadIdx.x == 0) {
+        unsigned long long kmin = w.qkeys[2 * s + 0], kmax = w.qkeys[2 * s + 1];
+        s_ok = kmin != ~0ull;
+        if (!s_ok) {                          // no valid point: the reference raises (insertion.py:78)
+          b.bounds[2 * s + 0] = b.bounds[2 * s + 1] = s_b[0] = s_b[1] = 0.0;
+          atomicOr(&b.status[s], R3D_S_NONFINITE);
+        } else {
+          double q_lo = ordered_key_inv(kmin), q_hi = ordered_key_inv(kmax);
+          s_b[0] = b.bounds[2 * s + 0] = acos(q_lo);     // max elevation, insertion.py:79
+          s_b[1] = b.bounds[2 * s + 1] = acos(q_hi);     // min elevation, insertion.py:78
+          w.q_ext[2 * s + 0] = q_lo;
+          w.q_ext[2 * s + 1] = q_hi;
+        }
+        b.n_far[s] = 0;
+        w.n_slow[s] = 0;
+      }
+      __syncthreads();
+      double max_el = s_b[0], min_el = s_b[1];
+      double d_el = (max_el - min_el) / (double)b.rows;
+      for (int k = threadIdx.x; k < b.rows + 2; k += kPT) {   // entry k holds edge k-1
+        double edge = min_el + 0.00001 + (double)(k - 1) * d_el;
+        // outside [0, pi] the cosine stops being monotone: clamp (such rows can hold no point anyway)
+        edge = edge < 0.0 ? 0.0 : (edge > kPi ? kPi : edge);
+        double c = cos(edge);
+        w.row_q[(int64_t)s * (b.rows + 2) + k] = c * fabs(c);   // compared with z*|z| / (x*x+y*y+z*z)
+      }
+      __syncthreads();
+    }
     uint16_t *st = b.stamp + (int64_t)s * npix;
     uint32_t *ev = b.ever + (int64_t)s * words;
     for (int p = blockIdx.x * kPT + threadIdx.x; p < words; p += gridDim.x * kPT) {
@@ -260,11 +246,15 @@ k_reset(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
         if ((int64_t)p * 32 + bit < npix) st[(int64_t)p * 32 + bit] = 0;
       }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      b.n_far[s] = 0;
-      w.n_slow[s] = 0;
-    }
   }
+}
+
+__global__ void k_col_table(r3d_batch_t b, BatchWs w) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > b.cols) return;
+  double alpha = (double)c * (kTwoPi / (double)b.cols) - kPi;   // direction angle of column edge c
+  w.col_dir[2 * c + 0] = cos(alpha);
+  w.col_dir[2 * c + 1] = sin(alpha);
 }
 
 // ---- step 0 / rebase: spherical projection -> pixel ids ------------------------------------------
@@ -1377,14 +1367,10 @@ static size_t insert_lds_bytes(const r3d_batch_t &b) {
 static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_t *list,
                             const int32_t *count, int rows, hipStream_t st) {
   int tiles = tiles_of(b);
-  int lb = (b.B + 255) / 256;
-  hipLaunchKernelGGL(k_bounds_init, dim3(lb), dim3(256), 0, st, list, count, w);
   hipLaunchKernelGGL(k_bounds, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w);
-  hipLaunchKernelGGL(k_bounds_finish, dim3(lb), dim3(256), 0, st, b, list, count, w);
-  hipLaunchKernelGGL(k_row_table, dim3((b.rows + 2 + 127) / 128, rows), dim3(128), 0, st, b, list, count, w);
   int64_t npix = (int64_t)b.rows * b.cols;
   int rb = (int)((npix / 32 + kPT - 1) / kPT);
-  hipLaunchKernelGGL(k_reset, dim3(rb < 1 ? 1 : rb, rows), dim3(kPT), 0, st, b, list, count, w);
+  hipLaunchKernelGGL(k_prepare, dim3(rb < 1 ? 1 : rb, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_project, dim3(project_blocks(b), rows), dim3(kPT), project_lds_bytes(b), st, b, list,
                      count, w, chunks_of(b));
   hipLaunchKernelGGL(k_project_slow, dim3(4, rows), dim3(kPT), 0, st, b, list, count, w);
@@ -1449,8 +1435,8 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream) {
     case R3D_K_BOUNDS:
       hipLaunchKernelGGL(k_bounds, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w);
       break;
-    case R3D_K_RESET:
-      hipLaunchKernelGGL(k_reset, dim3((int)((npix / 32 + kPT - 1) / kPT), b->B), dim3(kPT), 0, st, *b,
+    case R3D_K_PREPARE:
+      hipLaunchKernelGGL(k_prepare, dim3((int)((npix / 32 + kPT - 1) / kPT), b->B), dim3(kPT), 0, st, *b,
                          w.all_list, w.all_count, w);
       break;
     case R3D_K_PROJECT:
