@@ -101,8 +101,7 @@ class SceneBatch:
         Only the first n rows of every slab are written and uploaded state beyond them is never
         read (n_points bounds every kernel)."""
         assert len(scenes) == self.B
-        pin = self._staging()
-        hx, hl, hn = pin["xyzi"].numpy(), pin["label"].numpy().view(np.uint32), pin["n"].numpy()
+        hx, hl, hn = self.staging_views()
         for s, (xyzi, label) in enumerate(scenes):
             n = len(xyzi)
             if n > self.cap:
@@ -110,9 +109,42 @@ class SceneBatch:
             hn[s] = n
             hx[s, :n] = xyzi
             np.bitwise_and(label, 0xFFFF, out=hl[s, :n], casting="unsafe")
+        self.upload_staging()
+
+    def upload_staging(self):
+        """Upload what was written into ``_staging()`` (pinned views, e.g. by a reader thread)."""
+        pin = self._staging()
         self.xyzi.copy_(pin["xyzi"], non_blocking=True)
         self.label.copy_(pin["label"], non_blocking=True)
         self.n_points.copy_(pin["n"], non_blocking=True)
+
+    def staging_views(self):
+        """NumPy views of the pinned input slabs: xyzi [B,cap,4] float32, label [B,cap] uint32,
+        n [B] int32."""
+        pin = self._staging()
+        return pin["xyzi"].numpy(), pin["label"].numpy().view(np.uint32), pin["n"].numpy()
+
+    def download_views(self):
+        """Results as views of pinned host memory (valid until the next download): (xyzi [B,cap,4],
+        label [B,cap] uint32, check [B,log_cap,cols] or None, n_out [B], n_log [B])."""
+        torch = self.torch
+        self.raise_on_status()
+        if getattr(self, "_pin_out", None) is None:
+            self._pin_out = (torch.empty((self.B, self.cap, 4), dtype=torch.float32).pin_memory(),
+                             torch.empty((self.B, self.cap), dtype=torch.int32).pin_memory())
+        px, pl = self._pin_out
+        px.copy_(self.out_xyzi, non_blocking=True)
+        pl.copy_(self.out_label, non_blocking=True)
+        ck = None
+        if self.check is not None:
+            if getattr(self, "_pin_ck", None) is None or self._pin_ck.shape != self.check.shape:
+                self._pin_ck = torch.empty(self.check.shape, dtype=torch.float32).pin_memory()
+            self._pin_ck.copy_(self.check, non_blocking=True)
+            ck = self._pin_ck.numpy()
+        n_out = self.n_out.cpu().numpy()
+        n_log = self.n_log.cpu().numpy()
+        torch.cuda.current_stream().synchronize()
+        return px.numpy(), pl.numpy().view(np.uint32), ck, n_out, n_log
 
     def load_device(self, xyzi, label, n_points):
         """Same from tensors already on the device (copied into the batch slabs)."""
@@ -180,25 +212,43 @@ class SceneBatch:
             _lib.raise_status(int(st[s]), f"scene {s}")
 
     def results(self):
-        """Per scene: (xyzi float32 [n,4], label uint32 [n], check float32 [m,cols])."""
+        """Per scene: (xyzi float32 [n,4], label uint32 [n], check float32 [m,cols]), copies."""
+        ox, ol, ck, n_out, n_log = self.download_views()
+        return [(ox[s, :n_out[s]].copy(), ol[s, :n_out[s]].copy(),
+                 ck[s, :n_log[s]].copy() if ck is not None else None) for s in range(self.B)]
+
+    def run_inserts(self, candidates, min_points):
+        """The candidate loop of insertion.py:449-545 for every scene, after ``begin``: candidates
+        of a slot are tried in order, the slot's "still open" mask lives on the device, and the
+        host synchronises once, at the end.  Returns accepted[s][k] = index of the accepted
+        candidate of insert k of scene s, or -1."""
         torch = self.torch
-        self.raise_on_status()
-        n_out = self.n_out.cpu().numpy()
-        n_log = self.n_log.cpu().numpy()
-        if getattr(self, "_pin_out", None) is None:
-            self._pin_out = (torch.empty((self.B, self.cap, 4), dtype=torch.float32).pin_memory(),
-                             torch.empty((self.B, self.cap), dtype=torch.int32).pin_memory())
-        px, pl = self._pin_out
-        px.copy_(self.out_xyzi, non_blocking=True)
-        pl.copy_(self.out_label, non_blocking=True)
-        ck = self.check.cpu().numpy() if self.check is not None else None
-        torch.cuda.current_stream().synchronize()
-        ox, ol = px.numpy(), pl.numpy().view(np.uint32)
-        out = []
-        for s in range(self.B):
-            out.append((ox[s, :n_out[s]].copy(), ol[s, :n_out[s]].copy(),
-                        ck[s, :n_log[s]].copy() if ck is not None else None))
-        return out
+        B = self.B
+        k_max = max(len(c) for c in candidates)
+        log, keep = [], []
+        for k in range(k_max):
+            n_cand = max(len(c[k]) if k < len(c) else 0 for c in candidates)
+            need = torch.from_numpy(np.asarray([min_points[s][k] if k < len(candidates[s]) else 0
+                                                for s in range(B)], dtype=np.int32)).to(self.device)
+            still_open = None
+            for ci in range(n_cand):
+                smp = [candidates[s][k][ci] if k < len(candidates[s]) and ci < len(candidates[s][k]) else None
+                       for s in range(B)]
+                s5, off = self.pack_samples(smp)
+                _, acc = self.insert_device(s5, off, need, still_open, new_slot=(ci == 0))
+                acc = acc.clone()
+                log.append((k, ci, acc))
+                keep.append((s5, off, need, still_open))
+                if ci + 1 < n_cand:
+                    still_open = (1 - acc) if still_open is None else still_open * (1 - acc)
+        accepted = [[-1] * len(c) for c in candidates]
+        if log:
+            flags = torch.stack([a for _, _, a in log]).cpu().numpy()      # the one synchronisation
+            for (k, ci, _), row in zip(log, flags):
+                for s in np.nonzero(row)[0]:
+                    if k < len(accepted[s]) and accepted[s][k] < 0:
+                        accepted[s][k] = ci
+        return accepted
 
 
 def augment_batch(scenes, candidates, min_points, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN, device="cuda:0",
@@ -213,7 +263,6 @@ def augment_batch(scenes, candidates, min_points, rows=_lib.NUMROW, cols=_lib.NU
     calls (keyed by B) instead of being allocated every time.
     """
     B = len(scenes)
-    k_max = max(len(c) for c in candidates)
     grow = max(sum(max((len(x) for x in slot), default=0) for slot in c) for c in candidates)
     cap = max(len(x) for x, _ in scenes) + grow
     batch = reuse.get(B) if reuse is not None else None
@@ -226,18 +275,7 @@ def augment_batch(scenes, candidates, min_points, rows=_lib.NUMROW, cols=_lib.NU
             reuse[B] = batch
     batch.load(scenes)
     batch.begin()
-    accepted = [[-1] * len(c) for c in candidates]
-    for k in range(k_max):
-        n_cand = max(len(c[k]) if k < len(c) else 0 for c in candidates)
-        need = [min_points[s][k] if k < len(candidates[s]) else 0 for s in range(B)]
-        for ci in range(n_cand):
-            smp = [candidates[s][k][ci] if k < len(candidates[s]) and ci < len(candidates[s][k])
-                   and accepted[s][k] < 0 else None for s in range(B)]
-            active = [0 if x is None else 1 for x in smp]
-            _, acc = batch.insert(smp, need, active, new_slot=(ci == 0))
-            for s in range(B):
-                if active[s] and acc[s]:
-                    accepted[s][k] = ci
+    accepted = batch.run_inserts(candidates, min_points)
     batch.finish(check_cols)
     SceneBatch.last_rebases = int(batch.rebase.sum().item())
     return batch.results(), accepted
