@@ -263,3 +263,64 @@ def test_baseline_config_shapes(P, synth):
     vb, lb, cb, oacc = _oracle_chain(xyzi, label, sl, nd)
     assert acc[0] == oacc
     _check_scene(res[0], vb, lb, cb)
+
+
+def test_accept_threshold_and_degenerate_samples(P, synth):
+    """min_points exactly at / one above the visible count, a zero threshold with nothing visible,
+    a sample whose points all fall outside the elevation range, and a scene without a sample."""
+    xyzi, label = synth.make_scene(33, 48, 700)
+    good = synth.make_insert(21, "cyclist", centre_range=8.0)
+    s5 = synth.scene5_from_packed(xyzi, label)
+    _, _, acc0 = O.augment_scene(s5, [[good]], [1])
+    sc = O.add_space_for_spherical(s5)
+    sc, tr, lb, mx, mn = O.scene_field_of_view(sc)
+    _, vis, _ = O.evaluate_candidate(sc, tr, mx, mn, good)
+    nvis = len(vis)
+    assert nvis > 30
+    hidden = synth.make_insert(7, "car", centre_range=55.0)
+    hidden[:, 2] += 2.0
+    sky = synth.make_insert(5, "pedestrian", centre_range=3.0)
+    sky[:, 2] += 40.0                                    # far above the top beam: every row < 0
+    cases = [([[good]], [nvis]), ([[good]], [nvis + 1]), ([[hidden]], [0]), ([[sky]], [1]), ([[good], [hidden]], [1, 1])]
+    scenes = [(xyzi, label)] * len(cases)
+    res, acc = P.augment_batch(scenes, [c[0] for c in cases], [c[1] for c in cases])
+    for (slots, need), r, a in zip(cases, res, acc):
+        vb, lb_, cb, oacc = _oracle_chain(xyzi, label, slots, need)
+        assert a == oacc
+        _check_scene(r, vb, lb_, cb)
+    assert acc[0] == [0] and acc[1] == [-1] and acc[2] == [-1] and acc[3] == [-1] and acc[4] == [0, -1]
+    # a scene with no sample in a slot is left alone; the other scene of the batch still inserts
+    b = P.SceneBatch(2, len(xyzi) + 4096, 4096)
+    b.load([(xyzi, label), (xyzi, label)])
+    b.begin()
+    nv, ac = b.insert([good, None], [10, 10])
+    assert ac.tolist() == [1, 0] and nv[1] == 0
+    b.finish()
+    r = b.results()
+    assert np.array_equal(r[1][0], xyzi) and len(r[1][2]) == 0 and len(r[0][2]) == nvis
+
+
+def test_batch_object_is_reusable_and_capacity_is_checked(P, synth):
+    xyzi, label = synth.make_scene(34, 32, 600)
+    ins = [synth.make_insert(400 + k, kind, rng_range=(5.0, 12.0)) for k, kind in enumerate(["car", "pedestrian"])]
+    b = P.SceneBatch(1, len(xyzi) + 4096, 4096)
+    out = []
+    for _ in range(2):                                   # same descriptor, begin() resets everything
+        b.load([(xyzi, label)])
+        b.begin()
+        for x in ins:
+            b.insert([x], [10])
+        b.finish()
+        out.append(b.results()[0])
+    for x, y in zip(out[0], out[1]):
+        assert np.array_equal(x, y)
+    vb, lb, cb, _ = _oracle_chain(xyzi, label, [[x] for x in ins], [10, 10])
+    _check_scene(out[0], vb, lb, cb)
+    small = P.SceneBatch(1, len(xyzi) + 8, 8)            # no room for the visible points
+    small.load([(xyzi, label)])
+    small.begin()
+    nv, ac = small.insert([ins[0]], [10])
+    assert ac[0] == 0 and nv[0] > 8
+    with pytest.raises(ValueError):
+        small.finish()
+        small.results()
