@@ -95,6 +95,7 @@ __device__ __forceinline__ void load_point(const r3d_batch_t &b, int s, int i, i
 
 __device__ __forceinline__ bool point_alive_at(const r3d_batch_t &b, int s, int i, int p, int n_head,
                                                int npix, int words) {
+  if (p < 0) return false;                              // entombed by an earlier rebase
   if (i < n_head) return !((b.ever[(int64_t)s * words + (p >> 5)] >> (p & 31)) & 1u);
   int lr = b.tail_ref[(int64_t)s * b.log_cap + (i - n_head)];
   return (int)b.stamp[(int64_t)s * npix + p] <= b.log_birth[(int64_t)s * b.log_cap + lr];
@@ -103,6 +104,7 @@ __device__ __forceinline__ bool point_alive_at(const r3d_batch_t &b, int s, int 
 __device__ __forceinline__ bool point_alive(const r3d_batch_t &b, int s, int i, int n_head, int npix,
                                             int words) {
   int p = b.pix[(int64_t)s * b.cap + i];
+  if (p < 0) return false;                              // entombed by an earlier rebase
   if (i < n_head) return !((b.ever[(int64_t)s * words + (p >> 5)] >> (p & 31)) & 1u);
   int lr = b.tail_ref[(int64_t)s * b.log_cap + (i - n_head)];
   return (int)b.stamp[(int64_t)s * npix + p] <= b.log_birth[(int64_t)s * b.log_cap + lr];
@@ -811,7 +813,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
 #pragma unroll
     for (int u = 0; u < 4; ++u) p[u] = idx[u] >= 0 ? b.pix[(int64_t)s * b.cap + idx[u]] : 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) lp[u] = idx[u] >= 0 ? win.lpix(p[u]) : -1;
+    for (int u = 0; u < 4; ++u) lp[u] = (idx[u] >= 0 && p[u] >= 0) ? win.lpix(p[u]) : -1;
 #pragma unroll
     for (int u = 0; u < 4; ++u) ok[u] = lp[u] >= 0 && point_alive_at(b, s, idx[u], p[u], n_head, npix, words);
     double x[4], y[4], z[4];
@@ -1182,8 +1184,8 @@ k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
 
 // ---- rebase: one workgroup re-bases one flagged scene (rare path) --------------------------------
 // Triggered when an accepted insert may have moved the elevation bounds (k_insert, step 8).  Does,
-// for that scene only, what the reference does for every insert (insertion.py:373-375): drop the
-// culled points, recompute the bounds, re-project every point.  All phases run inside one block so
+// for that scene only, what the reference does for every insert (insertion.py:373-375): forget the
+// culled points, recompute the bounds, re-project every remaining point.  All phases run inside one block so
 // the idle case costs one empty launch; phases are separated by a device-scope fence + barrier
 // because later phases re-read what earlier ones wrote.
 constexpr int kRB = 1024;
@@ -1195,7 +1197,6 @@ __device__ __forceinline__ void phase_sync() {
 
 __global__ void __launch_bounds__(kRB)
 k_rebase(r3d_batch_t b, BatchWs w, int chunks) {
-  __shared__ int sm[kRB / 64 + 1];
   __shared__ unsigned long long s_min[kRB / 64], s_max[kRB / 64];
   const int tid = threadIdx.x;
   const int npix = b.rows * b.cols, words = (npix + 31) / 32;
@@ -1203,50 +1204,20 @@ k_rebase(r3d_batch_t b, BatchWs w, int chunks) {
   for (int li = blockIdx.x; li < cnt; li += gridDim.x) {
     const int s = w.rebase_list[li];
     const int n = b.n_total[s], n_head = b.n_head[s];
-    float4 *xyzi = reinterpret_cast<float4 *>(b.xyzi) + (int64_t)s * b.cap;
-    uint32_t *label = b.label + (int64_t)s * b.cap;
-    int32_t *tref = b.tail_ref + (int64_t)s * b.log_cap;
-    // (a) alive head points: the new n_head
-    int mine = 0;
-    for (int i = tid; i < n_head; i += kRB) mine += point_alive(b, s, i, n_head, npix, words) ? 1 : 0;
-    int new_head;
-    (void)block_escan_i32(mine, sm, new_head);
-    // (b) in-place stable compaction, tile by tile (write index <= read index)
-    int base = 0;
-    for (int t0 = 0; t0 < n; t0 += kRB) {
-      int i = t0 + tid;
-      int flag = (i < n && point_alive(b, s, i, n_head, npix, words)) ? 1 : 0;
-      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-      uint32_t lab = 0;
-      int tr = 0;
-      if (flag) {
-        p = xyzi[i];
-        lab = label[i];
-        if (i >= n_head) tr = tref[i - n_head];
-      }
-      int tot;
-      int ex = block_escan_i32(flag, sm, tot);      // barriers: every read of the tile is done
-      if (flag) {
-        int o = base + ex;
-        xyzi[o] = p;
-        label[o] = lab;
-        if (i >= n_head) tref[o - new_head] = tr;
-      }
-      base += tot;
-      phase_sync();
-    }
-    const int n_new = base;
-    if (tid == 0) {
-      b.n_head[s] = new_head;
-      b.n_total[s] = n_new;
-    }
+    int32_t *pix = b.pix + (int64_t)s * b.cap;
+    // (a) entomb the dead: a point whose pixel was visible after its birth gets pixel id -1 for
+    // good (the stamps that say so are about to be reset).  Nothing is moved: the input slab stays
+    // as it was loaded, r3d_batch_finish drops the entombed points like any other dead point.
+    for (int i = tid; i < n; i += kRB)
+      if (!point_alive(b, s, i, n_head, npix, words)) pix[i] = -1;
     phase_sync();
-    // (c) bounds (insertion.py:78-79) via the extreme z/r
+    // (b) bounds (insertion.py:78-79) via the extreme z/r of the living
     unsigned long long lmin = ~0ull, lmax = 0ull;
     int bad = 0;
-    for (int i = tid; i < n_new; i += kRB) {
+    for (int i = tid; i < n; i += kRB) {
+      if (pix[i] < 0) continue;
       double x, y, z;
-      load_point(b, s, i, new_head, x, y, z);
+      load_point(b, s, i, n_head, x, y, z);
       double q = z / sqrt(x * x + y * y + z * z);
       if (!(q >= -1.0 && q <= 1.0)) bad = 1;
       else {
@@ -1275,28 +1246,28 @@ k_rebase(r3d_batch_t b, BatchWs w, int chunks) {
       w.q_ext[2 * s + 1] = ordered_key_inv(lmax);
       b.n_far[s] = 0;
     }
-    // (d) reset the visibility stamps
+    // (c) reset the visibility stamps
     for (int p = tid; p < npix; p += kRB) {
       b.stamp[(int64_t)s * npix + p] = 0;
       if (p < words) b.ever[(int64_t)s * words + p] = 0u;
     }
     phase_sync();
-    // (e) re-project (insertion.py:74-76, :104-116): pixel ids and chunk boxes
+    // (d) re-project the living (insertion.py:74-76, :104-116): pixel ids and chunk boxes
     Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
     int flags = 0;
-    for (int i0 = 0; i0 < n_new; i0 += kRB) {
+    for (int i0 = 0; i0 < n; i0 += kRB) {
       int i = i0 + tid;
       BoxAcc box;
-      if (i < n_new) {
+      if (i < n && pix[i] >= 0) {
         double x, y, z;
-        load_point(b, s, i, new_head, x, y, z);
-        b.pix[(int64_t)s * b.cap + i] = project_point(b, s, bn, x, y, z, flags, box);
+        load_point(b, s, i, n_head, x, y, z);
+        pix[i] = project_point(b, s, bn, x, y, z, flags, box);
       }
       unsigned long long packed = box.wave_pack();
       int c0 = i0 + (tid & ~63);
-      if ((tid & 63) == 0 && c0 < n_new) w.chunk_box[(int64_t)s * chunks + (c0 >> 6)] = packed;
+      if ((tid & 63) == 0 && c0 < n) w.chunk_box[(int64_t)s * chunks + (c0 >> 6)] = packed;
     }
-    if (tid == 0) w.n_proj[s] = n_new;
+    if (tid == 0) w.n_proj[s] = n;
     if (flags) atomicOr(&b.status[s], flags);
     phase_sync();
   }

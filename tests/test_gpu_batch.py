@@ -324,3 +324,26 @@ def test_batch_object_is_reusable_and_capacity_is_checked(P, synth):
     with pytest.raises(ValueError):
         small.finish()
         small.results()
+
+
+def test_rebase_leaves_the_loaded_input_intact(P, synth):
+    """A rebase entombs dead points instead of compacting the slab: the same descriptor can run the
+    same frames again without being re-loaded, and gives the same bytes."""
+    xyzi, label = synth.make_scene(35, 32, 600)
+    ins = [blob_in_front_of_extreme(xyzi, "max"), synth.make_insert(410, "car", rng_range=(5.0, 12.0)),
+           blob_in_front_of_extreme(xyzi, "min"), synth.make_insert(411, "pedestrian", rng_range=(5.0, 12.0))]
+    b = P.SceneBatch(1, len(xyzi) + 4096, 4096)
+    b.load([(xyzi, label)])
+    out = []
+    for _ in range(2):
+        b.begin()                                        # no load() in between
+        for x in ins:
+            b.insert([x], [10])
+        assert int(b.rebase.sum().item()) >= 2
+        b.finish()
+        out.append(b.results()[0])
+        assert np.array_equal(b.xyzi[0, :len(xyzi)].cpu().numpy(), xyzi)
+    for x, y in zip(out[0], out[1]):
+        assert np.array_equal(x, y)
+    vb, lb, cb, _ = _oracle_chain(xyzi, label, [[x] for x in ins], [10] * 4)
+    _check_scene(out[0], vb, lb, cb)
