@@ -152,66 +152,4 @@ __device__ __forceinline__ int block_escan_i32(int v, int *sm, int &total) {
   return base + inc - v;
 }
 
-// ---- 5 x 3 closing / hole fill on a u64 range image (SENT = empty) ---------------------------
-// Accessor: unsigned long long operator()(int row, int col) for in-range coordinates.
-
-// closing.py:20-21: closed = erode(dilate(occ)), window 5 rows x 3 columns clipped at the borders.
-template <class Occ>
-__device__ __forceinline__ bool closed_at(const Occ &occ, int r, int c, int rows, int cols) {
-  for (int er = r - 2; er <= r + 2; ++er) {
-    if (er < 0 || er >= rows) continue;
-    for (int ec = c - 1; ec <= c + 1; ++ec) {
-      if (ec < 0 || ec >= cols) continue;
-      bool any = false;
-      for (int dr = er - 2; dr <= er + 2 && !any; ++dr) {
-        if (dr < 0 || dr >= rows) continue;
-        for (int dc = ec - 1; dc <= ec + 1; ++dc) {
-          if (dc < 0 || dc >= cols) continue;
-          if (occ(dr, dc)) {
-            any = true;
-            break;
-          }
-        }
-      }
-      if (!any) return false;
-    }
-  }
-  return true;
-}
-
-// closing.py:44-57: sum of ORIGINAL depths of occupied neighbours, drow outer, dcolumn inner,
-// divided by the neighbour count.  Returns false when there is no occupied neighbour.
-template <class Grid>
-__device__ __forceinline__ bool hole_mean(const Grid &g, int r, int c, int rows, int cols, double &out) {
-  double sum = 0.0;
-  int cnt = 0;
-  for (int dr = -2; dr <= 2; ++dr) {
-    int rr = r + dr;
-    if (rr < 0 || rr >= rows) continue;
-    for (int dc = -1; dc <= 1; ++dc) {
-      int cc = c + dc;
-      if (cc < 0 || cc >= cols) continue;
-      unsigned long long k = g(rr, cc);
-      if (k != R3D_SENT) {
-        ++cnt;
-        sum += key_depth(k);
-      }
-    }
-  }
-  if (cnt == 0) return false;
-  out = sum / (double)cnt;
-  return true;
-}
-
-// Smoothed depth (closing.py:26-62) of one pixel of a u64 image, evaluated on demand.
-template <class Grid>
-__device__ __forceinline__ double smoothed_depth(const Grid &g, int r, int c, int rows, int cols) {
-  unsigned long long k = g(r, c);
-  if (k != R3D_SENT) return key_depth(k);
-  auto occ = [&](int rr, int cc) { return g(rr, cc) != R3D_SENT; };
-  if (!closed_at(occ, r, c, rows, cols)) return R3D_EMPTY_DEPTH;
-  double m;
-  return hole_mean(g, r, c, rows, cols, m) ? m : R3D_EMPTY_DEPTH;
-}
-
 }  // namespace r3d
