@@ -97,21 +97,37 @@ k_front_view(double *__restrict__ pcl9, int64_t n, int rows, int cols, double ma
              int sample, unsigned long long *__restrict__ grid, int32_t *status) {
   Binning b = make_binning(max_el, min_el, rows, cols);
   int flags = 0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+  const int lane = threadIdx.x & 63;
+  // whole waves walk the cloud together so that the shuffles below always see all 64 lanes
+  const int64_t n_round = (n + 63) & ~63ll;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_round;
        i += (int64_t)gridDim.x * blockDim.x) {
-    double *p = pcl9 + i * 9;
-    int row, col;
-    int ok = bin_point(b, p[4], p[5], row, col);       // :104-105
-    if (!(ok & 1)) {
-      if (!sample) flags |= R3D_S_ROW_RANGE;           // assert :110
-      continue;                                        // :107-108
+    long long cell = -1 - lane;                        // no pixel: unique, never equal to a neighbour's
+    unsigned long long key = R3D_SENT;
+    if (i < n) {
+      double *p = pcl9 + i * 9;
+      int row, col;
+      int ok = bin_point(b, p[4], p[5], row, col);     // :104-105
+      if (!(ok & 1)) {
+        if (!sample) flags |= R3D_S_ROW_RANGE;         // assert :110; sample: skipped, :107-108
+      } else if (!(ok & 2)) {
+        flags |= R3D_S_COL_RANGE;                      // assert :112
+      } else {
+        p[8] = (double)(row * R3D_NUMCOLUMN + col);    // :116 / :127 (global constant)
+        cell = (long long)row * cols + col;
+        key = depth_key(p[3]);
+      }
     }
-    if (!(ok & 2)) {
-      flags |= R3D_S_COL_RANGE;                        // assert :112
-      continue;
+    // LiDAR files are ring-ordered: neighbouring lanes often hit the same pixel.  A segmented
+    // min over runs of equal pixels (wave shuffles) leaves one atomic per run (:118-125).
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      unsigned long long k2 = __shfl_down(key, o, 64);
+      long long c2 = __shfl_down(cell, o, 64);
+      if (lane + o < 64 && c2 == cell) key = k2 < key ? k2 : key;
     }
-    p[8] = (double)(row * R3D_NUMCOLUMN + col);        // :116 / :127 (global constant)
-    atomicMin(&grid[(int64_t)row * cols + col], depth_key(p[3]));   // :118-125
+    long long prev = __shfl_up(cell, 1, 64);
+    if (cell >= 0 && (lane == 0 || prev != cell)) atomicMin(&grid[cell], key);
   }
   flags = wave_or_i32(flags);
   if ((threadIdx.x & 63) == 0 && flags) atomicOr(status, flags);
