@@ -55,6 +55,8 @@ extern "C" {
 #define R3D_S_SAMPLE_TOO_LARGE 8  /* batched path: sample exceeds R3D_MAX_SAMPLE points */
 #define R3D_S_CAPACITY 16         /* batched path: merged cloud / log would exceed its capacity */
 #define R3D_S_FAR_OVERFLOW 32     /* batched path: more than R3D_FAR_CAP pixels beyond 500 m */
+#define R3D_S_WINDOW_TOO_LARGE 64 /* batched path: the insert's window of the range image does not fit the
+                                     kernel's LDS (far pixels on a range image much larger than 112x1440) */
 
 #define R3D_MAX_SAMPLE 8192       /* points per insert candidate in the batched path */
 #define R3D_FAR_CAP 1024

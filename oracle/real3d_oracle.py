@@ -351,8 +351,12 @@ def evaluate_candidate(scene_pcl9, scene_train, max_el, min_el, sample5,
     return occlusion_merge(scene_pcl9, sample9, scene_train, s_train)
 
 
-def augment_scene(scene5, candidates_per_insert, min_points):
+def augment_scene(scene5, candidates_per_insert, min_points, num_row=None, num_column=None):
     """Run the K-insert chain of one frame.
+
+    The grid is the module's NUMROW x NUMCOLUMN, read at call time: a user of the reference changes
+    the range-image size by editing those two globals (insertion.py:22-23), which also moves the
+    pixel ids of column 8 -- tests of other grid sizes patch both globals and nothing else.
 
     ``candidates_per_insert[k]`` is the ordered list of placement candidates (M x 5 float64
     arrays) tried for insert k, ``min_points[k]`` its acceptance threshold.  Follows
@@ -362,16 +366,18 @@ def augment_scene(scene5, candidates_per_insert, min_points):
     (``all_visible_parts``).  Returns (scene_pcl9, all_visible_parts9, accepted_index_per_insert).
     An insert whose candidates all fail leaves the scene unchanged and records -1.
     """
+    num_row = NUMROW if num_row is None else num_row
+    num_column = NUMCOLUMN if num_column is None else num_column
     scene = add_space_for_spherical(np.asarray(scene5, dtype=np.float64))
     all_visible = np.zeros((0, 9))
     accepted = []
     for cands, need in zip(candidates_per_insert, min_points):
-        scene, s_train, _, max_el, min_el = scene_field_of_view(scene)
+        scene, s_train, _, max_el, min_el = scene_field_of_view(scene, num_row, num_column)
         backup = scene
         chosen = -1
         for ci, sample5 in enumerate(cands):
             out, visible, _ = evaluate_candidate(backup, s_train, max_el, min_el,
-                                                 np.asarray(sample5, dtype=np.float64))
+                                                 np.asarray(sample5, dtype=np.float64), num_row, num_column)
             if len(visible) == 0 or len(visible) < need:       # :511-517
                 continue
             scene = np.append(out, visible, axis=0)            # :526

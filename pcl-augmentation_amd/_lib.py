@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreal3daug_hip.so")
 
 R3D_OK = 0
-S_NONFINITE, S_ROW_RANGE, S_COL_RANGE, S_SAMPLE_TOO_LARGE, S_CAPACITY, S_FAR_OVERFLOW = 1, 2, 4, 8, 16, 32
+S_NONFINITE, S_ROW_RANGE, S_COL_RANGE, S_SAMPLE_TOO_LARGE, S_CAPACITY, S_FAR_OVERFLOW, S_WINDOW_TOO_LARGE = 1, 2, 4, 8, 16, 32, 64
 STATUS_TEXT = {
     S_NONFINITE: "NaN/Inf coordinate or a point at the origin (reference: int() raises, insertion.py:104)",
     S_ROW_RANGE: "Rows in FoV went something wrong (assert insertion.py:110)",
@@ -21,6 +21,7 @@ STATUS_TEXT = {
     S_SAMPLE_TOO_LARGE: "sample has more than R3D_MAX_SAMPLE points",
     S_CAPACITY: "merged cloud or insert log exceeds its capacity",
     S_FAR_OVERFLOW: "more than R3D_FAR_CAP pixels deeper than 500 m",
+    S_WINDOW_TOO_LARGE: "the insert's window of the range image does not fit the kernel's LDS",
 }
 K_BOUNDS, K_PREPARE, K_PROJECT, K_ALIVE_COUNT, K_ALIVE_WRITE = 1, 2, 3, 4, 5
 NUMROW, NUMCOLUMN = 112, 1440

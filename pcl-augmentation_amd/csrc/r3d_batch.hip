@@ -639,7 +639,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
           if (!(ok & 2)) {
             flags |= R3D_S_COL_RANGE;                // assert :112
           } else {
-            key = ((uint32_t)(row * cols + col) << kIdxBits) | (uint32_t)j;
+            key = ((uint32_t)row << 16) | (uint32_t)col;    // re-keyed by window pixel below
             smp_r[j] = sp.r;
             ++nval;
             rmin = row < rmin ? row : rmin;
@@ -682,16 +682,6 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   }
   __syncthreads();
 
-  STAMP(1);
-  // -- 2. sort (pixel, sample index): the order of visible_sample (insertion.py:474-482) ---------
-  // Bitonic network; thread t owns elements t*E .. t*E+E-1.  Strides below E swap registers,
-  // strides below 64*E are wave shuffles, only the strides that cross waves go through LDS.
-  switch (pw <= kST ? 1 : pw / kST) {
-    case 1: block_bitonic_sort<1>(s_keys, pw, tid); break;
-    case 2: block_bitonic_sort<2>(s_keys, pw, tid); break;
-    case 4: block_bitonic_sort<4>(s_keys, pw, tid); break;
-    default: block_bitonic_sort<8>(s_keys, pw, tid); break;
-  }
   const int nvalid = *s_nvalid;
   const int n_far = b.n_far[s] < R3D_FAR_CAP ? b.n_far[s] : R3D_FAR_CAP;
   const int n_total = b.n_total[s], n_head = b.n_head[s], n_log = b.n_log[s];
@@ -749,18 +739,50 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   const bool c_lds = carve + (int64_t)wpx * 8 <= kLdsBytes;
   unsigned long long *s_ctile = reinterpret_cast<unsigned long long *>(smem + carve);
 
+  if (carve > kLdsBytes) {
+    // the bit images of the window do not fit next to the keys (only possible for the whole-image
+    // window of a far-pixel list on a range image much larger than the reference's): give up on
+    // this candidate, loudly
+    if (tid == 0) {
+      atomicOr(&b.status[s], R3D_S_WINDOW_TOO_LARGE);
+      n_visible[s] = 0;
+      accepted[s] = 0;
+    }
+    return;
+  }
   for (int i = tid; i < 6 * ww; i += kST) s_img[i] = 0u;
   if (s_lds)
     for (int i = tid; i < nvalid; i += kST) s_sdepth[i] = R3D_SENT;
   if (c_lds)
     for (int i = tid; i < wpx; i += kST) s_ctile[i] = R3D_SENT;
+  // keys = (window pixel, sample index): every valid sample pixel lies inside the window
+  for (int j = tid; j < pw; j += kST) {
+    uint32_t rc = s_keys[j];
+    if (rc != 0xFFFFFFFFu)
+      s_keys[j] = ((uint32_t)win.lpix_rc((int)(rc >> 16), (int)(rc & 0xFFFF)) << kIdxBits) | (uint32_t)j;
+  }
   __syncthreads();
+
+  STAMP(1);
+  // -- 2. sort (pixel, sample index): the order of visible_sample (insertion.py:474-482) ---------
+  // Bitonic network; thread t owns elements t*E .. t*E+E-1.  Strides below E swap registers,
+  // strides below 64*E are wave shuffles, only the strides that cross waves go through LDS.
+  switch (pw <= kST ? 1 : pw / kST) {
+    case 1: block_bitonic_sort<1>(s_keys, pw, tid); break;
+    case 2: block_bitonic_sort<2>(s_keys, pw, tid); break;
+    case 4: block_bitonic_sort<4>(s_keys, pw, tid); break;
+    default: block_bitonic_sort<8>(s_keys, pw, tid); break;
+  }
+
+  auto global_pix = [&](int lp) {
+    return win.row_of(lp >> 5) * cols + (win.word_of(lp >> 5) << 5) + (lp & 31);
+  };
 
   STAMP(3);
   // -- 3a. sample occupancy, rank of every occupied sample pixel -----------------------------------
   for (int k = tid; k < nvalid; k += kST) {
-    int p = (int)(s_keys[k] >> kIdxBits);
-    if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != p) A.set_local(win.lpix(p));
+    int lp = (int)(s_keys[k] >> kIdxBits);
+    if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != lp) A.set_local(lp);
   }
   __syncthreads();
   for (int base = 0; base < ww; base += kST) {           // exclusive prefix popcount over the words
@@ -780,15 +802,15 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   // sample depth per occupied pixel = min r over its points (insertion.py:118-125); runs are short
   for (int k = tid; k < nvalid; k += kST) {
     uint32_t key = s_keys[k];
-    int p = (int)(key >> kIdxBits);
-    if (k != 0 && (int)(s_keys[k - 1] >> kIdxBits) == p) continue;
+    int lp = (int)(key >> kIdxBits);
+    if (k != 0 && (int)(s_keys[k - 1] >> kIdxBits) == lp) continue;
     double best = smp_r[key & (kKeyCap - 1)];
-    for (int k2 = k + 1; k2 < nvalid && (int)(s_keys[k2] >> kIdxBits) == p; ++k2) {
+    for (int k2 = k + 1; k2 < nvalid && (int)(s_keys[k2] >> kIdxBits) == lp; ++k2) {
       double r2 = smp_r[s_keys[k2] & (kKeyCap - 1)];
       best = r2 < best ? r2 : best;
     }
-    if (s_lds) s_sdepth[sample_rank(win.lpix(p))] = depth_key(best);
-    else sgrid[p] = depth_key(best);
+    if (s_lds) s_sdepth[sample_rank(lp)] = depth_key(best);
+    else sgrid[global_pix(lp)] = depth_key(best);
   }
   auto sample_key = [&](int q, int lp) -> unsigned long long {   // lp = window-local pixel of q
     if (!A.get_local(lp)) return R3D_SENT;
@@ -980,7 +1002,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   STAMP(9);
   // -- 7. count the visible sample points, accept test (insertion.py:511-517) --------------------
   int mine = 0;
-  for (int k = tid; k < nvalid; k += kST) mine += vis.get_local(win.lpix((int)(s_keys[k] >> kIdxBits))) ? 1 : 0;
+  for (int k = tid; k < nvalid; k += kST) mine += vis.get_local((int)(s_keys[k] >> kIdxBits)) ? 1 : 0;
   int nvis;
   (void)block_escan_i32(mine, s_scan, nvis);
   int need = min_points[s];
@@ -997,8 +1019,8 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
     for (int k0 = 0; k0 < nvalid; k0 += kST) {
       int k = k0 + tid;
       uint32_t key = k < nvalid ? s_keys[k] : 0u;
-      int p = (int)(key >> kIdxBits);
-      int flag = (k < nvalid && vis.get_local(win.lpix(p))) ? 1 : 0;
+      int lp = (int)(key >> kIdxBits);
+      int flag = (k < nvalid && vis.get_local(lp)) ? 1 : 0;
       int tot;
       int ex = block_escan_i32(flag, s_scan, tot);
       if (flag) {
@@ -1012,7 +1034,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
         f.w = (float)q[3];
         reinterpret_cast<float4 *>(b.xyzi)[(int64_t)s * b.cap + dst] = f;
         b.label[(int64_t)s * b.cap + dst] = (uint32_t)(int64_t)q[4];
-        b.pix[(int64_t)s * b.cap + dst] = p;
+        b.pix[(int64_t)s * b.cap + dst] = global_pix(lp);
         b.tail_ref[(int64_t)s * b.log_cap + (dst - n_head)] = lr;
         double *l = b.log5 + ((int64_t)s * b.log_cap + lr) * 5;
         l[0] = q[0];
@@ -1056,8 +1078,8 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
     }
   if (!s_lds)
     for (int k = tid; k < nvalid; k += kST) {
-      int p = (int)(s_keys[k] >> kIdxBits);
-      if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != p) sgrid[p] = R3D_SENT;
+      int lp = (int)(s_keys[k] >> kIdxBits);
+      if (k == 0 || (int)(s_keys[k - 1] >> kIdxBits) != lp) sgrid[global_pix(lp)] = R3D_SENT;
     }
   STAMP(12);
 #ifdef R3D_STAMPS
@@ -1301,7 +1323,7 @@ static int check_batch(const r3d_batch_t *b) {
   if (!b) return fail(R3D_E_ARG, "batch: null descriptor");
   if (b->B <= 0 || b->rows <= 0 || b->cols <= 0 || b->cap <= 0 || b->log_cap <= 0)
     return fail(R3D_E_ARG, "batch: non-positive shape");
-  if (b->cap > (int64_t)1 << 30 || (int64_t)b->rows * b->cols > (int64_t)1 << (32 - kIdxBits))
+  if (b->cap > (int64_t)1 << 30 || b->rows > 65535 || b->cols > 65535 || (int64_t)b->rows * b->cols > (int64_t)1 << 30)
     return fail(R3D_E_ARG, "batch: cap or range image too large for 32-bit point / pixel ids");
   if (!b->xyzi || !b->label || !b->pix || !b->n_head || !b->n_total || !b->tail_ref || !b->log5 ||
       !b->log_birth || !b->n_log || !b->grid || !b->sgrid || !b->stamp || !b->ever || !b->bounds ||
@@ -1310,9 +1332,8 @@ static int check_batch(const r3d_batch_t *b) {
     return fail(R3D_E_ARG, "batch: null array");
   if (b->cols % 32 != 0)
     return fail(R3D_E_ARG, "batch: cols must be a multiple of 32 (row-aligned bit images)");
-  size_t lds = (size_t)kLdsFixed + (size_t)kKeyCap * 4 + 6 * (size_t)mask_words(*b) * 4 + 16;
-  if (lds > (size_t)kLdsBytes)
-    return fail(R3D_E_ARG, "batch: range image too large for the LDS-resident masks of k_insert");
+  if (((size_t)(b->cols + 1) * 2 + b->rows + 2) * sizeof(double) > 64 * 1024)
+    return fail(R3D_E_ARG, "batch: range image too large for the projection kernel's LDS edge tables");
   if (b->workspace_bytes < carve_batch(*b, nullptr).total)
     return fail(R3D_E_WORKSPACE, "batch: workspace smaller than r3d_batch_workspace_bytes()");
   return R3D_OK;

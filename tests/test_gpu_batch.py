@@ -347,3 +347,31 @@ def test_rebase_leaves_the_loaded_input_intact(P, synth):
         assert np.array_equal(x, y)
     vb, lb, cb, _ = _oracle_chain(xyzi, label, [[x] for x in ins], [10] * 4)
     _check_scene(out[0], vb, lb, cb)
+
+
+@pytest.mark.parametrize("rows,cols", [(448, 2880), (64, 2048), (16, 64)])
+def test_other_range_image_sizes(P, synth, monkeypatch, rows, cols):
+    """The grid is a parameter of the batched path (BASELINE config C5 proposes 448 x 2880); the
+    reference gets another grid by editing its two globals (insertion.py:22-23)."""
+    monkeypatch.setattr(O, "NUMROW", rows)
+    monkeypatch.setattr(O, "NUMCOLUMN", cols)
+    cases = [_random_case(synth, 40 + rows), _random_case(synth, 41 + rows, 64, 700, shuffle=True)]
+    xyzi, label = synth.make_scene(42 + rows, 48, 700)
+    blob = blob_in_front_of_extreme(xyzi, "max")
+    cases.append((xyzi, label, [[blob]] + cases[0][2][:3], [5, 20, 20, 20]))          # a rebase on this grid too
+    res, acc = P.augment_batch([(c[0], c[1]) for c in cases], [c[2] for c in cases], [c[3] for c in cases],
+                               rows=rows, cols=cols)
+    for c, r, a in zip(cases, res, acc):
+        vb, lb, cb, oacc = _oracle_chain(*c)
+        assert a == oacc
+        _check_scene(r, vb, lb, cb)
+
+
+def test_far_pixels_on_a_large_grid_are_reported(P, synth):
+    """A pixel deeper than 500 m makes the whole image the window; on a grid much larger than the
+    reference's that does not fit the insert kernel's LDS and must be reported, not mis-computed."""
+    xyzi, label = synth.make_scene(77, 32, 600)
+    xyzi[:40, :3] *= 700.0 / np.linalg.norm(xyzi[:40, :3], axis=1, keepdims=True)
+    slots = [[synth.make_insert(78, "car", centre_range=8.0, centre_az=1.0)]]
+    with pytest.raises(ValueError, match="window"):
+        P.augment_batch([(xyzi, label)], [slots], [[5]], rows=448, cols=2880)
