@@ -204,6 +204,71 @@ int r3d_batch_finish(const r3d_batch_t *b, float *check, int32_t check_cols, voi
 #define R3D_K_ALIVE_WRITE 5   /* k_alive_write: survivors, original order, into out_xyzi / out_label */
 int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream);
 
+/* =====================================================================================
+ * Level 3 -- placement search.
+ *
+ * Replaces find_possible_places of semantic_segmentation/Real3DAug/tools/find_spot.py:192-273 with
+ * its helpers rotate_bounding_box_2 (:42-76), check_bounding_box (:79-104), correct_height
+ * (:107-152) and cut_bounding_box (tools/cut_bbox.py:7-68): the sample and its box are turned
+ * around the sensor in 360 steps of one degree; a step is a possible placement when every sample
+ * point that falls inside the rich map lies on an allowed cell (:234-248), placement surface is
+ * found within the growing search radius (the box is then put on its mean height, and stays
+ * there for the following steps), no scene point other than placement surface is inside the
+ * box and no sample point is inside an annotated scene box.
+ *
+ * One query = one sample tried in one scene; queries are independent and run together.  The
+ * descriptors live in DEVICE memory, like every array they point to.
+ * ===================================================================================== */
+#define R3D_PLACE_ROTATIONS 360       /* find_spot.py:228 */
+#define R3D_PLACE_MAX_OK_LABELS 8
+#define R3D_PLACE_SURFACE_CAP 128     /* placement-surface points inside the first non-empty search radius */
+#define R3D_PLACE_MAX_RADII 64
+
+#define R3D_PS_SURFACE_OVERFLOW 1     /* more than R3D_PLACE_SURFACE_CAP surface points in the search radius */
+#define R3D_PS_NONFINITE 2            /* NaN / Inf in the sample, its box or the pose */
+
+/* flags[q][r-1] bits */
+#define R3D_PF_ON_SURFACE 1           /* :234-248 passed */
+#define R3D_PF_NEAR_ROAD 2            /* correct_height found surface (:251-254) */
+#define R3D_PF_SCENE_IN_BOX 4         /* a non-surface scene point inside the sample's box (:91-97) */
+#define R3D_PF_SAMPLE_IN_BOX 8        /* a sample point inside an annotated scene box (:99-103) */
+#define R3D_PF_POSSIBLE 16
+
+typedef struct r3d_place_query_t {
+  const double *scene;     /* current cloud, n_scene rows of scene_ld doubles: x y z at columns 0-2, the label at
+                              scene_label_col (scene_pcl N x 9, label column 7, insertion.py:433) */
+  const double *orig;      /* original cloud (height search, find_spot.py:123-131): original_pcl N x 5, label column 4 */
+  const double *boxes;     /* [n_boxes][10] annotated scene objects: centre x y z, quaternion x y z w, length, width, height */
+  const double *sample;    /* [m][5] x y z intensity label (sample_data['pcl']) */
+  const uint8_t *map;      /* [map_rows][map_cols] rich map */
+  int64_t n_scene, n_orig;
+  int32_t scene_ld, scene_label_col, orig_ld, orig_label_col;
+  int32_t n_boxes, m, map_rows, map_cols;
+  int32_t n_ok_labels;     /* labels an object of this class may stand on, in config order (:218-223) */
+  int32_t cand_cap;        /* room for this many candidate clouds at cand + cand_off */
+  int32_t ok_labels[R3D_PLACE_MAX_OK_LABELS];
+  uint64_t ok_map[4];      /* bit v set: map value v is an allowed surface */
+  double anno[10];         /* the sample's box after read_label_line (:155-189): centre, quaternion, length, width, height */
+  double pose[8];          /* rows 0 and 1 of the 4x4 pose (transformation_matrix) */
+  double map_move[2];      /* map_move[0], map_move[1] */
+  int64_t cand_off;        /* in doubles */
+} r3d_place_query_t;
+
+size_t r3d_places_workspace_bytes(int32_t n_queries, int32_t max_boxes);
+
+/* radius_sq (HOST array): radius**2 of the search steps that can still succeed (find_spot.py:121-140:
+ * 0.1, 0.1+0.1, ... while the next radius is <= 5), as the caller's interpreter evaluates them.
+ * Outputs (device): flags uint8 [Q][360]; n_possible int32 [Q]; rot_out int32 [Q][360] = rotation
+ * numbers (1..360) of the possible placements in order; anno_out double [Q][360][7] = box centre
+ * and quaternion of every possible placement, same order; cand = for placement ordinal j in
+ * [first_cand, first_cand + cand_cap) the m x 5 cloud at cand + cand_off + (j - first_cand)*m*5
+ * (deepcopy(sample_pcl), :258-264); status int32 [Q] (R3D_PS_*). */
+int r3d_find_possible_places(const r3d_place_query_t *queries, int32_t n_queries, int64_t max_n_scene,
+                             int64_t max_n_orig, int32_t max_m, int32_t max_boxes, const double *radius_sq,
+                             int32_t n_radii, uint8_t *flags, int32_t *n_possible, int32_t *rot_out,
+                             double *anno_out, double *cand, int32_t first_cand, int32_t *status,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

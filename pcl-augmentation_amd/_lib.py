@@ -49,6 +49,24 @@ class BatchDesc(C.Structure):
     ]
 
 
+class PlaceQuery(C.Structure):
+    """Mirror of r3d_place_query_t."""
+    _fields_ = [
+        ("scene", C.c_void_p), ("orig", C.c_void_p), ("boxes", C.c_void_p), ("sample", C.c_void_p), ("map", C.c_void_p),
+        ("n_scene", C.c_int64), ("n_orig", C.c_int64),
+        ("scene_ld", C.c_int32), ("scene_label_col", C.c_int32), ("orig_ld", C.c_int32), ("orig_label_col", C.c_int32),
+        ("n_boxes", C.c_int32), ("m", C.c_int32), ("map_rows", C.c_int32), ("map_cols", C.c_int32),
+        ("n_ok_labels", C.c_int32), ("cand_cap", C.c_int32),
+        ("ok_labels", C.c_int32 * 8), ("ok_map", C.c_uint64 * 4),
+        ("anno", C.c_double * 10), ("pose", C.c_double * 8), ("map_move", C.c_double * 2),
+        ("cand_off", C.c_int64),
+    ]
+
+
+PLACE_ROTATIONS, PLACE_SURFACE_CAP, PLACE_MAX_OK_LABELS = 360, 128, 8
+PS_SURFACE_OVERFLOW, PS_NONFINITE = 1, 2
+PF_ON_SURFACE, PF_NEAR_ROAD, PF_SCENE_IN_BOX, PF_SAMPLE_IN_BOX, PF_POSSIBLE = 1, 2, 4, 8, 16
+
 _P = C.c_void_p
 _SIGNATURES = {
     "r3d_version": (C.c_int, []),
@@ -70,6 +88,10 @@ _SIGNATURES = {
     "r3d_batch_insert": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "r3d_batch_finish": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int32, _P]),
     "r3d_batch_launch_one": (C.c_int, [C.POINTER(BatchDesc), C.c_int32, _P]),
+    "r3d_places_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "r3d_find_possible_places": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                           C.POINTER(C.c_double), C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P,
+                                           _P, C.c_size_t, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

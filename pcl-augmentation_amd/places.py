@@ -1,0 +1,166 @@
+"""Host side of the placement search (include/real3daug_hip.h, Level 3).
+
+``find_places`` runs many (scene, sample) queries of the reference's ``find_possible_places``
+(SS tools/find_spot.py:192-273) in one call of ``r3d_find_possible_places``.  The host only
+packs descriptors; every step of the search runs in the HIP kernels and there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def search_radii_sq():
+    """radius**2 of the steps of correct_height's growing search that can still succeed
+    (find_spot.py:119-140): the loop fails as soon as the *next* radius exceeds 5."""
+    out, radius = [], 0.1
+    while True:
+        sq = radius ** 2
+        radius += 0.1
+        if radius > 5:
+            return out
+        out.append(sq)
+
+
+class PlaceScene:
+    """Device-resident inputs of one scene, shared by the queries that use it."""
+
+    def __init__(self, point_cloud, original_pcl, scene_boxes, rich_map, map_move, transformation_matrix,
+                 scene_label_col=None, orig_label_col=None, device="cuda:0"):
+        torch = _lib.require_gpu()
+        self.device = device
+
+        def dev64(a):
+            if isinstance(a, torch.Tensor):
+                return a.to(device=device, dtype=torch.float64).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+
+        self.scene = dev64(point_cloud)
+        self.orig = dev64(original_pcl)
+        assert self.scene.dim() == 2 and self.orig.dim() == 2
+        # scene_pcl is N x 9 with the label in column 7 (insertion.py:433), original_pcl N x 5 with it in column 4
+        self.scene_label_col = (7 if self.scene.shape[1] == 9 else 4) if scene_label_col is None else scene_label_col
+        self.orig_label_col = (7 if self.orig.shape[1] == 9 else 4) if orig_label_col is None else orig_label_col
+        boxes = np.ascontiguousarray(scene_boxes, dtype=np.float64).reshape(-1, 10)
+        self.n_boxes = len(boxes)
+        self.boxes = torch.from_numpy(boxes if len(boxes) else np.zeros((1, 10))).to(device)
+        m = np.asarray(rich_map)
+        if m.dtype != np.uint8:
+            if not np.array_equal(m, np.floor(m)) or m.min() < 0 or m.max() > 255:
+                raise ValueError("the rich map must hold integer surface codes 0..255")
+            m = m.astype(np.uint8)
+        self.map = torch.from_numpy(np.ascontiguousarray(m)).to(device)
+        self.map_move = (float(np.asarray(map_move).reshape(-1)[0]), float(np.asarray(map_move).reshape(-1)[1]))
+        self.pose = np.asarray(transformation_matrix, dtype=np.float64)[:2, :4].reshape(8).copy()
+
+
+def _fill_query(qd, scene, sample_t, anno10, ok_labels, ok_map_values, cand_cap, cand_off):
+    qd.scene, qd.orig = scene.scene.data_ptr(), scene.orig.data_ptr()
+    qd.boxes, qd.sample, qd.map = scene.boxes.data_ptr(), sample_t.data_ptr(), scene.map.data_ptr()
+    qd.n_scene, qd.n_orig = scene.scene.shape[0], scene.orig.shape[0]
+    qd.scene_ld, qd.scene_label_col = scene.scene.shape[1], scene.scene_label_col
+    qd.orig_ld, qd.orig_label_col = scene.orig.shape[1], scene.orig_label_col
+    qd.n_boxes, qd.m = scene.n_boxes, sample_t.shape[0]
+    qd.map_rows, qd.map_cols = scene.map.shape
+    if len(ok_labels) > _lib.PLACE_MAX_OK_LABELS:
+        raise ValueError("at most 8 placement labels per class")
+    qd.n_ok_labels = len(ok_labels)
+    for i, v in enumerate(ok_labels):
+        qd.ok_labels[i] = int(v)
+    bits = [0, 0, 0, 0]
+    for v in ok_map_values:
+        if 0 <= int(v) <= 255:
+            bits[int(v) >> 6] |= 1 << (int(v) & 63)
+    for i in range(4):
+        qd.ok_map[i] = bits[i]
+    for i in range(10):
+        qd.anno[i] = float(anno10[i])
+    for i in range(8):
+        qd.pose[i] = float(scene.pose[i])
+    qd.map_move[0], qd.map_move[1] = scene.map_move
+    qd.cand_cap, qd.cand_off = int(cand_cap), int(cand_off)
+
+
+class PlaceBatch:
+    """Descriptors, outputs and workspace of a set of queries on the device; ``run`` launches the
+    search (asynchronously, on the current stream), ``results`` downloads and unpacks."""
+
+    def __init__(self, queries, cand_cap=360, device="cuda:0"):
+        torch = _lib.require_gpu()
+        self.lib = _lib.load()
+        self.device, self.cand_cap = device, int(cand_cap)
+        self.nq = nq = len(queries)
+        if nq == 0:
+            raise ValueError("no queries")
+        self.queries = queries
+        self.samples = [q["sample"] if isinstance(q["sample"], torch.Tensor) else
+                        torch.from_numpy(np.ascontiguousarray(q["sample"], dtype=np.float64).reshape(-1, 5)).to(device)
+                        for q in queries]
+        descs = (_lib.PlaceQuery * nq)()
+        cand_off, self.offs = 0, []
+        for i, q in enumerate(queries):
+            m = self.samples[i].shape[0]
+            if m == 0:
+                raise ValueError("empty sample")
+            _fill_query(descs[i], q["scene"], self.samples[i], q["anno"], q["ok_labels"], q["ok_map"], cand_cap, cand_off)
+            self.offs.append(cand_off)
+            cand_off += self.cand_cap * m * 5
+        self.d_desc = torch.from_numpy(np.frombuffer(descs, dtype=np.uint8).copy()).to(device)
+        rot = _lib.PLACE_ROTATIONS
+        self.flags = torch.zeros((nq, rot), dtype=torch.uint8, device=device)
+        self.n_possible = torch.zeros(nq, dtype=torch.int32, device=device)
+        self.rot_out = torch.zeros((nq, rot), dtype=torch.int32, device=device)
+        self.anno_out = torch.zeros((nq, rot, 7), dtype=torch.float64, device=device)
+        self.cand = torch.empty(max(cand_off, 1), dtype=torch.float64, device=device)
+        self.status = torch.zeros(nq, dtype=torch.int32, device=device)
+        self.max_boxes = max(q["scene"].n_boxes for q in queries)
+        self.ws_bytes = self.lib.r3d_places_workspace_bytes(nq, self.max_boxes)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        radii = search_radii_sq()
+        self.n_radii = len(radii)
+        self.radii_c = (C.c_double * len(radii))(*radii)
+        self.max_n_scene = max(q["scene"].scene.shape[0] for q in queries)
+        self.max_n_orig = max(q["scene"].orig.shape[0] for q in queries)
+        self.max_m = max(s.shape[0] for s in self.samples)
+        self.first_cand = 0
+
+    def run(self, first_cand=0):
+        self.first_cand = int(first_cand)
+        _lib.check(self.lib.r3d_find_possible_places(
+            self.d_desc.data_ptr(), self.nq, self.max_n_scene, self.max_n_orig, self.max_m, self.max_boxes,
+            self.radii_c, self.n_radii, self.flags.data_ptr(), self.n_possible.data_ptr(), self.rot_out.data_ptr(),
+            self.anno_out.data_ptr(), self.cand.data_ptr(), self.first_cand, self.status.data_ptr(),
+            self.ws.data_ptr(), self.ws_bytes, _lib.stream_ptr()), "r3d_find_possible_places")
+        return self
+
+    def results(self):
+        import torch
+        torch.cuda.synchronize()
+        flags_h, n_h, rot_h = self.flags.cpu().numpy(), self.n_possible.cpu().numpy(), self.rot_out.cpu().numpy()
+        anno_h, status_h, cand_h = self.anno_out.cpu().numpy(), self.status.cpu().numpy(), self.cand.cpu().numpy()
+        out = []
+        for i in range(self.nq):
+            if status_h[i] & _lib.PS_NONFINITE:
+                raise ValueError(f"query {i}: NaN/Inf in the sample, its box or the pose")
+            if status_h[i] & _lib.PS_SURFACE_OVERFLOW:
+                raise ValueError(f"query {i}: more than {_lib.PLACE_SURFACE_CAP} surface points inside the search radius")
+            n, m = int(n_h[i]), self.samples[i].shape[0]
+            k = max(0, min(n - self.first_cand, self.cand_cap))
+            clouds = cand_h[self.offs[i]: self.offs[i] + k * m * 5].reshape(k, m, 5).copy()
+            out.append({"flags": flags_h[i], "rotations": rot_h[i, :n].copy(), "anno": anno_h[i, :n].copy(),
+                        "clouds": clouds, "status": int(status_h[i])})
+        return out
+
+
+def find_places(queries, cand_cap=360, first_cand=0, device="cuda:0"):
+    """queries: list of dicts with keys ``scene`` (PlaceScene), ``sample`` (M x 5 float64),
+    ``anno`` (10 floats: centre, quaternion xyzw, length, width, height), ``ok_labels``,
+    ``ok_map`` (allowed map values).  Returns per query a dict: ``flags`` uint8[360],
+    ``rotations`` int32[n], ``anno`` float64[n,7], ``clouds`` float64[k,M,5] (placements
+    ``first_cand`` .. ``first_cand + cand_cap``), ``status``."""
+    if len(queries) == 0:
+        return []
+    return PlaceBatch(queries, cand_cap, device).run(first_cand).results()

@@ -1,0 +1,141 @@
+"""GPU parity of the placement search (-m gpu): rotation lists, candidate clouds and annotations
+are bit-identical to the fixtures captured from the reference's find_possible_places and to the
+oracle on fresh inputs; outcomes per step (off the surface / no road / collision) match too."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import find_spot_oracle as F
+from oracle import real3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+PLACEMENT = {11: [1, 3], 15: [1, 3], 18: [1, 3], 30: [2], 31: [1, 3], 32: [1, 3], 253: [1, 3], 255: [1, 3]}
+PLACEMENT_LABELS = {1: [40, 60], 2: [48], 3: [44]}
+CONFIG = {"insertion": {"placement": PLACEMENT, "placement_labels": PLACEMENT_LABELS}}
+CASES = ["places_cyclist.npz", "places_pedestrian.npz", "places_car_smallmap.npz"]
+
+
+@pytest.fixture(scope="module")
+def P(pkg):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return pkg
+
+
+def golden_inputs(g):
+    original = np.hstack((g["xyzi"].astype(np.float64), g["label"].astype(np.float64)[:, None]))
+    scene9 = O.add_space_for_spherical(np.vstack([original, g["extra"]]))
+    return original, scene9
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_function_level_drop_in_equals_reference(P, name):
+    g = load_golden(name)
+    original, scene9 = golden_inputs(g)
+    fs = P.Real3DAug.tools.find_spot
+    annos = [fs.read_label_line(str(l)) for l in g["anno_lines"]]
+    sample_data = {"pcl": g["sample"].copy(), "anno": np.array(str(g["sample_line"]))}
+    pcl, anno, rot = fs.find_possible_places(scene9, annos, sample_data, g["rich"].astype(np.float64), g["move"],
+                                             original, g["T"], CONFIG)
+    assert rot == list(g["out_rot"])
+    assert np.array_equal(np.array(pcl), g["out_pcl"])                      # bit for bit
+    got_c = np.array([[a["center"]["x"], a["center"]["y"], a["center"]["z"]] for a in anno])
+    got_q = np.array([[a["rotation"]["x"], a["rotation"]["y"], a["rotation"]["z"], a["rotation"]["w"]] for a in anno])
+    assert np.array_equal(got_c, g["out_centre"])
+    assert np.array_equal(got_q, g["out_quat"])
+
+
+def _random_query(synth, seed, cls, n_boxes, beams=32, n_az=500, dist=None):
+    rng = np.random.default_rng(seed)
+    xyzi, label = synth.make_scene(seed, beams, n_az, shuffle=bool(seed & 1))
+    label = label.copy()
+    ground = label == 40
+    label[ground & (xyzi[:, 1] > 3.0)] = 48
+    label[ground & (xyzi[:, 0] < -6.0) & (xyzi[:, 1] <= 3.0)] = 44
+    label[ground & ((xyzi[:, 0] - 6.0) ** 2 + (xyzi[:, 1] + 7.0) ** 2 < 4.6 ** 2)] = 72     # no surface there
+    original = synth.scene5_from_packed(xyzi, label)
+    T = np.eye(4)
+    a = rng.uniform(-3, 3)
+    T[:3, :3] = np.array([[np.cos(a), -np.sin(a), 0.01], [np.sin(a), np.cos(a), -0.02], [-0.01, 0.02, 1.0]])
+    T[:3, 3] = rng.uniform(-300, 300, 3)
+    half = 40
+    move = np.array([[int(np.floor(T[0, 3])) - half], [int(np.floor(T[1, 3])) - half], [0], [1]])
+    rich = np.zeros((2 * half + 1, 2 * half + 1), dtype=np.uint8)
+    world = (T @ np.hstack((original[:, :3], np.ones((len(original), 1)))).T - move).astype(int)
+    inside = (world[0] >= 0) & (world[0] < rich.shape[0]) & (world[1] >= 0) & (world[1] < rich.shape[1])
+    for value, labels in ((1, (40,)), (2, (48, 72)), (3, (44,))):
+        sel = inside & np.isin(original[:, 4], labels)
+        rich[world[0][sel], world[1][sel]] = value
+    kind = {30: "pedestrian", 31: "cyclist", 18: "car"}[cls]
+    length, width, height, _, _ = synth.INSERT_KINDS[kind]
+    m = int(rng.integers(20, 700))
+    dist0, phi, yaw = rng.uniform(4, 14), rng.uniform(-np.pi, np.pi), rng.uniform(-np.pi, np.pi)
+    dist = dist0 if dist is None else dist
+    p = rng.uniform(-0.5, 0.5, size=(m, 3)) * [length, width, height]
+    centre = np.array([dist * np.cos(phi), dist * np.sin(phi), -synth.SENSOR_HEIGHT + rng.uniform(-0.2, 0.2)])
+    cy, sy = np.cos(yaw), np.sin(yaw)
+    pts = np.stack([cy * p[:, 0] - sy * p[:, 1] + centre[0], sy * p[:, 0] + cy * p[:, 1] + centre[1],
+                    p[:, 2] + height / 2 + centre[2]], axis=1)
+    sample = np.column_stack([pts, rng.random(m), np.full(m, float(cls))])
+    line = " ".join([str(cls)] + [repr(float(v)) for v in (*centre, height, length, width, yaw)])
+    lines = []
+    for ang in rng.uniform(-np.pi, np.pi, size=n_boxes):
+        c = [dist * np.cos(ang), dist * np.sin(ang), -synth.SENSOR_HEIGHT]
+        lines.append(" ".join(["10"] + [repr(float(v)) for v in (*c, 1.5, 4.2, 1.8, rng.uniform(-3, 3))]))
+    ang = rng.uniform(-np.pi, np.pi)
+    blob = np.array([dist * np.cos(ang), dist * np.sin(ang), -synth.SENSOR_HEIGHT + 0.6]) + rng.normal(0, 0.3, (60, 3))
+    extra = np.column_stack([blob, rng.random(60), np.full(60, 10.0)])
+    scene9 = O.add_space_for_spherical(np.vstack([original, extra]))
+    return dict(original=original, scene9=scene9, T=T, move=move, rich=rich, sample=sample, line=line, lines=lines)
+
+
+def test_batch_of_queries_equals_oracle(P, synth):
+    """Several scenes and samples in one call: different sizes, classes, numbers of scene boxes (also none)."""
+    fs = P.Real3DAug.tools.find_spot
+    specs = [(21, 31, 2), (22, 30, 0), (23, 18, 4), (24, 31, 1)]
+    cases = [_random_query(synth, *s) for s in specs]
+    cases.append(_random_query(synth, 25, 30, 1, dist=9.2))       # walks through the patch without surface points
+    queries = []
+    for c in cases:
+        annos = [fs.read_label_line(l) for l in c["lines"]]
+        sa = fs.read_label_line(c["line"])
+        ok_map, ok_labels = fs.placement_surfaces(sa, CONFIG)
+        scene = P.PlaceScene(c["scene9"], c["original"], [fs._anno10(a) for a in annos], c["rich"], c["move"], c["T"])
+        queries.append({"scene": scene, "sample": c["sample"], "anno": fs._anno10(sa), "ok_labels": ok_labels,
+                        "ok_map": ok_map})
+    res = P.find_places(queries)
+    outcomes = set()
+    for c, r in zip(cases, res):
+        annos = [F.read_label_line(l) for l in c["lines"]]
+        pcl, anno, rot, not_on_road, collisions = F.find_possible_places(
+            c["scene9"], annos, c["sample"], c["line"], c["rich"].astype(np.float64), c["move"], c["original"], c["T"],
+            PLACEMENT, PLACEMENT_LABELS)
+        assert list(r["rotations"]) == rot
+        assert np.array_equal(r["clouds"], np.array(pcl).reshape(len(rot), len(c["sample"]), 5))
+        assert np.array_equal(r["anno"][:, :3], np.array([F.anno_center(a) for a in anno]).reshape(len(rot), 3))
+        assert np.array_equal(r["anno"][:, 3:], np.array([F.anno_quat(a) for a in anno]).reshape(len(rot), 4))
+        f = r["flags"]
+        assert int(((f & 1) == 0).sum()) == not_on_road
+        assert int((((f & 3) == 3) & ((f & 16) == 0)).sum()) == collisions
+        outcomes |= {"off"} if not_on_road else set()
+        outcomes |= {"hit"} if collisions else set()
+        outcomes |= {"far"} if int(((f & 3) == 1).sum()) else set()
+        outcomes |= {"ok"} if rot else set()
+    assert outcomes == {"off", "hit", "far", "ok"}, outcomes
+
+
+def test_candidate_window_and_flags(P, synth):
+    """first_cand / cand_cap return a window of the placements without changing the search."""
+    fs = P.Real3DAug.tools.find_spot
+    c = _random_query(synth, 31, 31, 1)
+    sa = fs.read_label_line(c["line"])
+    ok_map, ok_labels = fs.placement_surfaces(sa, CONFIG)
+    scene = P.PlaceScene(c["scene9"], c["original"], [fs._anno10(fs.read_label_line(l)) for l in c["lines"]], c["rich"],
+                         c["move"], c["T"])
+    q = {"scene": scene, "sample": c["sample"], "anno": fs._anno10(sa), "ok_labels": ok_labels, "ok_map": ok_map}
+    full = P.find_places([q])[0]
+    assert len(full["rotations"]) > 5
+    part = P.find_places([q], cand_cap=3, first_cand=2)[0]
+    assert list(part["rotations"]) == list(full["rotations"])
+    assert np.array_equal(part["clouds"], full["clouds"][2:5])
