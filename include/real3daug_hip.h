@@ -221,10 +221,12 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream);
  * ===================================================================================== */
 #define R3D_PLACE_ROTATIONS 360       /* find_spot.py:228 */
 #define R3D_PLACE_MAX_OK_LABELS 8
-#define R3D_PLACE_SURFACE_CAP 128     /* placement-surface points inside the first non-empty search radius */
+#define R3D_PLACE_SURFACE_CAP 128     /* surface points per step whose heights can be summed in order when their sum
+                                         depends on the order (never for float32 LiDAR heights of similar size) */
 #define R3D_PLACE_MAX_RADII 64
 
-#define R3D_PS_SURFACE_OVERFLOW 1     /* more than R3D_PLACE_SURFACE_CAP surface points in the search radius */
+#define R3D_PS_SURFACE_OVERFLOW 1     /* more than R3D_PLACE_SURFACE_CAP surface points in the search radius AND heights
+                                         whose sum depends on the order of addition */
 #define R3D_PS_NONFINITE 2            /* NaN / Inf in the sample, its box or the pose */
 
 /* flags[q][r-1] bits */

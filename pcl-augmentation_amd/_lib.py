@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libreal3daug_hip.so")
+# R3D_LIB: a diagnostic build of the same library (e.g. `make STAMPS=1`), never a different implementation
+LIB_PATH = os.environ.get("R3D_LIB") or os.path.join(_HERE, "libreal3daug_hip.so")
 
 R3D_OK = 0
 S_NONFINITE, S_ROW_RANGE, S_COL_RANGE, S_SAMPLE_TOO_LARGE, S_CAPACITY, S_FAR_OVERFLOW, S_WINDOW_TOO_LARGE = 1, 2, 4, 8, 16, 32, 64

@@ -36,10 +36,13 @@ constexpr int kRot = R3D_PLACE_ROTATIONS;
 constexpr int kCap = R3D_PLACE_SURFACE_CAP;
 constexpr int kPB = 256;                 // threads per block
 constexpr int kPointsPerBlock = 4096;    // points of one query handled by one block of the point passes
-constexpr int kBoxD = 15;                // 3x3 matrix, upper planes, lower planes
+constexpr int kBoxD = 18;                // 3x3 matrix, upper planes, lower planes, centre x y, bounding radius
+constexpr int kLdsBoxes = 32;            // scene boxes of a query kept in LDS by the sample chain
 constexpr double kCos1 = 0x1.ffec097f5af8ap-1;   // np.cos(np.deg2rad(1)), find_spot.py:52-59
 constexpr double kSin1 = 0x1.1df0b2b89dd1ep-6;   // np.sin(np.deg2rad(1))
 constexpr float kDegPerRad = 57.29577951308232f;
+constexpr int kMapWindowSide = 256;                       // cells per side of the map patch kept in LDS
+constexpr int kMapWindowWords = kMapWindowSide * kMapWindowSide / 32;
 
 struct PlaceWs {
   double *cx, *cy;              // [Q][360] box centre after step r
@@ -49,7 +52,9 @@ struct PlaceWs {
   int32_t *kstar;               // [Q][360] index of the first search radius that holds surface, -1 none
   double *road;                 // [Q][360] mean surface height
   double *planes;               // [Q][360][6] the sample box's upper / lower planes per axis
-  int32_t *surf_n;              // [Q][360]
+  int32_t *surf_n;              // [Q][360] number of surface points inside the step's radius
+  double *surf_sum, *surf_abs;  // [Q][360] sum of their heights and of the magnitudes, in arrival order
+  int32_t *surf_lsb;            // [Q][360] smallest exponent of a last mantissa bit among the heights
   unsigned long long *surf;     // [Q][360][kCap] (label rank << 40 | point index)
   uint32_t *hit;                // [Q][12] bit r: a non-surface scene point is inside the box of step r
   unsigned long long *gather_sq;// [Q] largest squared radius any step of the query needs (bits of a double)
@@ -70,6 +75,9 @@ PlaceWs carve_places(int32_t nq, int32_t max_boxes, void *base) {
   w.road = c.take<double>(qr);
   w.planes = c.take<double>(qr * 6);
   w.surf_n = c.take<int32_t>(qr);
+  w.surf_sum = c.take<double>(qr);
+  w.surf_abs = c.take<double>(qr);
+  w.surf_lsb = c.take<int32_t>(qr);
   w.surf = c.take<unsigned long long>(qr * kCap);
   w.hit = c.take<uint32_t>((size_t)nq * 12);
   w.gather_sq = c.take<unsigned long long>((size_t)nq);
@@ -155,7 +163,7 @@ __device__ __forceinline__ bool inside_box(const double *R, const double *up, co
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     double lhs = R[a] * x + R[3 + a] * y + R[6 + a] * z;
-    in = in && (lhs < up[a]) && (lhs > dn[a]);
+    in = in & (lhs < up[a]) & (lhs > dn[a]);
   }
   return in;
 }
@@ -220,6 +228,9 @@ __global__ void k_place_boxes(const r3d_place_query_t *Q, int nq, int max_boxes,
     o[9 + i] = up[i];
     o[12 + i] = dn[i];
   }
+  o[15] = b[0];
+  o[16] = b[1];
+  o[17] = sqrt(b[7] * b[7] / 4 + b[8] * b[8] / 4 + b[9] * b[9]) * 1.001 + 0.01;   // no box point is further from the centre
 }
 
 // The steps whose box centre can be within `reach` of the point (x, y): the centres lie on a circle
@@ -244,6 +255,30 @@ __device__ __forceinline__ bool steps_in_reach(float x, float y, float rho_c, fl
   return true;
 }
 
+// A cloud row: x y z at columns 0-2 and the label at `label_col` of rows `ld` doubles apart.  Rows
+// packed as [x y z label] (ld == 4) are read with two 16-byte loads.
+struct Pt {
+  double x, y, z, label;
+};
+__device__ __forceinline__ Pt load_point(const double *base, int64_t i, int ld, int label_col) {
+  Pt p;
+  if (ld == 4 && label_col == 3) {
+    const double2 *v = reinterpret_cast<const double2 *>(base + i * 4);
+    double2 a = v[0], b = v[1];
+    p.x = a.x;
+    p.y = a.y;
+    p.z = b.x;
+    p.label = b.y;
+  } else {
+    const double *r = base + i * ld;
+    p.x = r[0];
+    p.y = r[1];
+    p.z = r[2];
+    p.label = r[label_col];
+  }
+  return p;
+}
+
 __device__ __forceinline__ int label_rank(const r3d_place_query_t &qq, double label) {
   for (int j = 0; j < qq.n_ok_labels; ++j)
     if (label == (double)qq.ok_labels[j]) return j;
@@ -255,9 +290,9 @@ __device__ __forceinline__ int label_rank(const r3d_place_query_t &qq, double la
 // resolved_sq (the narrow pass found nothing that close, so it may have missed the true minimum).
 __global__ __launch_bounds__(kPB) void k_place_road_min(const r3d_place_query_t *Q, PlaceWs w, float reach, int mode,
                                                         double resolved_sq) {
-  const int q = blockIdx.y, tid = threadIdx.x;
+  const int q = blockIdx.x, tid = threadIdx.x;        // queries of one scene are neighbours: they share the chunk in L2
   const r3d_place_query_t &qq = Q[q];
-  const int64_t n = qq.n_orig, start = (int64_t)blockIdx.x * kPointsPerBlock;
+  const int64_t n = qq.n_orig, start = (int64_t)blockIdx.y * kPointsPerBlock;
   if (start >= n) return;
   __shared__ double s_cx[kRot], s_cy[kRot];
   __shared__ unsigned long long s_min[kRot];
@@ -276,10 +311,10 @@ __global__ __launch_bounds__(kPB) void k_place_road_min(const r3d_place_query_t 
   const float rho_c = sqrtf((float)(s_cx[0] * s_cx[0] + s_cy[0] * s_cy[0])), th1 = atan2f((float)s_cy[0], (float)s_cx[0]);
   const int64_t end = start + kPointsPerBlock < n ? start + kPointsPerBlock : n;
   for (int64_t i = start + tid; i < end; i += kPB) {
-    const double *p = qq.orig + i * qq.orig_ld;
-    double x = p[0], y = p[1], z = p[2];
-    if (!(z > -3.0)) continue;                                    // :133-134
-    if (label_rank(qq, p[qq.orig_label_col]) < 0) continue;       // :125-131
+    const Pt p = load_point(qq.orig, i, qq.orig_ld, qq.orig_label_col);
+    const double x = p.x, y = p.y;
+    if (!(p.z > -3.0)) continue;                                  // :133-134
+    if (label_rank(qq, p.label) < 0) continue;                    // :125-131
     int first, count;
     if (!steps_in_reach((float)x, (float)y, rho_c, th1, reach, first, count)) continue;
     for (int t = 0; t < count; ++t) {
@@ -312,14 +347,31 @@ __global__ void k_place_kstar(int nq, PlaceWs w, Radii rad) {
   }
   w.kstar[t] = k;
   w.surf_n[t] = 0;
+  w.surf_sum[t] = 0.0;
+  w.surf_abs[t] = 0.0;
+  w.surf_lsb[t] = INT32_MAX;
   if (k >= 0) atomicMax(&w.gather_sq[t / kRot], depth_key(rad.sq[k]));
 }
 
+// Exponent of the last set mantissa bit of a finite non-zero double: v is a multiple of 2^that.
+__device__ __forceinline__ int last_bit_exponent(double v) {
+  unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  int e = (int)((u >> 52) & 0x7FF);
+  unsigned long long mant = u & ((1ull << 52) - 1);
+  if (e == 0) return -1074 + (mant ? __ffsll((long long)mant) - 1 : 0);     // subnormal
+  mant |= 1ull << 52;
+  return e - 1075 + (__ffsll((long long)mant) - 1);
+}
+
 // ---- k_place_surface_gather: the points of `surface` (find_spot.py:123-134) of every step ---------
+// np.mean adds the heights row by row.  If all of them are multiples of 2^L and the sum of their
+// magnitudes stays below 2^(L+53), every partial sum in ANY order is exactly representable, so
+// the sum does not depend on the order and atomics may collect it (always so for LiDAR heights,
+// which are float32 values of similar size).  The ordered list is kept for the other case.
 __global__ __launch_bounds__(kPB) void k_place_surface_gather(const r3d_place_query_t *Q, PlaceWs w, Radii rad) {
-  const int q = blockIdx.y, tid = threadIdx.x;
+  const int q = blockIdx.x, tid = threadIdx.x;        // queries of one scene are neighbours: they share the chunk in L2
   const r3d_place_query_t &qq = Q[q];
-  const int64_t n = qq.n_orig, start = (int64_t)blockIdx.x * kPointsPerBlock;
+  const int64_t n = qq.n_orig, start = (int64_t)blockIdx.y * kPointsPerBlock;
   if (start >= n) return;
   const double reach_sq = key_depth(w.gather_sq[q]);
   if (!(reach_sq > 0.0)) return;                                  // no step found surface
@@ -336,10 +388,10 @@ __global__ __launch_bounds__(kPB) void k_place_surface_gather(const r3d_place_qu
   const float rho_c = sqrtf((float)(s_cx[0] * s_cx[0] + s_cy[0] * s_cy[0])), th1 = atan2f((float)s_cy[0], (float)s_cx[0]);
   const int64_t end = start + kPointsPerBlock < n ? start + kPointsPerBlock : n;
   for (int64_t i = start + tid; i < end; i += kPB) {
-    const double *p = qq.orig + i * qq.orig_ld;
-    double x = p[0], y = p[1], z = p[2];
-    if (!(z > -3.0)) continue;
-    int rank = label_rank(qq, p[qq.orig_label_col]);
+    const Pt p = load_point(qq.orig, i, qq.orig_ld, qq.orig_label_col);
+    const double x = p.x, y = p.y;
+    if (!(p.z > -3.0)) continue;
+    int rank = label_rank(qq, p.label);
     if (rank < 0) continue;
     int first, count;
     if (!steps_in_reach((float)x, (float)y, rho_c, th1, reach, first, count)) continue;
@@ -351,35 +403,63 @@ __global__ __launch_bounds__(kPB) void k_place_surface_gather(const r3d_place_qu
       size_t o = (size_t)q * kRot + r;
       int slot = atomicAdd(&w.surf_n[o], 1);
       if (slot < kCap) w.surf[o * kCap + slot] = ((unsigned long long)rank << 40) | (unsigned long long)i;
+      atomicAdd(&w.surf_sum[o], p.z);
+      atomicAdd(&w.surf_abs[o], fabs(p.z));
+      if (p.z != 0.0) atomicMin(&w.surf_lsb[o], last_bit_exponent(p.z));
     }
   }
 }
 
 // ---- k_place_road_level: np.mean(surface, axis=0)[2] (find_spot.py:144) and the box planes --------
-__global__ void k_place_road_level(const r3d_place_query_t *Q, int nq, PlaceWs w, int32_t *status) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nq * kRot) return;
-  const int q = t / kRot;
+// One wave per step.  The surface points are put in the reference's order (label order of the
+// config, then point order) by ranking their keys against each other, and their heights are
+// added one by one, like np.mean over the rows of `surface` does.
+__global__ __launch_bounds__(kPB) void k_place_road_level(const r3d_place_query_t *Q, int nq, PlaceWs w,
+                                                          int32_t *status) {
+  __shared__ double s_z[kPB / 64][kCap];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int t = blockIdx.x * (kPB / 64) + wv;
+  const bool live = t < nq * kRot;
+  const int q = live ? t / kRot : 0;
   const r3d_place_query_t &qq = Q[q];
-  double road = 0.0;
-  if (w.kstar[t] >= 0) {
-    int n = w.surf_n[t];
+  int n = 0, n_all = 0;
+  bool exact = false;
+  double sum_any_order = 0.0;
+  if (live && w.kstar[t] >= 0) {
+    n = n_all = w.surf_n[t];
+    sum_any_order = w.surf_sum[t];
+    const double mag = w.surf_abs[t];
+    const int lsb = w.surf_lsb[t];
+    // mag < 2^(ilogb(mag)+1); exact when that exponent is at most lsb + 53
+    exact = lsb == INT32_MAX || (isfinite(mag) && ilogb(mag) + 1 - lsb <= 53);
+    if (exact) n = 0;                                              // no need to order anything
     if (n > kCap) {
-      atomicOr(&status[q], R3D_PS_SURFACE_OVERFLOW);
+      if (lane == 0) atomicOr(&status[q], R3D_PS_SURFACE_OVERFLOW);
       n = kCap;
     }
-    unsigned long long *l = w.surf + (size_t)t * kCap;
-    for (int i = 1; i < n; ++i) {                                 // label order of the config, then point order
-      unsigned long long v = l[i];
-      int j = i - 1;
-      while (j >= 0 && l[j] > v) {
-        l[j + 1] = l[j];
-        --j;
-      }
-      l[j + 1] = v;
-    }
+  }
+  const unsigned long long *l = w.surf + (size_t)(live ? t : 0) * kCap;
+  static_assert(kCap == 128, "two keys per lane");
+  const unsigned long long k0 = lane < n ? l[lane] : R3D_SENT, k1 = lane + 64 < n ? l[lane + 64] : R3D_SENT;
+  const unsigned long long idx_mask = (1ull << 40) - 1;
+  const double z0 = lane < n ? qq.orig[(int64_t)(k0 & idx_mask) * qq.orig_ld + 2] : 0.0;
+  const double z1 = lane + 64 < n ? qq.orig[(int64_t)(k1 & idx_mask) * qq.orig_ld + 2] : 0.0;
+  int r0 = 0, r1 = 0;
+  for (int j = 0; j < n; ++j) {                                   // keys are distinct (point indices are)
+    unsigned long long kj = j < 64 ? __shfl(k0, j, 64) : __shfl(k1, j - 64, 64);
+    r0 += kj < k0 ? 1 : 0;
+    r1 += kj < k1 ? 1 : 0;
+  }
+  if (lane < n) s_z[wv][r0] = z0;
+  if (lane + 64 < n) s_z[wv][r1] = z1;
+  __syncthreads();
+  if (!live || lane != 0) return;
+  double road = 0.0;
+  if (exact && n_all > 0) {
+    road = sum_any_order / (double)n_all;
+  } else if (n > 0) {
     double acc = 0.0;
-    for (int i = 0; i < n; ++i) acc += qq.orig[(int64_t)(l[i] & ((1ull << 40) - 1)) * qq.orig_ld + 2];
+    for (int i = 0; i < n; ++i) acc += s_z[wv][i];
     road = acc / (double)n;
   }
   w.road[t] = road;
@@ -394,9 +474,9 @@ __global__ void k_place_road_level(const r3d_place_query_t *Q, int nq, PlaceWs w
 
 // ---- k_place_scene_in_box: cut_bounding_box(scene_pcl, sample_anno) minus surface (:91-97) --------
 __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_query_t *Q, PlaceWs w) {
-  const int q = blockIdx.y, tid = threadIdx.x;
+  const int q = blockIdx.x, tid = threadIdx.x;
   const r3d_place_query_t &qq = Q[q];
-  const int64_t n = qq.n_scene, start = (int64_t)blockIdx.x * kPointsPerBlock;
+  const int64_t n = qq.n_scene, start = (int64_t)blockIdx.y * kPointsPerBlock;
   if (start >= n) return;
   __shared__ double s_cx[kRot], s_cy[kRot];
   __shared__ unsigned char s_near[kRot];
@@ -419,9 +499,9 @@ __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_quer
   const float rho_c = sqrtf((float)(s_cx[0] * s_cx[0] + s_cy[0] * s_cy[0])), th1 = atan2f((float)s_cy[0], (float)s_cx[0]);
   const int64_t end = start + kPointsPerBlock < n ? start + kPointsPerBlock : n;
   for (int64_t i = start + tid; i < end; i += kPB) {
-    const double *p = qq.scene + i * qq.scene_ld;
-    double x = p[0], y = p[1], z = p[2];
-    if (label_rank(qq, p[qq.scene_label_col]) >= 0) continue;     // :94-95: surface may be inside the box
+    const Pt p = load_point(qq.scene, i, qq.scene_ld, qq.scene_label_col);
+    const double x = p.x, y = p.y, z = p.z;
+    if (label_rank(qq, p.label) >= 0) continue;                   // :94-95: surface may be inside the box
     int first, count;
     if (!steps_in_reach((float)x, (float)y, rho_c, th1, reach, first, count)) continue;
     for (int t = 0; t < count; ++t) {
@@ -439,43 +519,145 @@ __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_quer
   if (tid < 12 && s_hit[tid]) atomicOr(&w.hit[(size_t)q * 12 + tid], s_hit[tid]);
 }
 
+// Points per thread with which the sample chain takes a sample of m points.
+__host__ __device__ inline int chain_class(int m) {
+  int need = (m + kPB - 1) / kPB;
+  return need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 16 ? 16 : 32;
+}
+
 // ---- k_place_sample_chain: the loop of find_spot.py:228-269 on the sample's points ---------------
+// One workgroup per query; a thread keeps PPT points in registers through the 360 steps.  Per step:
+// rotate, look the map cell up (a patch of the map sits in LDS as one bit per cell), agree on
+// "all on allowed surface" across the workgroup, apply the height correction, test the points
+// against the scene boxes that can touch the sample at this step.  What a step needs from the
+// earlier kernels (road level, near flag, scene-in-box bit, box centre) is in LDS.  The per-point
+// code is branch-free over all PPT slots (slots past the sample's end compute on zeros and are
+// masked out of the votes), so the float64 chains of different points overlap.
+struct ChainLds {
+  uint32_t allowed[kMapWindowWords];   // bit = the map cell is an allowed surface, window of the map
+  double road[kRot], cx[kRot], cy[kRot];
+  double box[kLdsBoxes * kBoxD];
+  unsigned char near[kRot], flags[kRot], vote[2][kRot];
+  unsigned short rot[kRot];
+  uint32_t hit[12];
+  float red[2][kPB / 64];
+};
+
 template <int PPT>
-__global__ __launch_bounds__(kPB) void k_place_sample_chain(const r3d_place_query_t *Q, PlaceWs w, int max_boxes,
-                                                           uint8_t *flags, int32_t *n_possible, int32_t *rot_out,
-                                                           double *anno_out, double *cand, int32_t first_cand,
-                                                           int32_t *status) {
+__device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_query_t *Q, const PlaceWs &w, int max_boxes,
+                                             uint8_t *flags, int32_t *n_possible, int32_t *rot_out,
+                                             double *anno_out, double *cand, int32_t first_cand, int32_t *status) {
   const int q = blockIdx.x, tid = threadIdx.x;
   const r3d_place_query_t &qq = Q[q];
   const int m = qq.m;
+  uint32_t *s_allowed = lds.allowed;
+  double *s_road = lds.road, *s_cx = lds.cx, *s_cy = lds.cy, *s_box = lds.box;
+  unsigned char *s_near = lds.near, *s_flags = lds.flags;
+  unsigned char(*s_vote)[kRot] = lds.vote;
+  unsigned short *s_rot = lds.rot;
+  uint32_t *s_hit = lds.hit;
+  float(*s_red)[kPB / 64] = lds.red;
   double x[PPT], y[PPT], z[PPT];
+  bool valid[PPT];
   int bad_input = 0;
+  float rho2 = 0.f, ext2 = 0.f;                     // largest distance^2 from the sensor / from the box centre
+  const double ax = qq.anno[0], ay = qq.anno[1];
 #pragma unroll
   for (int u = 0; u < PPT; ++u) {
     int i = tid + u * kPB;
     x[u] = y[u] = z[u] = 0.0;
+    valid[u] = i < m;
     if (i < m) {
       x[u] = qq.sample[(size_t)i * 5 + 0];
       y[u] = qq.sample[(size_t)i * 5 + 1];
       z[u] = qq.sample[(size_t)i * 5 + 2];
       if (!(isfinite(x[u]) && isfinite(y[u]) && isfinite(z[u]))) bad_input = 1;
+      rho2 = fmaxf(rho2, (float)(x[u] * x[u] + y[u] * y[u]));
+      ext2 = fmaxf(ext2, (float)((x[u] - ax) * (x[u] - ax) + (y[u] - ay) * (y[u] - ay)));
     }
   }
   if (bad_input) atomicOr(&status[q], R3D_PS_NONFINITE);
+  for (int r = tid; r < kRot; r += kPB) {
+    size_t o = (size_t)q * kRot + r;
+    s_road[r] = w.road[o];
+    s_near[r] = w.kstar[o] >= 0 ? 1 : 0;
+    s_vote[0][r] = s_vote[1][r] = 0;
+    s_cx[r] = w.cx[o];
+    s_cy[r] = w.cy[o];
+  }
+  if (tid < 12) s_hit[tid] = w.hit[(size_t)q * 12 + tid];
+  const int nb = qq.n_boxes;
+  const double *gboxes = w.boxes + (size_t)q * max_boxes * kBoxD;
+  const bool lds_boxes = nb <= kLdsBoxes;
+  if (lds_boxes)
+    for (int i = tid; i < nb * kBoxD; i += kPB) s_box[i] = gboxes[i];
+  const double *boxes = lds_boxes ? s_box : gboxes;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    rho2 = fmaxf(rho2, __shfl_xor(rho2, o, 64));
+    ext2 = fmaxf(ext2, __shfl_xor(ext2, o, 64));
+  }
+  if ((tid & 63) == 0) {
+    s_red[0][tid >> 6] = rho2;
+    s_red[1][tid >> 6] = ext2;
+  }
+  __syncthreads();
   const double T00 = qq.pose[0], T01 = qq.pose[1], T02 = qq.pose[2], T03 = qq.pose[3];
   const double T10 = qq.pose[4], T11 = qq.pose[5], T12 = qq.pose[6], T13 = qq.pose[7];
   const double mv0 = qq.map_move[0], mv1 = qq.map_move[1];
-  const long long rows = qq.map_rows, cols = qq.map_cols;
-  const int nb = qq.n_boxes;
-  const double *boxes = w.boxes + (size_t)q * max_boxes * kBoxD;
+  const int rows = qq.map_rows, cols = qq.map_cols;
+  const uint8_t *map = qq.map;
+  const uint64_t okm0 = qq.ok_map[0], okm1 = qq.ok_map[1], okm2 = qq.ok_map[2], okm3 = qq.ok_map[3];
+  auto allowed = [&](unsigned v) -> bool {
+    uint64_t wv = v < 64 ? okm0 : v < 128 ? okm1 : v < 192 ? okm2 : okm3;
+    return (wv >> (v & 63)) & 1ull;
+  };
+  const int cand_cap = qq.cand_cap;
+  double *cand_q = cand + qq.cand_off;
+  const double *sample = qq.sample;
+  float rho = 0.f, ext = 0.f;
+  for (int i = 0; i < kPB / 64; ++i) {
+    rho = fmaxf(rho, s_red[0][i]);
+    ext = fmaxf(ext, s_red[1][i]);
+  }
+  rho = sqrtf(rho);
+  ext = sqrtf(ext) * 1.001f + 0.01f;                 // no sample point is further from the box centre (in x, y)
+  // The sample stays on a circle around the sensor, so it only ever looks at a patch of the map:
+  // that patch goes to LDS as one bit per cell (cells outside it are still read from memory).
+  int wr0, wc0, wh, ww;
+  {
+    double r0 = rho * sqrt(T00 * T00 + T01 * T01) + fabs(T02) * 8.0 + 2.0;
+    double r1 = rho * sqrt(T10 * T10 + T11 * T11) + fabs(T12) * 8.0 + 2.0;
+    double lo0 = floor(T03 - mv0 - r0), lo1 = floor(T13 - mv1 - r1);
+    lo0 = lo0 < 0.0 ? 0.0 : lo0;
+    lo1 = lo1 < 0.0 ? 0.0 : lo1;
+    double hi0 = T03 - mv0 + r0 + 1.0, hi1 = T13 - mv1 + r1 + 1.0;
+    hi0 = hi0 > (double)rows ? (double)rows : hi0;
+    hi1 = hi1 > (double)cols ? (double)cols : hi1;
+    bool none = !(hi0 > lo0 && hi1 > lo1);                        // also for NaN
+    wr0 = none ? 0 : (int)lo0;
+    wc0 = none ? 0 : (int)lo1;
+    int h = none ? 0 : (int)hi0 - wr0, wd = none ? 0 : (int)hi1 - wc0;
+    wh = h > kMapWindowSide ? kMapWindowSide : h;
+    ww = wd > kMapWindowSide ? kMapWindowSide : wd;
+  }
+  for (int wi = tid; wi < (wh * ww + 31) / 32; wi += kPB) {
+    uint32_t bits = 0u;
+    for (int b = 0; b < 32; ++b) {
+      int c = wi * 32 + b;
+      if (c >= wh * ww) break;
+      unsigned v = map[(size_t)(wr0 + c / ww) * cols + wc0 + c % ww];
+      bits |= (uint32_t)allowed(v) << b;
+    }
+    s_allowed[wi] = bits;
+  }
+  __syncthreads();
   double anno_z = qq.anno[2];
   int n_out = 0;
   for (int r = 0; r < kRot; ++r) {
-    const size_t o = (size_t)q * kRot + r;
     int bad = 0;
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
-      if (tid + u * kPB >= m) continue;
       // bbox_pcl[:, :3] = (z_rot_matrix @ bbox_pcl[:, :3].T).T, :72
       double nx = fma(0.0, z[u], fma(-kSin1, y[u], kCos1 * x[u]));
       double ny = fma(0.0, z[u], fma(kCos1, y[u], kSin1 * x[u]));
@@ -486,67 +668,111 @@ __global__ __launch_bounds__(kPB) void k_place_sample_chain(const r3d_place_quer
       // transformation_matrix @ [x y z 1], minus map_move, astype(int): :234-238
       double g0 = fma(T03, 1.0, fma(T02, nz, fma(T01, ny, T00 * nx))) - mv0;
       double g1 = fma(T13, 1.0, fma(T12, nz, fma(T11, ny, T10 * nx))) - mv1;
-      long long i0 = (long long)g0, i1 = (long long)g1;
-      if (i0 < rows && i0 > -1 && i1 < cols && i1 > -1) {         // :240-243
-        unsigned v = qq.map[i0 * cols + i1];
-        if (!((qq.ok_map[v >> 6] >> (v & 63)) & 1ull)) bad = 1;   // :245-248
-      }
+      // int() truncates: the index is in [0, rows) exactly when -1 < g0 < rows (:240-243)
+      const bool in_map = g0 > -1.0 && g0 < (double)rows && g1 > -1.0 && g1 < (double)cols;
+      const int i0 = in_map ? (int)g0 : 0, i1 = in_map ? (int)g1 : 0;
+      const int a = i0 - wr0, b = i1 - wc0;
+      const bool in_win = a >= 0 && a < wh && b >= 0 && b < ww;
+      const int c = in_win ? a * ww + b : 0;
+      bool ok = (s_allowed[c >> 5] >> (c & 31)) & 1u;
+      if (in_map && !in_win && valid[u]) ok = allowed(map[(size_t)i0 * cols + i1]);   // outside the patch: rare
+      bad |= (valid[u] && in_map && !ok) ? 1 : 0;                 // :245-248
     }
-    const bool on_surface = !__syncthreads_or(bad);
-    const bool near = w.kstar[o] >= 0;
+    if (bad) s_vote[0][r] = 1;                                    // one slot per step: no reset, one barrier
+    __syncthreads();
+    const bool on_surface = !s_vote[0][r];
+    const bool near = s_near[r];
     if (on_surface && near) {                                     // correct_height, :142-148
-      double road = w.road[o];
+      double road = s_road[r];
       double z_move = road - anno_z;
 #pragma unroll
       for (int u = 0; u < PPT; ++u) z[u] += z_move;
       anno_z = road;
     }
-    const bool scene_hit = (w.hit[(size_t)q * 12 + (r >> 5)] >> (r & 31)) & 1u;
+    const bool scene_hit = (s_hit[r >> 5] >> (r & 31)) & 1u;
     bool sample_hit = false;
     if (on_surface && near && !scene_hit && nb > 0) {             // :99-103
-      int in_any = 0;
+      // only boxes whose bounding circle reaches the sample's can hold one of its points
+      const float cxr = (float)s_cx[r], cyr = (float)s_cy[r];
+      int in_any = 0, tested = 0;
+      for (int b = 0; b < nb; ++b) {
+        const double *bx = boxes + (size_t)b * kBoxD;
+        float dx = (float)bx[15] - cxr, dy = (float)bx[16] - cyr, reach = (float)bx[17] + ext;
+        if (dx * dx + dy * dy > reach * reach) continue;          // uniform across the workgroup
+        tested = 1;
 #pragma unroll
-      for (int u = 0; u < PPT; ++u) {
-        if (tid + u * kPB >= m) continue;
-        for (int b = 0; b < nb; ++b) {
-          const double *bx = boxes + (size_t)b * kBoxD;
-          if (inside_box(bx, bx + 9, bx + 12, x[u], y[u], z[u])) in_any = 1;
-        }
+        for (int u = 0; u < PPT; ++u) in_any |= (valid[u] && inside_box(bx, bx + 9, bx + 12, x[u], y[u], z[u])) ? 1 : 0;
       }
-      sample_hit = __syncthreads_or(in_any);
+      if (tested) {
+        if (in_any) s_vote[1][r] = 1;
+        __syncthreads();
+        sample_hit = s_vote[1][r];
+      }
     }
     const bool possible = on_surface && near && !scene_hit && !sample_hit;
     if (tid == 0)
-      flags[o] = (uint8_t)((on_surface ? R3D_PF_ON_SURFACE : 0) | (near ? R3D_PF_NEAR_ROAD : 0) |
-                           (scene_hit ? R3D_PF_SCENE_IN_BOX : 0) | (sample_hit ? R3D_PF_SAMPLE_IN_BOX : 0) |
-                           (possible ? R3D_PF_POSSIBLE : 0));
+      s_flags[r] = (unsigned char)((on_surface ? R3D_PF_ON_SURFACE : 0) | (near ? R3D_PF_NEAR_ROAD : 0) |
+                                   (scene_hit ? R3D_PF_SCENE_IN_BOX : 0) | (sample_hit ? R3D_PF_SAMPLE_IN_BOX : 0) |
+                                   (possible ? R3D_PF_POSSIBLE : 0));
     if (possible) {                                               // :257-264
       int j = n_out - first_cand;
-      if (j >= 0 && j < qq.cand_cap) {
-        double *out = cand + qq.cand_off + (size_t)j * m * 5;
+      if (j >= 0 && j < cand_cap) {
+        double *out = cand_q + (size_t)j * m * 5;
 #pragma unroll
         for (int u = 0; u < PPT; ++u) {
           int i = tid + u * kPB;
-          if (i >= m) continue;
+          if (!valid[u]) continue;
           out[(size_t)i * 5 + 0] = x[u];
           out[(size_t)i * 5 + 1] = y[u];
           out[(size_t)i * 5 + 2] = z[u];
-          out[(size_t)i * 5 + 3] = qq.sample[(size_t)i * 5 + 3];
-          out[(size_t)i * 5 + 4] = qq.sample[(size_t)i * 5 + 4];
+          out[(size_t)i * 5 + 3] = sample[(size_t)i * 5 + 3];
+          out[(size_t)i * 5 + 4] = sample[(size_t)i * 5 + 4];
         }
       }
-      if (tid == 0) {
-        size_t oo = (size_t)q * kRot + n_out;
-        rot_out[oo] = r + 1;
-        anno_out[oo * 7 + 0] = w.cx[o];
-        anno_out[oo * 7 + 1] = w.cy[o];
-        anno_out[oo * 7 + 2] = anno_z;
-        for (int i = 0; i < 4; ++i) anno_out[oo * 7 + 3 + i] = w.quat[o * 4 + i];
-      }
+      if (tid == 0) s_rot[n_out] = (unsigned short)r;
       ++n_out;
     }
   }
+  __syncthreads();
+  // the annotation of a possible placement: centre (cx, cy, road level of that step), orientation
+  for (int r = tid; r < kRot; r += kPB) flags[(size_t)q * kRot + r] = s_flags[r];
+  for (int j = tid; j < n_out; j += kPB) {
+    int r = s_rot[j];
+    size_t o = (size_t)q * kRot + r, oo = (size_t)q * kRot + j;
+    rot_out[oo] = r + 1;
+    anno_out[oo * 7 + 0] = s_cx[r];
+    anno_out[oo * 7 + 1] = s_cy[r];
+    anno_out[oo * 7 + 2] = s_road[r];
+    for (int i = 0; i < 4; ++i) anno_out[oo * 7 + 3 + i] = w.quat[o * 4 + i];
+  }
   if (tid == 0) n_possible[q] = n_out;
+}
+
+// Samples of up to 2048 points (every class of the reference's object database) in one launch; the
+// workgroup picks the instance of its size class.  Larger samples: the second kernel.
+__global__ __launch_bounds__(kPB) void k_place_sample_chain(const r3d_place_query_t *Q, PlaceWs w, int max_boxes,
+                                                           uint8_t *flags, int32_t *n_possible, int32_t *rot_out,
+                                                           double *anno_out, double *cand, int32_t first_cand,
+                                                           int32_t *status) {
+  __shared__ ChainLds lds;
+  switch (chain_class(Q[blockIdx.x].m)) {
+    case 2: sample_chain<2>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
+    case 4: sample_chain<4>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
+    case 8: sample_chain<8>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
+    default: break;
+  }
+}
+
+__global__ __launch_bounds__(kPB) void k_place_sample_chain_large(const r3d_place_query_t *Q, PlaceWs w, int max_boxes,
+                                                                 uint8_t *flags, int32_t *n_possible,
+                                                                 int32_t *rot_out, double *anno_out, double *cand,
+                                                                 int32_t first_cand, int32_t *status) {
+  __shared__ ChainLds lds;
+  switch (chain_class(Q[blockIdx.x].m)) {
+    case 16: sample_chain<16>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
+    case 32: sample_chain<32>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
+    default: break;
+  }
 }
 
 }  // namespace
@@ -592,30 +818,24 @@ extern "C" int r3d_find_possible_places(const r3d_place_query_t *queries, int32_
   const int pb_scene = (int)((max_n_scene + kPointsPerBlock - 1) / kPointsPerBlock);
   const double narrow = 0.6;     // metres: what the first distance pass looks at
   if (pb_orig > 0) {
-    hipLaunchKernelGGL(k_place_road_min, dim3(pb_orig, n_queries), dim3(kPB), 0, st, queries, w,
+    hipLaunchKernelGGL(k_place_road_min, dim3(n_queries, pb_orig), dim3(kPB), 0, st, queries, w,
                        (float)(narrow * 1.01 + 0.05), 0, 0.0);
     if (reach_max > narrow * narrow)
-      hipLaunchKernelGGL(k_place_road_min, dim3(pb_orig, n_queries), dim3(kPB), 0, st, queries, w,
+      hipLaunchKernelGGL(k_place_road_min, dim3(n_queries, pb_orig), dim3(kPB), 0, st, queries, w,
                          (float)(sqrt(reach_max) * 1.01 + 0.05), 1, narrow * narrow);
   }
   hipLaunchKernelGGL(k_place_kstar, dim3((unsigned)((qr + 255) / 256)), dim3(256), 0, st, n_queries, w, rad);
   if (pb_orig > 0)
-    hipLaunchKernelGGL(k_place_surface_gather, dim3(pb_orig, n_queries), dim3(kPB), 0, st, queries, w, rad);
-  hipLaunchKernelGGL(k_place_road_level, dim3((unsigned)((qr + 255) / 256)), dim3(256), 0, st, queries, n_queries, w,
-                     status);
+    hipLaunchKernelGGL(k_place_surface_gather, dim3(n_queries, pb_orig), dim3(kPB), 0, st, queries, w, rad);
+  hipLaunchKernelGGL(k_place_road_level, dim3((unsigned)((qr + kPB / 64 - 1) / (kPB / 64))), dim3(kPB), 0, st, queries,
+                     n_queries, w, status);
   if (pb_scene > 0)
-    hipLaunchKernelGGL(k_place_scene_in_box, dim3(pb_scene, n_queries), dim3(kPB), 0, st, queries, w);
-  const int ppt = (max_m + kPB - 1) / kPB;
-#define R3D_CHAIN(P)                                                                                              \
-  hipLaunchKernelGGL(k_place_sample_chain<P>, dim3(n_queries), dim3(kPB), 0, st, queries, w, max_boxes, flags,   \
-                     n_possible, rot_out, anno_out, cand, first_cand, status)
-  if (ppt <= 1) R3D_CHAIN(1);
-  else if (ppt <= 2) R3D_CHAIN(2);
-  else if (ppt <= 4) R3D_CHAIN(4);
-  else if (ppt <= 8) R3D_CHAIN(8);
-  else if (ppt <= 16) R3D_CHAIN(16);
-  else R3D_CHAIN(32);
-#undef R3D_CHAIN
+    hipLaunchKernelGGL(k_place_scene_in_box, dim3(n_queries, pb_scene), dim3(kPB), 0, st, queries, w);
+  hipLaunchKernelGGL(k_place_sample_chain, dim3(n_queries), dim3(kPB), 0, st, queries, w, max_boxes, flags,
+                     n_possible, rot_out, anno_out, cand, first_cand, status);
+  if (chain_class(max_m) > 8)
+    hipLaunchKernelGGL(k_place_sample_chain_large, dim3(n_queries), dim3(kPB), 0, st, queries, w, max_boxes, flags,
+                       n_possible, rot_out, anno_out, cand, first_cand, status);
   R3D_LAUNCHED("placement kernels");
   return R3D_OK;
 }

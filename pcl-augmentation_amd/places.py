@@ -38,12 +38,15 @@ class PlaceScene:
                 return a.to(device=device, dtype=torch.float64).contiguous()
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
 
-        self.scene = dev64(point_cloud)
-        self.orig = dev64(original_pcl)
-        assert self.scene.dim() == 2 and self.orig.dim() == 2
+        scene, orig = dev64(point_cloud), dev64(original_pcl)
+        assert scene.dim() == 2 and orig.dim() == 2
         # scene_pcl is N x 9 with the label in column 7 (insertion.py:433), original_pcl N x 5 with it in column 4
-        self.scene_label_col = (7 if self.scene.shape[1] == 9 else 4) if scene_label_col is None else scene_label_col
-        self.orig_label_col = (7 if self.orig.shape[1] == 9 else 4) if orig_label_col is None else orig_label_col
+        scene_label_col = (7 if scene.shape[1] == 9 else 4) if scene_label_col is None else scene_label_col
+        orig_label_col = (7 if orig.shape[1] == 9 else 4) if orig_label_col is None else orig_label_col
+        # the search reads x y z and the label only: keep them as packed 32-byte rows
+        self.scene = scene[:, [0, 1, 2, scene_label_col]].contiguous()
+        self.orig = orig[:, [0, 1, 2, orig_label_col]].contiguous()
+        self.scene_label_col = self.orig_label_col = 3
         boxes = np.ascontiguousarray(scene_boxes, dtype=np.float64).reshape(-1, 10)
         self.n_boxes = len(boxes)
         self.boxes = torch.from_numpy(boxes if len(boxes) else np.zeros((1, 10))).to(device)

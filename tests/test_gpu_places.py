@@ -139,3 +139,43 @@ def test_candidate_window_and_flags(P, synth):
     part = P.find_places([q], cand_cap=3, first_cand=2)[0]
     assert list(part["rotations"]) == list(full["rotations"])
     assert np.array_equal(part["clouds"], full["clouds"][2:5])
+
+
+def _run_vs_oracle(P, c):
+    fs = P.Real3DAug.tools.find_spot
+    sa = fs.read_label_line(c["line"])
+    ok_map, ok_labels = fs.placement_surfaces(sa, CONFIG)
+    scene = P.PlaceScene(c["scene9"], c["original"], [fs._anno10(fs.read_label_line(l)) for l in c["lines"]], c["rich"],
+                         c["move"], c["T"])
+    r = P.find_places([{"scene": scene, "sample": c["sample"], "anno": fs._anno10(sa), "ok_labels": ok_labels,
+                        "ok_map": ok_map}])[0]
+    annos = [F.read_label_line(l) for l in c["lines"]]
+    pcl, anno, rot, _, _ = F.find_possible_places(c["scene9"], annos, c["sample"], c["line"], c["rich"].astype(np.float64),
+                                                  c["move"], c["original"], c["T"], PLACEMENT, PLACEMENT_LABELS)
+    assert list(r["rotations"]) == rot and len(rot) > 0
+    assert np.array_equal(r["clouds"], np.array(pcl).reshape(len(rot), len(c["sample"]), 5))
+    assert np.array_equal(r["anno"][:, :3], np.array([F.anno_center(a) for a in anno]).reshape(len(rot), 3))
+    return r
+
+
+def test_many_surface_points_in_the_search_radius(P, synth):
+    """A dense ring of road points under the sample's circle: far more surface points inside the
+    first search radius than the ordered list holds.  Their float32 heights sum exactly, so the
+    order-free sum must equal np.mean's row-by-row sum."""
+    ring = 1.73 / np.tan(np.deg2rad(24.8))                      # where the lowest beam meets the ground
+    c = _random_query(synth, 41, 31, 1, beams=8, n_az=20000, dist=ring)
+    cx, cy = (float(v) for v in c["line"].split(" ")[1:3])
+    near = (c["original"][:, 0] - cx) ** 2 + (c["original"][:, 1] - cy) ** 2 <= 0.1 ** 2
+    assert (near & np.isin(c["original"][:, 4], (40, 44))).sum() > 128
+    _run_vs_oracle(P, c)
+
+
+def test_heights_whose_sum_depends_on_the_order(P, synth):
+    """Genuine float64 heights (not float32 values): the partial sums round, so the heights must be
+    added in the reference's order (label order of the config, then point order)."""
+    c = _random_query(synth, 42, 31, 2)
+    rng = np.random.default_rng(5)
+    dz = rng.normal(0.0, 1e-3, size=len(c["original"]))
+    c["original"][:, 2] += dz
+    c["scene9"][:len(dz), 2] += dz
+    _run_vs_oracle(P, c)

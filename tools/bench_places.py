@@ -2,7 +2,7 @@
 """Timing of the placement search on the C2-shaped workload: B synthetic 120k-point scenes, K
 samples tried per scene (one query each), all queries in one call.
 
-    python tools/bench_places.py [B] [K] [cap]
+    python tools/bench_places.py [B] [K] [cap] [boxes per scene]
 
 Prints ms per call (HIP events around r3d_find_possible_places, inputs resident), queries/s and
 the equivalent rate of reference steps (360 per query)."""
@@ -22,7 +22,7 @@ PLACEMENT_LABELS = {1: [40, 60], 2: [48], 3: [44]}
 CONFIG = {"insertion": {"placement": PLACEMENT, "placement_labels": PLACEMENT_LABELS}}
 
 
-def make_scene(seed):
+def make_scene(seed, n_boxes=6):
     synth = pkg.synth
     xyzi, label = synth.make_scene(seed)
     label = label.copy()
@@ -44,7 +44,7 @@ def make_scene(seed):
     scene9[:, :3], scene9[:, 6], scene9[:, 7] = original[:, :3], original[:, 3], original[:, 4]
     rng = np.random.default_rng(seed)
     boxes = []
-    for ang in rng.uniform(-np.pi, np.pi, size=6):
+    for ang in rng.uniform(-np.pi, np.pi, size=n_boxes):
         d = rng.uniform(6, 25)
         boxes.append([d * np.cos(ang), d * np.sin(ang), -1.73, 0, 0, np.sin(ang / 2), np.cos(ang / 2), 4.2, 1.8, 1.5])
     return pkg.PlaceScene(scene9, original, boxes, rich, move, T)
@@ -66,9 +66,10 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     K = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     cap = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    n_boxes = int(sys.argv[4]) if len(sys.argv) > 4 else 6
     kinds = pkg.synth.CONFIG_INSERTS["C2"]
     t0 = time.time()
-    scenes = [make_scene(s) for s in range(B)]
+    scenes = [make_scene(s, n_boxes) for s in range(B)]
     queries = [make_query(scenes[s], s * 100 + k, kinds[k % len(kinds)]) for s in range(B) for k in range(K)]
     batch = pkg.places.PlaceBatch(queries, cand_cap=cap)
     print(f"setup {time.time() - t0:.1f} s, {len(queries)} queries, workspace {batch.ws_bytes / 2**20:.0f} MiB", flush=True)
