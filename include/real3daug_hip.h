@@ -193,6 +193,12 @@ int r3d_batch_insert(const r3d_batch_t *b, const double *samples5, const int64_t
  * [B*log_cap][check_cols] = check/{f}.bin rows from the log. */
 int r3d_batch_finish(const r3d_batch_t *b, float *check, int32_t check_cols, void *stream);
 
+/* The current merged cloud of every scene (scene_pcl as find_possible_places gets it, insertion.py:433-434,
+ * without the scratch columns): rows4 double [B][cap][4] = x y z label of the living points -- the
+ * surviving original points in their order, then the surviving inserted points with their float64
+ * coordinates -- and n_rows int32 [B].  Does not change the batch; may be called between inserts. */
+int r3d_batch_export_rows(const r3d_batch_t *b, double *rows4, int32_t *n_rows, void *stream);
+
 /* One streaming kernel of the batched path on its own, all scenes, for timing it in isolation
  * with HIP events (bench.py) and for rocprofv3: the state must be the one r3d_batch_begin
  * (BOUNDS, RESET, PROJECT) or r3d_batch_finish (ALIVE_COUNT, ALIVE_WRITE) leaves; every one of
@@ -254,6 +260,10 @@ typedef struct r3d_place_query_t {
   double pose[8];          /* rows 0 and 1 of the 4x4 pose (transformation_matrix) */
   double map_move[2];      /* map_move[0], map_move[1] */
   int64_t cand_off;        /* in doubles */
+  int64_t cand_stride;     /* doubles between consecutive candidate clouds of this query (>= m*5): with
+                              cand_off = start of the query's rows in a packed list of all queries and
+                              cand_stride = length of that list, candidate j of ALL queries is one packed
+                              sample list at cand + j*cand_stride -- what r3d_batch_insert takes */
 } r3d_place_query_t;
 
 size_t r3d_places_workspace_bytes(int32_t n_queries, int32_t max_boxes);
@@ -263,7 +273,7 @@ size_t r3d_places_workspace_bytes(int32_t n_queries, int32_t max_boxes);
  * Outputs (device): flags uint8 [Q][360]; n_possible int32 [Q]; rot_out int32 [Q][360] = rotation
  * numbers (1..360) of the possible placements in order; anno_out double [Q][360][7] = box centre
  * and quaternion of every possible placement, same order; cand = for placement ordinal j in
- * [first_cand, first_cand + cand_cap) the m x 5 cloud at cand + cand_off + (j - first_cand)*m*5
+ * [first_cand, first_cand + cand_cap) the m x 5 cloud at cand + cand_off + (j - first_cand)*cand_stride
  * (deepcopy(sample_pcl), :258-264); status int32 [Q] (R3D_PS_*). */
 int r3d_find_possible_places(const r3d_place_query_t *queries, int32_t n_queries, int64_t max_n_scene,
                              int64_t max_n_orig, int32_t max_m, int32_t max_boxes, const double *radius_sq,

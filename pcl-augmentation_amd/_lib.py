@@ -60,7 +60,7 @@ class PlaceQuery(C.Structure):
         ("n_ok_labels", C.c_int32), ("cand_cap", C.c_int32),
         ("ok_labels", C.c_int32 * 8), ("ok_map", C.c_uint64 * 4),
         ("anno", C.c_double * 10), ("pose", C.c_double * 8), ("map_move", C.c_double * 2),
-        ("cand_off", C.c_int64),
+        ("cand_off", C.c_int64), ("cand_stride", C.c_int64),
     ]
 
 
@@ -89,6 +89,7 @@ _SIGNATURES = {
     "r3d_batch_insert": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "r3d_batch_finish": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int32, _P]),
     "r3d_batch_launch_one": (C.c_int, [C.POINTER(BatchDesc), C.c_int32, _P]),
+    "r3d_batch_export_rows": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P]),
     "r3d_places_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "r3d_find_possible_places": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                            C.POINTER(C.c_double), C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P,

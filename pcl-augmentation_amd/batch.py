@@ -195,6 +195,18 @@ class SceneBatch:
         self._keep = (s5, off, mp, act)          # keep the inputs alive until the stream has run
         return nv.cpu().numpy().copy(), acc.cpu().numpy().copy()
 
+    def export_rows(self):
+        """The current merged clouds as float64 rows [x y z label] (what the placement search reads,
+        insertion.py:433): (rows [B,cap,4], n_rows [B]) device tensors; the batch is left unchanged."""
+        torch = self.torch
+        if getattr(self, "rows4", None) is None:
+            self.rows4 = torch.empty((self.B, self.cap, 4), dtype=torch.float64, device=self.device)
+            self.n_rows = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.r3d_batch_export_rows(C.byref(self.desc), C.c_void_p(self.rows4.data_ptr()),
+                                                  C.c_void_p(self.n_rows.data_ptr()), _lib.stream_ptr()),
+                   "r3d_batch_export_rows")
+        return self.rows4, self.n_rows
+
     def finish(self, check_cols=5):
         torch = self.torch
         if check_cols:

@@ -1151,7 +1151,8 @@ k_alive_count(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
 // straight into the output arrays.  The 8 alive tests of a thread are issued together, ranks come
 // from wave ballots and one small LDS table: a single barrier per tile.
 __global__ void __launch_bounds__(kPT)
-k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles, int chunks) {
+k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles, int chunks,
+              double *rows4, int32_t *n_rows) {
   __shared__ int s_cnt[kPerThread][kPT / 64];           // survivors of (row k, wave)
   __shared__ int s_pre[kPT / 64];
   int cnt = *count;
@@ -1171,7 +1172,8 @@ k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
 #pragma unroll
     for (int v = 0; v < kPT / 64; ++v) tile_base += s_pre[v];
     if (threadIdx.x == 0 && t0 + kTile >= n)                   // the scene's last tile publishes the total
-      b.n_out[s] = tile_base + w.tile_alive[(int64_t)s * tiles + blockIdx.x];
+      (rows4 ? n_rows : b.n_out)[s] = tile_base + w.tile_alive[(int64_t)s * tiles + blockIdx.x];
+    const int n_head = b.n_head[s];
     const float4 *src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
     float4 *dst = reinterpret_cast<float4 *>(b.out_xyzi) + (int64_t)s * b.cap;
     bool flag[kPerThread];
@@ -1196,8 +1198,16 @@ k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
       }
       if (flag[k]) {
         int i = t0 + k * kPT + threadIdx.x, o = mine + rank[k];
-        dst[o] = src[i];
-        b.out_label[(int64_t)s * b.cap + o] = b.label[(int64_t)s * b.cap + i];
+        if (rows4) {                                        // r3d_batch_export_rows: x y z label as float64
+          double x, y, z;
+          load_point(b, s, i, n_head, x, y, z);
+          double2 *row = reinterpret_cast<double2 *>(rows4 + ((int64_t)s * b.cap + o) * 4);
+          row[0] = make_double2(x, y);
+          row[1] = make_double2(z, (double)(b.label[(int64_t)s * b.cap + i] & 0xFFFFu));
+        } else {
+          dst[o] = src[i];
+          b.out_label[(int64_t)s * b.cap + o] = b.label[(int64_t)s * b.cap + i];
+        }
       }
     }
     __syncthreads();                                      // s_cnt is reused by the next scene
@@ -1371,10 +1381,12 @@ static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_
 }
 
 static int launch_compact(const r3d_batch_t &b, const BatchWs &w, const int32_t *list,
-                          const int32_t *count, int rows, hipStream_t st) {
+                          const int32_t *count, int rows, hipStream_t st, double *rows4 = nullptr,
+                          int32_t *n_rows = nullptr) {
   int tiles = tiles_of(b);
   hipLaunchKernelGGL(k_alive_count, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, tiles, chunks_of(b));
-  hipLaunchKernelGGL(k_alive_write, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, tiles, chunks_of(b));
+  hipLaunchKernelGGL(k_alive_write, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, tiles, chunks_of(b),
+                     rows4, n_rows);
   R3D_LAUNCHED("compaction kernels");
   return R3D_OK;
 }
@@ -1441,7 +1453,7 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream) {
       break;
     case R3D_K_ALIVE_WRITE:
       hipLaunchKernelGGL(k_alive_write, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w, tiles,
-                         chunks_of(*b));
+                         chunks_of(*b), (double *)nullptr, (int32_t *)nullptr);
       break;
     default:
       return fail(R3D_E_ARG, "batch_launch_one: unknown kernel id");
@@ -1474,6 +1486,14 @@ int r3d_batch_insert(const r3d_batch_t *b, const double *samples5, const int64_t
   hipLaunchKernelGGL(k_rebase, dim3(rb), dim3(kRB), 0, st, *b, w, chunks_of(*b));
   R3D_LAUNCHED("k_rebase");
   return R3D_OK;
+}
+
+int r3d_batch_export_rows(const r3d_batch_t *b, double *rows4, int32_t *n_rows, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  if (!rows4 || !n_rows) return fail(R3D_E_ARG, "batch_export_rows: null output");
+  BatchWs w = carve_batch(*b, b->workspace);
+  return launch_compact(*b, w, w.all_list, w.all_count, b->B, (hipStream_t)stream, rows4, n_rows);
 }
 
 int r3d_batch_finish(const r3d_batch_t *b, float *check, int32_t check_cols, void *stream) {

@@ -613,6 +613,7 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
     return (wv >> (v & 63)) & 1ull;
   };
   const int cand_cap = qq.cand_cap;
+  const int64_t cand_stride = qq.cand_stride;
   double *cand_q = cand + qq.cand_off;
   const double *sample = qq.sample;
   float rho = 0.f, ext = 0.f;
@@ -717,7 +718,7 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
     if (possible) {                                               // :257-264
       int j = n_out - first_cand;
       if (j >= 0 && j < cand_cap) {
-        double *out = cand_q + (size_t)j * m * 5;
+        double *out = cand_q + (size_t)j * cand_stride;
 #pragma unroll
         for (int u = 0; u < PPT; ++u) {
           int i = tid + u * kPB;

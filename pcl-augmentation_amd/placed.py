@@ -1,0 +1,96 @@
+"""Insert loop with placement search for a batch of frames: what the reference's driver does per
+frame between insertion.py:380 and :545, with both halves on the GPU.
+
+For one insert slot of every scene: ``find_possible_places`` on the scene's *current* cloud
+(find_spot.py:192-273 -> ``r3d_find_possible_places``), then the possible placements are tried
+in rotation order and the first one whose visible part reaches ``min_points`` is merged
+(insertion.py:449-526 -> ``r3d_batch_insert``); the accepted object's box joins the scene's
+annotations (:535).  Which sample is tried for which slot stays with the caller (the reference
+shuffles its object database, :396-400).  The candidate clouds never leave HBM: the search writes
+candidate j of all scenes as one packed sample list, which is what the insert call reads.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from .places import PlaceBatch, PlaceScene, upload_map
+
+
+class PlacedInserter:
+    def __init__(self, batch, rich_maps, map_moves, poses, scene_boxes):
+        """batch: a SceneBatch after ``begin``.  Per scene: rich map (2D integer codes), its
+        ``move`` (first two entries used), the 4 x 4 pose and the annotated boxes (k x 10:
+        centre, quaternion xyzw, length, width, height)."""
+        torch = _lib.require_gpu()
+        self.batch, self.torch = batch, torch
+        B = batch.B
+        assert len(rich_maps) == len(map_moves) == len(poses) == len(scene_boxes) == B
+        self.maps = [upload_map(m, batch.device) for m in rich_maps]
+        self.moves, self.poses = map_moves, poses
+        self.boxes = [np.asarray(b, dtype=np.float64).reshape(-1, 10) for b in scene_boxes]
+        # original_pcl (insertion.py:360): the clouds as loaded, as packed float64 rows
+        n0 = batch.n_points.cpu().numpy()
+        self.n_orig = [int(v) for v in n0]
+        self.orig_rows = torch.cat([batch.xyzi[:, :, :3].to(torch.float64),
+                                    (batch.label.to(torch.int64) & 0xFFFF).to(torch.float64)[:, :, None]], dim=2).contiguous()
+
+    def insert_slot(self, samples, annos, ok_labels, ok_maps, min_points, chunk=8):
+        """samples[s]: M x 5 float64 or None; annos[s]: the sample's box (10 floats) after
+        read_label_line; ok_labels[s] / ok_maps[s]: placement labels / map codes of its class.
+        Returns (rotation[s] = accepted rotation number or -1, n_possible[s])."""
+        torch, batch = self.torch, self.batch
+        B = batch.B
+        rows, n_rows = batch.export_rows()
+        n_rows_h = n_rows.cpu().numpy()
+        who = [s for s in range(B) if samples[s] is not None and len(samples[s])]
+        rotation, n_poss = [-1] * B, [0] * B
+        if not who:
+            return rotation, n_poss
+        queries = []
+        for s in who:
+            scene = PlaceScene(rows[s, :int(n_rows_h[s])], self.orig_rows[s, :self.n_orig[s]], self.boxes[s], self.maps[s],
+                               self.moves[s], self.poses[s], device=batch.device)
+            queries.append({"scene": scene, "sample": samples[s], "anno": annos[s], "ok_labels": ok_labels[s],
+                            "ok_map": ok_maps[s]})
+        pb = PlaceBatch(queries, cand_cap=chunk, device=batch.device, packed=True)
+        sizes = np.zeros(B, dtype=np.int64)
+        sizes[who] = [q.shape[0] for q in pb.samples]
+        off = np.zeros(B + 1, dtype=np.int64)
+        off[1:] = np.cumsum(sizes)
+        sample_off = torch.from_numpy(off).to(batch.device)
+        need = torch.from_numpy(np.asarray(min_points, dtype=np.int32)).to(batch.device)
+        who_t = torch.tensor(who, dtype=torch.int64, device=batch.device)
+        still_open = torch.zeros(B, dtype=torch.int32, device=batch.device)
+        still_open[who_t] = 1
+        accepted_at = torch.full((B,), -1, dtype=torch.int32, device=batch.device)
+        first, new_slot = 0, True
+        while True:
+            pb.run(first_cand=first)
+            n_possible = torch.zeros(B, dtype=torch.int32, device=batch.device)
+            n_possible[who_t] = pb.n_possible
+            for j in range(chunk):
+                active = still_open * (n_possible > first + j).to(torch.int32)
+                _, acc = batch.insert_device(pb.cand[j * pb.total:], sample_off, need, active, new_slot=new_slot)
+                new_slot = False
+                got = acc * active
+                accepted_at = torch.where(got > 0, torch.full_like(accepted_at, first + j), accepted_at)
+                still_open = still_open * (1 - got)
+            more = bool(((n_possible > first + chunk).to(torch.int32) * still_open).any().item())   # one sync per chunk
+            if not more:
+                break
+            first += chunk
+        acc_h, n_h = accepted_at.cpu().numpy(), n_possible.cpu().numpy()
+        rot_h, anno_h = pb.rot_out.cpu().numpy(), pb.anno_out.cpu().numpy()
+        batch.raise_on_status()
+        st = pb.status.cpu().numpy()
+        if st.any():
+            raise ValueError(f"placement search status {st[st != 0][0]} (see R3D_PS_*)")
+        for qi, s in enumerate(who):
+            n_poss[s] = int(n_h[s])
+            j = int(acc_h[s])
+            if j >= 0:
+                rotation[s] = int(rot_h[qi, j])
+                box = np.concatenate([anno_h[qi, j], np.asarray(annos[s], dtype=np.float64)[7:10]])
+                self.boxes[s] = np.vstack([self.boxes[s], box[None, :]])       # insertion.py:535
+        return rotation, n_poss

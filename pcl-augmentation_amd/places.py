@@ -25,6 +25,20 @@ def search_radii_sq():
         out.append(sq)
 
 
+def upload_map(rich_map, device):
+    """The rich map as a uint8 tensor on the device (device tensors pass through)."""
+    torch = _lib.require_gpu()
+    if isinstance(rich_map, torch.Tensor):
+        assert rich_map.dtype == torch.uint8 and rich_map.dim() == 2
+        return rich_map.to(device).contiguous()
+    m = np.asarray(rich_map)
+    if m.dtype != np.uint8:
+        if not np.array_equal(m, np.floor(m)) or m.min() < 0 or m.max() > 255:
+            raise ValueError("the rich map must hold integer surface codes 0..255")
+        m = m.astype(np.uint8)
+    return torch.from_numpy(np.ascontiguousarray(m)).to(device)
+
+
 class PlaceScene:
     """Device-resident inputs of one scene, shared by the queries that use it."""
 
@@ -40,27 +54,24 @@ class PlaceScene:
 
         scene, orig = dev64(point_cloud), dev64(original_pcl)
         assert scene.dim() == 2 and orig.dim() == 2
-        # scene_pcl is N x 9 with the label in column 7 (insertion.py:433), original_pcl N x 5 with it in column 4
-        scene_label_col = (7 if scene.shape[1] == 9 else 4) if scene_label_col is None else scene_label_col
-        orig_label_col = (7 if orig.shape[1] == 9 else 4) if orig_label_col is None else orig_label_col
+        # scene_pcl is N x 9 with the label in column 7 (insertion.py:433), original_pcl N x 5 with it in
+        # column 4; N x 4 rows are taken as already packed [x y z label] (SceneBatch.export_rows)
+        def label_col(t, given):
+            return given if given is not None else {9: 7, 5: 4, 4: 3}[t.shape[1]]
+        scene_label_col, orig_label_col = label_col(scene, scene_label_col), label_col(orig, orig_label_col)
         # the search reads x y z and the label only: keep them as packed 32-byte rows
-        self.scene = scene[:, [0, 1, 2, scene_label_col]].contiguous()
-        self.orig = orig[:, [0, 1, 2, orig_label_col]].contiguous()
+        self.scene = scene if scene.shape[1] == 4 else scene[:, [0, 1, 2, scene_label_col]].contiguous()
+        self.orig = orig if orig.shape[1] == 4 else orig[:, [0, 1, 2, orig_label_col]].contiguous()
         self.scene_label_col = self.orig_label_col = 3
         boxes = np.ascontiguousarray(scene_boxes, dtype=np.float64).reshape(-1, 10)
         self.n_boxes = len(boxes)
         self.boxes = torch.from_numpy(boxes if len(boxes) else np.zeros((1, 10))).to(device)
-        m = np.asarray(rich_map)
-        if m.dtype != np.uint8:
-            if not np.array_equal(m, np.floor(m)) or m.min() < 0 or m.max() > 255:
-                raise ValueError("the rich map must hold integer surface codes 0..255")
-            m = m.astype(np.uint8)
-        self.map = torch.from_numpy(np.ascontiguousarray(m)).to(device)
+        self.map = upload_map(rich_map, device)
         self.map_move = (float(np.asarray(map_move).reshape(-1)[0]), float(np.asarray(map_move).reshape(-1)[1]))
         self.pose = np.asarray(transformation_matrix, dtype=np.float64)[:2, :4].reshape(8).copy()
 
 
-def _fill_query(qd, scene, sample_t, anno10, ok_labels, ok_map_values, cand_cap, cand_off):
+def _fill_query(qd, scene, sample_t, anno10, ok_labels, ok_map_values, cand_cap, cand_off, cand_stride):
     qd.scene, qd.orig = scene.scene.data_ptr(), scene.orig.data_ptr()
     qd.boxes, qd.sample, qd.map = scene.boxes.data_ptr(), sample_t.data_ptr(), scene.map.data_ptr()
     qd.n_scene, qd.n_orig = scene.scene.shape[0], scene.orig.shape[0]
@@ -84,14 +95,17 @@ def _fill_query(qd, scene, sample_t, anno10, ok_labels, ok_map_values, cand_cap,
     for i in range(8):
         qd.pose[i] = float(scene.pose[i])
     qd.map_move[0], qd.map_move[1] = scene.map_move
-    qd.cand_cap, qd.cand_off = int(cand_cap), int(cand_off)
+    qd.cand_cap, qd.cand_off, qd.cand_stride = int(cand_cap), int(cand_off), int(cand_stride)
 
 
 class PlaceBatch:
     """Descriptors, outputs and workspace of a set of queries on the device; ``run`` launches the
     search (asynchronously, on the current stream), ``results`` downloads and unpacks."""
 
-    def __init__(self, queries, cand_cap=360, device="cuda:0"):
+    def __init__(self, queries, cand_cap=360, device="cuda:0", packed=False):
+        """packed=False: the candidate clouds of a query are contiguous ([cand_cap][m][5] per query).
+        packed=True: candidate j of all queries forms one packed sample list (rows of query q at
+        ``sample_off[q]``) at ``cand[j * total:]`` -- the layout ``r3d_batch_insert`` takes."""
         torch = _lib.require_gpu()
         self.lib = _lib.load()
         self.device, self.cand_cap = device, int(cand_cap)
@@ -103,14 +117,18 @@ class PlaceBatch:
                         torch.from_numpy(np.ascontiguousarray(q["sample"], dtype=np.float64).reshape(-1, 5)).to(device)
                         for q in queries]
         descs = (_lib.PlaceQuery * nq)()
-        cand_off, self.offs = 0, []
+        cand_off, self.offs, self.packed = 0, [], packed
+        self.total = sum(s.shape[0] for s in self.samples) * 5
         for i, q in enumerate(queries):
             m = self.samples[i].shape[0]
             if m == 0:
                 raise ValueError("empty sample")
-            _fill_query(descs[i], q["scene"], self.samples[i], q["anno"], q["ok_labels"], q["ok_map"], cand_cap, cand_off)
+            _fill_query(descs[i], q["scene"], self.samples[i], q["anno"], q["ok_labels"], q["ok_map"], cand_cap, cand_off,
+                        self.total if packed else m * 5)
             self.offs.append(cand_off)
-            cand_off += self.cand_cap * m * 5
+            cand_off += m * 5 if packed else self.cand_cap * m * 5
+        if packed:
+            cand_off = self.total * self.cand_cap
         self.d_desc = torch.from_numpy(np.frombuffer(descs, dtype=np.uint8).copy()).to(device)
         rot = _lib.PLACE_ROTATIONS
         self.flags = torch.zeros((nq, rot), dtype=torch.uint8, device=device)
@@ -152,7 +170,11 @@ class PlaceBatch:
                 raise ValueError(f"query {i}: more than {_lib.PLACE_SURFACE_CAP} surface points inside the search radius")
             n, m = int(n_h[i]), self.samples[i].shape[0]
             k = max(0, min(n - self.first_cand, self.cand_cap))
-            clouds = cand_h[self.offs[i]: self.offs[i] + k * m * 5].reshape(k, m, 5).copy()
+            if self.packed:
+                clouds = np.stack([cand_h[j * self.total + self.offs[i]: j * self.total + self.offs[i] + m * 5].reshape(m, 5)
+                                   for j in range(k)]) if k else np.zeros((0, m, 5))
+            else:
+                clouds = cand_h[self.offs[i]: self.offs[i] + k * m * 5].reshape(k, m, 5).copy()
             out.append({"flags": flags_h[i], "rotations": rot_h[i, :n].copy(), "anno": anno_h[i, :n].copy(),
                         "clouds": clouds, "status": int(status_h[i])})
         return out

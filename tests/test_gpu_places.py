@@ -179,3 +179,66 @@ def test_heights_whose_sum_depends_on_the_order(P, synth):
     c["original"][:, 2] += dz
     c["scene9"][:len(dz), 2] += dz
     _run_vs_oracle(P, c)
+
+
+def test_placed_insertion_chain_equals_oracle(P, synth):
+    """Placement search + occlusion merge for several slots of several scenes, everything on the
+    device, against the reference's sequence restated with the two oracles (insertion.py:371-545)."""
+    fs = P.Real3DAug.tools.find_spot
+    classes = [31, 30, 18, 31]
+    needs = [25, 10, 10 ** 6, 25]                   # the third slot can never be accepted: every placement is tried
+    cases = [_random_query(synth, 50 + s, classes[0], 2, n_az=400) for s in range(3)]
+    for c in cases:                                  # frames as loaded: without _random_query's "earlier insert"
+        c["scene9"] = c["scene9"][:len(c["original"])]
+    slots = []                                       # slots[k][s] = (sample, line)
+    for k, cls in enumerate(classes):
+        per_scene = []
+        for s in range(3):
+            q = _random_query(synth, 500 + 10 * k + s, cls, 0, beams=4, n_az=16)
+            per_scene.append((q["sample"][:150], q["line"]))
+        slots.append(per_scene)
+    # oracle chain
+    want = []
+    for s, c in enumerate(cases):
+        scene = c["scene9"].copy()
+        annos = [F.read_label_line(l) for l in c["lines"]]
+        all_visible, rots = np.zeros((0, 9)), []
+        for k in range(len(classes)):
+            scene, s_train, _, max_el, min_el = O.scene_field_of_view(scene)
+            smp, line = slots[k][s]
+            pcl, anno, rot, _, _ = F.find_possible_places(scene, annos, smp, line, c["rich"].astype(np.float64), c["move"],
+                                                          c["original"], c["T"], PLACEMENT, PLACEMENT_LABELS)
+            chosen = -1
+            for ci, cand in enumerate(pcl):
+                out, visible, _ = O.evaluate_candidate(scene, s_train, max_el, min_el, cand)
+                if len(visible) == 0 or len(visible) < needs[k]:
+                    continue
+                scene = np.append(out, visible, axis=0)
+                all_visible = np.append(all_visible, visible, axis=0)
+                annos.append(anno[ci])
+                chosen = rot[ci]
+                break
+            rots.append(chosen)
+        want.append((O.save_bytes_semantic(scene, all_visible), rots))
+    assert any(r[1][0] > 0 for r in want) and all(r[1][2] == -1 for r in want)
+    # device chain
+    n = max(len(c["original"]) for c in cases)
+    batch = P.SceneBatch(3, n + 150 * len(classes) + 64, 150 * len(classes) + 64)
+    batch.load([(c["original"][:, :4].astype(np.float32), c["original"][:, 4].astype(np.uint32)) for c in cases])
+    batch.begin()
+    ins = P.PlacedInserter(batch, [c["rich"] for c in cases], [c["move"] for c in cases], [c["T"] for c in cases],
+                           [[fs._anno10(fs.read_label_line(l)) for l in c["lines"]] for c in cases])
+    got_rots = [[] for _ in cases]
+    for k in range(len(classes)):
+        annos = [fs.read_label_line(slots[k][s][1]) for s in range(3)]
+        surf = [fs.placement_surfaces(a, CONFIG) for a in annos]
+        rot, n_poss = ins.insert_slot([slots[k][s][0] for s in range(3)], [fs._anno10(a) for a in annos],
+                                      [x[1] for x in surf], [x[0] for x in surf], [needs[k]] * 3, chunk=8)
+        for s in range(3):
+            got_rots[s].append(rot[s])
+    batch.finish()
+    res = batch.results()
+    for s in range(3):
+        assert got_rots[s] == want[s][1]
+        vb, lb, cb = want[s][0]
+        assert res[s][0].tobytes() == vb and res[s][1].tobytes() == lb and res[s][2].tobytes() == cb
