@@ -249,6 +249,8 @@ typedef struct r3d_place_query_t {
   const double *boxes;     /* [n_boxes][10] annotated scene objects: centre x y z, quaternion x y z w, length, width, height */
   const double *sample;    /* [m][5] x y z intensity label (sample_data['pcl']) */
   const uint8_t *map;      /* [map_rows][map_cols] rich map */
+  const float *scene_ranges, *orig_ranges; /* nullable: r3d_places_chunk_ranges() of the two clouds; lets the search
+                              skip the 64-point chunks that are out of reach (same results either way) */
   int64_t n_scene, n_orig;
   int32_t scene_ld, scene_label_col, orig_ld, orig_label_col;
   int32_t n_boxes, m, map_rows, map_cols;
@@ -267,6 +269,10 @@ typedef struct r3d_place_query_t {
 } r3d_place_query_t;
 
 size_t r3d_places_workspace_bytes(int32_t n_queries, int32_t max_boxes);
+
+/* ranges float [ceil(n/64)][2]: smallest and largest distance from the sensor's z axis among the points of
+ * every 64-point chunk of a cloud (rows of ld doubles, x y first). */
+int r3d_places_chunk_ranges(const double *rows, int64_t n, int32_t ld, float *ranges, void *stream);
 
 /* radius_sq (HOST array): radius**2 of the search steps that can still succeed (find_spot.py:121-140:
  * 0.1, 0.1+0.1, ... while the next radius is <= 5), as the caller's interpreter evaluates them.

@@ -54,6 +54,7 @@ class PlaceQuery(C.Structure):
     """Mirror of r3d_place_query_t."""
     _fields_ = [
         ("scene", C.c_void_p), ("orig", C.c_void_p), ("boxes", C.c_void_p), ("sample", C.c_void_p), ("map", C.c_void_p),
+        ("scene_ranges", C.c_void_p), ("orig_ranges", C.c_void_p),
         ("n_scene", C.c_int64), ("n_orig", C.c_int64),
         ("scene_ld", C.c_int32), ("scene_label_col", C.c_int32), ("orig_ld", C.c_int32), ("orig_label_col", C.c_int32),
         ("n_boxes", C.c_int32), ("m", C.c_int32), ("map_rows", C.c_int32), ("map_cols", C.c_int32),
@@ -91,6 +92,7 @@ _SIGNATURES = {
     "r3d_batch_launch_one": (C.c_int, [C.POINTER(BatchDesc), C.c_int32, _P]),
     "r3d_batch_export_rows": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P]),
     "r3d_places_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "r3d_places_chunk_ranges": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P]),
     "r3d_find_possible_places": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                            C.POINTER(C.c_double), C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P,
                                            _P, C.c_size_t, _P]),

@@ -35,6 +35,7 @@ using namespace r3d;
 constexpr int kRot = R3D_PLACE_ROTATIONS;
 constexpr int kCap = R3D_PLACE_SURFACE_CAP;
 constexpr int kPB = 256;                 // threads per block
+constexpr int kCB = 512;                 // threads per block of the sample chain
 constexpr int kPointsPerBlock = 4096;    // points of one query handled by one block of the point passes
 constexpr int kBoxD = 18;                // 3x3 matrix, upper planes, lower planes, centre x y, bounding radius
 constexpr int kLdsBoxes = 32;            // scene boxes of a query kept in LDS by the sample chain
@@ -55,6 +56,7 @@ struct PlaceWs {
   int32_t *surf_n;              // [Q][360] number of surface points inside the step's radius
   double *surf_sum, *surf_abs;  // [Q][360] sum of their heights and of the magnitudes, in arrival order
   int32_t *surf_lsb;            // [Q][360] smallest exponent of a last mantissa bit among the heights
+  int32_t *surf_list_n;         // [Q][360] entries appended to the ordered list (stops growing at kCap)
   unsigned long long *surf;     // [Q][360][kCap] (label rank << 40 | point index)
   uint32_t *hit;                // [Q][12] bit r: a non-surface scene point is inside the box of step r
   unsigned long long *gather_sq;// [Q] largest squared radius any step of the query needs (bits of a double)
@@ -78,6 +80,7 @@ PlaceWs carve_places(int32_t nq, int32_t max_boxes, void *base) {
   w.surf_sum = c.take<double>(qr);
   w.surf_abs = c.take<double>(qr);
   w.surf_lsb = c.take<int32_t>(qr);
+  w.surf_list_n = c.take<int32_t>(qr);
   w.surf = c.take<unsigned long long>(qr * kCap);
   w.hit = c.take<uint32_t>((size_t)nq * 12);
   w.gather_sq = c.take<unsigned long long>((size_t)nq);
@@ -260,17 +263,28 @@ __device__ __forceinline__ bool steps_in_reach(float x, float y, float rho_c, fl
 struct Pt {
   double x, y, z, label;
 };
+// Pointers that come out of a descriptor are generic to the compiler; every array a descriptor
+// points to lives in global memory, and saying so gives global_load instead of flat_load (which
+// also waits on the LDS counter).
+template <class T>
+using InGlobal = const __attribute__((address_space(1))) T *;
+template <class T>
+__device__ __forceinline__ InGlobal<T> in_global(const T *p) {
+  return (InGlobal<T>)p;
+}
+
 __device__ __forceinline__ Pt load_point(const double *base, int64_t i, int ld, int label_col) {
   Pt p;
   if (ld == 4 && label_col == 3) {
-    const double2 *v = reinterpret_cast<const double2 *>(base + i * 4);
-    double2 a = v[0], b = v[1];
+    typedef double pair_t __attribute__((ext_vector_type(2)));
+    InGlobal<pair_t> v = (InGlobal<pair_t>)(base + i * 4);
+    pair_t a = v[0], b = v[1];
     p.x = a.x;
     p.y = a.y;
     p.z = b.x;
     p.label = b.y;
   } else {
-    const double *r = base + i * ld;
+    InGlobal<double> r = in_global(base + i * ld);
     p.x = r[0];
     p.y = r[1];
     p.z = r[2];
@@ -279,10 +293,69 @@ __device__ __forceinline__ Pt load_point(const double *base, int64_t i, int ld, 
   return p;
 }
 
+// Distance range (from the sensor axis) of every 64-point chunk of a cloud: a scan in its native
+// order (ring by ring) has narrow ranges, and a point pass can skip the chunks that cannot be
+// within reach of the circle the sample moves on.  Rounded outwards; [0, inf) if anything is odd.
+__global__ __launch_bounds__(kPB) void k_chunk_ranges(const double *rows, int64_t n, int ld, float *ranges) {
+  const int lane = threadIdx.x & 63;
+  const int64_t chunk = (int64_t)blockIdx.x * (kPB / 64) + (threadIdx.x >> 6);
+  if (chunk * 64 >= n) return;
+  const int64_t i = chunk * 64 + lane;
+  float lo = INFINITY, hi = 0.f;
+  bool odd = false;
+  if (i < n) {
+    double x = rows[i * ld], y = rows[i * ld + 1];
+    float rho = sqrtf((float)(x * x + y * y));
+    odd = !isfinite(rho);
+    lo = hi = rho;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+  }
+  odd = __any(odd);
+  if (lane == 0) {
+    ranges[chunk * 2 + 0] = odd ? 0.f : lo * (1.f - 1e-6f);
+    ranges[chunk * 2 + 1] = odd ? INFINITY : hi * (1.f + 1e-6f);
+  }
+}
+
+// True when no point of the chunk can be within `reach` of the circle of radius rho_c.
+__device__ __forceinline__ bool chunk_out_of_reach(const float *ranges, int64_t chunk, float rho_c, float reach) {
+  if (!ranges) return false;
+  float lo = in_global(ranges)[chunk * 2], hi = in_global(ranges)[chunk * 2 + 1];
+  return lo > rho_c + reach || hi < rho_c - reach;
+}
+
+// The chunks of a block's 4096 points that are within reach, listed in LDS by the first wave with one
+// coalesced load of the ranges (a serial skip test per chunk would pay one memory latency each).
+static_assert(kPointsPerBlock == 64 * 64, "one ballot covers the chunks of a block");
+__device__ __forceinline__ int list_chunks_in_reach(const float *ranges, int64_t start, int64_t end, float rho_c,
+                                                    float reach, unsigned char *s_chunk, int *s_count) {
+  if (threadIdx.x < 64) {
+    int64_t c0 = start + (int64_t)threadIdx.x * 64;
+    bool take = c0 < end && !chunk_out_of_reach(ranges, c0 >> 6, rho_c, reach);
+    unsigned long long m = __ballot(take);
+    if (take) s_chunk[__popcll(m & ((1ull << threadIdx.x) - 1ull))] = (unsigned char)threadIdx.x;
+    if (threadIdx.x == 0) *s_count = __popcll(m);
+  }
+  __syncthreads();
+  return *s_count;
+}
+
 __device__ __forceinline__ int label_rank(const r3d_place_query_t &qq, double label) {
   for (int j = 0; j < qq.n_ok_labels; ++j)
     if (label == (double)qq.ok_labels[j]) return j;
   return -1;
+}
+
+// The query descriptor is read many times per point (labels, strides): stage it in LDS.
+__device__ __forceinline__ void stage_query(r3d_place_query_t &dst, const r3d_place_query_t *src) {
+  const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
+  uint32_t *d = reinterpret_cast<uint32_t *>(&dst);
+  for (int i = threadIdx.x; i < (int)(sizeof(r3d_place_query_t) / 4); i += blockDim.x) d[i] = s[i];
+  __syncthreads();
 }
 
 // ---- k_place_road_min: correct_height's distance test (find_spot.py:123) for every step at once ---
@@ -291,9 +364,11 @@ __device__ __forceinline__ int label_rank(const r3d_place_query_t &qq, double la
 __global__ __launch_bounds__(kPB) void k_place_road_min(const r3d_place_query_t *Q, PlaceWs w, float reach, int mode,
                                                         double resolved_sq) {
   const int q = blockIdx.x, tid = threadIdx.x;        // queries of one scene are neighbours: they share the chunk in L2
-  const r3d_place_query_t &qq = Q[q];
-  const int64_t n = qq.n_orig, start = (int64_t)blockIdx.y * kPointsPerBlock;
+  const int64_t n = Q[q].n_orig, start = (int64_t)blockIdx.y * kPointsPerBlock;
   if (start >= n) return;
+  __shared__ r3d_place_query_t qq;
+  __shared__ unsigned char s_chunk[64];
+  __shared__ int s_nchunk;
   __shared__ double s_cx[kRot], s_cy[kRot];
   __shared__ unsigned long long s_min[kRot];
   __shared__ unsigned char s_need[kRot];
@@ -308,9 +383,13 @@ __global__ __launch_bounds__(kPB) void k_place_road_min(const r3d_place_query_t 
     any |= need;
   }
   if (!__syncthreads_or(any)) return;
+  stage_query(qq, Q + q);
   const float rho_c = sqrtf((float)(s_cx[0] * s_cx[0] + s_cy[0] * s_cy[0])), th1 = atan2f((float)s_cy[0], (float)s_cx[0]);
   const int64_t end = start + kPointsPerBlock < n ? start + kPointsPerBlock : n;
-  for (int64_t i = start + tid; i < end; i += kPB) {
+  const int n_chunks = list_chunks_in_reach(qq.orig_ranges, start, end, rho_c, reach, s_chunk, &s_nchunk);
+  for (int a = tid >> 6; a < n_chunks; a += kPB / 64) {           // one 64-point chunk per wave and turn
+    const int64_t i = start + (int64_t)s_chunk[a] * 64 + (tid & 63);
+    if (i >= end) continue;
     const Pt p = load_point(qq.orig, i, qq.orig_ld, qq.orig_label_col);
     const double x = p.x, y = p.y;
     if (!(p.z > -3.0)) continue;                                  // :133-134
@@ -350,6 +429,7 @@ __global__ void k_place_kstar(int nq, PlaceWs w, Radii rad) {
   w.surf_sum[t] = 0.0;
   w.surf_abs[t] = 0.0;
   w.surf_lsb[t] = INT32_MAX;
+  w.surf_list_n[t] = 0;
   if (k >= 0) atomicMax(&w.gather_sq[t / kRot], depth_key(rad.sq[k]));
 }
 
@@ -370,24 +450,33 @@ __device__ __forceinline__ int last_bit_exponent(double v) {
 // which are float32 values of similar size).  The ordered list is kept for the other case.
 __global__ __launch_bounds__(kPB) void k_place_surface_gather(const r3d_place_query_t *Q, PlaceWs w, Radii rad) {
   const int q = blockIdx.x, tid = threadIdx.x;        // queries of one scene are neighbours: they share the chunk in L2
-  const r3d_place_query_t &qq = Q[q];
-  const int64_t n = qq.n_orig, start = (int64_t)blockIdx.y * kPointsPerBlock;
+  const int64_t n = Q[q].n_orig, start = (int64_t)blockIdx.y * kPointsPerBlock;
   if (start >= n) return;
   const double reach_sq = key_depth(w.gather_sq[q]);
   if (!(reach_sq > 0.0)) return;                                  // no step found surface
-  __shared__ double s_cx[kRot], s_cy[kRot], s_thr[kRot];
+  __shared__ r3d_place_query_t qq;
+  __shared__ unsigned char s_chunk[64];
+  __shared__ int s_nchunk;
+  __shared__ double s_cx[kRot], s_cy[kRot], s_thr[kRot], s_sum[kRot], s_abs[kRot];
+  __shared__ int s_cnt[kRot], s_lsb[kRot];
   for (int r = tid; r < kRot; r += kPB) {
     size_t o = (size_t)q * kRot + r;
     s_cx[r] = w.cx[o];
     s_cy[r] = w.cy[o];
     int k = w.kstar[o];
     s_thr[r] = k >= 0 ? rad.sq[k] : -1.0;
+    s_sum[r] = s_abs[r] = 0.0;
+    s_cnt[r] = 0;
+    s_lsb[r] = INT32_MAX;
   }
-  __syncthreads();
+  stage_query(qq, Q + q);
   const float reach = (float)sqrt(reach_sq) * 1.01f + 0.05f;
   const float rho_c = sqrtf((float)(s_cx[0] * s_cx[0] + s_cy[0] * s_cy[0])), th1 = atan2f((float)s_cy[0], (float)s_cx[0]);
   const int64_t end = start + kPointsPerBlock < n ? start + kPointsPerBlock : n;
-  for (int64_t i = start + tid; i < end; i += kPB) {
+  const int n_chunks = list_chunks_in_reach(qq.orig_ranges, start, end, rho_c, reach, s_chunk, &s_nchunk);
+  for (int a = tid >> 6; a < n_chunks; a += kPB / 64) {
+    const int64_t i = start + (int64_t)s_chunk[a] * 64 + (tid & 63);
+    if (i >= end) continue;
     const Pt p = load_point(qq.orig, i, qq.orig_ld, qq.orig_label_col);
     const double x = p.x, y = p.y;
     if (!(p.z > -3.0)) continue;
@@ -400,13 +489,26 @@ __global__ __launch_bounds__(kPB) void k_place_surface_gather(const r3d_place_qu
       r = r >= kRot ? r - kRot : r;
       double dx = x - s_cx[r], dy = y - s_cy[r];
       if (!(dx * dx + dy * dy <= s_thr[r])) continue;             // :123 with the step's radius
+      atomicAdd(&s_cnt[r], 1);
+      atomicAdd(&s_sum[r], p.z);
+      atomicAdd(&s_abs[r], fabs(p.z));
+      if (p.z != 0.0) atomicMin(&s_lsb[r], last_bit_exponent(p.z));
+      // the ordered list only matters while it is complete: stop appending once it is full
       size_t o = (size_t)q * kRot + r;
-      int slot = atomicAdd(&w.surf_n[o], 1);
-      if (slot < kCap) w.surf[o * kCap + slot] = ((unsigned long long)rank << 40) | (unsigned long long)i;
-      atomicAdd(&w.surf_sum[o], p.z);
-      atomicAdd(&w.surf_abs[o], fabs(p.z));
-      if (p.z != 0.0) atomicMin(&w.surf_lsb[o], last_bit_exponent(p.z));
+      if (__hip_atomic_load(&w.surf_list_n[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kCap) {
+        int slot = atomicAdd(&w.surf_list_n[o], 1);
+        if (slot < kCap) w.surf[o * kCap + slot] = ((unsigned long long)rank << 40) | (unsigned long long)i;
+      }
     }
+  }
+  __syncthreads();
+  for (int r = tid; r < kRot; r += kPB) {
+    if (!s_cnt[r]) continue;
+    size_t o = (size_t)q * kRot + r;
+    atomicAdd(&w.surf_n[o], s_cnt[r]);
+    atomicAdd(&w.surf_sum[o], s_sum[r]);
+    atomicAdd(&w.surf_abs[o], s_abs[r]);
+    atomicMin(&w.surf_lsb[o], s_lsb[r]);
   }
 }
 
@@ -475,10 +577,13 @@ __global__ __launch_bounds__(kPB) void k_place_road_level(const r3d_place_query_
 // ---- k_place_scene_in_box: cut_bounding_box(scene_pcl, sample_anno) minus surface (:91-97) --------
 __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_query_t *Q, PlaceWs w) {
   const int q = blockIdx.x, tid = threadIdx.x;
-  const r3d_place_query_t &qq = Q[q];
-  const int64_t n = qq.n_scene, start = (int64_t)blockIdx.y * kPointsPerBlock;
+  const int64_t n = Q[q].n_scene, start = (int64_t)blockIdx.y * kPointsPerBlock;
   if (start >= n) return;
+  __shared__ r3d_place_query_t qq;
+  __shared__ unsigned char s_chunk[64];
+  __shared__ int s_nchunk;
   __shared__ double s_cx[kRot], s_cy[kRot];
+  __shared__ float s_boxf[kRot][12];                // float copy of the step's box: matrix (9), centre (3)
   __shared__ unsigned char s_near[kRot];
   __shared__ uint32_t s_hit[12];
   int any = 0;
@@ -489,27 +594,44 @@ __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_quer
     int near = w.kstar[o] >= 0;
     s_near[r] = (unsigned char)near;
     any |= near;
+    for (int i = 0; i < 9; ++i) s_boxf[r][i] = (float)w.rotm[o * 9 + i];
+    s_boxf[r][9] = (float)w.cx[o];
+    s_boxf[r][10] = (float)w.cy[o];
+    s_boxf[r][11] = (float)w.road[o];
   }
   if (tid < 12) s_hit[tid] = 0u;
   if (!__syncthreads_or(any)) return;
+  stage_query(qq, Q + q);
   const double l = qq.anno[7], wd = qq.anno[8], h = qq.anno[9];
   const double reach_d = sqrt(l * l / 4 + wd * wd / 4 + h * h);     // no box point is further from the centre
   const float reach = (float)reach_d * 1.01f + 0.05f;
-  const double reach_sq = (double)reach * (double)reach;
+  const float hl = (float)l * 0.5f, hw = (float)wd * 0.5f, hh = (float)h;
   const float rho_c = sqrtf((float)(s_cx[0] * s_cx[0] + s_cy[0] * s_cy[0])), th1 = atan2f((float)s_cy[0], (float)s_cx[0]);
+  // float32 rounding of coordinates up to ~100 m is ~1e-5 m; the planes sit at |column|^2 * size, within
+  // 1e-12 of size for the unit quaternions of the chain
+  const float slack = 1e-3f + 1e-5f * (rho_c + reach + (float)fabs(qq.anno[2]) + 10.f);
   const int64_t end = start + kPointsPerBlock < n ? start + kPointsPerBlock : n;
-  for (int64_t i = start + tid; i < end; i += kPB) {
+  const int n_chunks = list_chunks_in_reach(qq.scene_ranges, start, end, rho_c, reach, s_chunk, &s_nchunk);
+  for (int a = tid >> 6; a < n_chunks; a += kPB / 64) {
+    const int64_t i = start + (int64_t)s_chunk[a] * 64 + (tid & 63);
+    if (i >= end) continue;
     const Pt p = load_point(qq.scene, i, qq.scene_ld, qq.scene_label_col);
     const double x = p.x, y = p.y, z = p.z;
     if (label_rank(qq, p.label) >= 0) continue;                   // :94-95: surface may be inside the box
     int first, count;
     if (!steps_in_reach((float)x, (float)y, rho_c, th1, reach, first, count)) continue;
+    const float xf = (float)x, yf = (float)y, zf = (float)z;
     for (int t = 0; t < count; ++t) {
       int r = first + t;
       r = r >= kRot ? r - kRot : r;
       if (!s_near[r]) continue;
-      double dx = x - s_cx[r], dy = y - s_cy[r];
-      if (dx * dx + dy * dy > reach_sq) continue;
+      // float32 look at the point in the box's frame, with slack: only what may be inside goes to the
+      // float64 planes of the reference
+      const float *bf = s_boxf[r];
+      float dx = xf - bf[9], dy = yf - bf[10], dz = zf - bf[11];
+      float u0 = bf[0] * dx + bf[3] * dy + bf[6] * dz, u1 = bf[1] * dx + bf[4] * dy + bf[7] * dz,
+            u2 = bf[2] * dx + bf[5] * dy + bf[8] * dz;
+      if (!(fabsf(u0) < hl + slack && fabsf(u1) < hw + slack && u2 > -slack && u2 < hh + slack)) continue;
       size_t o = (size_t)q * kRot + r;
       if (inside_box(w.rotm + o * 9, w.planes + o * 6, w.planes + o * 6 + 3, x, y, z))
         atomicOr(&s_hit[r >> 5], 1u << (r & 31));
@@ -521,8 +643,8 @@ __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_quer
 
 // Points per thread with which the sample chain takes a sample of m points.
 __host__ __device__ inline int chain_class(int m) {
-  int need = (m + kPB - 1) / kPB;
-  return need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 16 ? 16 : 32;
+  int need = (m + kCB - 1) / kCB;
+  return need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16;
 }
 
 // ---- k_place_sample_chain: the loop of find_spot.py:228-269 on the sample's points ---------------
@@ -540,7 +662,7 @@ struct ChainLds {
   unsigned char near[kRot], flags[kRot], vote[2][kRot];
   unsigned short rot[kRot];
   uint32_t hit[12];
-  float red[2][kPB / 64];
+  float red[2][kCB / 64];
 };
 
 template <int PPT>
@@ -556,7 +678,7 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
   unsigned char(*s_vote)[kRot] = lds.vote;
   unsigned short *s_rot = lds.rot;
   uint32_t *s_hit = lds.hit;
-  float(*s_red)[kPB / 64] = lds.red;
+  float(*s_red)[kCB / 64] = lds.red;
   double x[PPT], y[PPT], z[PPT];
   bool valid[PPT];
   int bad_input = 0;
@@ -564,20 +686,20 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
   const double ax = qq.anno[0], ay = qq.anno[1];
 #pragma unroll
   for (int u = 0; u < PPT; ++u) {
-    int i = tid + u * kPB;
+    int i = tid + u * kCB;
     x[u] = y[u] = z[u] = 0.0;
     valid[u] = i < m;
     if (i < m) {
-      x[u] = qq.sample[(size_t)i * 5 + 0];
-      y[u] = qq.sample[(size_t)i * 5 + 1];
-      z[u] = qq.sample[(size_t)i * 5 + 2];
+      x[u] = in_global(qq.sample)[(size_t)i * 5 + 0];
+      y[u] = in_global(qq.sample)[(size_t)i * 5 + 1];
+      z[u] = in_global(qq.sample)[(size_t)i * 5 + 2];
       if (!(isfinite(x[u]) && isfinite(y[u]) && isfinite(z[u]))) bad_input = 1;
       rho2 = fmaxf(rho2, (float)(x[u] * x[u] + y[u] * y[u]));
       ext2 = fmaxf(ext2, (float)((x[u] - ax) * (x[u] - ax) + (y[u] - ay) * (y[u] - ay)));
     }
   }
   if (bad_input) atomicOr(&status[q], R3D_PS_NONFINITE);
-  for (int r = tid; r < kRot; r += kPB) {
+  for (int r = tid; r < kRot; r += kCB) {
     size_t o = (size_t)q * kRot + r;
     s_road[r] = w.road[o];
     s_near[r] = w.kstar[o] >= 0 ? 1 : 0;
@@ -590,8 +712,7 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
   const double *gboxes = w.boxes + (size_t)q * max_boxes * kBoxD;
   const bool lds_boxes = nb <= kLdsBoxes;
   if (lds_boxes)
-    for (int i = tid; i < nb * kBoxD; i += kPB) s_box[i] = gboxes[i];
-  const double *boxes = lds_boxes ? s_box : gboxes;
+    for (int i = tid; i < nb * kBoxD; i += kCB) s_box[i] = gboxes[i];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     rho2 = fmaxf(rho2, __shfl_xor(rho2, o, 64));
@@ -606,7 +727,7 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
   const double T10 = qq.pose[4], T11 = qq.pose[5], T12 = qq.pose[6], T13 = qq.pose[7];
   const double mv0 = qq.map_move[0], mv1 = qq.map_move[1];
   const int rows = qq.map_rows, cols = qq.map_cols;
-  const uint8_t *map = qq.map;
+  InGlobal<uint8_t> map = in_global(qq.map);
   const uint64_t okm0 = qq.ok_map[0], okm1 = qq.ok_map[1], okm2 = qq.ok_map[2], okm3 = qq.ok_map[3];
   auto allowed = [&](unsigned v) -> bool {
     uint64_t wv = v < 64 ? okm0 : v < 128 ? okm1 : v < 192 ? okm2 : okm3;
@@ -615,9 +736,9 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
   const int cand_cap = qq.cand_cap;
   const int64_t cand_stride = qq.cand_stride;
   double *cand_q = cand + qq.cand_off;
-  const double *sample = qq.sample;
+  InGlobal<double> sample = in_global(qq.sample);
   float rho = 0.f, ext = 0.f;
-  for (int i = 0; i < kPB / 64; ++i) {
+  for (int i = 0; i < kCB / 64; ++i) {
     rho = fmaxf(rho, s_red[0][i]);
     ext = fmaxf(ext, s_red[1][i]);
   }
@@ -642,7 +763,7 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
     wh = h > kMapWindowSide ? kMapWindowSide : h;
     ww = wd > kMapWindowSide ? kMapWindowSide : wd;
   }
-  for (int wi = tid; wi < (wh * ww + 31) / 32; wi += kPB) {
+  for (int wi = tid; wi < (wh * ww + 31) / 32; wi += kCB) {
     uint32_t bits = 0u;
     for (int b = 0; b < 32; ++b) {
       int c = wi * 32 + b;
@@ -696,14 +817,18 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
       // only boxes whose bounding circle reaches the sample's can hold one of its points
       const float cxr = (float)s_cx[r], cyr = (float)s_cy[r];
       int in_any = 0, tested = 0;
-      for (int b = 0; b < nb; ++b) {
-        const double *bx = boxes + (size_t)b * kBoxD;
-        float dx = (float)bx[15] - cxr, dy = (float)bx[16] - cyr, reach = (float)bx[17] + ext;
-        if (dx * dx + dy * dy > reach * reach) continue;          // uniform across the workgroup
-        tested = 1;
+      auto test_boxes = [&](const double *boxes) {                // called with an LDS or a global pointer:
+        for (int b = 0; b < nb; ++b) {                            // keeps the address space known at both sites
+          const double *bx = boxes + (size_t)b * kBoxD;
+          float dx = (float)bx[15] - cxr, dy = (float)bx[16] - cyr, reach = (float)bx[17] + ext;
+          if (dx * dx + dy * dy > reach * reach) continue;        // uniform across the workgroup
+          tested = 1;
 #pragma unroll
-        for (int u = 0; u < PPT; ++u) in_any |= (valid[u] && inside_box(bx, bx + 9, bx + 12, x[u], y[u], z[u])) ? 1 : 0;
-      }
+          for (int u = 0; u < PPT; ++u) in_any |= (valid[u] && inside_box(bx, bx + 9, bx + 12, x[u], y[u], z[u])) ? 1 : 0;
+        }
+      };
+      if (lds_boxes) test_boxes(s_box);
+      else test_boxes(gboxes);
       if (tested) {
         if (in_any) s_vote[1][r] = 1;
         __syncthreads();
@@ -721,7 +846,7 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
         double *out = cand_q + (size_t)j * cand_stride;
 #pragma unroll
         for (int u = 0; u < PPT; ++u) {
-          int i = tid + u * kPB;
+          int i = tid + u * kCB;
           if (!valid[u]) continue;
           out[(size_t)i * 5 + 0] = x[u];
           out[(size_t)i * 5 + 1] = y[u];
@@ -736,8 +861,8 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
   }
   __syncthreads();
   // the annotation of a possible placement: centre (cx, cy, road level of that step), orientation
-  for (int r = tid; r < kRot; r += kPB) flags[(size_t)q * kRot + r] = s_flags[r];
-  for (int j = tid; j < n_out; j += kPB) {
+  for (int r = tid; r < kRot; r += kCB) flags[(size_t)q * kRot + r] = s_flags[r];
+  for (int j = tid; j < n_out; j += kCB) {
     int r = s_rot[j];
     size_t o = (size_t)q * kRot + r, oo = (size_t)q * kRot + j;
     rot_out[oo] = r + 1;
@@ -751,27 +876,27 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
 
 // Samples of up to 2048 points (every class of the reference's object database) in one launch; the
 // workgroup picks the instance of its size class.  Larger samples: the second kernel.
-__global__ __launch_bounds__(kPB) void k_place_sample_chain(const r3d_place_query_t *Q, PlaceWs w, int max_boxes,
+__global__ __launch_bounds__(kCB) void k_place_sample_chain(const r3d_place_query_t *Q, PlaceWs w, int max_boxes,
                                                            uint8_t *flags, int32_t *n_possible, int32_t *rot_out,
                                                            double *anno_out, double *cand, int32_t first_cand,
                                                            int32_t *status) {
   __shared__ ChainLds lds;
   switch (chain_class(Q[blockIdx.x].m)) {
+    case 1: sample_chain<1>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
     case 2: sample_chain<2>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
     case 4: sample_chain<4>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
-    case 8: sample_chain<8>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
     default: break;
   }
 }
 
-__global__ __launch_bounds__(kPB) void k_place_sample_chain_large(const r3d_place_query_t *Q, PlaceWs w, int max_boxes,
+__global__ __launch_bounds__(kCB) void k_place_sample_chain_large(const r3d_place_query_t *Q, PlaceWs w, int max_boxes,
                                                                  uint8_t *flags, int32_t *n_possible,
                                                                  int32_t *rot_out, double *anno_out, double *cand,
                                                                  int32_t first_cand, int32_t *status) {
   __shared__ ChainLds lds;
   switch (chain_class(Q[blockIdx.x].m)) {
+    case 8: sample_chain<8>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
     case 16: sample_chain<16>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
-    case 32: sample_chain<32>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
     default: break;
   }
 }
@@ -781,6 +906,16 @@ __global__ __launch_bounds__(kPB) void k_place_sample_chain_large(const r3d_plac
 extern "C" size_t r3d_places_workspace_bytes(int32_t n_queries, int32_t max_boxes) {
   if (n_queries <= 0 || max_boxes < 0) return 0;
   return carve_places(n_queries, max_boxes, nullptr).total;
+}
+
+extern "C" int r3d_places_chunk_ranges(const double *rows, int64_t n, int32_t ld, float *ranges, void *stream) {
+  if (!rows || !ranges || n < 0 || ld < 2) return fail(R3D_E_ARG, "places_chunk_ranges: bad argument");
+  if (n == 0) return R3D_OK;
+  int64_t chunks = (n + 63) / 64;
+  hipLaunchKernelGGL(k_chunk_ranges, dim3((unsigned)((chunks + kPB / 64 - 1) / (kPB / 64))), dim3(kPB), 0,
+                     static_cast<hipStream_t>(stream), rows, n, (int)ld, ranges);
+  R3D_LAUNCHED("k_chunk_ranges");
+  return R3D_OK;
 }
 
 extern "C" int r3d_find_possible_places(const r3d_place_query_t *queries, int32_t n_queries, int64_t max_n_scene,
@@ -794,7 +929,7 @@ extern "C" int r3d_find_possible_places(const r3d_place_query_t *queries, int32_
   if (n_queries <= 0 || n_queries > 65535) return fail(R3D_E_ARG, "places: 1..65535 queries per call");
   if (max_n_scene < 0 || max_n_orig < 0 || max_m <= 0 || max_boxes < 0 || first_cand < 0)
     return fail(R3D_E_ARG, "places: negative size");
-  if (max_m > kPB * 32) return fail(R3D_E_ARG, "places: samples are limited to 8192 points");
+  if (max_m > kCB * 16) return fail(R3D_E_ARG, "places: samples are limited to 8192 points");
   if (n_radii <= 0 || n_radii > R3D_PLACE_MAX_RADII) return fail(R3D_E_ARG, "places: 1..64 search radii");
   PlaceWs w = carve_places(n_queries, max_boxes, workspace);
   if (workspace_bytes < w.total) return fail(R3D_E_WORKSPACE, "places: workspace smaller than r3d_places_workspace_bytes()");
@@ -817,13 +952,18 @@ extern "C" int r3d_find_possible_places(const r3d_place_query_t *queries, int32_
                        n_queries, max_boxes, w);
   const int pb_orig = (int)((max_n_orig + kPointsPerBlock - 1) / kPointsPerBlock);
   const int pb_scene = (int)((max_n_scene + kPointsPerBlock - 1) / kPointsPerBlock);
-  const double narrow = 0.6;     // metres: what the first distance pass looks at
+  // distance passes of growing reach (metres); a pass only serves the steps whose minimum the
+  // previous one could not settle (nothing found within its reach)
+  const double reach_of_pass[3] = {0.6, 1.8, sqrt(reach_max)};
   if (pb_orig > 0) {
-    hipLaunchKernelGGL(k_place_road_min, dim3(n_queries, pb_orig), dim3(kPB), 0, st, queries, w,
-                       (float)(narrow * 1.01 + 0.05), 0, 0.0);
-    if (reach_max > narrow * narrow)
+    double settled = 0.0;
+    for (int pass = 0; pass < 3; ++pass) {
+      double reach_m = reach_of_pass[pass] < sqrt(reach_max) ? reach_of_pass[pass] : sqrt(reach_max);
+      if (pass > 0 && reach_m <= settled) break;
       hipLaunchKernelGGL(k_place_road_min, dim3(n_queries, pb_orig), dim3(kPB), 0, st, queries, w,
-                         (float)(sqrt(reach_max) * 1.01 + 0.05), 1, narrow * narrow);
+                         (float)(reach_m * 1.01 + 0.05), pass == 0 ? 0 : 1, settled * settled);
+      settled = reach_m;
+    }
   }
   hipLaunchKernelGGL(k_place_kstar, dim3((unsigned)((qr + 255) / 256)), dim3(256), 0, st, n_queries, w, rad);
   if (pb_orig > 0)
@@ -832,10 +972,10 @@ extern "C" int r3d_find_possible_places(const r3d_place_query_t *queries, int32_
                      n_queries, w, status);
   if (pb_scene > 0)
     hipLaunchKernelGGL(k_place_scene_in_box, dim3(n_queries, pb_scene), dim3(kPB), 0, st, queries, w);
-  hipLaunchKernelGGL(k_place_sample_chain, dim3(n_queries), dim3(kPB), 0, st, queries, w, max_boxes, flags,
+  hipLaunchKernelGGL(k_place_sample_chain, dim3(n_queries), dim3(kCB), 0, st, queries, w, max_boxes, flags,
                      n_possible, rot_out, anno_out, cand, first_cand, status);
-  if (chain_class(max_m) > 8)
-    hipLaunchKernelGGL(k_place_sample_chain_large, dim3(n_queries), dim3(kPB), 0, st, queries, w, max_boxes, flags,
+  if (chain_class(max_m) > 4)
+    hipLaunchKernelGGL(k_place_sample_chain_large, dim3(n_queries), dim3(kCB), 0, st, queries, w, max_boxes, flags,
                        n_possible, rot_out, anno_out, cand, first_cand, status);
   R3D_LAUNCHED("placement kernels");
   return R3D_OK;

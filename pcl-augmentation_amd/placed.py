@@ -34,6 +34,8 @@ class PlacedInserter:
         self.n_orig = [int(v) for v in n0]
         self.orig_rows = torch.cat([batch.xyzi[:, :, :3].to(torch.float64),
                                     (batch.label.to(torch.int64) & 0xFFFF).to(torch.float64)[:, :, None]], dim=2).contiguous()
+        from .places import chunk_ranges
+        self.orig_ranges = [chunk_ranges(self.orig_rows[s, :self.n_orig[s]]) for s in range(B)]
 
     def insert_slot(self, samples, annos, ok_labels, ok_maps, min_points, chunk=8):
         """samples[s]: M x 5 float64 or None; annos[s]: the sample's box (10 floats) after
@@ -50,7 +52,7 @@ class PlacedInserter:
         queries = []
         for s in who:
             scene = PlaceScene(rows[s, :int(n_rows_h[s])], self.orig_rows[s, :self.n_orig[s]], self.boxes[s], self.maps[s],
-                               self.moves[s], self.poses[s], device=batch.device)
+                               self.moves[s], self.poses[s], device=batch.device, orig_ranges=self.orig_ranges[s])
             queries.append({"scene": scene, "sample": samples[s], "anno": annos[s], "ok_labels": ok_labels[s],
                             "ok_map": ok_maps[s]})
         pb = PlaceBatch(queries, cand_cap=chunk, device=batch.device, packed=True)

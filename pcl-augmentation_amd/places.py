@@ -39,11 +39,22 @@ def upload_map(rich_map, device):
     return torch.from_numpy(np.ascontiguousarray(m)).to(device)
 
 
+def chunk_ranges(rows):
+    """r3d_places_chunk_ranges of a device tensor of rows (x y first): float32 [chunks, 2]."""
+    torch = _lib.require_gpu()
+    n = rows.shape[0]
+    out = torch.empty(((n + 63) // 64, 2), dtype=torch.float32, device=rows.device)
+    if n:
+        _lib.check(_lib.load().r3d_places_chunk_ranges(rows.data_ptr(), n, rows.shape[1], out.data_ptr(),
+                                                      _lib.stream_ptr()), "r3d_places_chunk_ranges")
+    return out
+
+
 class PlaceScene:
     """Device-resident inputs of one scene, shared by the queries that use it."""
 
     def __init__(self, point_cloud, original_pcl, scene_boxes, rich_map, map_move, transformation_matrix,
-                 scene_label_col=None, orig_label_col=None, device="cuda:0"):
+                 scene_label_col=None, orig_label_col=None, device="cuda:0", scene_ranges=None, orig_ranges=None):
         torch = _lib.require_gpu()
         self.device = device
 
@@ -63,6 +74,8 @@ class PlaceScene:
         self.scene = scene if scene.shape[1] == 4 else scene[:, [0, 1, 2, scene_label_col]].contiguous()
         self.orig = orig if orig.shape[1] == 4 else orig[:, [0, 1, 2, orig_label_col]].contiguous()
         self.scene_label_col = self.orig_label_col = 3
+        self.scene_ranges = chunk_ranges(self.scene) if scene_ranges is None else scene_ranges
+        self.orig_ranges = chunk_ranges(self.orig) if orig_ranges is None else orig_ranges
         boxes = np.ascontiguousarray(scene_boxes, dtype=np.float64).reshape(-1, 10)
         self.n_boxes = len(boxes)
         self.boxes = torch.from_numpy(boxes if len(boxes) else np.zeros((1, 10))).to(device)
@@ -74,6 +87,8 @@ class PlaceScene:
 def _fill_query(qd, scene, sample_t, anno10, ok_labels, ok_map_values, cand_cap, cand_off, cand_stride):
     qd.scene, qd.orig = scene.scene.data_ptr(), scene.orig.data_ptr()
     qd.boxes, qd.sample, qd.map = scene.boxes.data_ptr(), sample_t.data_ptr(), scene.map.data_ptr()
+    qd.scene_ranges = scene.scene_ranges.data_ptr() if scene.scene_ranges.numel() else None
+    qd.orig_ranges = scene.orig_ranges.data_ptr() if scene.orig_ranges.numel() else None
     qd.n_scene, qd.n_orig = scene.scene.shape[0], scene.orig.shape[0]
     qd.scene_ld, qd.scene_label_col = scene.scene.shape[1], scene.scene_label_col
     qd.orig_ld, qd.orig_label_col = scene.orig.shape[1], scene.orig_label_col
