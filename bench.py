@@ -74,6 +74,57 @@ def cpu_baseline(pkg, budget_s=20.0, max_scenes=16):
     return done, spent
 
 
+def placement_leg(pkg, torch, n_frames, with_cpu):
+    """r3d_find_possible_places on n_frames synthetic 120k-point frames x the 5 samples of config C2
+    (one query each, all in one call), inputs resident; the CPU figure is the oracle's
+    find_possible_places on the first queries."""
+    synth, fs = pkg.synth, pkg.Real3DAug.tools.find_spot
+    config = {"insertion": {"placement": synth.PLACEMENT, "placement_labels": synth.PLACEMENT_LABELS}}
+    frames = [synth.make_place_frame(s) for s in range(n_frames)]
+    queries, raw = [], []
+    for s, f in enumerate(frames):
+        scene9 = np.full((len(f["original"]), 9), -1.0)
+        scene9[:, :3], scene9[:, 6], scene9[:, 7] = f["original"][:, :3], f["original"][:, 3], f["original"][:, 4]
+        ps = pkg.PlaceScene(scene9, f["original"], f["boxes"], f["rich"], f["move"], f["pose"])
+        for k, kind in enumerate(KINDS):
+            smp, line = synth.make_place_sample(s * 100 + k, kind)
+            sa = fs.read_label_line(line)
+            ok_map, ok_labels = fs.placement_surfaces(sa, config)
+            queries.append({"scene": ps, "sample": smp, "anno": fs._anno10(sa), "ok_labels": ok_labels, "ok_map": ok_map})
+            if s == 0:
+                raw.append((scene9, f, smp, line))
+    pb = pkg.places.PlaceBatch(queries, cand_cap=4)
+    pb.run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        pb.run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    res = pb.results()
+    out = {"queries": len(queries), "ms_per_call": round(ms, 3), "queries_per_s": round(len(queries) / ms * 1e3, 1),
+           "rotation_steps_per_s": round(len(queries) * 360 / ms * 1e3, 1),
+           "mean_possible_placements": round(float(np.mean([len(r["rotations"]) for r in res])), 1),
+           "workload": f"{n_frames} synthetic 120k-point frames x 5 samples (2 pedestrians, 2 cyclists, 1 car), "
+                       "6 annotated boxes per frame, 141 x 141 rich map; timing excludes descriptor packing"}
+    if with_cpu:
+        from oracle import find_spot_oracle as F
+        t0, same = time.perf_counter(), True
+        for qi, (scene9, f, smp, line) in enumerate(raw):
+            annos = [F.make_annotation(b[:3], b[3:7], b[7], b[8], b[9]) for b in f["boxes"]]
+            _, _, rot, _, _ = F.find_possible_places(scene9, annos, smp, line, f["rich"].astype(np.float64), f["move"],
+                                                     f["original"], f["pose"], synth.PLACEMENT, synth.PLACEMENT_LABELS)
+            same = same and rot == list(res[qi]["rotations"])
+        secs = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(len(raw) / secs, 3), "unit": "queries/s", "cores": 1, "kind": "port",
+                               "sample": f"the {len(raw)} queries of the first frame through oracle.find_possible_places",
+                               "same_rotations_as_gpu": same}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +137,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per step instead of launching "
                     "every kernel from Python (measured: same step time at one stream, slower with several)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--placement", type=int, default=0, metavar="SCENES",
+                    help="also time the placement search (SURVEY.md par.8 f-1) on SCENES frames x 5 samples and add "
+                         "a `placement_search` object to the JSON line (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -276,6 +330,8 @@ def main():
             out["cpu_baseline"] = {"value": round(done / secs, 3), "unit": "scenes/s", "cores": 1, "kind": "port",
                                    "sample": f"{done} scenes of the same workload (120k points, 5 inserts) through "
                                              "oracle.augment_scene (NumPy port of the reference), one core"}
+        if args.placement > 0 and world == 1:
+            out["placement_search"] = placement_leg(pkg, torch, args.placement, not args.no_cpu_baseline)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -108,3 +108,51 @@ def scene5_from_packed(xyzi: np.ndarray, label: np.ndarray) -> np.ndarray:
     """float32 xyzi + uint32 label -> the N x 5 float64 array the reference's ``__getitem__``
     hands to the driver (SS tools/datasets.py:51-56: hstack promotes to float64)."""
     return np.hstack((xyzi.astype(np.float64), (label & 0xFFFF).astype(np.float64)[:, None]))
+
+
+# ---- placement-search inputs (SURVEY.md par.8 row f-1) ----------------------------------------------
+# semantic-kitti.yaml:22-34 for the three classes of INSERT_KINDS
+PLACEMENT = {18: [1, 3], 30: [2], 31: [1, 3]}
+PLACEMENT_LABELS = {1: [40, 60], 2: [48], 3: [44]}
+KIND_CLASS = {"pedestrian": 30, "cyclist": 31, "car": 18}
+
+
+def make_place_frame(seed: int, n_boxes: int = 6, n_beams: int = 64, n_az: int = 1875):
+    """One frame for the placement search: the scan of ``make_scene`` with part of its ground
+    relabelled sidewalk (48, y > 4 m) and parking (44, x < -8 m), a pose, the 1 m rich map
+    rasterised from the ground labels (road 1, sidewalk 2, parking 3) with its ``move`` and
+    ``n_boxes`` annotated objects.  Returns a dict: original (N x 5 float64), rich (uint8), move
+    (4 x 1), pose (4 x 4), boxes (k x 10: centre, quaternion xyzw, length, width, height)."""
+    xyzi, label = make_scene(seed, n_beams, n_az)
+    label = label.copy()
+    ground = label == 40
+    label[ground & (xyzi[:, 1] > 4.0)] = 48
+    label[ground & (xyzi[:, 0] < -8.0) & (xyzi[:, 1] <= 4.0)] = 44
+    original = scene5_from_packed(xyzi, label)
+    pose = np.eye(4)
+    pose[:3, 3] = [500.5 + seed, -200.25, 1.7]
+    half = 70
+    move = np.array([[int(np.floor(pose[0, 3])) - half], [int(np.floor(pose[1, 3])) - half], [0], [1]])
+    rich = np.zeros((2 * half + 1, 2 * half + 1), dtype=np.uint8)
+    world = (pose @ np.hstack((original[:, :3], np.ones((len(original), 1)))).T - move).astype(int)
+    inside = (world[0] >= 0) & (world[0] < rich.shape[0]) & (world[1] >= 0) & (world[1] < rich.shape[1])
+    for value, labels in ((1, (40,)), (2, (48,)), (3, (44,))):
+        sel = inside & np.isin(original[:, 4], labels)
+        rich[world[0][sel], world[1][sel]] = value
+    rng = np.random.default_rng(seed)
+    boxes = []
+    for ang in rng.uniform(-np.pi, np.pi, size=n_boxes):
+        d = rng.uniform(6, 25)
+        boxes.append([d * np.cos(ang), d * np.sin(ang), -SENSOR_HEIGHT, 0, 0, np.sin(ang / 2), np.cos(ang / 2), 4.2, 1.8, 1.5])
+    return {"xyzi": xyzi, "label": label, "original": original, "rich": rich, "move": move, "pose": pose,
+            "boxes": np.asarray(boxes, dtype=np.float64).reshape(-1, 10)}
+
+
+def make_place_sample(seed: int, kind: str):
+    """A sample of the object database for the placement search: (M x 5 points, label line
+    'class x y z height length width rot_z' as cut_object/cut_out.py:113-121 writes it)."""
+    smp = make_insert(seed, kind)
+    length, width, height, _, _ = INSERT_KINDS[kind]
+    centre = [smp[:, 0].mean(), smp[:, 1].mean(), smp[:, 2].min()]
+    line = " ".join([str(KIND_CLASS[kind])] + [repr(float(v)) for v in (*centre, height, length, width, 0.3)])
+    return smp, line

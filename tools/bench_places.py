@@ -17,46 +17,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("pcl-augmentation_amd")
 import torch  # noqa: E402
 
-PLACEMENT = {18: [1, 3], 30: [2], 31: [1, 3]}
-PLACEMENT_LABELS = {1: [40, 60], 2: [48], 3: [44]}
-CONFIG = {"insertion": {"placement": PLACEMENT, "placement_labels": PLACEMENT_LABELS}}
+CONFIG = {"insertion": {"placement": pkg.synth.PLACEMENT, "placement_labels": pkg.synth.PLACEMENT_LABELS}}
 
 
 def make_scene(seed, n_boxes=6):
-    synth = pkg.synth
-    xyzi, label = synth.make_scene(seed)
-    label = label.copy()
-    ground = label == 40
-    label[ground & (xyzi[:, 1] > 4.0)] = 48
-    label[ground & (xyzi[:, 0] < -8.0) & (xyzi[:, 1] <= 4.0)] = 44
-    original = synth.scene5_from_packed(xyzi, label)
-    T = np.eye(4)
-    T[:3, 3] = [500.5 + seed, -200.25, 1.7]
-    half = 70
-    move = np.array([[int(np.floor(T[0, 3])) - half], [int(np.floor(T[1, 3])) - half], [0], [1]])
-    rich = np.zeros((2 * half + 1, 2 * half + 1), dtype=np.uint8)
-    world = (T @ np.hstack((original[:, :3], np.ones((len(original), 1)))).T - move).astype(int)
-    inside = (world[0] >= 0) & (world[0] < rich.shape[0]) & (world[1] >= 0) & (world[1] < rich.shape[1])
-    for value, labels in ((1, (40,)), (2, (48,)), (3, (44,))):
-        sel = inside & np.isin(original[:, 4], labels)
-        rich[world[0][sel], world[1][sel]] = value
-    scene9 = np.full((len(original), 9), -1.0)
-    scene9[:, :3], scene9[:, 6], scene9[:, 7] = original[:, :3], original[:, 3], original[:, 4]
-    rng = np.random.default_rng(seed)
-    boxes = []
-    for ang in rng.uniform(-np.pi, np.pi, size=n_boxes):
-        d = rng.uniform(6, 25)
-        boxes.append([d * np.cos(ang), d * np.sin(ang), -1.73, 0, 0, np.sin(ang / 2), np.cos(ang / 2), 4.2, 1.8, 1.5])
-    return pkg.PlaceScene(scene9, original, boxes, rich, move, T)
+    f = pkg.synth.make_place_frame(seed, n_boxes)
+    scene9 = np.full((len(f["original"]), 9), -1.0)
+    scene9[:, :3], scene9[:, 6], scene9[:, 7] = f["original"][:, :3], f["original"][:, 3], f["original"][:, 4]
+    return pkg.PlaceScene(scene9, f["original"], f["boxes"], f["rich"], f["move"], f["pose"])
 
 
 def make_query(scene, seed, kind):
-    synth, fs = pkg.synth, pkg.Real3DAug.tools.find_spot
-    cls = {"pedestrian": 30, "cyclist": 31, "car": 18}[kind]
-    smp = synth.make_insert(seed, kind)
-    length, width, height, _, _ = synth.INSERT_KINDS[kind]
-    centre = [smp[:, 0].mean(), smp[:, 1].mean(), smp[:, 2].min()]
-    line = " ".join([str(cls)] + [repr(float(v)) for v in (*centre, height, length, width, 0.3)])
+    fs = pkg.Real3DAug.tools.find_spot
+    smp, line = pkg.synth.make_place_sample(seed, kind)
     sa = fs.read_label_line(line)
     ok_map, ok_labels = fs.placement_surfaces(sa, CONFIG)
     return {"scene": scene, "sample": smp, "anno": fs._anno10(sa), "ok_labels": ok_labels, "ok_map": ok_map}
