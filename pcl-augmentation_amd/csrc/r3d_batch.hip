@@ -686,7 +686,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   const int n_far = b.n_far[s] < R3D_FAR_CAP ? b.n_far[s] : R3D_FAR_CAP;
   const int n_total = b.n_total[s], n_head = b.n_head[s], n_log = b.n_log[s];
 
-  STAMP(2);
+  STAMP(1);
   // -- 3. the window: candidates lie within 2 rows / 1 column of a sample pixel, their closing
   // looks 4 rows / 2 columns further.  Pixels deeper than 500 m (far list) can be visible
   // anywhere: whole image.
@@ -763,7 +763,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
   }
   __syncthreads();
 
-  STAMP(1);
+  STAMP(2);
   // -- 2. sort (pixel, sample index): the order of visible_sample (insertion.py:474-482) ---------
   // Bitonic network; thread t owns elements t*E .. t*E+E-1.  Strides below E swap registers,
   // strides below 64*E are wave shuffles, only the strides that cross waves go through LDS.

@@ -11,7 +11,7 @@ batch = pkg.SceneBatch(B, 120000 + grow, grow)
 batch.load(scenes)
 need = torch.full((B,), 20, dtype=torch.int32, device=batch.device)
 packed = [batch.pack_samples([inserts[s][k] for s in range(B)]) for k in range(5)]
-names = ["project", "sort", "window", "occ+rank+sdepth", "scene tile", "D bits", "closing", "cands", "evaluate", "count", "commit", "cleanup"]
+names = ["project", "window", "re-key + sort", "occ+rank+sdepth", "scene tile", "D bits", "closing", "cands", "evaluate", "count", "commit", "cleanup"]
 for rep in range(2):
     batch.begin()
     sums = np.zeros(B)
