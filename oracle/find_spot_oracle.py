@@ -286,3 +286,85 @@ def find_possible_places(point_cloud, scene_annotation, sample_pcl, sample_anno_
         else:
             object_collision += 1
     return out_pcl, out_anno, out_rot, not_on_road, object_collision
+
+
+# ==== object-detection flavour: object_detection/Real3DAug/tools/find_spot.py ========================
+def read_label_line_od(line):
+    """OD find_spot.py:179-224: a KITTI label_2 line (camera frame) -> annotation in the LiDAR frame."""
+    it = line.split(" ")
+    height, width, length = float(it[8]), float(it[9]), float(it[10])
+    x, y, z = float(it[11]), float(it[12]), float(it[13])
+    rot_y = float(it[14])
+    c_height, c_width, c_length = height + 0.1, length + 0.1, width + 0.1            # :198-200
+    cx, cy, cz = float(z) + 0.27, float(x) * -1, float(y) * -1 - 0.08                # :202-204
+    a = float(rot_y) * -1
+    m = np.array([[math.cos(a), -1 * math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]], dtype=np.float64)
+    q = matrix_to_quat(m)
+    return make_annotation([cx, cy, cz], q, c_length, c_width, c_height, it[0])      # OD make_dictionary keeps the string
+
+
+def rotate_bounding_box_od(bbox_pcl, annotation):
+    """OD find_spot.py:72-105: as rotate_bounding_box_2, but the points are turned one by one with
+    np.dot(z_rot_matrix, column) -- the BLAS matrix x vector kernel, which accumulates in another
+    order than the matrix x matrix kernel (module docstring)."""
+    rot = quat_to_matrix(quat_normalize(anno_quat(annotation)))
+    q = matrix_to_quat(blas_matmul(rot, Z1))
+    c = blas_matvec3(Z1, anno_center(annotation))
+    x, y, z = bbox_pcl[:, 0].copy(), bbox_pcl[:, 1].copy(), bbox_pcl[:, 2].copy()
+    for i in range(3):                                                                # :94-99
+        bbox_pcl[:, i] = fma(Z1[i, 2], z, fma(Z1[i, 0], x, Z1[i, 1] * y))
+    return bbox_pcl, make_annotation(c, q, annotation["length"], annotation["width"], annotation["height"],
+                                     annotation["class"])
+
+
+def on_road_od(sample_pcl, map_, map_move):
+    """OD find_spot.py:261-275: some sample point falls inside the map and every one that does lies
+    on a cell of value 1."""
+    g0 = sample_pcl[:, 0] - map_move[0]
+    g1 = sample_pcl[:, 1] - map_move[1]
+    inside = ~((g0 < 0) | (g0 >= map_.shape[0]) | (g1 < 0) | (g1 >= map_.shape[1]))
+    if not inside.any():
+        return False
+    cells = np.asarray(map_)[g0[inside].astype(np.int64), g1[inside].astype(np.int64)]
+    return bool((cells == 1).all())
+
+
+def check_bounding_box_od(scene_pcl, scene_anno, sample_pcl, sample_anno):
+    """OD find_spot.py:108-135: scene points of label 1 inside the box collide; under a pedestrian
+    only those at least 0.1 m above the box bottom (:123-124)."""
+    inside = scene_pcl[box_mask(scene_pcl, sample_anno)]
+    inside = inside[inside[:, 7] == 1]
+    if sample_anno["class"] == "Pedestrian":
+        inside = inside[inside[:, 2] >= sample_anno["center"]["z"] + 0.1]
+    if len(inside):
+        return False
+    for a in scene_anno:
+        if box_mask(sample_pcl, a).any():
+            return False
+    return True
+
+
+def find_possible_places_od(point_cloud, scene_annotation, sample_pcl, sample_anno_line, map_, map_move, original_pcl,
+                            road_label):
+    """OD find_spot.py:227-304.  map_move = (min_x, min_y); road_label = config['labels']['Road']."""
+    sample_pcl = np.array(sample_pcl, dtype=np.float64, copy=True)
+    sample_pcl[:, 4] = 1                                                              # :249
+    anno = read_label_line_od(sample_anno_line)
+    out_pcl, out_anno, out_rot = [], [], []
+    not_on_road = object_collision = 0
+    for rot in range(1, 361):
+        sample_pcl, anno = rotate_bounding_box_od(sample_pcl, anno)
+        if not on_road_od(sample_pcl, map_, map_move):
+            not_on_road += 1
+            continue
+        sample_pcl, anno, near_road = correct_height(original_pcl, sample_pcl, anno, [road_label])   # :155-158
+        if not near_road:
+            not_on_road += 1                                                          # :280
+            continue
+        if check_bounding_box_od(point_cloud, scene_annotation, sample_pcl, anno):
+            out_pcl.append(sample_pcl.copy())
+            out_anno.append(anno)
+            out_rot.append(rot)
+        else:
+            object_collision += 1
+    return out_pcl, out_anno, out_rot, not_on_road, object_collision

@@ -2,7 +2,8 @@
 """Golden fixtures for the placement search, made by running the
 REFERENCE's own ``find_possible_places`` (SS tools/find_spot.py:192-273) in this container:
 
-    python tests/golden/make_golden_places.py
+    python tests/golden/make_golden_places.py            # semantic_segmentation tree
+    python tests/golden/make_golden_places.py --od       # object_detection tree (OD tools/find_spot.py:227-304)
 
 ``/root/reference`` is read-only and never travels to the GPU box; only arrays are written.
 Two API renames stand between the reference and today's libraries and are bridged here, in the
@@ -153,7 +154,119 @@ CASES = {
 }
 
 
+REF_OD = "/root/reference/object_detection/Real3DAug"
+
+
+def import_reference_od():
+    """The object-detection copy (its ``tools`` is a namespace package with relative imports);
+    run in its own process (``--od``): both trees call their package ``tools``."""
+    from scipy.spatial.transform import Rotation
+
+    class OldRotation:
+        def __init__(self, r):
+            self._r = r
+
+        @staticmethod
+        def from_quat(q):
+            return OldRotation(Rotation.from_quat(q))
+
+        @staticmethod
+        def from_dcm(m):
+            return OldRotation(Rotation.from_matrix(m))
+
+        def as_dcm(self):
+            return self._r.as_matrix()
+
+        def as_quat(self):
+            return self._r.as_quat()
+
+    sys.path.insert(0, REF_OD)
+    from tools import cut_bbox, find_spot      # noqa: E402
+    find_spot.R = OldRotation
+    cut_bbox.R = OldRotation
+    return find_spot
+
+
+def kitti_line(cls, centre_lidar, height, length, width, yaw_lidar):
+    """A label_2 line whose LiDAR-frame reading (OD find_spot.py:186-224) is the given box, up to the
+    constant offsets the reference adds (0.1 m on the sizes, 0.27 / -0.08 m on the centre)."""
+    x_cam, y_cam, z_cam = -centre_lidar[1], -(centre_lidar[2] + 0.08), centre_lidar[0] - 0.27
+    vals = [0.0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, height - 0.1, length - 0.1, width - 0.1, x_cam, y_cam, z_cam, -yaw_lidar]
+    return " ".join([cls] + [repr(float(v)) if not isinstance(v, int) else str(v) for v in vals])
+
+
+def build_case_od(seed, cls, beams=32, n_az=600, m_points=60):
+    synth = __import__("importlib").import_module("pcl-augmentation_amd.synth")
+    rng = np.random.default_rng(seed)
+    xyzi, label = synth.make_scene(seed, beams, n_az, collapse_labels_to_road=True)          # labels {40, 1}
+    label = label.copy()
+    hole = (label == 40) & ((xyzi[:, 0] - 2.0) ** 2 + (xyzi[:, 1] + 9.0) ** 2 < 5.3 ** 2)
+    label[hole] = 1                                                     # no road points there
+    original = synth.scene5_from_packed(xyzi, label)
+    half = 45
+    move = np.array([-half + 0.37, -half - 0.21])
+    rich = np.zeros((2 * half, 2 * half))
+    g = (original[:, :2] - move)
+    ok = (original[:, 4] == 40) | hole                                  # the hole still counts as road in the map
+    gi = g[ok].astype(int)
+    keep = (gi[:, 0] >= 0) & (gi[:, 0] < rich.shape[0]) & (gi[:, 1] >= 0) & (gi[:, 1] < rich.shape[1])
+    rich[gi[keep, 0], gi[keep, 1]] = 1
+    rich[:, :30] = 0                                                    # a strip that is not road
+    kind = {"Pedestrian": "pedestrian", "Cyclist": "cyclist", "Car": "car"}[cls]
+    length, width, height, _, _ = synth.INSERT_KINDS[kind]
+    dist, phi, yaw = 9.0 + rng.uniform(-1, 1), rng.uniform(-np.pi, np.pi), rng.uniform(-np.pi, np.pi)
+    p = rng.uniform(-0.5, 0.5, size=(m_points, 3)) * [length, width, height]
+    centre = np.array([dist * np.cos(phi), dist * np.sin(phi), -synth.SENSOR_HEIGHT + 0.13])
+    cy, sy = np.cos(yaw), np.sin(yaw)
+    pts = np.stack([cy * p[:, 0] - sy * p[:, 1] + centre[0], sy * p[:, 0] + cy * p[:, 1] + centre[1],
+                    p[:, 2] + height / 2 + centre[2]], axis=1)
+    sample = np.column_stack([pts, rng.random(m_points, dtype=np.float32).astype(np.float64), np.full(m_points, 7.0)])
+    sample_line = kitti_line(cls, centre, height, length, width, yaw)
+    anno_lines = []
+    for ang in rng.uniform(-np.pi, np.pi, size=3):
+        c = np.array([dist * np.cos(ang), dist * np.sin(ang), -synth.SENSOR_HEIGHT])
+        anno_lines.append(kitti_line("Car", c, 1.5, 4.2, 1.8, rng.uniform(-np.pi, np.pi)))
+    ang = rng.uniform(-np.pi, np.pi)
+    blob = np.array([dist * np.cos(ang), dist * np.sin(ang), -synth.SENSOR_HEIGHT + 0.6]) + rng.normal(0, 0.25, size=(80, 3))
+    extra = np.column_stack([blob, rng.random(80), np.full(80, 1.0)])
+    return dict(xyzi=xyzi, label=label, extra=extra, sample=sample, sample_line=sample_line, anno_lines=anno_lines,
+                rich=rich.astype(np.uint8), move=move, original=original, scene5=np.vstack([original, extra]))
+
+
+def run_case_od(fs, case):
+    from oracle import real3d_oracle as O
+    scene9 = O.add_space_for_spherical(case["scene5"])
+    annos = [fs.read_label_line(l) for l in case["anno_lines"]]
+    config = {"labels": {"Road": 40}}
+    map_data = {"map": case["rich"].astype(np.float64), "min_x": case["move"][0], "min_y": case["move"][1]}
+    sample_data = {"pcl": case["sample"].copy(), "anno": np.array(case["sample_line"])}
+    pcl, anno, rot = fs.find_possible_places(scene9, annos, sample_data, map_data, case["original"].copy(), config)
+    m = len(case["sample"])
+    return dict(out_rot=np.array(rot, dtype=np.int32),
+                out_pcl=np.array(pcl, dtype=np.float64).reshape(len(rot), m, 5),
+                out_centre=np.array([[a["center"]["x"], a["center"]["y"], a["center"]["z"]] for a in anno]).reshape(len(rot), 3),
+                out_quat=np.array([[a["rotation"]["x"], a["rotation"]["y"], a["rotation"]["z"], a["rotation"]["w"]]
+                                   for a in anno]).reshape(len(rot), 4))
+
+
+CASES_OD = {"places_od_car": dict(seed=21, cls="Car"), "places_od_pedestrian": dict(seed=22, cls="Pedestrian")}
+
+
+def main_od():
+    fs = import_reference_od()
+    for name, kw in CASES_OD.items():
+        case = build_case_od(**kw)
+        out = run_case_od(fs, case)
+        keep = {k: case[k] for k in ("xyzi", "label", "extra", "sample", "rich", "move")}
+        keep["sample_line"] = np.array(case["sample_line"])
+        keep["anno_lines"] = np.array(case["anno_lines"])
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **keep, **out)
+        print(name, "possible:", len(out["out_rot"]), "first:", out["out_rot"][:8])
+
+
 def main():
+    if "--od" in sys.argv:
+        return main_od()
     fs = import_reference()
     for name, kw in CASES.items():
         case = build_case(**kw)

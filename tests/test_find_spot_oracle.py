@@ -66,3 +66,17 @@ def test_mean_along_rows_is_a_sequential_sum():
         for v in a[:, 2]:
             acc += float(v)
         assert np.mean(a, axis=0)[2] == acc / n
+
+
+@pytest.mark.parametrize("name", ["places_od_car.npz", "places_od_pedestrian.npz"])
+def test_od_oracle_equals_reference_outputs(name):
+    """object_detection flavour (OD tools/find_spot.py:227-304)."""
+    g = load_golden(name)
+    original, scene9, _ = oracle_inputs({**g, "anno_lines": []})
+    annos = [F.read_label_line_od(str(l)) for l in g["anno_lines"]]
+    pcl, anno, rot, not_on_road, collisions = F.find_possible_places_od(
+        scene9, annos, g["sample"], str(g["sample_line"]), g["rich"].astype(np.float64), g["move"], original, 40)
+    assert rot == list(g["out_rot"]) and 0 < len(rot) < 360 and collisions > 0
+    assert np.array_equal(np.array(pcl), g["out_pcl"])
+    assert np.array_equal(np.array([F.anno_center(a) for a in anno]), g["out_centre"])
+    assert np.array_equal(np.array([F.anno_quat(a) for a in anno]), g["out_quat"])
