@@ -242,6 +242,15 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream);
 #define R3D_PF_SAMPLE_IN_BOX 8        /* a sample point inside an annotated scene box (:99-103) */
 #define R3D_PF_POSSIBLE 16
 
+/* r3d_place_query_t.flavour: the object_detection tree's find_spot.py differs from the semantic_segmentation one in */
+#define R3D_PQ_POINTWISE_ROTATION 1   /* points turned one by one (OD find_spot.py:94-99: np.dot per point, another BLAS
+                                         accumulation order than the SS matrix product, :72) */
+#define R3D_PQ_MAP_NEEDS_POINT 2      /* OD :261-275: map position = x, y - map_move (identity pose rows), inside the map
+                                         when 0 <= position < size, and at least one sample point must be inside */
+#define R3D_PQ_COLLIDE_LABEL 4        /* OD :120-121: scene points of label collide_label collide (SS :92-97: every label
+                                         that is not placement surface) */
+#define R3D_PQ_COLLIDE_ABOVE 8        /* OD :123-124 ('Pedestrian'): only points with z >= box bottom + collide_dz */
+
 typedef struct r3d_place_query_t {
   const double *scene;     /* current cloud, n_scene rows of scene_ld doubles: x y z at columns 0-2, the label at
                               scene_label_col (scene_pcl N x 9, label column 7, insertion.py:433) */
@@ -266,6 +275,9 @@ typedef struct r3d_place_query_t {
                               cand_off = start of the query's rows in a packed list of all queries and
                               cand_stride = length of that list, candidate j of ALL queries is one packed
                               sample list at cand + j*cand_stride -- what r3d_batch_insert takes */
+  int32_t flavour;         /* R3D_PQ_* bits, 0 = semantic_segmentation */
+  int32_t collide_label;
+  double collide_dz;
 } r3d_place_query_t;
 
 size_t r3d_places_workspace_bytes(int32_t n_queries, int32_t max_boxes);

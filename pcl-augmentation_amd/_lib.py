@@ -62,11 +62,13 @@ class PlaceQuery(C.Structure):
         ("ok_labels", C.c_int32 * 8), ("ok_map", C.c_uint64 * 4),
         ("anno", C.c_double * 10), ("pose", C.c_double * 8), ("map_move", C.c_double * 2),
         ("cand_off", C.c_int64), ("cand_stride", C.c_int64),
+        ("flavour", C.c_int32), ("collide_label", C.c_int32), ("collide_dz", C.c_double),
     ]
 
 
 PLACE_ROTATIONS, PLACE_SURFACE_CAP, PLACE_MAX_OK_LABELS = 360, 128, 8
 PS_SURFACE_OVERFLOW, PS_NONFINITE = 1, 2
+PQ_POINTWISE_ROTATION, PQ_MAP_NEEDS_POINT, PQ_COLLIDE_LABEL, PQ_COLLIDE_ABOVE = 1, 2, 4, 8
 PF_ON_SURFACE, PF_NEAR_ROAD, PF_SCENE_IN_BOX, PF_SAMPLE_IN_BOX, PF_POSSIBLE = 1, 2, 4, 8, 16
 
 _P = C.c_void_p

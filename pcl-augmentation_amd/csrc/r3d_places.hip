@@ -606,6 +606,7 @@ __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_quer
   const double reach_d = sqrt(l * l / 4 + wd * wd / 4 + h * h);     // no box point is further from the centre
   const float reach = (float)reach_d * 1.01f + 0.05f;
   const float hl = (float)l * 0.5f, hw = (float)wd * 0.5f, hh = (float)h;
+  const bool od_label = qq.flavour & R3D_PQ_COLLIDE_LABEL, od_above = qq.flavour & R3D_PQ_COLLIDE_ABOVE;
   const float rho_c = sqrtf((float)(s_cx[0] * s_cx[0] + s_cy[0] * s_cy[0])), th1 = atan2f((float)s_cy[0], (float)s_cx[0]);
   // float32 rounding of coordinates up to ~100 m is ~1e-5 m; the planes sit at |column|^2 * size, within
   // 1e-12 of size for the unit quaternions of the chain
@@ -617,7 +618,8 @@ __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_quer
     if (i >= end) continue;
     const Pt p = load_point(qq.scene, i, qq.scene_ld, qq.scene_label_col);
     const double x = p.x, y = p.y, z = p.z;
-    if (label_rank(qq, p.label) >= 0) continue;                   // :94-95: surface may be inside the box
+    if (od_label ? !(p.label == (double)qq.collide_label)         // OD :120-121
+                 : label_rank(qq, p.label) >= 0) continue;        // SS :94-95: surface may be inside the box
     int first, count;
     if (!steps_in_reach((float)x, (float)y, rho_c, th1, reach, first, count)) continue;
     const float xf = (float)x, yf = (float)y, zf = (float)z;
@@ -633,6 +635,7 @@ __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_quer
             u2 = bf[2] * dx + bf[5] * dy + bf[8] * dz;
       if (!(fabsf(u0) < hl + slack && fabsf(u1) < hw + slack && u2 > -slack && u2 < hh + slack)) continue;
       size_t o = (size_t)q * kRot + r;
+      if (od_above && !(z >= w.road[o] + qq.collide_dz)) continue;  // OD :123-124, the box bottom is the road level
       if (inside_box(w.rotm + o * 9, w.planes + o * 6, w.planes + o * 6 + 3, x, y, z))
         atomicOr(&s_hit[r >> 5], 1u << (r & 31));
     }
@@ -659,7 +662,7 @@ struct ChainLds {
   uint32_t allowed[kMapWindowWords];   // bit = the map cell is an allowed surface, window of the map
   double road[kRot], cx[kRot], cy[kRot];
   double box[kLdsBoxes * kBoxD];
-  unsigned char near[kRot], flags[kRot], vote[2][kRot];
+  unsigned char near[kRot], flags[kRot], vote[3][kRot];
   unsigned short rot[kRot];
   uint32_t hit[12];
   float red[2][kCB / 64];
@@ -703,7 +706,7 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
     size_t o = (size_t)q * kRot + r;
     s_road[r] = w.road[o];
     s_near[r] = w.kstar[o] >= 0 ? 1 : 0;
-    s_vote[0][r] = s_vote[1][r] = 0;
+    s_vote[0][r] = s_vote[1][r] = s_vote[2][r] = 0;
     s_cx[r] = w.cx[o];
     s_cy[r] = w.cy[o];
   }
@@ -733,6 +736,8 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
     uint64_t wv = v < 64 ? okm0 : v < 128 ? okm1 : v < 192 ? okm2 : okm3;
     return (wv >> (v & 63)) & 1ull;
   };
+  const bool pointwise = qq.flavour & R3D_PQ_POINTWISE_ROTATION, od_map = qq.flavour & R3D_PQ_MAP_NEEDS_POINT;
+  const double map_lo = od_map ? 0.0 : -1.0;         // OD: 0 <= position; SS: int() of (-1, 0) is cell 0
   const int cand_cap = qq.cand_cap;
   const int64_t cand_stride = qq.cand_stride;
   double *cand_q = cand + qq.cand_off;
@@ -777,13 +782,21 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
   double anno_z = qq.anno[2];
   int n_out = 0;
   for (int r = 0; r < kRot; ++r) {
-    int bad = 0;
+    int bad = 0, in_any_map = 0;
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
-      // bbox_pcl[:, :3] = (z_rot_matrix @ bbox_pcl[:, :3].T).T, :72
-      double nx = fma(0.0, z[u], fma(-kSin1, y[u], kCos1 * x[u]));
-      double ny = fma(0.0, z[u], fma(kCos1, y[u], kSin1 * x[u]));
-      double nz = fma(1.0, z[u], fma(0.0, y[u], 0.0 * x[u]));
+      // SS :72  bbox_pcl[:, :3] = (z_rot_matrix @ bbox_pcl[:, :3].T).T   (matrix product: a0*b0, fma, fma)
+      // OD :94-99  np.dot(z_rot_matrix, column) per point             (matrix x vector: fma(a2,b2, fma(a0,b0, a1*b1)))
+      double nx, ny, nz;
+      if (pointwise) {
+        nx = fma(0.0, z[u], fma(kCos1, x[u], -kSin1 * y[u]));
+        ny = fma(0.0, z[u], fma(kSin1, x[u], kCos1 * y[u]));
+        nz = fma(1.0, z[u], fma(0.0, x[u], 0.0 * y[u]));
+      } else {
+        nx = fma(0.0, z[u], fma(-kSin1, y[u], kCos1 * x[u]));
+        ny = fma(0.0, z[u], fma(kCos1, y[u], kSin1 * x[u]));
+        nz = fma(1.0, z[u], fma(0.0, y[u], 0.0 * x[u]));
+      }
       x[u] = nx;
       y[u] = ny;
       z[u] = nz;
@@ -791,7 +804,9 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
       double g0 = fma(T03, 1.0, fma(T02, nz, fma(T01, ny, T00 * nx))) - mv0;
       double g1 = fma(T13, 1.0, fma(T12, nz, fma(T11, ny, T10 * nx))) - mv1;
       // int() truncates: the index is in [0, rows) exactly when -1 < g0 < rows (:240-243)
-      const bool in_map = g0 > -1.0 && g0 < (double)rows && g1 > -1.0 && g1 < (double)cols;
+      const bool in_map = (od_map ? g0 >= map_lo : g0 > map_lo) && g0 < (double)rows &&
+                          (od_map ? g1 >= map_lo : g1 > map_lo) && g1 < (double)cols;
+      in_any_map |= (valid[u] && in_map) ? 1 : 0;
       const int i0 = in_map ? (int)g0 : 0, i1 = in_map ? (int)g1 : 0;
       const int a = i0 - wr0, b = i1 - wc0;
       const bool in_win = a >= 0 && a < wh && b >= 0 && b < ww;
@@ -801,8 +816,9 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
       bad |= (valid[u] && in_map && !ok) ? 1 : 0;                 // :245-248
     }
     if (bad) s_vote[0][r] = 1;                                    // one slot per step: no reset, one barrier
+    if (od_map && in_any_map) s_vote[2][r] = 1;
     __syncthreads();
-    const bool on_surface = !s_vote[0][r];
+    const bool on_surface = !s_vote[0][r] && (!od_map || s_vote[2][r]);
     const bool near = s_near[r];
     if (on_surface && near) {                                     // correct_height, :142-148
       double road = s_road[r];

@@ -84,7 +84,8 @@ class PlaceScene:
         self.pose = np.asarray(transformation_matrix, dtype=np.float64)[:2, :4].reshape(8).copy()
 
 
-def _fill_query(qd, scene, sample_t, anno10, ok_labels, ok_map_values, cand_cap, cand_off, cand_stride):
+def _fill_query(qd, scene, sample_t, anno10, ok_labels, ok_map_values, cand_cap, cand_off, cand_stride,
+                flavour=0, collide_label=0, collide_dz=0.0):
     qd.scene, qd.orig = scene.scene.data_ptr(), scene.orig.data_ptr()
     qd.boxes, qd.sample, qd.map = scene.boxes.data_ptr(), sample_t.data_ptr(), scene.map.data_ptr()
     qd.scene_ranges = scene.scene_ranges.data_ptr() if scene.scene_ranges.numel() else None
@@ -111,6 +112,7 @@ def _fill_query(qd, scene, sample_t, anno10, ok_labels, ok_map_values, cand_cap,
         qd.pose[i] = float(scene.pose[i])
     qd.map_move[0], qd.map_move[1] = scene.map_move
     qd.cand_cap, qd.cand_off, qd.cand_stride = int(cand_cap), int(cand_off), int(cand_stride)
+    qd.flavour, qd.collide_label, qd.collide_dz = int(flavour), int(collide_label), float(collide_dz)
 
 
 class PlaceBatch:
@@ -139,7 +141,8 @@ class PlaceBatch:
             if m == 0:
                 raise ValueError("empty sample")
             _fill_query(descs[i], q["scene"], self.samples[i], q["anno"], q["ok_labels"], q["ok_map"], cand_cap, cand_off,
-                        self.total if packed else m * 5)
+                        self.total if packed else m * 5, q.get("flavour", 0), q.get("collide_label", 0),
+                        q.get("collide_dz", 0.0))
             self.offs.append(cand_off)
             cand_off += m * 5 if packed else self.cand_cap * m * 5
         if packed:
@@ -198,7 +201,8 @@ class PlaceBatch:
 def find_places(queries, cand_cap=360, first_cand=0, device="cuda:0"):
     """queries: list of dicts with keys ``scene`` (PlaceScene), ``sample`` (M x 5 float64),
     ``anno`` (10 floats: centre, quaternion xyzw, length, width, height), ``ok_labels``,
-    ``ok_map`` (allowed map values).  Returns per query a dict: ``flags`` uint8[360],
+    ``ok_map`` (allowed map values); for the object-detection flavour also ``flavour``
+    (``_lib.PQ_*`` bits), ``collide_label``, ``collide_dz``.  Returns per query a dict: ``flags`` uint8[360],
     ``rotations`` int32[n], ``anno`` float64[n,7], ``clouds`` float64[k,M,5] (placements
     ``first_cand`` .. ``first_cand + cand_cap``), ``status``."""
     if len(queries) == 0:

@@ -242,3 +242,22 @@ def test_placed_insertion_chain_equals_oracle(P, synth):
         assert got_rots[s] == want[s][1]
         vb, lb, cb = want[s][0]
         assert res[s][0].tobytes() == vb and res[s][1].tobytes() == lb and res[s][2].tobytes() == cb
+
+
+@pytest.mark.parametrize("name", ["places_od_car.npz", "places_od_pedestrian.npz"])
+def test_object_detection_flavour_equals_reference(P, name):
+    """OD tools/find_spot.py:227-304: per-point rotation, map test without pose, Road-only height
+    search, label-1 collisions, the pedestrian height rule."""
+    g = load_golden(name)
+    original, scene9 = golden_inputs(g)
+    fs = P.Real3DAug.tools.find_spot_od
+    annos = [fs.read_label_line(str(l)) for l in g["anno_lines"]]
+    sample_data = {"pcl": g["sample"].copy(), "anno": np.array(str(g["sample_line"]))}
+    map_data = {"map": g["rich"].astype(np.float64), "min_x": g["move"][0], "min_y": g["move"][1]}
+    pcl, anno, rot = fs.find_possible_places(scene9, annos, sample_data, map_data, original, {"labels": {"Road": 40}})
+    assert rot == list(g["out_rot"])
+    assert np.array_equal(np.array(pcl), g["out_pcl"])
+    assert np.array_equal(np.array([[a["center"]["x"], a["center"]["y"], a["center"]["z"]] for a in anno]), g["out_centre"])
+    assert np.array_equal(np.array([[a["rotation"]["x"], a["rotation"]["y"], a["rotation"]["z"], a["rotation"]["w"]]
+                                    for a in anno]), g["out_quat"])
+    assert anno[0]["class"] == str(g["sample_line"]).split(" ")[0]
