@@ -299,6 +299,24 @@ int r3d_find_possible_places(const r3d_place_query_t *queries, int32_t n_queries
                              double *anno_out, double *cand, int32_t first_cand, int32_t *status,
                              void *workspace, size_t workspace_bytes, void *stream);
 
+/* =====================================================================================
+ * cut_bounding_box for many boxes of one cloud.
+ *
+ * Replaces tools/cut_bbox.py:7-68 (strict = 1: strictly inside the six faces) and the box half of
+ * separate_bbox :71-123 (strict = 0: a point is outside when beyond a face, so points on a face
+ * stay in the box) as the object-database creation calls them once per annotated object of a
+ * frame (cut_object/cut_out.py:100-157: the points inside the box whose label is the object's).
+ * rows: n rows of ld doubles, x y z first, the label at label_col (< 0: no label filter);
+ * boxes10 [k][10] = centre, quaternion xyzw, length, width, height (annotation_move already
+ * subtracted from the centre); box_labels [k] (nullable, NaN = any label).  counts [k] = number
+ * of points inside; index [k][index_cap] = their row numbers in cloud order (entries beyond
+ * index_cap are dropped, counts says how many there are).
+ * ===================================================================================== */
+size_t r3d_cut_boxes_workspace_bytes(int64_t n, int32_t k);
+int r3d_cut_boxes(const double *rows, int64_t n, int32_t ld, int32_t label_col, const double *boxes10,
+                  const double *box_labels, int32_t k, int32_t strict, int32_t *counts, int32_t *index,
+                  int64_t index_cap, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

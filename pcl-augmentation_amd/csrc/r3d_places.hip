@@ -996,3 +996,170 @@ extern "C" int r3d_find_possible_places(const r3d_place_query_t *queries, int32_
   R3D_LAUNCHED("placement kernels");
   return R3D_OK;
 }
+
+// =====================================================================================
+// cut_bounding_box for many boxes at once (tools/cut_bbox.py:7-68; the object-database
+// creation of cut_object/cut_out.py:100-157 calls it once per annotated object of a frame).
+// Per box: the indices of the cloud's points inside it, in cloud order.  Pass 1 leaves one
+// bit per (box, point) and per-tile counts, pass 2 turns the counts of a box into offsets,
+// pass 3 writes the indices at offset + rank.
+// =====================================================================================
+namespace {
+constexpr int kCutTile = 2048;          // points per block: 256 threads x 8
+
+struct CutBox {
+  double R[9], up[3], dn[3];
+  double label;                         // NaN: any label
+  float cx, cy, cz, reach;              // bounding sphere around the (bottom) centre
+};
+
+__global__ void k_cut_prepare(const double *boxes10, const double *labels, int k, int strict, CutBox *out) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= k) return;
+  const double *q = boxes10 + (size_t)b * 10;
+  CutBox c;
+  quat_to_matrix(quat_normalize(Quat{q[3], q[4], q[5], q[6]}), c.R);
+  box_planes(c.R, q[0], q[1], q[2], q[7], q[8], q[9], c.up, c.dn);
+  c.label = labels ? labels[b] : NAN;
+  c.cx = (float)q[0];
+  c.cy = (float)q[1];
+  c.cz = (float)q[2];
+  c.reach = (float)sqrt(q[7] * q[7] / 4 + q[8] * q[8] / 4 + q[9] * q[9]) * 1.001f + 0.01f;
+  (void)strict;
+  out[b] = c;
+}
+
+// strict: cut_bounding_box keeps lhs < up and lhs > dn (:30-64); separate_bbox (:71-123) calls a
+// point outside when lhs > up or lhs < dn, so its box keeps the faces (and NaN rows).
+__device__ __forceinline__ bool cut_inside(const CutBox &c, double x, double y, double z, int strict) {
+  bool in = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    double lhs = c.R[a] * x + c.R[3 + a] * y + c.R[6 + a] * z;
+    in = in & (strict ? (lhs < c.up[a]) & (lhs > c.dn[a]) : !(lhs > c.up[a]) & !(lhs < c.dn[a]));
+  }
+  return in;
+}
+
+__global__ __launch_bounds__(256) void k_cut_flags(const double *rows, int64_t n, int ld, int label_col,
+                                                  const CutBox *boxes, int k, int strict,
+                                                  unsigned long long *bits, int32_t *tile_cnt, int tiles) {
+  __shared__ CutBox s_box;
+  __shared__ int s_cnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t t0 = (int64_t)blockIdx.x * kCutTile;
+  const int64_t words = (n + 63) / 64;
+  double x[8], y[8], z[8], lab[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    int64_t i = t0 + u * 256 + tid;
+    x[u] = y[u] = z[u] = lab[u] = 0.0;
+    if (i < n) {
+      x[u] = rows[i * ld];
+      y[u] = rows[i * ld + 1];
+      z[u] = rows[i * ld + 2];
+      lab[u] = label_col >= 0 ? rows[i * ld + label_col] : 0.0;
+    }
+  }
+  for (int b = 0; b < k; ++b) {
+    __syncthreads();
+    if (tid < (int)(sizeof(CutBox) / 4))
+      reinterpret_cast<uint32_t *>(&s_box)[tid] = reinterpret_cast<const uint32_t *>(boxes + b)[tid];
+    if (tid < 4) s_cnt[tid] = 0;
+    __syncthreads();
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int64_t i = t0 + u * 256 + tid;
+      bool in = false;
+      if (i < n) {
+        float dx = (float)x[u] - s_box.cx, dy = (float)y[u] - s_box.cy, dz = (float)z[u] - s_box.cz;
+        // far from the box: outside for sure (a NaN coordinate fails this test and takes the exact one)
+        if (!(dx * dx + dy * dy + dz * dz > s_box.reach * s_box.reach)) in = cut_inside(s_box, x[u], y[u], z[u], strict);
+        if (in && s_box.label == s_box.label) in = lab[u] == s_box.label;
+      }
+      unsigned long long m = __ballot(in);
+      if (lane == 0 && t0 + u * 256 + wave * 64 < n) {
+        bits[(size_t)b * words + ((t0 + u * 256 + wave * 64) >> 6)] = m;
+        mine += __popcll(m);
+      }
+    }
+    if (lane == 0) s_cnt[wave] = mine;
+    __syncthreads();
+    if (tid == 0) tile_cnt[(size_t)b * tiles + blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  }
+}
+
+__global__ void k_cut_offsets(int32_t *tile_cnt, int tiles, int k, int32_t *counts) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= k) return;
+  int run = 0;
+  for (int t = 0; t < tiles; ++t) {
+    int c = tile_cnt[(size_t)b * tiles + t];
+    tile_cnt[(size_t)b * tiles + t] = run;
+    run += c;
+  }
+  counts[b] = run;
+}
+
+__global__ __launch_bounds__(256) void k_cut_write(int64_t n, int k, const unsigned long long *bits,
+                                                  const int32_t *tile_off, int tiles, int32_t *index,
+                                                  int64_t index_cap) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int64_t t0 = (int64_t)blockIdx.x * kCutTile, words = (n + 63) / 64;
+  if (t0 >= n) return;
+  // the tile's 32 words in index order: word w covers points t0 + 64 w ..; every wave takes 8 of them
+  int run = tile_off[(size_t)b * tiles + blockIdx.x];
+  __shared__ int s_pre[32];
+  if (tid < 32) {
+    int64_t wd = (t0 >> 6) + tid;
+    int c = wd < words ? __popcll(bits[(size_t)b * words + wd]) : 0;
+    int inc = c;
+    for (int o = 1; o < 32; o <<= 1) {
+      int v = __shfl_up(inc, o, 64);
+      if (tid >= o) inc += v;
+    }
+    s_pre[tid] = inc - c;
+  }
+  __syncthreads();
+  for (int w8 = 0; w8 < 8; ++w8) {
+    int wi = wave * 8 + w8;
+    int64_t wd = (t0 >> 6) + wi;
+    if (wd >= words) break;
+    unsigned long long m = bits[(size_t)b * words + wd];
+    if ((m >> lane) & 1ull) {
+      int64_t o = (int64_t)run + s_pre[wi] + __popcll(m & ((1ull << lane) - 1ull));
+      if (o < index_cap) index[(size_t)b * index_cap + o] = (int32_t)(wd * 64 + lane);
+    }
+  }
+}
+}  // namespace
+
+extern "C" size_t r3d_cut_boxes_workspace_bytes(int64_t n, int32_t k) {
+  if (n < 0 || k <= 0) return 0;
+  size_t words = (size_t)(n + 63) / 64, tiles = (size_t)(n + kCutTile - 1) / kCutTile;
+  return align_up(sizeof(CutBox) * (size_t)k) + align_up(words * 8 * (size_t)k) + align_up((tiles + 1) * 4 * (size_t)k);
+}
+
+extern "C" int r3d_cut_boxes(const double *rows, int64_t n, int32_t ld, int32_t label_col, const double *boxes10,
+                             const double *box_labels, int32_t k, int32_t strict, int32_t *counts, int32_t *index,
+                             int64_t index_cap, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!rows || !boxes10 || !counts || !index || !workspace) return fail(R3D_E_ARG, "cut_boxes: null argument");
+  if (n <= 0 || n > (int64_t)1 << 31 || ld < 3 || k <= 0 || k > 65535 || label_col >= ld || index_cap <= 0)
+    return fail(R3D_E_ARG, "cut_boxes: bad shape");
+  if (workspace_bytes < r3d_cut_boxes_workspace_bytes(n, k)) return fail(R3D_E_WORKSPACE, "cut_boxes: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int tiles = (int)((n + kCutTile - 1) / kCutTile);
+  Carver c(workspace);
+  CutBox *boxes = c.take<CutBox>((size_t)k);
+  unsigned long long *bits = c.take<unsigned long long>((size_t)((n + 63) / 64) * k);
+  int32_t *tile_cnt = c.take<int32_t>((size_t)(tiles + 1) * k);
+  hipLaunchKernelGGL(k_cut_prepare, dim3((k + 63) / 64), dim3(64), 0, st, boxes10, box_labels, (int)k, (int)strict, boxes);
+  hipLaunchKernelGGL(k_cut_flags, dim3(tiles), dim3(256), 0, st, rows, n, (int)ld, (int)label_col, boxes, (int)k,
+                     (int)strict, bits, tile_cnt, tiles);
+  hipLaunchKernelGGL(k_cut_offsets, dim3((k + 63) / 64), dim3(64), 0, st, tile_cnt, tiles, (int)k, counts);
+  hipLaunchKernelGGL(k_cut_write, dim3(tiles, k), dim3(256), 0, st, n, (int)k, bits, tile_cnt, tiles, index, index_cap);
+  R3D_LAUNCHED("cut_boxes kernels");
+  return R3D_OK;
+}

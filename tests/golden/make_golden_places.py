@@ -4,6 +4,7 @@ REFERENCE's own ``find_possible_places`` (SS tools/find_spot.py:192-273) in this
 
     python tests/golden/make_golden_places.py            # semantic_segmentation tree
     python tests/golden/make_golden_places.py --od       # object_detection tree (OD tools/find_spot.py:227-304)
+    python tests/golden/make_golden_places.py --cut      # tools/cut_bbox.py: cut_bounding_box, separate_bbox
 
 ``/root/reference`` is read-only and never travels to the GPU box; only arrays are written.
 Two API renames stand between the reference and today's libraries and are bridged here, in the
@@ -264,9 +265,39 @@ def main_od():
         print(name, "possible:", len(out["out_rot"]), "first:", out["out_rot"][:8])
 
 
+def main_cut():
+    """cut_bounding_box / separate_bbox of tools/cut_bbox.py on a cloud with points on the faces."""
+    fs = import_reference()
+    from tools import cut_bbox
+    rng = np.random.default_rng(5)
+    n = 2500
+    pc = np.column_stack([rng.uniform(-6, 6, n), rng.uniform(-6, 6, n), rng.uniform(-2, 2, n), rng.random(n),
+                          rng.choice([10.0, 30.0, 40.0], n)])
+    pc[:40, 0] = 1.0 + 2.0                          # on the +length face of box 0 (identity orientation)
+    pc[40:80, 2] = -1.0                             # on its bottom face
+    pc[80:90, 1] = np.nan
+    quats = [[0, 0, 0, 1], [0, 0, np.sin(0.35), np.cos(0.35)], list(rng.normal(size=4)), [0.1, -0.2, 0.3, 0.9]]
+    boxes = [[1.0, 0.5, -1.0] + quats[0] + [4.0, 2.0, 1.5], [-2.0, 1.0, -1.5] + quats[1] + [4.2, 1.8, 1.6],
+             [0.5, -2.0, -0.5] + quats[2] + [3.0, 3.0, 2.0], [2.0, 2.0, 0.0] + quats[3] + [1.0, 5.0, 1.0]]
+    move = [0.25, -0.5, 0.125]
+    out = {"pc": pc, "boxes": np.array(boxes), "move": np.array(move)}
+    for b, bx in enumerate(boxes):
+        anno = {"center": {"x": bx[0], "y": bx[1], "z": bx[2]}, "rotation": {"x": bx[3], "y": bx[4], "z": bx[5], "w": bx[6]},
+                "length": bx[7], "width": bx[8], "height": bx[9]}
+        out[f"cut{b}"] = cut_bbox.cut_bounding_box(pc, anno)
+        out[f"cutm{b}"] = cut_bbox.cut_bounding_box(pc, anno, move)
+        with np.errstate(invalid="ignore"):
+            scene, box = cut_bbox.separate_bbox(pc, anno)
+        out[f"sep_scene{b}"], out[f"sep_box{b}"] = scene, box
+        print("box", b, "cut", len(out[f"cut{b}"]), "moved", len(out[f"cutm{b}"]), "separate", len(scene), len(box))
+    np.savez_compressed(os.path.join(HERE, "cut_bbox.npz"), **out)
+
+
 def main():
     if "--od" in sys.argv:
         return main_od()
+    if "--cut" in sys.argv:
+        return main_cut()
     fs = import_reference()
     for name, kw in CASES.items():
         case = build_case(**kw)

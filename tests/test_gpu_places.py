@@ -261,3 +261,29 @@ def test_object_detection_flavour_equals_reference(P, name):
     assert np.array_equal(np.array([[a["rotation"]["x"], a["rotation"]["y"], a["rotation"]["z"], a["rotation"]["w"]]
                                     for a in anno]), g["out_quat"])
     assert anno[0]["class"] == str(g["sample_line"]).split(" ")[0]
+
+
+def test_cut_bounding_box_and_separate_bbox_equal_reference(P):
+    """tools/cut_bbox.py:7-123 (fixture from the reference's functions): strict faces for
+    cut_bounding_box, faces and NaN rows kept by separate_bbox, annotation_move, general
+    orientations, and all boxes of a frame in one call."""
+    g = load_golden("cut_bbox.npz")
+    cb = P.Real3DAug.tools.cut_bbox
+    pc, move = g["pc"], list(g["move"])
+    annos = []
+    for b, bx in enumerate(g["boxes"]):
+        anno = {"center": {"x": bx[0], "y": bx[1], "z": bx[2]}, "rotation": {"x": bx[3], "y": bx[4], "z": bx[5], "w": bx[6]},
+                "length": bx[7], "width": bx[8], "height": bx[9]}
+        annos.append(anno)
+        assert np.array_equal(cb.cut_bounding_box(pc, anno), g[f"cut{b}"], equal_nan=True)
+        assert np.array_equal(cb.cut_bounding_box(pc, anno, move), g[f"cutm{b}"], equal_nan=True)
+        scene, box = cb.separate_bbox(pc, anno)
+        assert np.array_equal(scene, g[f"sep_scene{b}"], equal_nan=True)
+        assert np.array_equal(box, g[f"sep_box{b}"], equal_nan=True)
+    many = cb.cut_boxes(pc, annos)
+    for b in range(len(annos)):
+        assert np.array_equal(many[b], g[f"cut{b}"], equal_nan=True)
+    only = cb.cut_boxes(pc, annos, classes=[10.0, 30.0, 40.0, 10.0])
+    for b, cls in enumerate([10.0, 30.0, 40.0, 10.0]):
+        want = g[f"cut{b}"]
+        assert np.array_equal(only[b], want[want[:, 4] == cls], equal_nan=True)
