@@ -317,6 +317,28 @@ int r3d_cut_boxes(const double *rows, int64_t n, int32_t ld, int32_t label_col, 
                   const double *box_labels, int32_t k, int32_t strict, int32_t *counts, int32_t *index,
                   int64_t index_cap, void *workspace, size_t workspace_bytes, void *stream);
 
+/* =====================================================================================
+ * Rich-map rasterisation: the __main__ block of
+ * semantic_segmentation/rich_map/drivable_area_map.py:122-206 for one sequence.
+ *
+ * xyzi / label: a frame as read from its velodyne .bin and labels .label files; pose16: the frame's
+ * row-major 4x4 transform_matrix (tools/datasets.py:62-67).
+ * r3d_map_bounds: folds the frame's world x / y extremes into minmax[4] = {min x, max x, min y,
+ *   max y} as order-preserving keys (:143-150); initialise to {~0, 0, ~0, 0}, decode with
+ *   key >> 63 ? key & ~(1 << 63) : ~key  (r3d_device.hpp ordered_key).
+ * r3d_map_splat: :172-200 for one frame into keys[size_x * size_y] (zero-initialised, shared by
+ *   the frames of the sequence); frame_no = the frame's position in processing order.  Labels
+ *   are config['insertion']['placement_labels'][1], [2], [3] (road, sidewalk, parking).
+ *   status bit 0: a surface point outside the map (the reference's assert :180).
+ * r3d_map_finish: keys -> map values 0..3 as float64 (what np.savez stores, :205) and / or uint8.
+ * ===================================================================================== */
+int r3d_map_bounds(const float *xyzi, int64_t n, const double *pose16, uint64_t *minmax, void *stream);
+int r3d_map_splat(const float *xyzi, const uint32_t *label, int64_t n, const double *pose16,
+                  const int32_t *labels_road, int32_t n_road, const int32_t *labels_sidewalk, int32_t n_sidewalk,
+                  const int32_t *labels_parking, int32_t n_parking, double min_x, double min_y, int32_t size_x,
+                  int32_t size_y, int64_t frame_no, uint64_t *keys, int32_t *status, void *stream);
+int r3d_map_finish(const uint64_t *keys, int64_t cells, double *map64, uint8_t *map8, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,5 +18,6 @@ from .pipeline import AugmentPipeline, Frame  # noqa: F401
 from . import places  # noqa: F401
 from .places import PlaceScene, find_places  # noqa: F401
 from .placed import PlacedInserter  # noqa: F401
+from .rich_map import build_rich_map  # noqa: F401
 
-__all__ = ["SceneBatch", "augment_batch", "run_sharded", "shard_indices", "AugmentPipeline", "Frame", "Real3DAug", "synth", "R3DError", "places", "PlaceScene", "find_places", "PlacedInserter"]
+__all__ = ["SceneBatch", "augment_batch", "run_sharded", "shard_indices", "AugmentPipeline", "Frame", "Real3DAug", "synth", "R3DError", "places", "PlaceScene", "find_places", "PlacedInserter", "build_rich_map"]

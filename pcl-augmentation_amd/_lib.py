@@ -97,6 +97,11 @@ _SIGNATURES = {
     "r3d_cut_boxes_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "r3d_cut_boxes": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int64,
                                 _P, C.c_size_t, _P]),
+    "r3d_map_bounds": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_double), _P, _P]),
+    "r3d_map_splat": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int32,
+                                C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_double, C.c_double,
+                                C.c_int32, C.c_int32, C.c_int64, _P, _P, _P]),
+    "r3d_map_finish": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "r3d_places_chunk_ranges": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P]),
     "r3d_find_possible_places": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                            C.POINTER(C.c_double), C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P,

@@ -80,3 +80,14 @@ def test_od_oracle_equals_reference_outputs(name):
     assert np.array_equal(np.array(pcl), g["out_pcl"])
     assert np.array_equal(np.array([F.anno_center(a) for a in anno]), g["out_centre"])
     assert np.array_equal(np.array([F.anno_quat(a) for a in anno]), g["out_quat"])
+
+
+def test_rich_map_oracle_equals_the_reference_script():
+    """oracle/rich_map_oracle.py against the map the reference's drivable_area_map.py wrote."""
+    from oracle import rich_map_oracle as M
+    g = load_golden("rich_map.npz")
+    frames = [(g[f"xyzi{f}"], g[f"label{f}"], g["transforms"][f]) for f in range(len(g["transforms"]))]
+    area, move = M.build_rich_map(frames, list(g["labels_road"]), list(g["labels_sidewalk"]), list(g["labels_parking"]))
+    assert np.array_equal(move, g["move"])
+    assert np.array_equal(area, g["map"].astype(np.float64))
+    assert all((area == c).any() for c in range(4))

@@ -287,3 +287,16 @@ def test_cut_bounding_box_and_separate_bbox_equal_reference(P):
     for b, cls in enumerate([10.0, 30.0, 40.0, 10.0]):
         want = g[f"cut{b}"]
         assert np.array_equal(only[b], want[want[:, 4] == cls], equal_nan=True)
+
+
+def test_rich_map_equals_the_reference_script(P):
+    """drivable_area_map.py:122-206 on the fixture sequence: map size, move and every cell."""
+    g = load_golden("rich_map.npz")
+    frames = [(g[f"xyzi{f}"], g[f"label{f}"], g["transforms"][f]) for f in range(len(g["transforms"]))]
+    labels = {1: list(g["labels_road"]), 2: list(g["labels_sidewalk"]), 3: list(g["labels_parking"])}
+    area, move = P.build_rich_map(frames, labels)
+    assert area.dtype == np.float64 and np.array_equal(move, g["move"])
+    assert np.array_equal(area, g["map"].astype(np.float64))
+    area8, _ = P.build_rich_map(frames[::-1], labels, as_uint8=True)       # another frame order: another last writer
+    assert area8.shape == area.shape and not np.array_equal(area8, g["map"])
+    assert np.array_equal(area8 == 3, g["map"] == 3)                        # parking does not depend on the order
