@@ -300,3 +300,47 @@ def test_rich_map_equals_the_reference_script(P):
     area8, _ = P.build_rich_map(frames[::-1], labels, as_uint8=True)       # another frame order: another last writer
     assert area8.shape == area.shape and not np.array_equal(area8, g["map"])
     assert np.array_equal(area8 == 3, g["map"] == 3)                        # parking does not depend on the order
+
+
+def _far_query(synth, seed, m, n_boxes, dist):
+    """A sample of m points on a circle of radius `dist` over a wide road map: exercises the large
+    sample instances, more scene boxes than fit LDS and map cells outside the LDS patch."""
+    rng = np.random.default_rng(seed)
+    xyzi, label = synth.make_scene(seed, 16, 300)
+    scale = dist / 20.0                                                    # stretch the scan so that road reaches `dist`
+    xyzi = xyzi.copy()
+    xyzi[:, :2] *= scale
+    ang = np.linspace(-np.pi, np.pi, 3000, endpoint=False)                 # a band of road under the circle
+    rad = dist + rng.normal(0.0, 0.6, size=ang.size)
+    band = np.stack([rad * np.cos(ang), rad * np.sin(ang), np.full(ang.size, -synth.SENSOR_HEIGHT), rng.random(ang.size)],
+                    axis=1).astype(np.float32)
+    xyzi, label = np.vstack([xyzi, band]), np.concatenate([label, np.full(ang.size, 40, dtype=np.uint32)])
+    original = synth.scene5_from_packed(xyzi, label)
+    T = np.eye(4)
+    T[:3, 3] = [10.25, -7.5, 0.0]
+    half = int(dist * 1.2) + 10
+    move = np.array([[int(np.floor(T[0, 3])) - half], [int(np.floor(T[1, 3])) - half], [0], [1]])
+    rich = np.ones((2 * half + 1, 2 * half + 1), dtype=np.uint8)
+    rich[:, : half // 2] = 0                                               # part of the circle is off the road
+    length, width, height = 4.2, 1.8, 1.5
+    phi, yaw = rng.uniform(-np.pi, np.pi), rng.uniform(-np.pi, np.pi)
+    p = rng.uniform(-0.5, 0.5, size=(m, 3)) * [length, width, height]
+    centre = np.array([dist * np.cos(phi), dist * np.sin(phi), -synth.SENSOR_HEIGHT])
+    cy, sy = np.cos(yaw), np.sin(yaw)
+    pts = np.stack([cy * p[:, 0] - sy * p[:, 1] + centre[0], sy * p[:, 0] + cy * p[:, 1] + centre[1],
+                    p[:, 2] + height / 2 + centre[2]], axis=1)
+    sample = np.column_stack([pts, rng.random(m), np.full(m, 18.0)])
+    line = " ".join(["18"] + [repr(float(v)) for v in (*centre, height, length, width, yaw)])
+    lines = []
+    for ang in rng.uniform(-np.pi, np.pi, size=n_boxes):
+        c = [dist * np.cos(ang), dist * np.sin(ang), -synth.SENSOR_HEIGHT]
+        lines.append(" ".join(["10"] + [repr(float(v)) for v in (*c, 1.5, 1.0, 1.0, rng.uniform(-3, 3))]))
+    scene9 = O.add_space_for_spherical(original)
+    return dict(original=original, scene9=scene9, T=T, move=move, rich=rich, sample=sample, line=line, lines=lines)
+
+
+@pytest.mark.parametrize("m,n_boxes,dist", [(2500, 3, 20.0), (5000, 40, 20.0), (300, 2, 170.0)])
+def test_large_samples_many_boxes_and_far_circles(P, synth, m, n_boxes, dist):
+    c = _far_query(synth, 60 + n_boxes, m, n_boxes, dist)
+    r = _run_vs_oracle(P, c)
+    assert 0 < len(r["rotations"]) < 360
