@@ -32,6 +32,7 @@ class SceneBatch:
         self.torch = torch
         self.lib = _lib.load()
         self.device = torch.device(device)
+        cap = (int(cap) + 63) // 64 * 64          # whole 64-point chunks per slab (chunk tables of the placement search)
         self.B, self.cap, self.log_cap, self.rows, self.cols = int(B), int(cap), int(log_cap), int(rows), int(cols)
         npix = self.rows * self.cols
         words = (npix + 31) // 32

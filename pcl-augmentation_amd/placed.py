@@ -14,7 +14,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _lib
-from .places import PlaceBatch, PlaceScene, upload_map
+from .places import PlaceBatch, chunk_ranges, scene_view, upload_map
 
 
 class PlacedInserter:
@@ -27,15 +27,22 @@ class PlacedInserter:
         B = batch.B
         assert len(rich_maps) == len(map_moves) == len(poses) == len(scene_boxes) == B
         self.maps = [upload_map(m, batch.device) for m in rich_maps]
-        self.moves, self.poses = map_moves, poses
+        self.moves = [(float(np.asarray(m).reshape(-1)[0]), float(np.asarray(m).reshape(-1)[1])) for m in map_moves]
+        self.poses = [np.asarray(p, dtype=np.float64)[:2, :4].reshape(8).copy() for p in poses]
         self.boxes = [np.asarray(b, dtype=np.float64).reshape(-1, 10) for b in scene_boxes]
         # original_pcl (insertion.py:360): the clouds as loaded, as packed float64 rows
         n0 = batch.n_points.cpu().numpy()
         self.n_orig = [int(v) for v in n0]
         self.orig_rows = torch.cat([batch.xyzi[:, :, :3].to(torch.float64),
                                     (batch.label.to(torch.int64) & 0xFFFF).to(torch.float64)[:, :, None]], dim=2).contiguous()
-        from .places import chunk_ranges
-        self.orig_ranges = [chunk_ranges(self.orig_rows[s, :self.n_orig[s]]) for s in range(B)]
+        # 64-point chunks of a scene are whole chunks of the slab when its stride is a multiple of 64
+        self.chunked = batch.cap % 64 == 0
+        if self.chunked:
+            r = chunk_ranges(self.orig_rows.view(B * batch.cap, 4)).view(B, batch.cap // 64, 2)
+            # (a scene's last chunk may take in rows past its end: its range only gets wider, which is safe)
+            self.orig_ranges = [r[s, :(self.n_orig[s] + 63) // 64] for s in range(B)]
+        else:
+            self.orig_ranges = [chunk_ranges(self.orig_rows[s, :self.n_orig[s]]) for s in range(B)]
 
     def insert_slot(self, samples, annos, ok_labels, ok_maps, min_points, chunk=8):
         """samples[s]: M x 5 float64 or None; annos[s]: the sample's box (10 floats) after
@@ -49,12 +56,28 @@ class PlacedInserter:
         rotation, n_poss = [-1] * B, [0] * B
         if not who:
             return rotation, n_poss
+        # one upload for the boxes of all scenes, one launch for the chunk ranges of all current clouds
+        max_b = max(1, max(len(b) for b in self.boxes))
+        boxes_h = np.zeros((B, max_b, 10))
+        for s in range(B):
+            boxes_h[s, :len(self.boxes[s])] = self.boxes[s]
+        boxes_d = torch.from_numpy(boxes_h).to(batch.device)
+        if self.chunked:
+            all_ranges = chunk_ranges(rows.view(B * batch.cap, 4)).view(B, batch.cap // 64, 2)
+        in_who = set(who)
+        smp_rows, smp_off = batch.pack_samples([samples[s] if s in in_who else None for s in range(B)])
+        smp_off_h = smp_off.cpu().numpy()
         queries = []
         for s in who:
-            scene = PlaceScene(rows[s, :int(n_rows_h[s])], self.orig_rows[s, :self.n_orig[s]], self.boxes[s], self.maps[s],
-                               self.moves[s], self.poses[s], device=batch.device, orig_ranges=self.orig_ranges[s])
-            queries.append({"scene": scene, "sample": samples[s], "anno": annos[s], "ok_labels": ok_labels[s],
-                            "ok_map": ok_maps[s]})
+            n = int(n_rows_h[s])
+            if self.chunked:
+                rng_s = all_ranges[s, :(n + 63) // 64]
+            else:
+                rng_s = chunk_ranges(rows[s, :n])
+            scene = scene_view(rows[s, :n], self.orig_rows[s, :self.n_orig[s]], boxes_d[s], len(self.boxes[s]), self.maps[s],
+                               self.moves[s], self.poses[s], rng_s, self.orig_ranges[s])
+            queries.append({"scene": scene, "sample": smp_rows[int(smp_off_h[s]):int(smp_off_h[s + 1])], "anno": annos[s],
+                            "ok_labels": ok_labels[s], "ok_map": ok_maps[s]})
         pb = PlaceBatch(queries, cand_cap=chunk, device=batch.device, packed=True)
         sizes = np.zeros(B, dtype=np.int64)
         sizes[who] = [q.shape[0] for q in pb.samples]

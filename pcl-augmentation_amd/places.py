@@ -84,6 +84,18 @@ class PlaceScene:
         self.pose = np.asarray(transformation_matrix, dtype=np.float64)[:2, :4].reshape(8).copy()
 
 
+def scene_view(scene_rows, orig_rows, boxes_t, n_boxes, map_t, map_move, pose8, scene_ranges, orig_ranges):
+    """A PlaceScene over device tensors that are already in the layout the search reads (packed
+    [x y z label] rows, uploaded boxes / map, chunk ranges): no copies, no launches."""
+    ps = PlaceScene.__new__(PlaceScene)
+    ps.device = scene_rows.device
+    ps.scene, ps.orig, ps.scene_label_col, ps.orig_label_col = scene_rows, orig_rows, 3, 3
+    ps.boxes, ps.n_boxes, ps.map = boxes_t, int(n_boxes), map_t
+    ps.map_move, ps.pose = map_move, pose8
+    ps.scene_ranges, ps.orig_ranges = scene_ranges, orig_ranges
+    return ps
+
+
 def _fill_query(qd, scene, sample_t, anno10, ok_labels, ok_map_values, cand_cap, cand_off, cand_stride,
                 flavour=0, collide_label=0, collide_dz=0.0):
     qd.scene, qd.orig = scene.scene.data_ptr(), scene.orig.data_ptr()
