@@ -55,6 +55,8 @@ extern "C" {
 #define R3D_S_SAMPLE_TOO_LARGE 8  /* batched path: sample exceeds R3D_MAX_SAMPLE points */
 #define R3D_S_CAPACITY 16         /* batched path: merged cloud / log would exceed its capacity */
 #define R3D_S_FAR_OVERFLOW 32     /* batched path: more than R3D_FAR_CAP pixels beyond 500 m */
+#define R3D_S_CHAIN_TIMEOUT 128   /* r3d_batch_insert_many: a slot gave up waiting for the scene's previous slot */
+#define R3D_S_CHAIN_LAYOUT 256    /* r3d_batch_insert_many: a slot did not run on the XCD of the scene's previous slot */
 #define R3D_S_WINDOW_TOO_LARGE 64 /* batched path: the insert's window of the range image does not fit the
                                      kernel's LDS (far pixels on a range image much larger than 112x1440) */
 
@@ -192,6 +194,18 @@ int r3d_batch_insert(const r3d_batch_t *b, const double *samples5, const int64_t
  * labels/{f}.label (SS tools/datasets.py:72-84).  check (nullable) float32
  * [B*log_cap][check_cols] = check/{f}.bin rows from the log. */
 int r3d_batch_finish(const r3d_batch_t *b, float *check, int32_t check_cols, void *stream);
+
+/* n_slots consecutive insert slots with ONE candidate each (the reference's loop when the first
+ * placement of every object is tried, insertion.py:371-545).  With B a multiple of 8 they run in one
+ * launch in which slot k of a scene starts as soon as slot k-1 of the SAME scene is done, instead of
+ * after the slowest scene of the whole batch; otherwise as n_slots calls of r3d_batch_insert.  The
+ * arguments are HOST arrays of n_slots device pointers with the meaning they have in
+ * r3d_batch_insert (active may be null, or hold nulls); slot k runs as step first_step + k.  Same
+ * results as n_slots calls of r3d_batch_insert. */
+int r3d_batch_insert_many(const r3d_batch_t *b, int32_t n_slots, const double *const *samples5,
+                          const int64_t *const *sample_off, const int32_t *const *min_points,
+                          const int32_t *const *active, int32_t first_step, int32_t *const *n_visible,
+                          int32_t *const *accepted, void *stream);
 
 /* The current merged cloud of every scene (scene_pcl as find_possible_places gets it, insertion.py:433-434,
  * without the scratch columns): rows4 double [B][cap][4] = x y z label of the living points -- the

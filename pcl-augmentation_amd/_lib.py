@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("R3D_LIB") or os.path.join(_HERE, "libreal3daug_hip.so
 
 R3D_OK = 0
 S_NONFINITE, S_ROW_RANGE, S_COL_RANGE, S_SAMPLE_TOO_LARGE, S_CAPACITY, S_FAR_OVERFLOW, S_WINDOW_TOO_LARGE = 1, 2, 4, 8, 16, 32, 64
+S_CHAIN_TIMEOUT, S_CHAIN_LAYOUT = 128, 256
 STATUS_TEXT = {
     S_NONFINITE: "NaN/Inf coordinate or a point at the origin (reference: int() raises, insertion.py:104)",
     S_ROW_RANGE: "Rows in FoV went something wrong (assert insertion.py:110)",
@@ -23,6 +24,8 @@ STATUS_TEXT = {
     S_CAPACITY: "merged cloud or insert log exceeds its capacity",
     S_FAR_OVERFLOW: "more than R3D_FAR_CAP pixels deeper than 500 m",
     S_WINDOW_TOO_LARGE: "the insert's window of the range image does not fit the kernel's LDS",
+    S_CHAIN_TIMEOUT: "insert_many: a slot gave up waiting for the scene's previous slot",
+    S_CHAIN_LAYOUT: "insert_many: a slot did not run on the XCD of the scene's previous slot",
 }
 K_BOUNDS, K_PREPARE, K_PROJECT, K_ALIVE_COUNT, K_ALIVE_WRITE = 1, 2, 3, 4, 5
 NUMROW, NUMCOLUMN = 112, 1440
@@ -92,6 +95,7 @@ _SIGNATURES = {
     "r3d_batch_insert": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "r3d_batch_finish": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int32, _P]),
     "r3d_batch_launch_one": (C.c_int, [C.POINTER(BatchDesc), C.c_int32, _P]),
+    "r3d_batch_insert_many": (C.c_int, [C.POINTER(BatchDesc), C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "r3d_batch_export_rows": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P]),
     "r3d_places_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "r3d_cut_boxes_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),

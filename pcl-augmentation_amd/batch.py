@@ -174,6 +174,22 @@ class SceneBatch:
             _lib.stream_ptr()), "r3d_batch_insert")
         return self.n_visible, self.accepted
 
+    def insert_many_device(self, packed, min_points):
+        """Several slots with one candidate each in ONE launch (``r3d_batch_insert_many``): packed =
+        list of (samples5, sample_off) device tensors per slot, min_points = list of int32 device
+        tensors.  Returns (n_visible [K,B], accepted [K,B]) device tensors."""
+        torch = self.torch
+        K = len(packed)
+        nv = torch.zeros((K, self.B), dtype=torch.int32, device=self.device)
+        acc = torch.zeros((K, self.B), dtype=torch.int32, device=self.device)
+        ptrs = lambda xs: (C.c_void_p * K)(*[C.c_void_p(x) for x in xs])
+        _lib.check(self.lib.r3d_batch_insert_many(
+            C.byref(self.desc), K, ptrs([p[0].data_ptr() for p in packed]), ptrs([p[1].data_ptr() for p in packed]),
+            ptrs([m.data_ptr() for m in min_points]), None, self.step + 1, ptrs([nv[k].data_ptr() for k in range(K)]),
+            ptrs([acc[k].data_ptr() for k in range(K)]), _lib.stream_ptr()), "r3d_batch_insert_many")
+        self.step += K
+        return nv, acc
+
     def pack_samples(self, samples):
         """list of (M x 5 float64 | None) per scene -> (samples5, sample_off) device tensors."""
         torch = self.torch
@@ -238,6 +254,17 @@ class SceneBatch:
         torch = self.torch
         B = self.B
         k_max = max(len(c) for c in candidates)
+        if k_max and all(len(slot) <= 1 for c in candidates for slot in c):
+            # one candidate per slot everywhere: all slots in one call (r3d_batch_insert_many)
+            packed, needs = [], []
+            for k in range(k_max):
+                packed.append(self.pack_samples([c[k][0] if k < len(c) and len(c[k]) else None for c in candidates]))
+                needs.append(torch.from_numpy(np.asarray([min_points[s][k] if k < len(candidates[s]) else 0
+                                                          for s in range(B)], dtype=np.int32)).to(self.device))
+            _, acc = self.insert_many_device(packed, needs)
+            self._keep = (packed, needs)
+            acc_h = acc.cpu().numpy()                                        # the one synchronisation
+            return [[0 if acc_h[k, s] else -1 for k in range(len(candidates[s]))] for s in range(B)]
         log, keep = [], []
         for k in range(k_max):
             n_cand = max(len(c[k]) if k < len(c) else 0 for c in candidates)

@@ -39,6 +39,7 @@ struct BatchWs {
   double *q_ext;                // [B*2] min and max of z/r (the points that hold the elevation bounds)
   int32_t *n_slow;              // [B] points queued for k_project_slow
   unsigned long long *alive_bits; // [B*chunks] survivor bit of every point (k_alive_count -> k_alive_write)
+  int32_t *chain_progress;        // [B] slots of the scene completed by the running k_insert_chain
   int64_t cand_stride;          // uint32 entries of `cand` per scene: max(2*npix, cap)
   size_t total;
 };
@@ -69,6 +70,7 @@ static BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.q_ext = c.take<double>((size_t)b.B * 2);
   w.n_slow = c.take<int32_t>((size_t)b.B);
   w.alive_bits = c.take<unsigned long long>((size_t)b.B * chunks_of(b));
+  w.chain_progress = c.take<int32_t>((size_t)b.B);
   w.total = c.off;
   return w;
 }
@@ -573,12 +575,14 @@ __device__ __forceinline__ double mean_of_keys(const unsigned long long (&v)[15]
 constexpr int kLdsBytes = 160 * 1024;
 constexpr int kLdsFixed = 256 + kKeyCap / 8;      // counters + out-of-bounds bits
 
-__global__ void __launch_bounds__(kST)
-k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__restrict__ sample_off,
-         const int32_t *__restrict__ min_points, const int32_t *__restrict__ active, int step,
-         int32_t *__restrict__ n_visible, int32_t *__restrict__ accepted, BatchWs w, int chunks) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int s = blockIdx.x;
+// One placement candidate of scene s (one workgroup).  CHAIN: the caller re-bases the scene itself
+// when the return value says so, instead of the list that k_rebase reads.
+template <bool CHAIN>
+__device__ __forceinline__ bool
+insert_scene(const r3d_batch_t &b, const double *__restrict__ samples5, const int64_t *__restrict__ sample_off,
+             const int32_t *__restrict__ min_points, const int32_t *__restrict__ active, int step,
+             int32_t *__restrict__ n_visible, int32_t *__restrict__ accepted, const BatchWs &w, int chunks,
+             const int s, unsigned char *smem) {
   const int tid = threadIdx.x;
   const int rows = b.rows, cols = b.cols;
   const int npix = rows * cols;
@@ -602,7 +606,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
       accepted[s] = 0;
       if (m64 > kKeyCap && (!active || active[s])) atomicOr(&b.status[s], R3D_S_SAMPLE_TOO_LARGE);
     }
-    return;
+    return false;
   }
   const int m = (int)m64;
   int pw = 64;
@@ -748,7 +752,7 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
       n_visible[s] = 0;
       accepted[s] = 0;
     }
-    return;
+    return false;
   }
   for (int i = tid; i < 6 * ww; i += kST) s_img[i] = 0u;
   if (s_lds)
@@ -1098,11 +1102,22 @@ k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__re
       b.n_log[s] = n_log + nvis;
       if (*s_rebase) {
         b.rebase[s] += 1;                                       // single writer per scene
-        w.rebase_list[atomicAdd(w.n_rebase, 1)] = s;
+        if (!CHAIN) w.rebase_list[atomicAdd(w.n_rebase, 1)] = s;
       }
     }
   }
+  return accept && *s_rebase != 0;        // s_rebase was last written before the barrier that ends step 8
 }
+
+__global__ void __launch_bounds__(kST)
+k_insert(r3d_batch_t b, const double *__restrict__ samples5, const int64_t *__restrict__ sample_off,
+         const int32_t *__restrict__ min_points, const int32_t *__restrict__ active, int step,
+         int32_t *__restrict__ n_visible, int32_t *__restrict__ accepted, BatchWs w, int chunks) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  (void)insert_scene<false>(b, samples5, sample_off, min_points, active, step, n_visible, accepted, w, chunks,
+                            (int)blockIdx.x, smem);
+}
+
 
 // ---- compaction: drop dead points (finish, or rebase) ------------------------------------------
 __global__ void __launch_bounds__(kPT)
@@ -1227,14 +1242,11 @@ __device__ __forceinline__ void phase_sync() {
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(kRB)
-k_rebase(r3d_batch_t b, BatchWs w, int chunks) {
-  __shared__ unsigned long long s_min[kRB / 64], s_max[kRB / 64];
+__device__ __forceinline__ void rebase_scene(const r3d_batch_t &b, const BatchWs &w, int chunks, const int s,
+                                             unsigned long long *s_min, unsigned long long *s_max) {
   const int tid = threadIdx.x;
   const int npix = b.rows * b.cols, words = (npix + 31) / 32;
-  const int cnt = *w.n_rebase;
-  for (int li = blockIdx.x; li < cnt; li += gridDim.x) {
-    const int s = w.rebase_list[li];
+  {
     const int n = b.n_total[s], n_head = b.n_head[s];
     int32_t *pix = b.pix + (int64_t)s * b.cap;
     // (a) entomb the dead: a point whose pixel was visible after its birth gets pixel id -1 for
@@ -1303,6 +1315,14 @@ k_rebase(r3d_batch_t b, BatchWs w, int chunks) {
     if (flags) atomicOr(&b.status[s], flags);
     phase_sync();
   }
+}
+
+__global__ void __launch_bounds__(kRB)
+k_rebase(r3d_batch_t b, BatchWs w, int chunks) {
+  __shared__ unsigned long long s_min[kRB / 64], s_max[kRB / 64];
+  const int tid = threadIdx.x;
+  const int cnt = *w.n_rebase;
+  for (int li = blockIdx.x; li < cnt; li += gridDim.x) rebase_scene(b, w, chunks, w.rebase_list[li], s_min, s_max);
   // the last block to leave clears the list for the next insert call
   if (tid == 0) {
     __threadfence();
@@ -1312,6 +1332,80 @@ k_rebase(r3d_batch_t b, BatchWs w, int chunks) {
       *w.n_rebase = 0;
     }
   }
+}
+
+// ---- k_insert_chain: several insert slots of every scene in one launch ----------------------------
+// The slots of ONE scene depend on each other, the scenes do not.  With one launch per slot every
+// slot waits for the slowest scene of the previous one; here workgroup (slot k, scene s) only waits
+// for (k-1, s), so the launch lasts as long as the slowest scene's whole chain.
+//
+// Order: workgroups are numbered slot-major and the dispatcher hands them out in that order, so every
+// (k-1, s) is resident before any (k, s) starts to wait; the wait is bounded all the same (~2 s,
+// then R3D_S_CHAIN_TIMEOUT and the scene's remaining slots are skipped).
+// Visibility: a device-scope release (__threadfence) writes the XCD's L2 back and, executed by every
+// workgroup, slowed the whole kernel down by 2x.  It is not needed: workgroups go to the XCDs round
+// robin by their number and B is a multiple of 8, so (k, s) runs on the XCD of (k-1, s) and shares
+// its L2.  The producer only has to wait until its stores have left the CU (L1 is write-through),
+// the consumer only has to drop its CU's L1 and scalar cache.  The XCD ids are checked at run time
+// (R3D_S_CHAIN_LAYOUT if the assumption ever failed).
+constexpr int kMaxChain = 8;
+struct ChainSlots {
+  const double *samples5[kMaxChain];
+  const int64_t *sample_off[kMaxChain];
+  const int32_t *min_points[kMaxChain];
+  const int32_t *active[kMaxChain];
+  int32_t *n_visible[kMaxChain];
+  int32_t *accepted[kMaxChain];
+};
+
+__device__ __forceinline__ int xcc_id() {
+  return (int)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xF;   // HW_REG_XCC_ID[3:0]
+}
+
+__global__ void __launch_bounds__(kST)
+k_insert_chain(r3d_batch_t b, ChainSlots slots, int first_step, BatchWs w, int chunks) {
+  extern __shared__ __align__(16) unsigned char smem[];     // all of the CU's LDS: no static __shared__ here
+  int &s_go = reinterpret_cast<int *>(smem)[31];             // after insert_scene's counters and scan cells
+  unsigned long long *s_min = reinterpret_cast<unsigned long long *>(smem + 4096), *s_max = s_min + kRB / 64;
+  const int k = (int)blockIdx.x / b.B, s = (int)blockIdx.x % b.B;
+  const int tid = threadIdx.x;
+  if (k > 0) {
+    if (tid == 0) {
+      int seen = 0;                                             // progress: slots done | xcc id << 8; < 0: abandoned
+      for (long long spin = 0; spin < (1ll << 21); ++spin) {
+        seen = __hip_atomic_load(&w.chain_progress[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen < 0 || (seen & 0xFF) >= k) break;
+        __builtin_amdgcn_s_sleep(32);
+      }
+      int go = seen >= 0 && (seen & 0xFF) >= k;
+      if (go && (seen >> 8) != xcc_id()) {                      // not on the producer's XCD: its L2 may be stale
+        atomicOr(&b.status[s], R3D_S_CHAIN_LAYOUT);
+        go = 0;
+      } else if (!go && seen >= 0) {
+        atomicOr(&b.status[s], R3D_S_CHAIN_TIMEOUT);
+      }
+      if (!go) __hip_atomic_store(&w.chain_progress[s], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_go = go;
+    }
+    __syncthreads();
+    if (!s_go) {
+      if (tid == 0) {
+        slots.n_visible[k][s] = 0;
+        slots.accepted[k][s] = 0;
+      }
+      return;
+    }
+    // what (k-1, s) wrote is in this XCD's L2: drop the CU's vector L1 and scalar cache
+    asm volatile("buffer_inv sc0\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+  bool rebase = insert_scene<true>(b, slots.samples5[k], slots.sample_off[k], slots.min_points[k], slots.active[k],
+                                   first_step + k, slots.n_visible[k], slots.accepted[k], w, chunks, s, smem);
+  __syncthreads();
+  if (rebase) rebase_scene(b, w, chunks, s, s_min, s_max);     // rare; its phases use device-scope fences
+  __builtin_amdgcn_s_waitcnt(0);                                // this wave's stores have reached L2
+  __syncthreads();
+  if (tid == 0)
+    __hip_atomic_store(&w.chain_progress[s], (k + 1) | (xcc_id() << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // check/{f}.bin rows from the log (SS tools/datasets.py:73-75, :86-88; OD :77, :91-93).
@@ -1485,6 +1579,55 @@ int r3d_batch_insert(const r3d_batch_t *b, const double *samples5, const int64_t
   int rb = b->B < kRebaseRows ? b->B : kRebaseRows;
   hipLaunchKernelGGL(k_rebase, dim3(rb), dim3(kRB), 0, st, *b, w, chunks_of(*b));
   R3D_LAUNCHED("k_rebase");
+  return R3D_OK;
+}
+
+int r3d_batch_insert_many(const r3d_batch_t *b, int32_t n_slots, const double *const *samples5,
+                          const int64_t *const *sample_off, const int32_t *const *min_points,
+                          const int32_t *const *active, int32_t first_step, int32_t *const *n_visible,
+                          int32_t *const *accepted, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  if (!samples5 || !sample_off || !min_points || !n_visible || !accepted || n_slots < 1 || first_step < 1 ||
+      first_step + n_slots - 1 > 65535)
+    return fail(R3D_E_ARG, "batch_insert_many: null pointer, no slot or step outside [1, 65535]");
+  for (int k = 0; k < n_slots; ++k)
+    if (!samples5[k] || !sample_off[k] || !min_points[k] || !n_visible[k] || !accepted[k])
+      return fail(R3D_E_ARG, "batch_insert_many: null pointer in a slot");
+  if (b->B % 8 != 0) {
+    // the chained kernel needs slot k of a scene on the XCD of slot k-1 (see k_insert_chain): one launch per slot
+    for (int k = 0; k < n_slots; ++k) {
+      rc = r3d_batch_insert(b, samples5[k], sample_off[k], min_points[k], active ? active[k] : nullptr, first_step + k,
+                            n_visible[k], accepted[k], stream);
+      if (rc != R3D_OK) return rc;
+    }
+    return R3D_OK;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  BatchWs w = carve_batch(*b, b->workspace);
+  size_t lds = insert_lds_bytes(*b);
+  static thread_local size_t lds_opted = 0;
+  if (lds > lds_opted) {
+    R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_chain),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_opted = lds;
+  }
+  for (int k0 = 0; k0 < n_slots; k0 += kMaxChain) {
+    int nk = n_slots - k0 < kMaxChain ? n_slots - k0 : kMaxChain;
+    ChainSlots sl{};
+    for (int k = 0; k < nk; ++k) {
+      sl.samples5[k] = samples5[k0 + k];
+      sl.sample_off[k] = sample_off[k0 + k];
+      sl.min_points[k] = min_points[k0 + k];
+      sl.active[k] = active ? active[k0 + k] : nullptr;
+      sl.n_visible[k] = n_visible[k0 + k];
+      sl.accepted[k] = accepted[k0 + k];
+    }
+    R3D_HIP(hipMemsetAsync(w.chain_progress, 0, (size_t)b->B * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_insert_chain, dim3(b->B * nk), dim3(kST), lds, st, *b, sl, (int)(first_step + k0), w,
+                       chunks_of(*b));
+    R3D_LAUNCHED("k_insert_chain");
+  }
   return R3D_OK;
 }
 

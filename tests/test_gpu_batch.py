@@ -375,3 +375,45 @@ def test_far_pixels_on_a_large_grid_are_reported(P, synth):
     slots = [[synth.make_insert(78, "car", centre_range=8.0, centre_az=1.0)]]
     with pytest.raises(ValueError, match="window"):
         P.augment_batch([(xyzi, label)], [slots], [[5]], rows=448, cols=2880)
+
+
+@pytest.mark.parametrize("n_scenes", [8, 6])
+def test_insert_many_equals_slot_by_slot_calls(P, synth, n_scenes):
+    """r3d_batch_insert_many against the oracle chain: with 8 scenes the slots run in one launch
+    (slot k of a scene waits only for slot k-1 of the same scene), with 6 as one launch per slot.
+    Rejected slots, forced rebases in the middle of the chain, ragged scenes, an empty sample,
+    and more slots (9) than one launch takes (8)."""
+    import torch
+    cases = []
+    for s in range(n_scenes):
+        xyzi, label = synth.make_scene(70 + s, 48, 600 + 40 * s, shuffle=bool(s & 1))
+        ins = [synth.make_insert(700 + 10 * s + k, kind, rng_range=(4.0, 25.0))
+               for k, kind in enumerate(["pedestrian", "car", "cyclist", "car", "pedestrian", "cyclist", "car", "pedestrian", "car"])]
+        if s == 2:
+            ins[1] = blob_in_front_of_extreme(xyzi, "max")            # culls a bound holder: rebase inside the chain
+        if s == 4:
+            ins[3] = blob_in_front_of_extreme(xyzi, "min")
+        cases.append((xyzi, label, ins))
+    K = 9
+    need = [[20, 20, 10 ** 6, 20, 20, 20, 20, 20, 20] for _ in cases]   # slot 2 is never accepted
+    B = len(cases)
+    cap = max(len(c[0]) for c in cases) + sum(max(len(c[2][k]) for c in cases) for k in range(K)) + 64
+    batch = P.SceneBatch(B, cap, cap)
+    for rep in range(3):                                               # the same descriptor again: progress flags reset
+        batch.load([(c[0], c[1]) for c in cases])
+        batch.begin()
+        packed, needs = [], []
+        for k in range(K):
+            smp = [c[2][k] if not (k == 5 and i == 3) else None for i, c in enumerate(cases)]   # one empty sample
+            packed.append(batch.pack_samples(smp))
+            needs.append(torch.tensor([need[i][k] for i in range(B)], dtype=torch.int32, device=batch.device))
+        nv, acc = batch.insert_many_device(packed, needs)
+        batch.finish()
+        batch.raise_on_status()
+    res, acc_h = batch.results(), acc.cpu().numpy()
+    assert int(batch.rebase.sum().item()) >= 2
+    for i, c in enumerate(cases):
+        slots = [[c[2][k]] if not (k == 5 and i == 3) else [] for k in range(K)]
+        vb, lb, cb, oacc = _oracle_chain(c[0], c[1], slots, need[i])
+        assert [0 if a == 0 else -1 for a in oacc] == [0 if acc_h[k, i] else -1 for k in range(K)]
+        _check_scene(res[i], vb, lb, cb)
