@@ -69,6 +69,66 @@ class AugmentPipeline:
             label = np.where(label == self.road_label, self.road_label, 1).astype(np.uint32)
         return np.ascontiguousarray(xyzi), np.ascontiguousarray(label.astype(np.uint32))
 
+    # -- placement search + merge (the whole per-frame body of insertion.py:352-549) -------------------
+    def _process_placed(self, scenes, infos, slots):
+        """scenes as in _process_hip; infos[s] = (rich_map, map_move, pose 4x4, boxes k x 10);
+        slots[s] = list of dicts {sample, anno (10 floats), ok_labels, ok_map, min_points, name}."""
+        from .batch import SceneBatch
+        from .placed import PlacedInserter
+        B = len(scenes)
+        k_max = max(len(sl) for sl in slots)
+        grow = sum(max((len(sl[k]["sample"]) if k < len(sl) else 0) for sl in slots) for k in range(k_max))
+        cap = max(len(x) for x, _ in scenes) + grow
+        batch = self._batches.get(("placed", B))
+        if batch is None or batch.cap < cap or batch.log_cap < max(grow, 1):
+            batch = SceneBatch(B, int(cap * 1.05) + 64, max(grow, 1) * 2, device=self.device)
+            self._batches[("placed", B)] = batch
+        batch.load(scenes)
+        batch.begin()
+        ins = PlacedInserter(batch, [i[0] for i in infos], [i[1] for i in infos], [i[2] for i in infos], [i[3] for i in infos])
+        chosen = [[] for _ in range(B)]
+        for k in range(k_max):
+            have = [sl[k] if k < len(sl) else None for sl in slots]
+            rot, _ = ins.insert_slot([h["sample"] if h else None for h in have], [h["anno"] if h else None for h in have],
+                                     [h["ok_labels"] if h else None for h in have], [h["ok_map"] if h else None for h in have],
+                                     [h["min_points"] if h else 0 for h in have])
+            for s in range(B):
+                if have[s]:
+                    chosen[s].append(rot[s])
+        batch.finish(self.check_cols)
+        return batch.results(), chosen
+
+    def run_placed(self, frames, scene_info_for, slots_for):
+        """Frames with the placement search in the loop: scene_info_for(i) -> (rich_map, map_move,
+        pose, boxes) of frame i, slots_for(i) -> the samples to insert (see _process_placed).  Writes
+        what ``run`` writes plus ``added_objects/{f}.txt`` with one line per inserted object,
+        '<name> with rotation: <r>' (insertion.py:513)."""
+        infos, frame_ids = {}, []           # filled by the reader thread, consumed in the same order by the GPU leg
+
+        def candidates_and_id(i):
+            infos[i] = scene_info_for(i)
+            frame_ids.append(i)
+            return slots_for(i), None
+
+        def process_placed(scenes, cands, _):
+            ids = frame_ids[:len(scenes)]
+            del frame_ids[:len(scenes)]
+            results, chosen = self._process_placed(scenes, [infos.pop(i) for i in ids], cands)
+            os.makedirs(os.path.join(self.output_path, self.folder, "added_objects"), exist_ok=True)
+            for i, sl, ch in zip(ids, cands, chosen):
+                with open(os.path.join(self.output_path, self.folder, "added_objects", f"{frames[i].name}.txt"), "w") as fh:
+                    for h, r in zip(sl, ch):
+                        if r > 0:
+                            fh.write(f"{h.get('name', 'object')} with rotation: {r}\n")
+            return results, chosen
+
+        saved = self.process
+        self.process = process_placed
+        try:
+            return self.run(frames, candidates_and_id)
+        finally:
+            self.process = saved
+
     def run(self, frames, candidates_for):
         """Process every frame; returns a dict of counters and timings.
 

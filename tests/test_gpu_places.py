@@ -344,3 +344,67 @@ def test_large_samples_many_boxes_and_far_circles(P, synth, m, n_boxes, dist):
     c = _far_query(synth, 60 + n_boxes, m, n_boxes, dist)
     r = _run_vs_oracle(P, c)
     assert 0 < len(r["rotations"]) < 360
+
+
+def test_file_to_file_with_placement(P, synth, tmp_path):
+    """AugmentPipeline.run_placed: frames from disk, placement search + merge on the device, written
+    velodyne / labels / check files and added_objects lines against the two oracles."""
+    import os
+    fs = P.Real3DAug.tools.find_spot
+    root = tmp_path / "data"
+    os.makedirs(root / "velodyne")
+    os.makedirs(root / "labels")
+    cases, frames = [], []
+    for i in range(3):
+        c = _random_query(synth, 80 + i, 31, 2, n_az=400)
+        c["scene9"] = c["scene9"][:len(c["original"])]
+        xyzi = c["original"][:, :4].astype(np.float32)
+        label = c["original"][:, 4].astype(np.uint32)
+        xyzi.tofile(root / "velodyne" / f"{i:06d}.bin")
+        (label | (np.uint32(i + 3) << 16)).astype(np.uint32).tofile(root / "labels" / f"{i:06d}.label")
+        frames.append(P.Frame(str(root / "velodyne" / f"{i:06d}.bin"), str(root / "labels" / f"{i:06d}.label")))
+        slots = []
+        for k, cls in enumerate([31, 30]):
+            q = _random_query(synth, 800 + 10 * i + k, cls, 0, beams=4, n_az=16)
+            slots.append((q["sample"][:120], q["line"], 15, f"obj{i}{k}"))
+        cases.append((c, slots))
+
+    def scene_info_for(i):
+        c = cases[i][0]
+        return c["rich"], c["move"], c["T"], [fs._anno10(fs.read_label_line(l)) for l in c["lines"]]
+
+    def slots_for(i):
+        out = []
+        for smp, line, need, name in cases[i][1]:
+            a = fs.read_label_line(line)
+            ok_map, ok_labels = fs.placement_surfaces(a, CONFIG)
+            out.append({"sample": smp, "anno": fs._anno10(a), "ok_labels": ok_labels, "ok_map": ok_map, "min_points": need,
+                        "name": name})
+        return out
+
+    pipe = P.AugmentPipeline(str(tmp_path / "out"), "placed", dataset="semantic", batch_size=2)
+    stats = pipe.run_placed(frames, scene_info_for, slots_for)
+    assert stats["written"] == 3
+    for i, (c, slots) in enumerate(cases):
+        scene = c["scene9"].copy()
+        annos = [F.read_label_line(l) for l in c["lines"]]
+        all_visible, lines = np.zeros((0, 9)), []
+        for smp, line, need, name in slots:
+            scene, s_train, _, max_el, min_el = O.scene_field_of_view(scene)
+            pcl, anno, rot, _, _ = F.find_possible_places(scene, annos, smp, line, c["rich"].astype(np.float64), c["move"],
+                                                          c["original"], c["T"], PLACEMENT, PLACEMENT_LABELS)
+            for ci, cand in enumerate(pcl):
+                out, visible, _ = O.evaluate_candidate(scene, s_train, max_el, min_el, cand)
+                if len(visible) == 0 or len(visible) < need:
+                    continue
+                scene = np.append(out, visible, axis=0)
+                all_visible = np.append(all_visible, visible, axis=0)
+                annos.append(anno[ci])
+                lines.append(f"{name} with rotation: {rot[ci]}\n")
+                break
+        vb, lb, cb = O.save_bytes_semantic(scene, all_visible)
+        base = tmp_path / "out" / "placed"
+        assert (base / "velodyne" / f"{i:06d}.bin").read_bytes() == vb
+        assert (base / "labels" / f"{i:06d}.label").read_bytes() == lb
+        assert (base / "check" / f"{i:06d}.bin").read_bytes() == cb
+        assert (base / "added_objects" / f"{i:06d}.txt").read_text() == "".join(lines) and lines
