@@ -324,14 +324,41 @@ __device__ __forceinline__ int project_point(const r3d_batch_t &b, int s, const 
 //         the cross product with the edges' unit vectors).
 // Margins are relative 4e-12 resp. 1e-12 (the L1 norm bounds r from above), three orders of
 // magnitude above the rounding of the products and of the reference's own float64 evaluation.
+// Cheap float32 angle guesses for fast_bin (about 1e-5 rad, a few per mille of a bin): whatever they
+// get wrong the float64 confirmation rejects, so their accuracy only decides how many points take the
+// slow path, never a result.
+__device__ __forceinline__ float guess_acosf(float q) {
+  if (fabsf(q) > 0.5f) return acosf(q);                       // steep beams: the library routine
+  float q2 = q * q;                                           // asin series, error < 3e-6 for |q| <= 0.5
+  float p = fmaf(q2, 0.02237216f, 0.03038194f);
+  p = fmaf(p, q2, 0.04464286f);
+  p = fmaf(p, q2, 0.075f);
+  p = fmaf(p, q2, 0.16666667f);
+  return 1.57079637f - fmaf(p * q2, q, q);
+}
+__device__ __forceinline__ float guess_atan2f(float y, float x) {
+  float ax = fabsf(x), ay = fabsf(y);
+  float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  float t = mn * __frcp_rn(mx), t2 = t * t;                   // atan on [0, 1], odd polynomial, error ~1e-5
+  float p = fmaf(-0.01172120f, t2, 0.05265332f);
+  p = fmaf(p, t2, -0.11643287f);
+  p = fmaf(p, t2, 0.19354346f);
+  p = fmaf(p, t2, -0.33262347f);
+  p = fmaf(p, t2, 0.99997726f);
+  float a = p * t;
+  a = ay > ax ? 1.57079637f - a : a;
+  a = x < 0.f ? 3.14159274f - a : a;
+  return y < 0.f ? -a : a;
+}
+
 __device__ __forceinline__ bool fast_bin(const Binning &bn, const double *__restrict__ row_cc,
                                          const double *__restrict__ col_dir, float inv_del, float inv_daz,
                                          float elo, float xf, float yf, float zf, double x, double y, double z,
                                          double ss, int &row, int &col) {
   float qf = zf * __frsqrt_rn(xf * xf + yf * yf + zf * zf);
   qf = qf < -1.f ? -1.f : (qf > 1.f ? 1.f : qf);
-  int rg = (int)floorf((acosf(qf) - elo) * inv_del);
-  int cg = (int)((atan2f(yf, xf) + 3.14159274f) * inv_daz);
+  int rg = (int)floorf((guess_acosf(qf) - elo) * inv_del);
+  int cg = (int)((guess_atan2f(yf, xf) + 3.14159274f) * inv_daz);
   rg = rg < 0 ? 0 : (rg > bn.rows - 1 ? bn.rows - 1 : rg);
   cg = cg < 0 ? 0 : (cg > bn.cols - 1 ? bn.cols - 1 : cg);
   row = rg;
