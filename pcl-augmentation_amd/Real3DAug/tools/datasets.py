@@ -89,3 +89,32 @@ class KITTI:
         xyzi, _, _ = pack_for_save(point_cloud)
         _, _, check = pack_for_save(added_points, 4)
         write_frame(self.save_output_folder, folder, name, xyzi, None, check, False)
+
+
+class Waymo:
+    """The Waymo flavour of ``save_data`` (SS tools/datasets.py:287-303): the LiDAR offset that
+    ``__getitem__`` subtracted (:259) is added back in float64, then the casts of ``pack_for_save``
+    and three ``.npy`` files.  Waymo clouds are genuine float64 after that subtraction, so they go
+    through the Level-1 functions (N x 9 float64), not through the float32 slabs of ``SceneBatch``."""
+
+    LiDAR_location = np.array([1.22, 0, 2])           # :226
+
+    def __init__(self, config):
+        self.config = config
+
+    def remove_space_for_spherical(self, point_cloud):
+        return remove_space_for_spherical(point_cloud)
+
+    def save_data(self, point_cloud, added_points, folder, name, idx=None):
+        point_cloud = np.array(point_cloud, dtype=np.float64, copy=True)
+        added_points = np.array(added_points, dtype=np.float64, copy=True)
+        point_cloud[:, 0:3] += self.LiDAR_location                                  # :288
+        added_points[:, 0:3] += self.LiDAR_location                                 # :289
+        xyzi, label, _ = pack_for_save(point_cloud)
+        _, _, check = pack_for_save(added_points, 5)
+        base = os.path.join(self.config["path"]["output_path"], folder)
+        for sub in ("lidar", "labels_v3_2", "check"):
+            os.makedirs(os.path.join(base, sub), exist_ok=True)
+        np.save(os.path.join(base, "lidar", f"{name}.npy"), xyzi)                    # :297
+        np.save(os.path.join(base, "labels_v3_2", f"{name}.npy"), label.reshape(-1, 1))   # :299, N x 1 uint32
+        np.save(os.path.join(base, "check", f"{name}.npy"), check)                   # :301

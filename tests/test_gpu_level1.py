@@ -194,3 +194,29 @@ def test_save_bytes(R, tmp_path):
     ds.KITTI({"path": {"output_path": str(tmp_path)}}).save_data(merged, added, "od", "000001", 0, [])
     assert (tmp_path / "od/velodyne/000001.bin").read_bytes() == g["velodyne_bin"].tobytes()
     assert (tmp_path / "od/check/000001.bin").read_bytes() == g["check_bin"].tobytes()
+
+
+def test_save_data_waymo(R, tmp_path):
+    """SS tools/datasets.py:287-303: LiDAR offset added back in float64, float32 / uint32 casts,
+    three .npy files (restated here with NumPy: the casts are plain astype calls)."""
+    g = load_golden("chain_c20k.npz")
+    merged = np.full((len(g["merged"]), 9), -1.0)
+    merged[:, [0, 1, 2, 6, 7]] = g["merged"]
+    merged[:, :3] -= np.array([1.22, 0, 2])                     # what __getitem__ leaves (:259): genuine float64
+    added = np.full((len(g["all_visible"]), 9), -1.0)
+    added[:, [0, 1, 2, 6, 7]] = g["all_visible"]
+    added[:, :3] -= np.array([1.22, 0, 2])
+    keep_m, keep_a = merged.copy(), added.copy()
+    R.tools.datasets.Waymo({"path": {"output_path": str(tmp_path)}}).save_data(merged, added, "w", "f0", 0)
+    assert np.array_equal(merged, keep_m) and np.array_equal(added, keep_a)
+    want = keep_m.copy()
+    want[:, :3] += np.array([1.22, 0, 2])
+    wadd = keep_a.copy()
+    wadd[:, :3] += np.array([1.22, 0, 2])
+    lidar = np.load(tmp_path / "w/lidar/f0.npy")
+    labels = np.load(tmp_path / "w/labels_v3_2/f0.npy")
+    check = np.load(tmp_path / "w/check/f0.npy")
+    assert lidar.dtype == np.float32 and np.array_equal(lidar, want[:, [0, 1, 2, 6]].astype(np.float32))
+    assert labels.dtype == np.uint32 and labels.shape == (len(want), 1)
+    assert np.array_equal(labels[:, 0], want[:, 7].astype(np.uint32))
+    assert check.dtype == np.float32 and np.array_equal(check, wadd[:, [0, 1, 2, 6, 7]].astype(np.float32))
