@@ -5,9 +5,13 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 One "step" is one pass of the hot path over one batch: r3d_batch_begin (elevation bounds,
-spherical projection + range-image min-reduce), five r3d_batch_insert calls (sample projection,
-closing / hole fill on the candidate pixels, visibility mask, cull, append) and r3d_batch_finish
-(compaction into the velodyne/.bin + labels/.label + check/.bin byte layout).  With N > 1 the
+spherical projection), the five insert slots (r3d_batch_insert_many: sample projection, closing /
+hole fill on the candidate pixels, visibility mask, cull, append) and r3d_batch_finish (compaction
+into the velodyne/.bin + labels/.label + check/.bin byte layout).  By default two steps are in
+flight: consecutive steps alternate between two HBM-resident copies of the batch on two HIP
+streams, as consecutive batches of a real run would, so that the streaming kernels of one step fill
+the CUs that the latency-bound insert kernel of the other leaves idle (`--overlap 1`: one step at
+a time; that rate is also reported, as config.scenes_per_s_one_step_in_flight).  With N > 1 the
 driver starts one process per GPU (torchrun); every rank runs its own batch of 256 scenes (weak
 scaling, scenes are independent, no collective on the data path), the timed region is bracketed
 by a barrier + synchronize and the maximum over ranks is reported.
@@ -134,6 +138,11 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="the batch is processed as this many sub-batches on separate HIP streams, so that "
                          "one scene's long insert does not idle the other CUs")
+    ap.add_argument("--overlap", type=int, default=2,
+                    help="consecutive steps alternate between this many full-size batches, each on its own HIP stream, "
+                         "so that the streaming kernels of one step can fill the CUs the insert kernel of the "
+                         "previous step leaves idle (1 = every step on the same batch and stream; ignored with "
+                         "--streams / --graph / --per-slot-launches)")
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per step instead of launching "
                     "every kernel from Python (measured: same step time at one stream, slower with several)")
     ap.add_argument("--per-slot-launches", action="store_true",
@@ -206,6 +215,20 @@ def main():
 
     enqueue_step()                      # first call outside any capture (sets kernel attributes)
     torch.cuda.synchronize()
+    # --overlap D: D whole batches, step i runs on batch / stream i % D and is not joined until the end
+    depth = 1 if (args.streams > 1 or args.graph or args.per_slot_launches) else max(1, args.overlap)
+    lanes = [(batch, packed, need)] + [make_batch(0, B) for _ in range(depth - 1)] if depth > 1 else []
+    lane_streams = [torch.cuda.Stream() for _ in lanes]
+    lane_no = [0]
+
+    def enqueue_overlapped():
+        lane = lane_no[0] % depth
+        lane_no[0] += 1
+        bt, pk, nd = lanes[lane]
+        with torch.cuda.stream(lane_streams[lane]):
+            bt.begin()
+            _, bt.last_acc = bt.insert_many_device(pk, [nd] * len(pk))
+            bt.finish(check_cols=0)
     graph = None
     if args.graph:
         # the ~25 launches of one step are captured once into a hipGraph and replayed per step
@@ -214,7 +237,9 @@ def main():
             enqueue_step()
 
     def one_step():
-        if graph is not None:
+        if depth > 1:
+            enqueue_overlapped()
+        elif graph is not None:
             graph.replay()
         else:
             enqueue_step()
@@ -249,8 +274,20 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=batch.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    for bt, _, _ in subs:
+    for bt, _, _ in subs + lanes[1:]:
         bt.raise_on_status()
+    if depth > 1:                                   # every lane worked on the same input: same output sizes
+        ref_out = lanes[0][0].n_out.cpu().numpy()
+        assert all(np.array_equal(bt.n_out.cpu().numpy(), ref_out) for bt, _, _ in lanes[1:])
+        # the same K steps one at a time, for the record (not the headline value)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            enqueue_step()
+        torch.cuda.synchronize()
+        serial_elapsed = time.perf_counter() - t1
+    else:
+        serial_elapsed = elapsed
     n_out = np.concatenate([bt.n_out.cpu().numpy() for bt, _, _ in subs])
     n_accepted = int(sum(int(bt.last_acc.sum().item()) for bt, _, _ in subs))
     rebases = sum(int(bt.rebase.sum().item()) for bt, _, _ in subs)   # informational: a rebase leaves the inputs intact
@@ -307,7 +344,7 @@ def main():
         for name, k in kernels.items():
             k["GBps"] = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9
             k["frac"] = k["GBps"] / HBM_PEAK_GBS
-            k["share_of_step"] = k["ms"] * k["launches_per_step"] / (1e3 * elapsed / args.steps)
+            k["share_of_step"] = k["ms"] * k["launches_per_step"] / (1e3 * serial_elapsed / args.steps)   # of a step run alone
         dominant = max(kernels, key=lambda k: kernels[k]["ms"] * kernels[k]["launches_per_step"])
         dk = kernels[dominant]
         roofline = {
@@ -343,7 +380,8 @@ def main():
                                    "(2 pedestrians, 2 cyclists, 1 car), per GPU",
                        "scenes_per_gpu": B, "points_per_scene": int(n_pts / B), "inserts_per_scene": len(KINDS),
                        "range_image": [batch.rows, batch.cols], "inserts_accepted": n_accepted, "inserts_tried": B * len(KINDS),
-                       "sub_batches_on_streams": n_sub, "hip_graph": graph is not None,
+                       "sub_batches_on_streams": n_sub, "hip_graph": graph is not None, "steps_in_flight": depth,
+                       "scenes_per_s_one_step_in_flight": round(B * world * args.steps / serial_elapsed, 1),
                        "insert_api": "r3d_batch_insert x5" if args.per_slot_launches else "r3d_batch_insert_many(5)",
                        "rebases_in_timed_steps": rebases, "settle_steps_in_setup": settle,
                        "mean_points_out": float(n_out.mean())},
