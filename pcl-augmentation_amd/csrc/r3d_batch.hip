@@ -1093,7 +1093,12 @@ insert_scene(const r3d_batch_t &b, const double *__restrict__ samples5, const in
         else atomicOr(s_flags, R3D_S_FAR_OVERFLOW);
       }
       stamp[q] = (uint16_t)step;
-      atomicOr(&ever[q >> 5], 1u << (q & 31));
+    }
+    // "this pixel was visible at some step": the visible bits of a window word are the bits of one word
+    // of the scene's `ever` image (window columns are whole words), and only this workgroup writes it
+    for (int e = tid; e < ww; e += kST) {
+      uint32_t bits = vis.w[e];
+      if (bits) ever[(win.row_of(e) * cols >> 5) + win.word_of(e)] |= bits;
     }
   }
   __syncthreads();
