@@ -215,6 +215,12 @@ def main():
 
     enqueue_step()                      # first call outside any capture (sets kernel attributes)
     torch.cuda.synchronize()
+    if not args.per_slot_launches and int((batch.status & (pkg._lib.S_CHAIN_TIMEOUT | pkg._lib.S_CHAIN_LAYOUT)).sum().item()):
+        # the one-launch insert could not order a scene's slots on this device: fall back, and say so
+        args.per_slot_launches = True
+        batch.status.zero_()
+        enqueue_step()
+        torch.cuda.synchronize()
     # --overlap D: D whole batches, step i runs on batch / stream i % D and is not joined until the end
     depth = 1 if (args.streams > 1 or args.graph or args.per_slot_launches) else max(1, args.overlap)
     lanes = [(batch, packed, need)] + [make_batch(0, B) for _ in range(depth - 1)] if depth > 1 else []

@@ -201,7 +201,10 @@ int r3d_batch_finish(const r3d_batch_t *b, float *check, int32_t check_cols, voi
  * after the slowest scene of the whole batch; otherwise as n_slots calls of r3d_batch_insert.  The
  * arguments are HOST arrays of n_slots device pointers with the meaning they have in
  * r3d_batch_insert (active may be null, or hold nulls); slot k runs as step first_step + k.  Same
- * results as n_slots calls of r3d_batch_insert. */
+ * results as n_slots calls of r3d_batch_insert.  The one-launch form relies on the order in which the
+ * hardware hands out workgroups and on their placement on the XCDs; both are checked while it runs
+ * (R3D_S_CHAIN_TIMEOUT, R3D_S_CHAIN_LAYOUT: the results of a flagged scene are not valid), and the
+ * environment variable R3D_NO_CHAIN=1 selects the per-slot form unconditionally. */
 int r3d_batch_insert_many(const r3d_batch_t *b, int32_t n_slots, const double *const *samples5,
                           const int64_t *const *sample_off, const int32_t *const *min_points,
                           const int32_t *const *active, int32_t first_step, int32_t *const *n_visible,

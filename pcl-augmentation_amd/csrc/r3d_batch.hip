@@ -12,6 +12,8 @@
 #include "r3d_device.hpp"
 #include "r3d_host.hpp"
 
+#include <cstdlib>
+
 namespace r3d {
 
 constexpr int kPT = 256;             // threads of the streaming kernels
@@ -1626,7 +1628,8 @@ int r3d_batch_insert_many(const r3d_batch_t *b, int32_t n_slots, const double *c
   for (int k = 0; k < n_slots; ++k)
     if (!samples5[k] || !sample_off[k] || !min_points[k] || !n_visible[k] || !accepted[k])
       return fail(R3D_E_ARG, "batch_insert_many: null pointer in a slot");
-  if (b->B % 8 != 0) {
+  static const bool no_chain = getenv("R3D_NO_CHAIN") != nullptr;      // escape hatch: always one launch per slot
+  if (b->B % 8 != 0 || no_chain) {
     // the chained kernel needs slot k of a scene on the XCD of slot k-1 (see k_insert_chain): one launch per slot
     for (int k = 0; k < n_slots; ++k) {
       rc = r3d_batch_insert(b, samples5[k], sample_off[k], min_points[k], active ? active[k] : nullptr, first_step + k,
