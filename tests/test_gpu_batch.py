@@ -417,3 +417,45 @@ def test_insert_many_equals_slot_by_slot_calls(P, synth, n_scenes):
         vb, lb, cb, oacc = _oracle_chain(c[0], c[1], slots, need[i])
         assert [0 if a == 0 else -1 for a in oacc] == [0 if acc_h[k, i] else -1 for k in range(K)]
         _check_scene(res[i], vb, lb, cb)
+
+
+def test_insert_many_reports_the_same_status_as_single_calls(P, synth):
+    """Error paths inside the one-launch chain (8 scenes): a sample above R3D_MAX_SAMPLE, a log that
+    overflows, a non-finite sample point -- same status bits, counts and accept flags as one call per
+    slot on a second descriptor, and the scenes behind a failing slot still get their later slots."""
+    import torch
+    B, K = 8, 4
+    scenes = [synth.make_scene(90 + s, 32, 500) for s in range(B)]
+    ins = [[synth.make_insert(900 + 10 * s + k, "pedestrian", rng_range=(5.0, 15.0)) for k in range(K)] for s in range(B)]
+    ins[1][1] = np.tile(ins[1][1], (21, 1))[:8200]                      # > 8192 points
+    ins[2][0] = ins[2][0].copy()
+    ins[2][0][5, 0] = np.nan                                           # NaN coordinate
+    ins[3] = [synth.make_insert(950 + k, "car", rng_range=(5.0, 9.0)) for k in range(K)]   # 4 x 1500 points: log too small
+    n = max(len(x) for x, _ in scenes)
+    out = []
+    for mode in ("many", "single"):
+        batch = P.SceneBatch(B, n + 9000, 4000)
+        batch.load(scenes)
+        batch.begin()
+        packed = [batch.pack_samples([ins[s][k] for s in range(B)]) for k in range(K)]
+        need = torch.full((B,), 10, dtype=torch.int32, device=batch.device)
+        if mode == "many":
+            nv, acc = batch.insert_many_device(packed, [need] * K)
+            nv, acc = nv.cpu().numpy(), acc.cpu().numpy()
+        else:
+            nvs, accs = [], []
+            for s5, off in packed:
+                a, c = batch.insert_device(s5, off, need)
+                nvs.append(a.cpu().numpy().copy())
+                accs.append(c.cpu().numpy().copy())
+            nv, acc = np.stack(nvs), np.stack(accs)
+        batch.finish()
+        out.append((batch.status.cpu().numpy().copy(), nv, acc, batch.n_out.cpu().numpy().copy(),
+                    batch.out_xyzi.cpu().numpy().copy()))
+    (st_a, nv_a, acc_a, no_a, xy_a), (st_b, nv_b, acc_b, no_b, xy_b) = out
+    assert np.array_equal(st_a, st_b) and np.array_equal(nv_a, nv_b) and np.array_equal(acc_a, acc_b)
+    assert np.array_equal(no_a, no_b)
+    for s in range(B):
+        assert np.array_equal(xy_a[s, :no_a[s]], xy_b[s, :no_b[s]])
+    assert st_a[1] & 8 and st_a[2] & 1 and st_a[3] & 16 and not st_a[0] and not st_a[4]
+    assert acc_a[2, 1] == 1 and acc_a[1, 2] == 1                       # slots after a failed one still run
