@@ -459,3 +459,17 @@ def test_insert_many_reports_the_same_status_as_single_calls(P, synth):
         assert np.array_equal(xy_a[s, :no_a[s]], xy_b[s, :no_b[s]])
     assert st_a[1] & 8 and st_a[2] & 1 and st_a[3] & 16 and not st_a[0] and not st_a[4]
     assert acc_a[2, 1] == 1 and acc_a[1, 2] == 1                       # slots after a failed one still run
+
+
+def test_c5_scan_on_the_proposed_448x2880_grid(P, synth, monkeypatch):
+    """BASELINE config C5 as SURVEY.md par.8d proposes it: a 256-beam ~1M-point scan on a 448 x 2880
+    range image (the reference gets that grid by editing insertion.py:22-23), a few inserts."""
+    monkeypatch.setattr(O, "NUMROW", 448)
+    monkeypatch.setattr(O, "NUMCOLUMN", 2880)
+    xyzi, label = synth.make_scene(501, n_beams=256, n_az=3906)
+    sl = [[x] for x in synth.make_inserts(501, ["car", "pedestrian", "cyclist", "car"])]
+    nd = [20] * len(sl)
+    res, acc = P.augment_batch([(xyzi, label)], [sl], [nd], rows=448, cols=2880)
+    vb, lb, cb, oacc = _oracle_chain(xyzi, label, sl, nd)
+    assert acc[0] == oacc and any(a == 0 for a in oacc)
+    _check_scene(res[0], vb, lb, cb)
