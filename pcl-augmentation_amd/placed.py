@@ -44,9 +44,11 @@ class PlacedInserter:
         else:
             self.orig_ranges = [chunk_ranges(self.orig_rows[s, :self.n_orig[s]]) for s in range(B)]
 
-    def insert_slot(self, samples, annos, ok_labels, ok_maps, min_points, chunk=8):
+    def insert_slot(self, samples, annos, ok_labels, ok_maps, min_points, chunk=8, flavours=None):
         """samples[s]: M x 5 float64 or None; annos[s]: the sample's box (10 floats) after
-        read_label_line; ok_labels[s] / ok_maps[s]: placement labels / map codes of its class.
+        read_label_line; ok_labels[s] / ok_maps[s]: placement labels / map codes of its class;
+        flavours[s] (optional): dict with ``flavour`` / ``collide_label`` / ``collide_dz`` for the
+        object-detection rules (``find_spot_od.place_query`` builds them).
         Returns (rotation[s] = accepted rotation number or -1, n_possible[s])."""
         torch, batch = self.torch, self.batch
         B = batch.B
@@ -77,7 +79,7 @@ class PlacedInserter:
             scene = scene_view(rows[s, :n], self.orig_rows[s, :self.n_orig[s]], boxes_d[s], len(self.boxes[s]), self.maps[s],
                                self.moves[s], self.poses[s], rng_s, self.orig_ranges[s])
             queries.append({"scene": scene, "sample": smp_rows[int(smp_off_h[s]):int(smp_off_h[s + 1])], "anno": annos[s],
-                            "ok_labels": ok_labels[s], "ok_map": ok_maps[s]})
+                            "ok_labels": ok_labels[s], "ok_map": ok_maps[s], **((flavours[s] or {}) if flavours else {})})
         pb = PlaceBatch(queries, cand_cap=chunk, device=batch.device, packed=True)
         sizes = np.zeros(B, dtype=np.int64)
         sizes[who] = [q.shape[0] for q in pb.samples]

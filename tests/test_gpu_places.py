@@ -408,3 +408,40 @@ def test_file_to_file_with_placement(P, synth, tmp_path):
         assert (base / "labels" / f"{i:06d}.label").read_bytes() == lb
         assert (base / "check" / f"{i:06d}.bin").read_bytes() == cb
         assert (base / "added_objects" / f"{i:06d}.txt").read_text() == "".join(lines) and lines
+
+
+def test_placed_insertion_object_detection_flavour(P, synth):
+    """PlacedInserter with the object-detection rules (OD find_spot.py:227-304, OD insertion.py) on the
+    OD fixture's inputs: accepted rotation and written bytes against the OD oracle + the merge oracle."""
+    g = load_golden("places_od_pedestrian.npz")
+    fs = P.Real3DAug.tools.find_spot_od
+    original = np.hstack((g["xyzi"].astype(np.float64), g["label"].astype(np.float64)[:, None]))
+    anno_lines = [str(l) for l in g["anno_lines"]]
+    sample_anno = fs.read_label_line(str(g["sample_line"]))
+    q = fs.place_query(None, g["sample"], sample_anno, 40)
+    batch = P.SceneBatch(8, len(original) + 1024, 1024)                  # 8 equal scenes: the one-launch insert path
+    batch.load([(g["xyzi"], g["label"])] * 8)
+    batch.begin()
+    ins = P.PlacedInserter(batch, [g["rich"]] * 8, [g["move"]] * 8, [np.eye(4)] * 8,
+                           [[fs._anno10(fs.read_label_line(l)) for l in anno_lines]] * 8)
+    need = 12
+    rot, n_poss = ins.insert_slot([q["sample"]] * 8, [q["anno"]] * 8, [q["ok_labels"]] * 8, [q["ok_map"]] * 8, [need] * 8,
+                                  flavours=[{k: q[k] for k in ("flavour", "collide_label", "collide_dz")}] * 8)
+    batch.finish(check_cols=4)
+    res = batch.results()
+    scene = O.add_space_for_spherical(original)
+    scene, s_train, _, max_el, min_el = O.scene_field_of_view(scene)
+    annos = [F.read_label_line_od(l) for l in anno_lines]
+    pcl, anno, rots, _, _ = F.find_possible_places_od(scene, annos, g["sample"], str(g["sample_line"]),
+                                                      g["rich"].astype(np.float64), g["move"], original, 40)
+    chosen, all_visible = -1, np.zeros((0, 9))
+    for ci, cand in enumerate(pcl):
+        out, visible, _ = O.evaluate_candidate(scene, s_train, max_el, min_el, cand)
+        if len(visible) == 0 or len(visible) < need:
+            continue
+        scene, all_visible, chosen = np.append(out, visible, axis=0), visible, rots[ci]
+        break
+    assert chosen > 0 and rot == [chosen] * 8 and n_poss == [len(rots)] * 8
+    vb, cb = O.save_bytes_kitti(scene, all_visible)
+    for r in res:
+        assert r[0].tobytes() == vb and r[2].tobytes() == cb
