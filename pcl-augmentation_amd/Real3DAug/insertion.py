@@ -7,7 +7,6 @@ Paths cited are relative to the reference root, SS = semantic_segmentation/.
 """
 from __future__ import annotations
 
-import ctypes as C
 
 import numpy as np
 

@@ -5,8 +5,6 @@ The tests run in ``r3d_cut_boxes``; there is no CPU fallback.
 """
 from __future__ import annotations
 
-import ctypes as C
-
 import numpy as np
 
 from ... import _lib

@@ -9,8 +9,6 @@ import os
 import sys
 import time
 
-import numpy as np
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("pcl-augmentation_amd")
 import torch  # noqa: E402
