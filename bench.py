@@ -394,7 +394,7 @@ def main():
             "roofline": roofline,
             "pipeline_alg_GBps_per_gpu": round(step_bytes * args.steps / elapsed / 1e9, 1),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only: the other ranks would wait at the barrier
             done, secs = cpu_baseline(pkg)
             out["cpu_baseline"] = {"value": round(done / secs, 3), "unit": "scenes/s", "cores": 1, "kind": "port",
                                    "sample": f"{done} scenes of the same workload (120k points, 5 inserts) through "
