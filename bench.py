@@ -215,7 +215,7 @@ def main():
 
     enqueue_step()                      # first call outside any capture (sets kernel attributes)
     torch.cuda.synchronize()
-    if not args.per_slot_launches and int((batch.status & (pkg._lib.S_CHAIN_TIMEOUT | pkg._lib.S_CHAIN_LAYOUT)).sum().item()):
+    if not args.per_slot_launches and int((batch.status & pkg._lib.S_CHAIN_TIMEOUT).sum().item()):
         # the one-launch insert could not order a scene's slots on this device: fall back, and say so
         args.per_slot_launches = True
         batch.status.zero_()

@@ -56,7 +56,6 @@ extern "C" {
 #define R3D_S_CAPACITY 16         /* batched path: merged cloud / log would exceed its capacity */
 #define R3D_S_FAR_OVERFLOW 32     /* batched path: more than R3D_FAR_CAP pixels beyond 500 m */
 #define R3D_S_CHAIN_TIMEOUT 128   /* r3d_batch_insert_many: a slot gave up waiting for the scene's previous slot */
-#define R3D_S_CHAIN_LAYOUT 256    /* r3d_batch_insert_many: a slot did not run on the XCD of the scene's previous slot */
 #define R3D_S_WINDOW_TOO_LARGE 64 /* batched path: the insert's window of the range image does not fit the
                                      kernel's LDS (far pixels on a range image much larger than 112x1440) */
 
@@ -196,15 +195,15 @@ int r3d_batch_insert(const r3d_batch_t *b, const double *samples5, const int64_t
 int r3d_batch_finish(const r3d_batch_t *b, float *check, int32_t check_cols, void *stream);
 
 /* n_slots consecutive insert slots with ONE candidate each (the reference's loop when the first
- * placement of every object is tried, insertion.py:371-545).  With B a multiple of 8 they run in one
- * launch in which slot k of a scene starts as soon as slot k-1 of the SAME scene is done, instead of
- * after the slowest scene of the whole batch; otherwise as n_slots calls of r3d_batch_insert.  The
+ * placement of every object is tried, insertion.py:371-545) in one launch in which slot k of a
+ * scene starts as soon as slot k-1 of the SAME scene is done, instead of after the slowest scene of
+ * the whole batch.  The
  * arguments are HOST arrays of n_slots device pointers with the meaning they have in
  * r3d_batch_insert (active may be null, or hold nulls); slot k runs as step first_step + k.  Same
- * results as n_slots calls of r3d_batch_insert.  The one-launch form relies on the order in which the
- * hardware hands out workgroups and on their placement on the XCDs; both are checked while it runs
- * (R3D_S_CHAIN_TIMEOUT, R3D_S_CHAIN_LAYOUT: the results of a flagged scene are not valid), and the
- * environment variable R3D_NO_CHAIN=1 selects the per-slot form unconditionally. */
+ * results as n_slots calls of r3d_batch_insert.  The hand-off between the slots of a scene is an
+ * agent-scope release / acquire and does not depend on where the workgroups run; the waits are
+ * bounded (R3D_S_CHAIN_TIMEOUT: the scene's later slots were not run, its results are not valid),
+ * and the environment variable R3D_NO_CHAIN=1 selects one launch per slot unconditionally. */
 int r3d_batch_insert_many(const r3d_batch_t *b, int32_t n_slots, const double *const *samples5,
                           const int64_t *const *sample_off, const int32_t *const *min_points,
                           const int32_t *const *active, int32_t first_step, int32_t *const *n_visible,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("R3D_LIB") or os.path.join(_HERE, "libreal3daug_hip.so
 
 R3D_OK = 0
 S_NONFINITE, S_ROW_RANGE, S_COL_RANGE, S_SAMPLE_TOO_LARGE, S_CAPACITY, S_FAR_OVERFLOW, S_WINDOW_TOO_LARGE = 1, 2, 4, 8, 16, 32, 64
-S_CHAIN_TIMEOUT, S_CHAIN_LAYOUT = 128, 256
+S_CHAIN_TIMEOUT = 128
 STATUS_TEXT = {
     S_NONFINITE: "NaN/Inf coordinate or a point at the origin (reference: int() raises, insertion.py:104)",
     S_ROW_RANGE: "Rows in FoV went something wrong (assert insertion.py:110)",
@@ -25,7 +25,6 @@ STATUS_TEXT = {
     S_FAR_OVERFLOW: "more than R3D_FAR_CAP pixels deeper than 500 m",
     S_WINDOW_TOO_LARGE: "the insert's window of the range image does not fit the kernel's LDS",
     S_CHAIN_TIMEOUT: "insert_many: a slot gave up waiting for the scene's previous slot",
-    S_CHAIN_LAYOUT: "insert_many: a slot did not run on the XCD of the scene's previous slot",
 }
 K_BOUNDS, K_PREPARE, K_PROJECT, K_ALIVE_COUNT, K_ALIVE_WRITE = 1, 2, 3, 4, 5
 NUMROW, NUMCOLUMN = 112, 1440

@@ -264,10 +264,10 @@ class SceneBatch:
             _, acc = self.insert_many_device(packed, needs)
             self._keep = (packed, needs)
             acc_h = acc.cpu().numpy()                                        # the one synchronisation
-            bad = int((self.status & (_lib.S_CHAIN_TIMEOUT | _lib.S_CHAIN_LAYOUT)).sum().item())
+            bad = int((self.status & _lib.S_CHAIN_TIMEOUT).sum().item())
             if bad:
                 raise _lib.R3DError("r3d_batch_insert_many could not order the slots of a scene on this device "
-                                    "(status R3D_S_CHAIN_*); set R3D_NO_CHAIN=1 to insert slot by slot")
+                                    "(status R3D_S_CHAIN_TIMEOUT); set R3D_NO_CHAIN=1 to insert slot by slot")
             return [[0 if acc_h[k, s] else -1 for k in range(len(candidates[s]))] for s in range(B)]
         log, keep = [], []
         for k in range(k_max):

@@ -1373,15 +1373,19 @@ k_rebase(r3d_batch_t b, BatchWs w, int chunks) {
 // slot waits for the slowest scene of the previous one; here workgroup (slot k, scene s) only waits
 // for (k-1, s), so the launch lasts as long as the slowest scene's whole chain.
 //
-// Order: workgroups are numbered slot-major and the dispatcher hands them out in that order, so every
-// (k-1, s) is resident before any (k, s) starts to wait; the wait is bounded all the same (~2 s,
-// then R3D_S_CHAIN_TIMEOUT and the scene's remaining slots are skipped).
-// Visibility: a device-scope release (__threadfence) writes the XCD's L2 back and, executed by every
-// workgroup, slowed the whole kernel down by 2x.  It is not needed: workgroups go to the XCDs round
-// robin by their number and B is a multiple of 8, so (k, s) runs on the XCD of (k-1, s) and shares
-// its L2.  The producer only has to wait until its stores have left the CU (L1 is write-through),
-// the consumer only has to drop its CU's L1 and scalar cache.  The XCD ids are checked at run time
-// (R3D_S_CHAIN_LAYOUT if the assumption ever failed).
+// Hand-off (cdna_hip_programming.md, Guideline 16; correct for any placement of the workgroups on
+// CUs and XCDs): the producer's waves drain their stores (s_waitcnt vmcnt(0)), the workgroup meets
+// at a barrier, ONE lane executes the agent-scope release, waits again and stores the scene's
+// progress word with a relaxed agent-scope atomic.  The consumer polls that one word relaxed from
+// ONE lane (s_sleep between polls), then that lane executes ONE agent-scope acquire and waits, the
+// workgroup meets, and only then does anybody load the scene's data (the scalar cache is dropped
+// too: counters are read through it).  A device-scope fence in EVERY thread instead of one lane
+// made the whole kernel 2x slower.  The progress words are zeroed by a memset node before every
+// launch.
+// Liveness, not correctness, leans on the dispatcher: workgroups are numbered slot-major and handed
+// out in that order, so (k-1, s) is resident or done before (k, s) starts to wait.  The wait is
+// bounded all the same (~2 s): on a timeout the scene is flagged (R3D_S_CHAIN_TIMEOUT), its later
+// slots are skipped and the caller is told; nothing hangs and nothing is silently wrong.
 constexpr int kMaxChain = 8;
 struct ChainSlots {
   const double *samples5[kMaxChain];
@@ -1392,10 +1396,6 @@ struct ChainSlots {
   int32_t *accepted[kMaxChain];
 };
 
-__device__ __forceinline__ int xcc_id() {
-  return (int)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xF;   // HW_REG_XCC_ID[3:0]
-}
-
 __global__ void __launch_bounds__(kST)
 k_insert_chain(r3d_batch_t b, ChainSlots slots, int first_step, BatchWs w, int chunks) {
   extern __shared__ __align__(16) unsigned char smem[];     // all of the CU's LDS: no static __shared__ here
@@ -1405,21 +1405,22 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int first_step, BatchWs w, int c
   const int tid = threadIdx.x;
   if (k > 0) {
     if (tid == 0) {
-      int seen = 0;                                             // progress: slots done | xcc id << 8; < 0: abandoned
+      int seen = 0;                                             // progress: slots of the scene done; < 0: abandoned
       for (long long spin = 0; spin < (1ll << 21); ++spin) {
         seen = __hip_atomic_load(&w.chain_progress[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen < 0 || (seen & 0xFF) >= k) break;
+        if (seen < 0 || seen >= k) break;
         __builtin_amdgcn_s_sleep(32);
       }
-      int go = seen >= 0 && (seen & 0xFF) >= k;
-      if (go && (seen >> 8) != xcc_id()) {                      // not on the producer's XCD: its L2 may be stale
-        atomicOr(&b.status[s], R3D_S_CHAIN_LAYOUT);
-        go = 0;
-      } else if (!go && seen >= 0) {
-        atomicOr(&b.status[s], R3D_S_CHAIN_TIMEOUT);
-      }
+      int go = seen >= k;
+      if (!go && seen >= 0) atomicOr(&b.status[s], R3D_S_CHAIN_TIMEOUT);
       if (!go) __hip_atomic_store(&w.chain_progress[s], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_go = go;
+      // ONE agent-scope acquire after the relaxed poll: drops this CU's stale vector-L1 lines; the wait
+      // holds the barrier below until the invalidate has landed
+      if (go) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
     }
     __syncthreads();
     if (!s_go) {
@@ -1429,17 +1430,22 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int first_step, BatchWs w, int c
       }
       return;
     }
-    // what (k-1, s) wrote is in this XCD's L2: drop the CU's vector L1 and scalar cache
-    asm volatile("buffer_inv sc0\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // handed-off words also travel the scalar path (uniform loads of counters): drop the scalar cache too
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
   }
   bool rebase = insert_scene<true>(b, slots.samples5[k], slots.sample_off[k], slots.min_points[k], slots.active[k],
                                    first_step + k, slots.n_visible[k], slots.accepted[k], w, chunks, s, smem);
   __syncthreads();
   if (rebase) rebase_scene(b, w, chunks, s, s_min, s_max);     // rare; its phases use device-scope fences
-  __builtin_amdgcn_s_waitcnt(0);                                // this wave's stores have reached L2
+  // publish: every storing wave drains its stores, the workgroup meets, ONE lane does the agent-scope
+  // release (then waits again: the order fence -> wait -> flag matters) and stores the flag relaxed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0)
-    __hip_atomic_store(&w.chain_progress[s], (k + 1) | (xcc_id() << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&w.chain_progress[s], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // check/{f}.bin rows from the log (SS tools/datasets.py:73-75, :86-88; OD :77, :91-93).
@@ -1629,8 +1635,7 @@ int r3d_batch_insert_many(const r3d_batch_t *b, int32_t n_slots, const double *c
     if (!samples5[k] || !sample_off[k] || !min_points[k] || !n_visible[k] || !accepted[k])
       return fail(R3D_E_ARG, "batch_insert_many: null pointer in a slot");
   static const bool no_chain = getenv("R3D_NO_CHAIN") != nullptr;      // escape hatch: always one launch per slot
-  if (b->B % 8 != 0 || no_chain) {
-    // the chained kernel needs slot k of a scene on the XCD of slot k-1 (see k_insert_chain): one launch per slot
+  if (no_chain) {
     for (int k = 0; k < n_slots; ++k) {
       rc = r3d_batch_insert(b, samples5[k], sample_off[k], min_points[k], active ? active[k] : nullptr, first_step + k,
                             n_visible[k], accepted[k], stream);

@@ -379,10 +379,10 @@ def test_far_pixels_on_a_large_grid_are_reported(P, synth):
 
 @pytest.mark.parametrize("n_scenes", [8, 6])
 def test_insert_many_equals_slot_by_slot_calls(P, synth, n_scenes):
-    """r3d_batch_insert_many against the oracle chain: with 8 scenes the slots run in one launch
-    (slot k of a scene waits only for slot k-1 of the same scene), with 6 as one launch per slot.
-    Rejected slots, forced rebases in the middle of the chain, ragged scenes, an empty sample,
-    and more slots (9) than one launch takes (8)."""
+    """r3d_batch_insert_many against the oracle chain: the slots run in one launch in which slot k of
+    a scene waits only for slot k-1 of the same scene (batch sizes that are and are not a multiple of
+    the number of XCDs).  Rejected slots, forced rebases in the middle of the chain, ragged scenes,
+    an empty sample, and more slots (9) than one launch takes (8)."""
     import torch
     cases = []
     for s in range(n_scenes):
