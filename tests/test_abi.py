@@ -46,6 +46,26 @@ def test_batch_descriptor_matches_header(pkg):
     assert ctypes.sizeof(pkg._lib.BatchDesc) == 4 * 4 + 2 * 8 + 21 * 8 + 2 * 8
 
 
+def test_place_query_matches_header(pkg):
+    """r3d_place_query_t: field order of the ctypes mirror = field order of the header, natural
+    alignment (the library never sees a query built with another layout than it reads)."""
+    text = open(os.path.join(ROOT, "include", "real3daug_hip.h")).read()
+    body = re.search(r"typedef struct r3d_place_query_t \{(.*?)\} r3d_place_query_t;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.replace("*", " ").replace("const", " ").split()
+        first = names.index(next(n for n in names if n not in
+                                 ("int32_t", "int64_t", "uint32_t", "uint8_t", "uint64_t", "float", "double")))
+        fields += [re.sub(r"\[.*", "", n.strip(",")) for n in names[first:]]
+    assert [f for f, _ in pkg._lib.PlaceQuery._fields_] == fields
+    assert ctypes.sizeof(pkg._lib.PlaceQuery) == 7 * 8 + 2 * 8 + 10 * 4 + 8 * 4 + 4 * 8 + (10 + 8 + 2) * 8 + 2 * 8 + 2 * 4 + 8
+    assert len(pkg.places.search_radii_sq()) == 49 and pkg.places.search_radii_sq()[0] == 0.1 ** 2
+
+
 def test_bad_arguments_are_reported_without_a_gpu(pkg):
     lib = pkg._lib.load()
     assert lib.r3d_add_space_for_spherical(None, -1, None, None) == -1
