@@ -73,6 +73,17 @@ def test_bad_arguments_are_reported_without_a_gpu(pkg):
     assert lib.r3d_fill_spherical(None, 0, None, None, None) == -1
     assert lib.r3d_front_view_workspace_bytes(112, 1440) >= 112 * 1440 * 8
     assert lib.r3d_batch_workspace_bytes(None) == 0
+    # the later levels: placement search, cut boxes, rich map
+    assert lib.r3d_places_workspace_bytes(0, 0) == 0 and lib.r3d_places_workspace_bytes(4, 3) > 4 * 360 * 8
+    assert lib.r3d_find_possible_places(None, 1, 0, 0, 1, 0, None, 1, None, None, None, None, None, 0, None, None, 0, None) == -1
+    assert b"places" in lib.r3d_last_error()
+    assert lib.r3d_cut_boxes_workspace_bytes(1000, 0) == 0 and lib.r3d_cut_boxes_workspace_bytes(1000, 2) > 0
+    assert lib.r3d_cut_boxes(None, 10, 5, 4, None, None, 1, 1, None, None, 10, None, 0, None) == -1
+    assert lib.r3d_map_bounds(None, 10, None, None, None) == -1
+    assert lib.r3d_map_finish(None, 0, None, None, None) == -1
+    assert lib.r3d_places_chunk_ranges(None, 10, 4, None, None) == -1
+    assert lib.r3d_batch_insert_many(None, 1, None, None, None, None, 1, None, None, None) == -1
+    assert lib.r3d_batch_export_rows(None, None, None, None) == -1
 
 
 def test_no_cpu_fallback(pkg):
