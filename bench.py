@@ -324,7 +324,6 @@ def main():
         # per-slot launches: 5 x (k_insert + idle k_rebase); otherwise one k_insert_chain launch
         t_insert_all = event_time_ms(torch, five_inserts) - t_begin
         batch.finish(check_cols=0)
-        t_count = event_time_ms(torch, one(L.K_ALIVE_COUNT))
         t_write = event_time_ms(torch, one(L.K_ALIVE_WRITE))
         t_finish = event_time_ms(torch, lambda: batch.finish(check_cols=0))
         n_out_pts = float(batch.n_out.sum().item())
@@ -338,9 +337,8 @@ def main():
             **({"k_insert": {"ms": t_insert_all / len(KINDS), "launches_per_step": len(KINDS),
                              "alg_bytes": 80.0 * m_pts / len(KINDS)}} if args.per_slot_launches else
                {"k_insert_chain": {"ms": t_insert_all, "launches_per_step": 1, "alg_bytes": 80.0 * m_pts}}),
-            "k_alive_count": {"ms": t_count, "launches_per_step": 1, "alg_bytes": 4.0 * n_pts},
             "k_alive_write": {"ms": t_write, "launches_per_step": 1, "alg_bytes": 20.0 * n_pts + 20.0 * n_out_pts},
-            "k_prepare": {"ms": t_reset, "launches_per_step": 1, "alg_bytes": B * batch.rows * batch.cols / 8.0},
+            "k_prepare": {"ms": t_reset, "launches_per_step": 1, "alg_bytes": 0.0},
         }
         pmc = {}
         try:

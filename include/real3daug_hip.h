@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define R3D_VERSION 0x00010000
+#define R3D_VERSION 0x00020000
 
 #define R3D_NUMROW 112        /* insertion.py:22 */
 #define R3D_NUMCOLUMN 1440    /* insertion.py:23; the pixel id always multiplies by THIS (:116,:127) */
@@ -56,8 +56,9 @@ extern "C" {
 #define R3D_S_CAPACITY 16         /* batched path: merged cloud / log would exceed its capacity */
 #define R3D_S_FAR_OVERFLOW 32     /* batched path: more than R3D_FAR_CAP pixels beyond 500 m */
 #define R3D_S_CHAIN_TIMEOUT 128   /* r3d_batch_insert_many: a slot gave up waiting for the scene's previous slot */
-#define R3D_S_WINDOW_TOO_LARGE 64 /* batched path: the insert's window of the range image does not fit the
-                                     kernel's LDS (far pixels on a range image much larger than 112x1440) */
+#define R3D_S_WINDOW_TOO_LARGE 64 /* batched path: the bit images of the insert's window of the range image plus the
+                                     sample's per-point arrays exceed one CU's LDS (a sample that covers more
+                                     than ~200 000 pixels) */
 
 #define R3D_MAX_SAMPLE 8192       /* points per insert candidate in the batched path */
 #define R3D_FAR_CAP 1024
@@ -148,12 +149,7 @@ typedef struct r3d_batch {
   double *log5;          /* [B*log_cap][5] x y z intensity label, float64 as the sample had them */
   int32_t *log_birth;    /* [B*log_cap] step at which the row was inserted */
   int32_t *n_log;        /* [B] */
-  /* per-scene range-image state */
-  uint64_t *grid;        /* [B*rows*cols] scratch: scene range image (bits of min r) inside the window
-                            of the insert being evaluated; all-ones (= empty) between calls */
-  uint64_t *sgrid;       /* [B*rows*cols] scratch: sample range image, all-ones between calls */
-  uint16_t *stamp;       /* [B*rows*cols] last step at which the pixel was visible (0 = never) */
-  uint32_t *ever;        /* [B*ceil(rows*cols/32)] bit set = stamp != 0 */
+  /* per-scene range-image state (pixel ids above; liveness, chunk boxes and tile counts live in the workspace) */
   double *bounds;        /* [B][2] max elevation, min elevation */
   int32_t *far_pix;      /* [B*R3D_FAR_CAP] occupied pixels deeper than 500 m */
   int32_t *n_far;        /* [B] */
@@ -169,8 +165,8 @@ typedef struct r3d_batch {
 
 size_t r3d_batch_workspace_bytes(const r3d_batch_t *b);
 
-/* Once per descriptor, before the first r3d_batch_begin: marks the two scratch range images
- * (grid, sgrid) all-empty.  Every later call leaves them all-empty again. */
+/* Once per descriptor, before the first r3d_batch_begin: the tables that depend only on the shape
+ * (column edges of the projection). */
 int r3d_batch_create(const r3d_batch_t *b, void *stream);
 
 /* Step 0 (insertion.py:362, :373-375 for every scene): n_points (device int32[B]) points per
@@ -220,9 +216,8 @@ int r3d_batch_export_rows(const r3d_batch_t *b, double *rows4, int32_t *n_rows, 
  * (BOUNDS, RESET, PROJECT) or r3d_batch_finish (ALIVE_COUNT, ALIVE_WRITE) leaves; every one of
  * them is idempotent on that state. */
 #define R3D_K_BOUNDS 1        /* k_bounds: min / max of z/r per scene (insertion.py:74-79) */
-#define R3D_K_PREPARE 2       /* k_prepare: bounds from the extremes, row-edge table, visibility stamps to zero */
+#define R3D_K_PREPARE 2       /* k_prepare: bounds from the extremes, row-edge table, living points per tile */
 #define R3D_K_PROJECT 3       /* k_project: pixel id of every point (insertion.py:74-76, :104-116) */
-#define R3D_K_ALIVE_COUNT 4   /* k_alive_count: survivor bits and per-tile counts (insertion.py:472-473) */
 #define R3D_K_ALIVE_WRITE 5   /* k_alive_write: survivors, original order, into out_xyzi / out_label */
 int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream);
 

@@ -23,10 +23,10 @@ STATUS_TEXT = {
     S_SAMPLE_TOO_LARGE: "sample has more than R3D_MAX_SAMPLE points",
     S_CAPACITY: "merged cloud or insert log exceeds its capacity",
     S_FAR_OVERFLOW: "more than R3D_FAR_CAP pixels deeper than 500 m",
-    S_WINDOW_TOO_LARGE: "the insert's window of the range image does not fit the kernel's LDS",
+    S_WINDOW_TOO_LARGE: "the insert's window of the range image and the sample's arrays do not fit one CU's LDS",
     S_CHAIN_TIMEOUT: "insert_many: a slot gave up waiting for the scene's previous slot",
 }
-K_BOUNDS, K_PREPARE, K_PROJECT, K_ALIVE_COUNT, K_ALIVE_WRITE = 1, 2, 3, 4, 5
+K_BOUNDS, K_PREPARE, K_PROJECT, K_ALIVE_WRITE = 1, 2, 3, 5
 NUMROW, NUMCOLUMN = 112, 1440
 MAX_SAMPLE = 8192
 FAR_CAP = 1024
@@ -44,7 +44,6 @@ class BatchDesc(C.Structure):
         ("xyzi", C.c_void_p), ("label", C.c_void_p), ("pix", C.c_void_p),
         ("n_head", C.c_void_p), ("n_total", C.c_void_p), ("tail_ref", C.c_void_p),
         ("log5", C.c_void_p), ("log_birth", C.c_void_p), ("n_log", C.c_void_p),
-        ("grid", C.c_void_p), ("sgrid", C.c_void_p), ("stamp", C.c_void_p), ("ever", C.c_void_p),
         ("bounds", C.c_void_p), ("far_pix", C.c_void_p),
         ("n_far", C.c_void_p), ("rebase", C.c_void_p), ("status", C.c_void_p),
         ("out_xyzi", C.c_void_p), ("out_label", C.c_void_p), ("n_out", C.c_void_p),

@@ -27,15 +27,13 @@ class SceneBatch:
     last_rebases = 0      # rebases counted by the most recent augment_batch (diagnostics / tests)
 
     def __init__(self, B, cap, log_cap, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN, device="cuda:0",
-                 exact_projection=False):
+                 exact_projection=False, debug=0):
         torch = _lib.require_gpu()
         self.torch = torch
         self.lib = _lib.load()
         self.device = torch.device(device)
         cap = (int(cap) + 63) // 64 * 64          # whole 64-point chunks per slab (chunk tables of the placement search)
         self.B, self.cap, self.log_cap, self.rows, self.cols = int(B), int(cap), int(log_cap), int(rows), int(cols)
-        npix = self.rows * self.cols
-        words = (npix + 31) // 32
         dev = self.device
 
         def z(shape, dt):
@@ -50,10 +48,6 @@ class SceneBatch:
         self.log5 = z((B, log_cap, 5), torch.float64)
         self.log_birth = z((B, log_cap), torch.int32)
         self.n_log = z((B,), torch.int32)
-        self.grid = z((B, npix), torch.int64)
-        self.sgrid = z((B, npix), torch.int64)
-        self.stamp = z((B, npix), torch.int16)
-        self.ever = z((B, words), torch.int32)
         self.bounds = z((B, 2), torch.float64)
         self.far_pix = z((B, _lib.FAR_CAP), torch.int32)
         self.n_far = z((B,), torch.int32)
@@ -71,9 +65,10 @@ class SceneBatch:
         d = _lib.BatchDesc()
         # reserved bit 0: evaluate the reference's float64 formula for every point instead of the
         # verified float32 guess (diagnostic; results are identical, tests/test_gpu_batch.py)
-        d.B, d.rows, d.cols, d.reserved, d.cap, d.log_cap = B, rows, cols, 1 if exact_projection else 0, cap, log_cap
+        # `debug`: further diagnostic bits (2 / 4 / 8 / 16: force the insert kernel's other routes, csrc/r3d_insert.hip)
+        d.B, d.rows, d.cols, d.reserved, d.cap, d.log_cap = B, rows, cols, (1 if exact_projection else 0) | int(debug), cap, log_cap
         for name in ("xyzi", "label", "pix", "n_head", "n_total", "tail_ref", "log5", "log_birth", "n_log",
-                     "grid", "sgrid", "stamp", "ever", "bounds", "far_pix", "n_far", "rebase",
+                     "bounds", "far_pix", "n_far", "rebase",
                      "status", "out_xyzi", "out_label", "n_out"):
             setattr(d, name, getattr(self, name).data_ptr())
         d.workspace, d.workspace_bytes = 0, 0

@@ -1,0 +1,250 @@
+// Shared by the translation units of the batched path (Level 2): r3d_batch.hip (step 0, rebase,
+// compaction) and r3d_insert.hip (the insert kernels).
+//
+// State of a scene between r3d_batch_begin and r3d_batch_finish:
+//   pix[i]         pixel id of point i under the scene's current elevation bounds; written by the
+//                  projection (step 0 / rebase) and for appended points, never changed otherwise
+//   alive bit i    one bit per point, 64 points ("chunk") per word: cleared when the point's pixel
+//                  turns visible for an accepted insert (insertion.py:472-473), set for appended points
+//   chunk_box[c]   row / column bounding box of the pixels of chunk c (all of its points, dead or alive)
+//   tile_alive[t]  living points of the 2048-point tile t: the compaction's offsets without a counting pass
+#pragma once
+
+#include "r3d_device.hpp"
+#include "r3d_host.hpp"
+
+namespace r3d {
+
+constexpr int kPT = 256;             // threads of the streaming kernels
+constexpr int kPerThread = 8;
+constexpr int kTile = kPT * kPerThread;   // points per block tile
+constexpr int kKeyCap = R3D_MAX_SAMPLE;
+constexpr int kMaxChain = 32;        // insert slots of one k_insert_chain launch
+constexpr int kRecInts = 16;         // int32 words of a published slot record
+
+struct BatchWs {
+  unsigned long long *qkeys;    // [B][2] ordered keys of min / max of z/r
+  int32_t *tile_alive;          // [B*tiles] living points per tile
+  uint32_t *cand;               // [B*cand_stride] per-scene scratch lists (slow-projection queue; insert fallbacks)
+  int32_t *all_list;            // [B] identity
+  int32_t *all_count;           // [1] = B
+  unsigned long long *chunk_box; // [B*chunks] rows/cols bounding box of 64 consecutive points
+  unsigned long long *alive;    // [B*chunks] alive bit of every point
+  double *row_q;                // [B*(rows+2)] c*|c|, c = cos of the row edges (entry k: edge k-1)
+  double *col_dir;              // [(cols+1)*2] unit vector of every column edge
+  double *q_ext;                // [B*2] min and max of z/r (the points that hold the elevation bounds)
+  int32_t *n_slow;              // [B] points queued for k_project_slow
+  int32_t *chain_progress;      // [B] slots of the scene completed by the running k_insert_chain (< 0: see r3d_insert.hip)
+  int32_t *n_total0;            // [B] n_total when the running k_insert_chain was launched
+  int32_t *defer_from;          // [B] first slot of the launch left to k_insert_big (n_slots: none)
+  int32_t *recs;                // [B*kMaxChain*kRecInts] what every finished slot of the launch publishes
+  int64_t cand_stride;          // uint32 entries of `cand` per scene
+  size_t total;
+};
+
+inline int tiles_of(const r3d_batch_t &b) { return (int)((b.cap + kTile - 1) / kTile); }
+inline int chunks_of(const r3d_batch_t &b) { return (int)((b.cap + 63) / 64); }
+
+inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
+  BatchWs w;
+  Carver c(base);
+  int tiles = tiles_of(b);
+  w.qkeys = c.take<unsigned long long>((size_t)b.B * 2);
+  w.tile_alive = c.take<int32_t>((size_t)b.B * tiles);
+  // per-scene scratch: the slow-projection queue (<= cap entries); far pixels and their minima
+  int64_t need = 4 * R3D_FAR_CAP + 64;
+  w.cand_stride = need > b.cap ? need : b.cap;
+  w.cand_stride = (w.cand_stride + 1) & ~(int64_t)1;
+  w.cand = c.take<uint32_t>((size_t)b.B * w.cand_stride);
+  w.all_list = c.take<int32_t>((size_t)b.B);
+  w.all_count = c.take<int32_t>(1);
+  w.chunk_box = c.take<unsigned long long>((size_t)b.B * chunks_of(b));
+  w.alive = c.take<unsigned long long>((size_t)b.B * chunks_of(b));
+  w.row_q = c.take<double>((size_t)b.B * (b.rows + 2));
+  w.col_dir = c.take<double>((size_t)(b.cols + 1) * 2);
+  w.q_ext = c.take<double>((size_t)b.B * 2);
+  w.n_slow = c.take<int32_t>((size_t)b.B);
+  w.chain_progress = c.take<int32_t>((size_t)b.B);
+  w.n_total0 = c.take<int32_t>((size_t)b.B);
+  w.defer_from = c.take<int32_t>((size_t)b.B);
+  w.recs = c.take<int32_t>((size_t)b.B * kMaxChain * kRecInts);
+  w.total = c.off;
+  return w;
+}
+
+int check_batch(const r3d_batch_t *b);
+
+#ifdef __HIPCC__
+// ---- cloud access ---------------------------------------------------------------------------
+// A cloud point is float32-exact (head, from velodyne .bin) or a float64 inserted point (tail)
+// whose exact coordinates live in the log; xyzi holds the float32 rounding of tail points so the
+// output .bin bytes are a plain copy.
+__device__ __forceinline__ void load_point(const r3d_batch_t &b, int s, int i, int n_head, double &x,
+                                           double &y, double &z) {
+  if (i < n_head) {
+    float4 p = reinterpret_cast<const float4 *>(b.xyzi)[(int64_t)s * b.cap + i];
+    x = (double)p.x;
+    y = (double)p.y;
+    z = (double)p.z;
+  } else {
+    int lr = b.tail_ref[(int64_t)s * b.log_cap + (i - n_head)];
+    const double *q = b.log5 + ((int64_t)s * b.log_cap + lr) * 5;
+    x = q[0];
+    y = q[1];
+    z = q[2];
+  }
+}
+
+__device__ __forceinline__ unsigned long long pack_box(int rmin, int rmax, int cmin, int cmax) {
+  return (unsigned long long)(rmin & 0xFFFF) | ((unsigned long long)(rmax & 0xFFFF) << 16) |
+         ((unsigned long long)(cmin & 0xFFFF) << 32) | ((unsigned long long)(cmax & 0xFFFF) << 48);
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// Row / column bounding box of the pixels of one wave's 64 points.
+struct BoxAcc {
+  u16x2 lo = {0xFFFF, 0xFFFF}, hi = {0, 0};        // (row, col) minima and maxima
+  __device__ __forceinline__ void add(int row, int col) {
+    u16x2 v = {(unsigned short)row, (unsigned short)col};
+    lo = __builtin_elementwise_min(lo, v);
+    hi = __builtin_elementwise_max(hi, v);
+  }
+  __device__ __forceinline__ void add_box(unsigned long long bx) {      // union with a packed box
+    int rmin = (int)(bx & 0xFFFF), rmax = (int)((bx >> 16) & 0xFFFF);
+    if (rmin > rmax) return;                                            // empty
+    add(rmin, (int)((bx >> 32) & 0xFFFF));
+    add(rmax, (int)((bx >> 48) & 0xFFFF));
+  }
+  __device__ __forceinline__ unsigned long long wave_pack() {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {                 // two packed 16-bit reductions per step
+      int tl = __shfl_xor(__builtin_bit_cast(int, lo), o, 64);
+      int th = __shfl_xor(__builtin_bit_cast(int, hi), o, 64);
+      lo = __builtin_elementwise_min(lo, __builtin_bit_cast(u16x2, tl));
+      hi = __builtin_elementwise_max(hi, __builtin_bit_cast(u16x2, th));
+    }
+    return pack_box(lo.x, hi.x, lo.y, hi.y);           // rmin > rmax: empty box
+  }
+};
+
+// The reference formula for one point (insertion.py:74-76, :104-116) as a real function call: inlined,
+// the float64 atan2 / acos of the device library raise the register count of every kernel that
+// contains them by ~70 VGPRs.  ok: bit 0 row in range, bit 1 column in range, bit 2 angles finite,
+// bit 3 elevation outside [min_el, max_el].
+struct SphBin {
+  double r;
+  int row, col, ok;
+};
+static __device__ __attribute__((noinline)) SphBin spherical_bin(double max_el, double min_el, int rows, int cols, double x,
+                                                          double y, double z) {
+  Binning bn = make_binning(max_el, min_el, rows, cols);
+  Sph sp = spherical(x, y, z);
+  SphBin o;
+  o.r = sp.r;
+  o.ok = bin_point(bn, sp.az, sp.el, o.row, o.col);
+  if (isfinite(sp.el) && isfinite(sp.az)) o.ok |= 4;
+  if (sp.el < min_el || sp.el > max_el) o.ok |= 8;
+  return o;
+}
+
+// One scene point under the reference formula: returns its pixel, accumulates the wave's box, the far
+// list and the status flags.
+__device__ __forceinline__ int project_point(const r3d_batch_t &b, int s, const Binning &bn, double x,
+                                             double y, double z, int &flags, BoxAcc &box) {
+  SphBin sb = spherical_bin(bn.max_el, bn.min_el, bn.rows, bn.cols, x, y, z);
+  struct { double r; } sp = {sb.r};
+  int row = sb.row, col = sb.col, p = 0;
+  int ok = sb.ok;
+  if (!(ok & 1)) flags |= (ok & 4) ? R3D_S_ROW_RANGE : R3D_S_NONFINITE;          // assert :110
+  else if (!(ok & 2)) flags |= R3D_S_COL_RANGE;                                   // assert :112
+  else {
+    p = row * b.cols + col;
+    box.add(row, col);
+    if (sp.r > R3D_EMPTY_DEPTH) {           // "first hit overwrites the 500": insertion.py:122-125
+      int f = atomicAdd(&b.n_far[s], 1);
+      if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
+      else flags |= R3D_S_FAR_OVERFLOW;
+    }
+  }
+  return p;
+}
+
+__device__ __forceinline__ bool alive_bit(const BatchWs &w, int chunks, int s, int i) {
+  return (w.alive[(int64_t)s * chunks + (i >> 6)] >> (i & 63)) & 1ull;
+}
+
+// ---- rebase: one workgroup re-bases one scene (rare path) ------------------------------------------
+// Triggered when an accepted insert may have moved the elevation bounds.  Does, for that scene only,
+// what the reference does for every insert (insertion.py:373-375): recompute the bounds over the
+// living points and re-project them.  Dead points keep their (stale) pixel id and their cleared
+// alive bit; nothing is moved, the loaded input stays intact.  Phases are separated by a
+// device-scope fence + barrier because later phases re-read what earlier ones wrote.
+__device__ __forceinline__ void phase_sync() {
+  __threadfence();
+  __syncthreads();
+}
+
+template <int NT>
+__device__ __forceinline__ void rebase_scene(const r3d_batch_t &b, const BatchWs &w, int chunks, const int s,
+                                             unsigned long long *s_min, unsigned long long *s_max) {
+  const int tid = threadIdx.x;
+  const int n = b.n_total[s], n_head = b.n_head[s];
+  int32_t *pix = b.pix + (int64_t)s * b.cap;
+  // (a) bounds (insertion.py:78-79) via the extreme z/r of the living
+  unsigned long long lmin = ~0ull, lmax = 0ull;
+  int bad = 0;
+  for (int i = tid; i < n; i += NT) {
+    if (!alive_bit(w, chunks, s, i)) continue;
+    double x, y, z;
+    load_point(b, s, i, n_head, x, y, z);
+    double q = z / sqrt(x * x + y * y + z * z);
+    if (!(q >= -1.0 && q <= 1.0)) bad = 1;
+    else {
+      unsigned long long kq = ordered_key(q);
+      lmin = kq < lmin ? kq : lmin;
+      lmax = kq > lmax ? kq : lmax;
+    }
+  }
+  lmin = wave_min_u64(lmin);
+  lmax = wave_max_u64(lmax);
+  if ((tid & 63) == 0) {
+    s_min[tid >> 6] = lmin;
+    s_max[tid >> 6] = lmax;
+  }
+  if (bad) atomicOr(&b.status[s], R3D_S_NONFINITE);
+  __syncthreads();
+  if (tid == 0) {
+    for (int v = 1; v < NT / 64; ++v) {
+      lmin = s_min[v] < lmin ? s_min[v] : lmin;
+      lmax = s_max[v] > lmax ? s_max[v] : lmax;
+    }
+    double max_el = acos(ordered_key_inv(lmin)), min_el = acos(ordered_key_inv(lmax));
+    b.bounds[2 * s + 0] = max_el;
+    b.bounds[2 * s + 1] = min_el;
+    w.q_ext[2 * s + 0] = ordered_key_inv(lmin);
+    w.q_ext[2 * s + 1] = ordered_key_inv(lmax);
+    b.n_far[s] = 0;
+  }
+  phase_sync();
+  // (b) re-project the living (insertion.py:74-76, :104-116): pixel ids and chunk boxes
+  Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
+  int flags = 0;
+  for (int i0 = 0; i0 < n; i0 += NT) {
+    int i = i0 + tid;
+    BoxAcc box;
+    if (i < n && alive_bit(w, chunks, s, i)) {
+      double x, y, z;
+      load_point(b, s, i, n_head, x, y, z);
+      pix[i] = project_point(b, s, bn, x, y, z, flags, box);
+    }
+    unsigned long long packed = box.wave_pack();
+    int c0 = i0 + (tid & ~63);
+    if ((tid & 63) == 0 && c0 < n) w.chunk_box[(int64_t)s * chunks + (c0 >> 6)] = packed;
+  }
+  if (flags) atomicOr(&b.status[s], flags);
+  phase_sync();
+}
+#endif  // __HIPCC__
+
+}  // namespace r3d

@@ -1,0 +1,1418 @@
+// Level 2, the insert step: one placement candidate of one scene per workgroup
+// (insertion.py:455-526), all slots of all scenes of a call in ONE launch.
+//
+// What a workgroup does for (slot k, scene s) -- "pair" below:
+//   sample phase  (reads only the sample and the scene's elevation bounds)
+//     project the sample (reference formula, float64), window of the range image around it,
+//     occupancy bits, counting sort of the points by (pixel, index) = the order of visible_sample
+//     (:474-482), min depth per occupied pixel, 5x3 closing (closing.py:9-23) as word-parallel
+//     dilate / erode, list of candidate pixels (where the sample is closed).
+//   scene phase   (reads the scene: chunk boxes, alive bits, pixel ids, coordinates)
+//     the scene's range image inside the window, min-reduced in LDS from the LIVING points whose
+//     64-point chunk touches the window (:118-125); closing; on the candidates: smoothed sample depth
+//     < smoothed scene depth (closing.py:26-62, insertion.py:467); count, accept test (:511-517).
+//   commit        (writes the scene)
+//     append the visible points (:526), clear the alive bit of every scene point in a visible
+//     pixel (:470-473), extend chunk boxes / tile counts / far list / log.
+//
+// The K slots of ONE scene depend on each other, but only where they overlap in the image.  So a
+// pair evaluates SPECULATIVELY against the state the scene had when the pair started (the slots
+// < p0 that had finished by then), touching nothing; then it waits for slot k-1 of its scene,
+// reads what the slots p0..k-1 published (accepted? rows / columns of their visible pixels, a
+// rebase, a far pixel) and commits if none of them changed a pixel its evaluation read -- rows
+// [rmin-6, rmax+6] x columns [cmin-3, cmax+3] around its sample pixels: candidates lie within 2 rows
+// / 1 column of a sample pixel, their hole means look 2 / 1 further, their closing 4 / 2 further.
+// Otherwise it evaluates again, now after its predecessors.  The chain of a scene therefore costs one
+// evaluation plus K commits instead of K evaluations.
+//
+// Hand-off between the slots of a scene (cdna_hip_programming.md, Guideline 16; correct for any
+// placement of the workgroups): every storing wave drains (s_waitcnt vmcnt(0)), barrier, ONE lane does
+// the agent-scope release, waits again and stores the scene's progress word (relaxed, agent scope);
+// the consumer polls that word relaxed from ONE lane, then ONE agent-scope acquire + wait, barrier,
+// scalar cache dropped.  Reads of a speculative evaluation race with the commits of the scene's
+// running predecessors by design: those only write points and bits the evaluation either does not
+// look at (indices >= its base count) or that lie in pixels whose change is detected afterwards.
+// Liveness leans on in-order dispatch (workgroups are numbered slot-major, and a scene's slots stay
+// on block ids of one residue mod 8, i.e. on one XCD's queue); the wait is bounded by wall clock
+// all the same: R3D_S_CHAIN_TIMEOUT flags the scene, its later slots are skipped.
+//
+// Working set: everything lives in the workgroup's LDS (`lds_cap` bytes, a few workgroups per CU).
+// A pair whose depth tile, candidate list or chunk list does not fit uses the scene's global
+// scratch instead and therefore runs after its predecessors; a pair whose per-point arrays do not
+// fit either is left, with the rest of its scene's chain, to k_insert_big (one 1024-thread
+// workgroup with all of a CU's LDS per scene, launched behind the chain kernel, idle otherwise).
+#include "r3d_batch.hpp"
+
+#include <cstdlib>
+
+namespace r3d {
+
+// diagnostic bits of r3d_batch_t.reserved (tests force every path with them)
+constexpr int kDbgSerial = 2;        // never speculate
+constexpr int kDbgBands = 4;         // the depth tile in bands of at most 3 candidate rows
+constexpr int kDbgDefer = 8;         // every pair is left to k_insert_big
+constexpr int kDbgDropPublish = 16;  // slot 0 of scene 0 does not publish: its successors time out
+
+struct ChainSlots {
+  const double *samples5[kMaxChain];
+  const int64_t *sample_off[kMaxChain];
+  const int32_t *min_points[kMaxChain];
+  const int32_t *active[kMaxChain];
+  int32_t *n_visible[kMaxChain];
+  int32_t *accepted[kMaxChain];
+};
+
+// published record of a finished slot
+enum { REC_FLAGS = 0, REC_NTOTAL, REC_RLO, REC_RHI, REC_CLO0, REC_CHI0, REC_CLO1, REC_CHI1 };
+constexpr int kRecAccepted = 1, kRecRebased = 2, kRecFar = 4;
+constexpr int kProgTimeout = -1, kProgDeferred = -2;
+
+// ---- window of the range image: rows [r_lo, r_hi] x one or two column intervals of whole 32-pixel
+// words (two when the object straddles the azimuth seam) ---------------------------------------------
+struct Window {
+  int r_lo, r_hi, n_iv, jl0, jh0, jl1, jh1, nj0, njw, nrw, cols;
+  // window-local word index of image word (row r, word j), -1 outside the window
+  __device__ __forceinline__ int lword(int r, int j) const {
+    if (r < r_lo || r > r_hi) return -1;
+    int k;
+    if (j >= jl0 && j <= jh0) k = j - jl0;
+    else if (n_iv > 1 && j >= jl1 && j <= jh1) k = nj0 + j - jl1;
+    else return -1;
+    return (r - r_lo) * njw + k;
+  }
+  __device__ __forceinline__ int row_of(int e) const { return r_lo + e / njw; }      // e: local word
+  __device__ __forceinline__ int word_of(int e) const {
+    int k = e % njw;
+    return k < nj0 ? jl0 + k : jl1 + (k - nj0);
+  }
+  __device__ __forceinline__ int lpix_rc(int r, int c) const {  // window-local pixel, -1 outside
+    int lw = lword(r, c >> 5);
+    return lw < 0 ? -1 : (lw << 5) + (c & 31);
+  }
+  __device__ __forceinline__ bool touches_words(int jmin, int jmax) const {
+    return (jmin <= jh0 && jmax >= jl0) || (n_iv > 1 && jmin <= jh1 && jmax >= jl1);
+  }
+};
+
+// The pixels whose scene depth an evaluation reads: the window's rows x exact column intervals.
+struct DTile {
+  int r0, r1, n_iv, c00, c10, c01, c11, w0, W, npx;      // interval 0: [c00, c10], interval 1: [c01, c11]
+  __device__ __forceinline__ int index(int r, int c) const {
+    if (r < r0 || r > r1) return -1;
+    int k;
+    if (c >= c00 && c <= c10) k = c - c00;
+    else if (n_iv > 1 && c >= c01 && c <= c11) k = w0 + c - c01;
+    else return -1;
+    return (r - r0) * W + k;
+  }
+};
+
+struct WinImage {
+  uint32_t *w;
+  __device__ __forceinline__ bool get_local(int lp) const { return (w[lp >> 5] >> (lp & 31)) & 1u; }
+  __device__ __forceinline__ void set_local(int lp) { atomicOr(&w[lp >> 5], 1u << (lp & 31)); }
+  __device__ __forceinline__ uint32_t word(const Window &win, int r, int j) const {
+    int lw = win.lword(r, j);
+    return lw < 0 ? 0u : w[lw];
+  }
+};
+
+// OR of a word with its horizontal neighbours' bits (columns c-1, c, c+1), clipped at the row ends.
+__device__ __forceinline__ uint32_t hor3(const WinImage &m, const Window &win, int r, int j) {
+  uint32_t c = m.word(win, r, j), l = m.word(win, r, j - 1), rr = m.word(win, r, j + 1);
+  return c | (c << 1) | (l >> 31) | (c >> 1) | (rr << 31);
+}
+// AND of the same three columns; a neighbour outside the IMAGE does not constrain (erosion border).
+__device__ __forceinline__ uint32_t hand3(const WinImage &m, const Window &win, int r, int j, int wpr) {
+  uint32_t c = m.word(win, r, j);
+  uint32_t l = j > 0 ? (m.word(win, r, j - 1) >> 31) : 1u;
+  uint32_t rr = j < wpr - 1 ? (m.word(win, r, j + 1) << 31) : 0x80000000u;
+  return c & ((c << 1) | l) & ((c >> 1) | rr);
+}
+
+// closing.py:44-57 on up to 15 already loaded keys (R3D_SENT = empty): sum over the occupied ones,
+// drow outer / dcolumn inner, divided by their count.
+__device__ __forceinline__ double mean_of_keys(const unsigned long long (&v)[15]) {
+  double sum = 0.0;
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 15; ++k)
+    if (v[k] != R3D_SENT) {
+      ++cnt;
+      sum += key_depth(v[k]);
+    }
+  return cnt ? sum / (double)cnt : R3D_EMPTY_DEPTH;
+}
+
+// Diagnostic builds (make STAMPS=1) record a 100 MHz wall-clock stamp per phase in the first bytes
+// of the scene's out_xyzi slab (scratch until r3d_batch_finish), 16 stamps per slot;
+// tools/stamps_insert.py reads them.
+#ifdef R3D_STAMPS
+#define STAMP(i)                                                                                         \
+  do {                                                                                                   \
+    __syncthreads();                                                                                     \
+    if (tid == 0) reinterpret_cast<long long *>(b.out_xyzi + (int64_t)s * b.cap * 4)[slot_no * 16 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
+// header of a workgroup's LDS (ints)
+enum {
+  H_NVALID = 0, H_NCAND, H_REBASE, H_FLAGS, H_RMIN, H_RMAX, H_CMIN0, H_CMIN1, H_CMAX0, H_CMAX1,
+  H_NLIST, H_CARRY, H_EXT0, H_EXT1, H_NOCC, H_NVIS, H_VRMIN, H_VRMAX, H_VCMIN0, H_VCMIN1, H_VCMAX0,
+  H_VCMAX1, H_FARADD, H_FILL,
+  H_GO = 28,          // chain logic: broadcast cell (not touched by the phases)
+  H_SCAN = 32         // block scan cells [NT/64 + 1]
+};
+constexpr int kHdrBytes = 512;
+
+enum { kOk = 0, kNoFit = 1, kNeedSerial = 2 };
+
+// A value every lane holds (read from LDS or global memory): into a scalar register.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int NT>
+struct Ins {
+  const r3d_batch_t &b;
+  const BatchWs &w;
+  unsigned char *smem;
+  const int lds_cap, s, chunks, slot_no;
+  const int tid, rows, cols, npix, wpr;
+  int *H, *scan;
+  // the slot's candidate
+  const double *rows5;
+  int m, need, step;
+  // sample phase results
+  Binning bn;
+  Window win;
+  DTile dt;
+  int nvalid, ww, nocc, ncand, r1;
+  uint32_t *s_oob, *s_lp, *s_img, *s_rank;
+  uint16_t *s_F, *s_start;
+  unsigned long long *s_sdepth;
+  WinImage A, T, Cs, D, E;
+  // scene phase results
+  uint16_t *s_V;
+  uint32_t *s_cand;
+  unsigned long long *s_dtile;
+  unsigned char *s_list;                 // chunk list, 24-byte entries growing down from the end of the LDS
+  DTile bt;                              // the band of the tile currently in LDS
+  int list_cap, nlist, nvis, n_base, n_far;
+  bool accept;
+
+  __device__ __forceinline__ Ins(const r3d_batch_t &b_, const BatchWs &w_, unsigned char *smem_, int lds_cap_, int s_,
+                                 int chunks_, int slot_no_)
+      : b(b_), w(w_), smem(smem_), lds_cap(lds_cap_), s(s_), chunks(chunks_), slot_no(slot_no_), tid(threadIdx.x),
+        rows(b_.rows), cols(b_.cols), npix(b_.rows * b_.cols), wpr(b_.cols >> 5) {
+    H = reinterpret_cast<int *>(smem);
+    scan = H + H_SCAN;
+    nvalid = ww = nocc = ncand = nvis = nlist = 0;
+    accept = false;
+  }
+
+  // chunk list entry i: { alive word, kill mask, chunk number, rows of its box }
+  __device__ __forceinline__ unsigned long long &l_alive(int i) const {
+    return *reinterpret_cast<unsigned long long *>(s_list - 24 * (i + 1));
+  }
+  __device__ __forceinline__ unsigned long long &l_kill(int i) const {
+    return *reinterpret_cast<unsigned long long *>(s_list - 24 * (i + 1) + 8);
+  }
+  __device__ __forceinline__ uint32_t &l_chunk(int i) const {
+    return *reinterpret_cast<uint32_t *>(s_list - 24 * (i + 1) + 16);
+  }
+  __device__ __forceinline__ uint32_t &l_rows(int i) const {       // first row | last row << 16 of the chunk's box
+    return *reinterpret_cast<uint32_t *>(s_list - 24 * (i + 1) + 20);
+  }
+  __device__ __forceinline__ int rank_of(int lp) const {
+    return (int)s_rank[lp >> 5] + __popc(A.w[lp >> 5] & ((1u << (lp & 31)) - 1u));
+  }
+  __device__ __forceinline__ int global_pix(int lp) const {
+    return win.row_of(lp >> 5) * cols + (win.word_of(lp >> 5) << 5) + (lp & 31);
+  }
+  __device__ __forceinline__ unsigned long long sample_key(int lp) const {   // lp = window-local pixel
+    return A.get_local(lp) ? s_sdepth[rank_of(lp)] : R3D_SENT;
+  }
+  __device__ __forceinline__ unsigned long long scene_key(int r, int c) const {
+    int dl = bt.index(r, c);
+    return dl < 0 ? R3D_SENT : s_dtile[dl];
+  }
+
+  // ================================================================================================
+  // sample phase.  kOk, or kNoFit when the per-point / per-pixel arrays exceed this kernel's LDS.
+  // ================================================================================================
+  __device__ __forceinline__ int sample_phase() {
+    accept = false;
+    nvis = 0;
+    int carve = kHdrBytes;
+    s_oob = reinterpret_cast<uint32_t *>(smem + carve);
+    carve += ((m + 31) >> 5) * 4;
+    s_lp = reinterpret_cast<uint32_t *>(smem + carve);
+    carve += m * 4;
+    s_F = reinterpret_cast<uint16_t *>(smem + carve);
+    carve = (carve + m * 2 + 7) & ~7;
+    if (carve > lds_cap) return kNoFit;
+    __syncthreads();                                         // the previous use of this LDS is over
+    for (int i = tid; i < ((m + 31) >> 5); i += NT) s_oob[i] = 0u;
+    if (tid < H_GO)
+      H[tid] = (tid == H_RMIN || tid == H_CMIN0 || tid == H_CMIN1 || tid == H_VRMIN || tid == H_VCMIN0 || tid == H_VCMIN1)
+                   ? 0x7FFFFFFF
+                   : (tid == H_RMAX || tid == H_CMAX0 || tid == H_CMAX1 || tid == H_EXT0 || tid == H_EXT1 ||
+                      tid == H_VRMAX || tid == H_VCMAX0 || tid == H_VCMAX1)
+                         ? -1
+                         : 0;
+    __syncthreads();
+    bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], rows, cols);
+
+    STAMP(0);
+    // -- 1. project the sample with the scene's bounds, sample=True (insertion.py:455-459) ---------
+    {
+      // column ranges are kept per image half so that an object across the azimuth seam (columns
+      // 0 and cols-1) yields two narrow windows instead of one full-width window
+      const int half = cols >> 1;
+      int rmin = 0x7FFFFFFF, rmax = -1, cmin0 = 0x7FFFFFFF, cmax0 = -1, cmin1 = 0x7FFFFFFF, cmax1 = -1;
+      int nval = 0, flags = 0;
+      for (int j = tid; j < m; j += NT) {
+        uint32_t key = 0xFFFFFFFFu;
+        const double *q = rows5 + (int64_t)j * 5;
+        SphBin sb = spherical_bin(bn.max_el, bn.min_el, rows, cols, q[0], q[1], q[2]);
+        int row = sb.row, col = sb.col;
+        if (!(sb.ok & 4)) {
+          flags |= R3D_S_NONFINITE;
+        } else if (sb.ok & 1) {                      // rows outside [0, rows) are skipped (:107-108)
+          if (!(sb.ok & 2)) {
+            flags |= R3D_S_COL_RANGE;                // assert :112
+          } else {
+            key = ((uint32_t)row << 16) | (uint32_t)col;    // re-keyed by window pixel below
+            ++nval;
+            rmin = row < rmin ? row : rmin;
+            rmax = row > rmax ? row : rmax;
+            if (col < half) {
+              cmin0 = col < cmin0 ? col : cmin0;
+              cmax0 = col > cmax0 ? col : cmax0;
+            } else {
+              cmin1 = col < cmin1 ? col : cmin1;
+              cmax1 = col > cmax1 ? col : cmax1;
+            }
+            if (sb.ok & 8) atomicOr(&s_oob[j >> 5], 1u << (j & 31));
+          }
+        }
+        s_lp[j] = key;
+      }
+      nval = wave_sum_i32(nval);
+      flags = wave_or_i32(flags);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        int t;
+        t = __shfl_xor(rmin, o, 64); rmin = t < rmin ? t : rmin;
+        t = __shfl_xor(rmax, o, 64); rmax = t > rmax ? t : rmax;
+        t = __shfl_xor(cmin0, o, 64); cmin0 = t < cmin0 ? t : cmin0;
+        t = __shfl_xor(cmax0, o, 64); cmax0 = t > cmax0 ? t : cmax0;
+        t = __shfl_xor(cmin1, o, 64); cmin1 = t < cmin1 ? t : cmin1;
+        t = __shfl_xor(cmax1, o, 64); cmax1 = t > cmax1 ? t : cmax1;
+      }
+      if ((tid & 63) == 0) {
+        atomicAdd(&H[H_NVALID], nval);
+        if (flags) atomicOr(&H[H_FLAGS], flags);
+        atomicMin(&H[H_RMIN], rmin);
+        atomicMax(&H[H_RMAX], rmax);
+        atomicMin(&H[H_CMIN0], cmin0);
+        atomicMax(&H[H_CMAX0], cmax0);
+        atomicMin(&H[H_CMIN1], cmin1);
+        atomicMax(&H[H_CMAX1], cmax1);
+      }
+    }
+    __syncthreads();
+    nvalid = uni(H[H_NVALID]);
+
+    STAMP(1);
+    // -- 2. the window: candidates lie within 2 rows / 1 column of a sample pixel, their closing
+    // looks 4 rows / 2 columns further ---------------------------------------------------------------
+    win.cols = cols;
+    win.n_iv = 1;
+    win.jl0 = win.jl1 = win.jh1 = 0;
+    win.jh0 = -1;
+    win.r_lo = 0;
+    win.r_hi = -1;                                          // nothing valid: empty window
+    dt.n_iv = 0;
+    dt.c00 = dt.c01 = dt.c11 = 0;
+    dt.c10 = -1;
+    if (nvalid > 0) {
+      const int rmin = uni(H[H_RMIN]), rmax = uni(H[H_RMAX]);
+      const int cmin0 = uni(H[H_CMIN0]), cmax0 = uni(H[H_CMAX0]), cmin1 = uni(H[H_CMIN1]), cmax1 = uni(H[H_CMAX1]);
+      win.r_lo = rmin - 6 < 0 ? 0 : rmin - 6;
+      win.r_hi = rmax + 6 > rows - 1 ? rows - 1 : rmax + 6;
+      const bool h0 = cmax0 >= 0, h1 = cmax1 >= 0;
+      // exact column interval of either image half, and the whole words that hold it
+      const int lo0 = cmin0 - 3 < 0 ? 0 : cmin0 - 3, hi0 = cmax0 + 3 > cols - 1 ? cols - 1 : cmax0 + 3;
+      const int lo1 = cmin1 - 3 < 0 ? 0 : cmin1 - 3, hi1 = cmax1 + 3 > cols - 1 ? cols - 1 : cmax1 + 3;
+      if (h0 && h1) {
+        const bool merge_w = (lo1 >> 5) <= (hi0 >> 5) + 1, merge_c = lo1 <= hi0 + 1;
+        win.n_iv = merge_w ? 1 : 2;
+        win.jl0 = lo0 >> 5;
+        win.jh0 = merge_w ? ((hi1 >> 5) > (hi0 >> 5) ? (hi1 >> 5) : (hi0 >> 5)) : (hi0 >> 5);
+        win.jl1 = merge_w ? 0 : (lo1 >> 5);
+        win.jh1 = merge_w ? 0 : (hi1 >> 5);
+        dt.n_iv = merge_c ? 1 : 2;
+        dt.c00 = lo0;
+        dt.c10 = merge_c ? (hi1 > hi0 ? hi1 : hi0) : hi0;
+        dt.c01 = merge_c ? 0 : lo1;
+        dt.c11 = merge_c ? 0 : hi1;
+      } else {
+        const int lo = h0 ? lo0 : lo1, hi = h0 ? hi0 : hi1;
+        win.jl0 = lo >> 5;
+        win.jh0 = hi >> 5;
+        dt.n_iv = 1;
+        dt.c00 = lo;
+        dt.c10 = hi;
+      }
+    }
+    win.nj0 = win.jh0 - win.jl0 + 1;
+    win.njw = win.nj0 + (win.n_iv > 1 ? win.jh1 - win.jl1 + 1 : 0);
+    win.nrw = win.r_hi - win.r_lo + 1;
+    ww = win.nrw * win.njw;                                 // window words
+    dt.r0 = win.r_lo;
+    dt.r1 = win.r_hi;
+    dt.w0 = dt.c10 - dt.c00 + 1;
+    dt.W = dt.n_iv == 0 ? 0 : dt.w0 + (dt.n_iv > 1 ? dt.c11 - dt.c01 + 1 : 0);
+    dt.npx = win.nrw * dt.W;
+
+    // bit images: sample occupancy | scratch (dilations, then visible pixels) | sample closed |
+    // scene occupancy | scene closed | occupied sample pixels before each window word
+    if ((int64_t)carve + 6ll * ww * 4 > lds_cap) return kNoFit;
+    s_img = reinterpret_cast<uint32_t *>(smem + carve);
+    carve = (carve + 6 * ww * 4 + 7) & ~7;
+    A.w = s_img;
+    T.w = s_img + ww;
+    Cs.w = s_img + 2 * ww;
+    D.w = s_img + 3 * ww;
+    E.w = s_img + 4 * ww;
+    s_rank = s_img + 5 * ww;
+    for (int i = tid; i < 6 * ww; i += NT) s_img[i] = 0u;
+    // every valid sample pixel lies inside the window
+    for (int j = tid; j < m; j += NT) {
+      uint32_t rc = s_lp[j];
+      if (rc != 0xFFFFFFFFu) s_lp[j] = (uint32_t)win.lpix_rc((int)(rc >> 16), (int)(rc & 0xFFFF));
+    }
+    __syncthreads();
+
+    STAMP(2);
+    // -- 3. sample occupancy, rank of every occupied sample pixel ------------------------------------
+    for (int j = tid; j < m; j += NT) {
+      uint32_t lp = s_lp[j];
+      if (lp != 0xFFFFFFFFu) A.set_local((int)lp);
+    }
+    __syncthreads();
+    for (int base = 0; base < ww; base += NT) {            // exclusive prefix popcount over the words
+      int e = base + tid;
+      int c = e < ww ? __popc(A.w[e]) : 0;
+      int tot;
+      int ex = block_escan_i32(c, scan, tot);
+      int carry0 = H[H_CARRY];
+      if (e < ww) s_rank[e] = (uint32_t)(carry0 + ex);
+      __syncthreads();
+      if (tid == 0) H[H_CARRY] = carry0 + tot;
+      __syncthreads();
+    }
+    nocc = uni(H[H_CARRY]);
+
+    // per occupied pixel: first sorted point, min depth; scratch: counters, unordered placement
+    s_start = reinterpret_cast<uint16_t *>(smem + carve);
+    carve = (carve + (nocc + 1) * 2 + 7) & ~7;
+    s_sdepth = reinterpret_cast<unsigned long long *>(smem + carve);
+    carve += nocc * 8;
+    r1 = carve;                                             // scratch from here on
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + carve);
+    uint16_t *s_U = reinterpret_cast<uint16_t *>(smem + carve + nocc * 4);
+    if (carve + nocc * 4 + nvalid * 2 > lds_cap) return kNoFit;
+    for (int i = tid; i < nocc; i += NT) {
+      s_cnt[i] = 0u;
+      s_sdepth[i] = R3D_SENT;
+    }
+    if (tid == 0) H[H_CARRY] = 0;
+    __syncthreads();
+
+    STAMP(3);
+    // -- 4. counting sort by (pixel, sample index): the order of visible_sample (insertion.py:474-482)
+    for (int j = tid; j < m; j += NT) {
+      uint32_t lp = s_lp[j];
+      if (lp != 0xFFFFFFFFu) atomicAdd(&s_cnt[rank_of((int)lp)], 1u);
+    }
+    __syncthreads();
+    for (int base = 0; base < nocc; base += NT) {
+      int e = base + tid;
+      int c = e < nocc ? (int)s_cnt[e] : 0;
+      int tot;
+      int ex = block_escan_i32(c, scan, tot);
+      int carry0 = H[H_CARRY];
+      if (e < nocc) {
+        s_start[e] = (uint16_t)(carry0 + ex);
+        s_cnt[e] = (uint32_t)(carry0 + ex);                 // the pixel's cursor
+      }
+      __syncthreads();
+      if (tid == 0) H[H_CARRY] = carry0 + tot;
+      __syncthreads();
+    }
+    if (tid == 0) s_start[nocc] = (uint16_t)nvalid;
+    for (int j = tid; j < m; j += NT) {
+      uint32_t lp = s_lp[j];
+      if (lp != 0xFFFFFFFFu) s_U[atomicAdd(&s_cnt[rank_of((int)lp)], 1u)] = (uint16_t)j;
+    }
+    __syncthreads();
+    // a point's place inside its pixel's run = how many points of the run have a smaller index;
+    // depth of the pixel = min r over its points (insertion.py:118-125)
+    for (int j = tid; j < m; j += NT) {
+      uint32_t lp = s_lp[j];
+      if (lp == 0xFFFFFFFFu) continue;
+      int rk = rank_of((int)lp);
+      int a = s_start[rk], z = s_start[rk + 1], before = 0;
+      for (int p = a; p < z; ++p) before += (int)s_U[p] < j ? 1 : 0;
+      s_F[a + before] = (uint16_t)j;
+      const double *q = rows5 + (int64_t)j * 5;
+      double x = q[0], y = q[1], zc = q[2];
+      unsigned long long key = depth_key(sqrt(x * x + y * y + zc * zc));
+      atomicMin(&s_sdepth[rk], key);
+    }
+    __syncthreads();
+
+    STAMP(4);
+    // -- 5. closing of the sample's occupancy (closing.py:9-23) by word-parallel dilate / erode; exact
+    // on every row at least 2 inside the window (or at the image border): candidates are ------------
+    for (int pass = 0; pass < 2; ++pass) {
+      const WinImage &src = pass == 0 ? A : T;
+      WinImage &dst = pass == 0 ? T : Cs;
+      for (int e = tid; e < ww; e += NT) {
+        int r = win.row_of(e), j = win.word_of(e);
+        uint32_t acc = pass ? 0xFFFFFFFFu : 0u;
+        for (int dr = -2; dr <= 2; ++dr) {
+          int rr = r + dr;
+          if (rr < 0 || rr >= rows) continue;
+          if (pass) acc &= hand3(src, win, rr, j, wpr);
+          else acc |= hor3(src, win, rr, j);
+        }
+        dst.w[e] = acc;
+      }
+      __syncthreads();
+    }
+    // candidate pixels: where the sample is closed
+    {
+      int c = 0;
+      for (int e = tid; e < ww; e += NT) c += __popc(Cs.w[e]);
+      c = wave_sum_i32(c);
+      if ((tid & 63) == 0 && c) atomicAdd(&H[H_NCAND], c);
+    }
+    __syncthreads();
+    ncand = uni(H[H_NCAND]);
+    STAMP(5);
+    return kOk;
+  }
+
+  // The chunks that can hold a point of the window: bounding box touches it, somebody alive (4 chunks
+  // per thread in flight).
+  __device__ __forceinline__ void build_list(const unsigned long long *boxes, const unsigned long long *alive, int n_chunks) {
+    constexpr int kU = 4;
+    for (int c0 = tid; c0 < n_chunks; c0 += kU * NT) {
+      unsigned long long bx[kU], aw[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        int c = c0 + u * NT;
+        bx[u] = c < n_chunks ? boxes[c] : 0xFFFFull;          // empty box
+        aw[u] = c < n_chunks ? __hip_atomic_load(&alive[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        int c = c0 + u * NT;
+        int left = n_base - (c << 6);                       // points of the chunk below the base count
+        unsigned long long a = aw[u];
+        if (left < 64) a = left > 0 ? a & ((1ull << left) - 1ull) : 0ull;
+        int rmin = (int)(bx[u] & 0xFFFF), rmax = (int)((bx[u] >> 16) & 0xFFFF);
+        int jmin = (int)((bx[u] >> 32) & 0xFFFF) >> 5, jmax = (int)((bx[u] >> 48) & 0xFFFF) >> 5;
+        bool hit = a && rmin <= win.r_hi && rmax >= win.r_lo && win.touches_words(jmin, jmax);
+        if (hit) {
+          int slot = atomicAdd(&H[H_NLIST], 1);
+          if (slot < list_cap) {
+            l_alive(slot) = a;
+            l_kill(slot) = 0ull;
+            l_chunk(slot) = (uint32_t)c;
+            l_rows(slot) = (uint32_t)rmin | ((uint32_t)rmax << 16);
+          }
+        }
+      }
+    }
+  }
+
+  // The living points of the listed chunks whose pixel lies in rows [bt.r0, bt.r1] of the tile are
+  // min-reduced into the band in LDS (insertion.py:118-125).  A wave takes one listed chunk per step
+  // (64 consecutive points: one coalesced load of pixel ids), 8 chunks in flight; coordinates are
+  // loaded only for the points inside the band.  all_rows_bits: also set the scene occupancy bit of
+  // every point of the window (banded tiles: the occupancy of the whole window is needed up front).
+  __device__ __forceinline__ void gather(bool all_rows_bits, const uint16_t *sub, int nsub) {
+    constexpr int kPer = 8;
+    const int n_head = uni(b.n_head[s]);
+    const double q_min = w.q_ext[2 * s + 0], q_max = w.q_ext[2 * s + 1];
+    const int32_t *pixs = b.pix + (int64_t)s * b.cap;
+    const float4 *xyzi = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
+    const int nitems = (sub ? nsub : nlist) << 6;           // sub: the entries whose rows reach the band
+    for (int e0 = tid; e0 < nitems; e0 += kPer * NT) {
+      int idx[kPer], p[kPer], dl[kPer];
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        int e = e0 + u * NT;
+        idx[u] = -1;
+        if (e < nitems) {
+          int ent = sub ? (int)sub[e >> 6] : (e >> 6);
+          if ((l_alive(ent) >> (e & 63)) & 1ull) idx[u] = (int)(l_chunk(ent) << 6) + (e & 63);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) p[u] = idx[u] >= 0 ? pixs[idx[u]] : 0;
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        dl[u] = -1;
+        if (idx[u] >= 0) {
+          int r = p[u] / cols, c = p[u] - r * cols;
+          dl[u] = bt.index(r, c);
+          if (all_rows_bits && dt.index(r, c) >= 0) D.set_local(win.lpix_rc(r, c));
+        }
+      }
+      // coordinates: four float32 points in flight at a time
+#pragma unroll
+      for (int h = 0; h < kPer; h += 4) {
+        float4 f[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          f[u] = make_float4(1.f, 0.f, 0.f, 0.f);
+          if (dl[h + u] >= 0 && idx[h + u] < n_head) f[u] = xyzi[idx[h + u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (dl[h + u] < 0) continue;
+          double x = (double)f[u].x, y = (double)f[u].y, z = (double)f[u].z;
+          if (idx[h + u] >= n_head) load_point(b, s, idx[h + u], n_head, x, y, z);   // an inserted point: float64, from the log
+          double r = sqrt(x * x + y * y + z * z);
+          atomicMin(&s_dtile[dl[h + u]], depth_key(r));
+          // the points that hold the elevation bounds (max elevation = acos(min z/r)): if the pixel of
+          // one of them turns out visible it is culled and the bounds may move (any holder will do).
+          // z/r is only evaluated for the points that can be one (|z - q r| tiny).
+          double tol = 1e-9 * r;
+          if (fabs(z - q_min * r) <= tol && z / r == q_min) H[H_EXT0] = p[h + u];
+          if (fabs(z - q_max * r) <= tol && z / r == q_max) H[H_EXT1] = p[h + u];
+        }
+      }
+    }
+  }
+
+  // 5-row x 3-column closing (closing.py:9-23) of one bit image of the window: src -> tmp -> dst.
+  __device__ __forceinline__ void closing(const WinImage &src, WinImage &tmp, WinImage &dst) {
+    for (int pass = 0; pass < 2; ++pass) {
+      const WinImage &from = pass == 0 ? src : tmp;
+      WinImage &to = pass == 0 ? tmp : dst;
+      for (int e = tid; e < ww; e += NT) {
+        int r = win.row_of(e), j = win.word_of(e);
+        uint32_t acc = pass ? 0xFFFFFFFFu : 0u;
+        for (int dr = -2; dr <= 2; ++dr) {
+          int rr = r + dr;
+          if (rr < 0 || rr >= rows) continue;
+          if (pass) acc &= hand3(from, win, rr, j, wpr);
+          else acc |= hor3(from, win, rr, j);
+        }
+        to.w[e] = acc;
+      }
+      __syncthreads();
+    }
+  }
+
+  // ================================================================================================
+  // scene phase against the first n_base_ points of the cloud.  kOk (results in LDS: visible bits
+  // in T, s_V, kill masks in the chunk list, nvis, accept, header), kNoFit when this kernel's LDS
+  // cannot hold the chunk list plus one band of the tile, or kNeedSerial when the scene has pixels
+  // beyond 500 m and `serial` is false (their culling is not a matter of the window).
+  // ================================================================================================
+  __device__ __forceinline__ int scene_phase(int n_base_, bool serial) {
+    n_base = uni(n_base_);
+    n_far = uni(b.n_far[s] < R3D_FAR_CAP ? b.n_far[s] : R3D_FAR_CAP);
+    nvis = 0;
+    accept = false;
+    if (nvalid == 0) return kOk;
+    if (n_far > 0 && !serial) return kNeedSerial;
+    // carve the scratch region: visible list | band: candidates, depth tile | ... | chunk list (from the end)
+    int carve = r1;
+    s_V = reinterpret_cast<uint16_t *>(smem + carve);
+    carve = (carve + nvalid * 2 + 7) & ~7;
+    s_list = smem + (lds_cap & ~7);
+    const int W = dt.W;
+    const int min_band = 5 * W * 8 + W * 4;                   // one candidate row: 5 tile rows, W candidates
+    list_cap = ((lds_cap & ~7) - carve - min_band) / 24;
+    if (list_cap < 8) return kNoFit;
+
+    if (tid == 0) {
+      H[H_NLIST] = 0;
+      H[H_EXT0] = H[H_EXT1] = -1;
+      H[H_NVIS] = 0;
+      H[H_REBASE] = 0;
+      H[H_VRMIN] = H[H_VCMIN0] = H[H_VCMIN1] = 0x7FFFFFFF;
+      H[H_VRMAX] = H[H_VCMAX0] = H[H_VCMAX1] = -1;
+    }
+    __syncthreads();
+
+    STAMP(6);
+    // -- 6. the chunks that can hold a point of the window --------------------------------------------
+    build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, (n_base + 63) >> 6);
+    __syncthreads();
+    nlist = uni(H[H_NLIST]);
+    if (nlist > list_cap) return kNoFit;
+    const int band_bytes = (lds_cap & ~7) - 24 * nlist - carve;
+    s_cand = reinterpret_cast<uint32_t *>(smem + carve);
+
+    // rows of the candidates (the closed sample lies within 2 rows of a sample pixel); the tile as ONE
+    // band when it fits (rows of the whole window: the occupancy bits then come from the tile), else
+    // in bands of `per` candidate rows with 2 rows of halo on either side
+    const int cr0 = uni(H[H_RMIN]) - 2 < 0 ? 0 : uni(H[H_RMIN]) - 2;
+    const int cr1 = uni(H[H_RMAX]) + 2 > rows - 1 ? rows - 1 : uni(H[H_RMAX]) + 2;
+    const bool single = !(b.reserved & kDbgBands) && (int64_t)ncand * 4 + (int64_t)dt.npx * 8 + 8 <= band_bytes;
+    int per = cr1 - cr0 + 1;
+    if (!single) {
+      per = (band_bytes - 4 * W * 8 - 8) / (12 * W);
+      if (b.reserved & kDbgBands) per = per > 3 ? 3 : per;
+      if (per < 1) return kNoFit;
+    }
+
+    STAMP(7);
+    WinImage &vis = T;
+    for (int a0 = cr0; a0 <= cr1; a0 += per) {
+      const int a1 = a0 + per - 1 > cr1 ? cr1 : a0 + per - 1;
+      // -- 7. this band of the scene's range image, from the living points -----------------------------
+      bt = dt;
+      if (!single) {
+        bt.r0 = a0 - 2 < dt.r0 ? dt.r0 : a0 - 2;
+        bt.r1 = a1 + 2 > dt.r1 ? dt.r1 : a1 + 2;
+      }
+      bt.npx = (bt.r1 - bt.r0 + 1) * W;
+      // candidates of the band's rows first (their count decides where the tile starts); with bands,
+      // also the listed chunks whose rows reach this band (a scan in ring order has one-row chunks)
+      if (tid == 0) H[H_FILL] = H[H_CARRY] = 0;
+      __syncthreads();
+      for (int e = (a0 - win.r_lo) * win.njw + tid; e < (a1 - win.r_lo + 1) * win.njw; e += NT) {
+        uint32_t bits = Cs.w[e];
+        if (!bits) continue;
+        int pos = atomicAdd(&H[H_FILL], __popc(bits));
+        while (bits) {
+          int bit = __ffs(bits) - 1;
+          bits &= bits - 1;
+          s_cand[pos++] = (uint32_t)((e << 5) + bit);
+        }
+      }
+      const bool first = a0 == cr0;
+      uint16_t *s_sub = s_V;                                   // the visible list is built after the last band
+      const bool use_sub = !single && !first && nlist <= nvalid;
+      if (use_sub)
+        for (int i = tid; i < nlist; i += NT) {
+          uint32_t rr = l_rows(i);
+          if ((int)(rr & 0xFFFF) <= bt.r1 && (int)(rr >> 16) >= bt.r0) s_sub[atomicAdd(&H[H_CARRY], 1)] = (uint16_t)i;
+        }
+      __syncthreads();
+      const int nc = uni(H[H_FILL]), nsub = uni(H[H_CARRY]);
+      s_dtile = reinterpret_cast<unsigned long long *>(smem + ((carve + nc * 4 + 7) & ~7));
+      for (int i = tid; i < bt.npx; i += NT) s_dtile[i] = R3D_SENT;
+      if (first && !single)
+        for (int e = tid; e < ww; e += NT) D.w[e] = 0u;
+      __syncthreads();
+      gather(first && !single, use_sub ? s_sub : nullptr, nsub);
+      __syncthreads();
+
+      if (first) {
+        STAMP(8);
+        if (single) {                                          // scene occupancy bits, from the tile's pixels
+          for (int e = tid; e < ww; e += NT) D.w[e] = 0u;
+          __syncthreads();
+          for (int i = tid; i < bt.npx; i += NT) {
+            if (s_dtile[i] == R3D_SENT) continue;
+            int r = bt.r0 + i / W, k = i % W;
+            int c = k < dt.w0 ? dt.c00 + k : dt.c01 + (k - dt.w0);
+            D.set_local(win.lpix_rc(r, c));
+          }
+          __syncthreads();
+        }
+        // -- 8. closing of the scene's occupancy ------------------------------------------------------
+        closing(D, T, E);
+        for (int e = tid; e < ww; e += NT) T.w[e] = 0u;        // from here on: the visible pixels
+        __syncthreads();
+        STAMP(9);
+      }
+
+      // -- 9. visibility on the candidates: smoothed sample depth < smoothed scene depth (:461-467) ----
+      {
+        const int half = cols >> 1;
+        int v_n = 0, v_rmin = 0x7FFFFFFF, v_rmax = -1, v_cmin0 = 0x7FFFFFFF, v_cmax0 = -1, v_cmin1 = 0x7FFFFFFF, v_cmax1 = -1;
+        for (int ci = tid; ci < nc; ci += NT) {
+          int lp = (int)s_cand[ci];
+          int r = win.row_of(lp >> 5), c = (win.word_of(lp >> 5) << 5) + (lp & 31);
+          double sd = R3D_EMPTY_DEPTH, cd = R3D_EMPTY_DEPTH;
+          const bool a = A.get_local(lp), d = D.get_local(lp);
+          const bool c_hole = !d && E.get_local(lp);
+          if (a) sd = key_depth(sample_key(lp));
+          if (d) cd = key_depth(scene_key(r, c));
+          // hole means (closing.py:44-57): the 15 neighbour keys are gathered first, one image at a time
+          // (one register array), then summed in the reference's order
+          if (!a) {                                            // a candidate is closed: a hole of the sample
+            unsigned long long v[15];
+#pragma unroll
+            for (int dr = -2; dr <= 2; ++dr)
+#pragma unroll
+              for (int dc = -1; dc <= 1; ++dc) {
+                int rr = r + dr, cc = c + dc, k = (dr + 2) * 3 + (dc + 1);
+                v[k] = R3D_SENT;
+                if (rr < 0 || rr >= rows || cc < 0 || cc >= cols) continue;
+                int lp2 = win.lpix_rc(rr, cc);                 // inside the window: holes are >= 2 rows in
+                if (lp2 >= 0) v[k] = sample_key(lp2);
+              }
+            sd = mean_of_keys(v);
+          }
+          if (c_hole) {
+            unsigned long long v[15];
+#pragma unroll
+            for (int dr = -2; dr <= 2; ++dr)
+#pragma unroll
+              for (int dc = -1; dc <= 1; ++dc) {
+                int rr = r + dr, cc = c + dc, k = (dr + 2) * 3 + (dc + 1);
+                v[k] = R3D_SENT;
+                if (rr < 0 || rr >= rows || cc < 0 || cc >= cols) continue;
+                v[k] = scene_key(rr, cc);
+              }
+            cd = mean_of_keys(v);
+          }
+          if (sd < cd) {
+            vis.set_local(lp);
+            v_rmin = r < v_rmin ? r : v_rmin;
+            v_rmax = r > v_rmax ? r : v_rmax;
+            if (c < half) {
+              v_cmin0 = c < v_cmin0 ? c : v_cmin0;
+              v_cmax0 = c > v_cmax0 ? c : v_cmax0;
+            } else {
+              v_cmin1 = c < v_cmin1 ? c : v_cmin1;
+              v_cmax1 = c > v_cmax1 ? c : v_cmax1;
+            }
+            if (a) {                                           // its sample points are visible (:474)
+              int rk = rank_of(lp);
+              int p0 = s_start[rk], p1 = s_start[rk + 1];
+              v_n += p1 - p0;
+              for (int p = p0; p < p1; ++p) {
+                int j = s_F[p];
+                if ((s_oob[j >> 5] >> (j & 31)) & 1u) H[H_REBASE] = 1;   // bounds move: new extreme elevation
+              }
+            }
+          }
+        }
+        v_n = wave_sum_i32(v_n);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          int t;
+          t = __shfl_xor(v_rmin, o, 64); v_rmin = t < v_rmin ? t : v_rmin;
+          t = __shfl_xor(v_rmax, o, 64); v_rmax = t > v_rmax ? t : v_rmax;
+          t = __shfl_xor(v_cmin0, o, 64); v_cmin0 = t < v_cmin0 ? t : v_cmin0;
+          t = __shfl_xor(v_cmax0, o, 64); v_cmax0 = t > v_cmax0 ? t : v_cmax0;
+          t = __shfl_xor(v_cmin1, o, 64); v_cmin1 = t < v_cmin1 ? t : v_cmin1;
+          t = __shfl_xor(v_cmax1, o, 64); v_cmax1 = t > v_cmax1 ? t : v_cmax1;
+        }
+        if ((tid & 63) == 0 && v_rmax >= 0) {
+          atomicAdd(&H[H_NVIS], v_n);
+          atomicMin(&H[H_VRMIN], v_rmin);
+          atomicMax(&H[H_VRMAX], v_rmax);
+          atomicMin(&H[H_VCMIN0], v_cmin0);
+          atomicMax(&H[H_VCMAX0], v_cmax0);
+          atomicMin(&H[H_VCMIN1], v_cmin1);
+          atomicMax(&H[H_VCMAX1], v_cmax1);
+        }
+      }
+      __syncthreads();
+    }
+
+    STAMP(10);
+    // -- 10. accept test (insertion.py:511-517); the visible points in order; who dies -----------------
+    nvis = uni(H[H_NVIS]);
+    accept = nvis > 0 && nvis >= need;
+    if (accept) {
+      if (tid == 0) {
+        for (int h = 0; h < 2; ++h) {
+          int q = H[H_EXT0 + h];
+          if (q >= 0) {
+            int r = q / cols;
+            int lp = win.lpix_rc(r, q - r * cols);
+            if (lp >= 0 && vis.get_local(lp)) H[H_REBASE] = 1;     // a point that holds a bound is culled
+          }
+        }
+      }
+      int base = 0;
+      for (int k0 = 0; k0 < nvalid; k0 += NT) {
+        int k = k0 + tid;
+        int flag = (k < nvalid && vis.get_local((int)s_lp[s_F[k]])) ? 1 : 0;
+        int tot;
+        int ex = block_escan_i32(flag, scan, tot);
+        if (flag) s_V[base + ex] = (uint16_t)k;
+        base += tot;
+      }
+      // every living scene point in a visible pixel dies (:470-473): one mask per listed chunk, so that
+      // the commit is a handful of atomics
+      {
+        constexpr int kPer = 8;
+        const int lane = tid & 63;
+        const int32_t *pixs = b.pix + (int64_t)s * b.cap;
+        const int nitems = nlist << 6;
+        for (int e0 = tid; e0 < nitems; e0 += kPer * NT) {
+          int p[kPer];
+          bool on[kPer];
+#pragma unroll
+          for (int u = 0; u < kPer; ++u) {
+            int e = e0 + u * NT;
+            on[u] = e < nitems && ((l_alive(e >> 6) >> (e & 63)) & 1ull);
+            p[u] = on[u] ? pixs[(int)(l_chunk(e >> 6) << 6) + (e & 63)] : 0;
+          }
+#pragma unroll
+          for (int u = 0; u < kPer; ++u) {
+            int e = e0 + u * NT;
+            bool kill = false;
+            if (on[u]) {
+              int r = p[u] / cols;
+              int lp = win.lpix_rc(r, p[u] - r * cols);
+              kill = lp >= 0 && vis.get_local(lp);
+            }
+            unsigned long long mask = __ballot(kill);
+            if (lane == 0 && e < nitems) l_kill(e >> 6) = mask;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    STAMP(11);
+    return kOk;
+  }
+
+  // ================================================================================================
+  // commit of an accepted candidate: append (insertion.py:526), cull (:470-473).  Returns true when
+  // the scene must be re-based (the elevation bounds may have moved).  `flags_out`: kRec* bits.
+  // ================================================================================================
+  __device__ __forceinline__ bool commit(int &flags_out, int &n_total_after) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n_total = uni(b.n_total[s]), n_log = uni(b.n_log[s]), n_head = uni(b.n_head[s]);
+    const int tiles = (int)((b.cap + kTile - 1) / kTile);
+    n_total_after = n_total;
+    flags_out = 0;
+    if (accept && ((int64_t)n_total + nvis > b.cap || (int64_t)n_log + nvis > b.log_cap)) {
+      accept = false;
+      if (tid == 0) atomicOr(&b.status[s], R3D_S_CAPACITY);
+    }
+    if (tid == 0 && H[H_FLAGS]) atomicOr(&b.status[s], H[H_FLAGS]);
+    if (!accept) return false;
+    unsigned long long *alive = w.alive + (int64_t)s * chunks;
+    int32_t *tile_alive = w.tile_alive + (int64_t)s * tiles;
+    // -- the visible points, in (pixel, index) order, behind the cloud; one 64-point chunk per wave step
+    {
+      const int c_first = n_total >> 6, c_last = (n_total + nvis - 1) >> 6;
+      for (int ci = c_first + wave; ci <= c_last; ci += NT / 64) {
+        int dst = (ci << 6) + lane, o = dst - n_total;
+        bool valid = o >= 0 && o < nvis;
+        BoxAcc box;
+        if (valid) {
+          int j = s_F[s_V[o]];
+          int lp = (int)s_lp[j];
+          int row = win.row_of(lp >> 5), col = (win.word_of(lp >> 5) << 5) + (lp & 31);
+          const double *q = rows5 + (int64_t)j * 5;
+          double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+          int lr = n_log + o;
+          float4 f;
+          f.x = (float)q0;
+          f.y = (float)q1;
+          f.z = (float)q2;
+          f.w = (float)q3;
+          reinterpret_cast<float4 *>(b.xyzi)[(int64_t)s * b.cap + dst] = f;
+          b.label[(int64_t)s * b.cap + dst] = (uint32_t)(int64_t)q4;
+          b.pix[(int64_t)s * b.cap + dst] = row * cols + col;
+          b.tail_ref[(int64_t)s * b.log_cap + (dst - n_head)] = lr;
+          double *l = b.log5 + ((int64_t)s * b.log_cap + lr) * 5;
+          l[0] = q0;
+          l[1] = q1;
+          l[2] = q2;
+          l[3] = q3;
+          l[4] = q4;
+          b.log_birth[(int64_t)s * b.log_cap + lr] = step;
+          box.add(row, col);
+        }
+        const bool old_chunk = (ci << 6) < n_total;           // holds earlier points: extend its box
+        if (lane == 0 && old_chunk) box.add_box(w.chunk_box[(int64_t)s * chunks + ci]);
+        unsigned long long packed = box.wave_pack();
+        unsigned long long living = __ballot(valid);
+        if (lane == 0) {
+          w.chunk_box[(int64_t)s * chunks + ci] = packed;
+          if (old_chunk) atomicOr(&alive[ci], living);
+          else alive[ci] = living;
+          atomicAdd(&tile_alive[(ci << 6) / kTile], __popcll(living));
+        }
+      }
+    }
+    // -- the scene points in visible pixels die
+    for (int i = tid; i < nlist; i += NT) {
+      unsigned long long mask = l_kill(i);
+      if (!mask) continue;
+      int c = (int)l_chunk(i);
+      atomicAnd(&alive[c], ~mask);
+      atomicSub(&tile_alive[(c << 6) / kTile], __popcll(mask));
+    }
+    // -- pixels that now hold a return beyond 500 m join the far list
+    for (int o = tid; o < nvis; o += NT) {
+      int k = s_V[o];
+      int lp = (int)s_lp[s_F[k]];
+      int rk = rank_of(lp);
+      if (k != (int)s_start[rk]) continue;                    // once per pixel
+      if (key_depth(s_sdepth[rk]) > R3D_EMPTY_DEPTH) {
+        int f = atomicAdd(&b.n_far[s], 1);
+        if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = global_pix(lp);
+        else atomicOr(&b.status[s], R3D_S_FAR_OVERFLOW);
+        H[H_FARADD] = 1;
+      }
+    }
+    // -- scene pixels deeper than 500 m are visible to any accepted insert whose sample is empty there
+    // (500 < depth, insertion.py:99,:467): not a matter of the window.  Rare: two passes over the cloud.
+    if (n_far > 0) far_pass(n_total);
+    __syncthreads();
+    const bool rebase = uni(H[H_REBASE]) != 0;
+    flags_out = kRecAccepted | (rebase ? kRecRebased : 0) | ((H[H_FARADD] || n_far > 0) ? kRecFar : 0);
+    n_total_after = n_total + nvis;
+    if (tid == 0) {
+      b.n_total[s] = n_total + nvis;
+      b.n_log[s] = n_log + nvis;
+      if (rebase) b.rebase[s] += 1;                           // single writer per scene
+    }
+    return rebase;
+  }
+
+  // The far pixels that are not candidates of this insert: smoothed sample depth 500 there, the scene's
+  // depth is the raw minimum (the pixel is occupied): visible iff that minimum exceeds 500.
+  __device__ __forceinline__ void far_pass(int n_total) {
+    const int lane = tid & 63;
+    const int n_head = b.n_head[s];
+    const int tiles = (int)((b.cap + kTile - 1) / kTile);
+    uint32_t *fpx = w.cand + (int64_t)s * w.cand_stride;      // the scene's scratch: far pixels, their minima
+    unsigned long long *fmin = reinterpret_cast<unsigned long long *>(fpx + R3D_FAR_CAP);
+    const double q_min = w.q_ext[2 * s + 0], q_max = w.q_ext[2 * s + 1];
+    const int32_t *pixs = b.pix + (int64_t)s * b.cap;
+    unsigned long long *alive = w.alive + (int64_t)s * chunks;
+    int32_t *tile_alive = w.tile_alive + (int64_t)s * tiles;
+    __syncthreads();
+    for (int f = tid; f < n_far; f += NT) {
+      int p = b.far_pix[(int64_t)s * R3D_FAR_CAP + f];
+      int r = p / cols;
+      int lp = win.lpix_rc(r, p - r * cols);
+      bool is_cand = lp >= 0 && Cs.get_local(lp);
+      fpx[f] = is_cand ? 0xFFFFFFFFu : (uint32_t)p;
+      fmin[f] = R3D_SENT;
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int i0 = 0; i0 < n_total; i0 += NT) {
+        int i = i0 + tid;
+        bool kill = false;
+        if (i < n_total && ((__hip_atomic_load(&alive[i >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (i & 63)) & 1ull)) {
+          uint32_t p = (uint32_t)pixs[i];
+          int hit = -1;
+          for (int f = 0; f < n_far; ++f)
+            if (fpx[f] == p) {
+              hit = f;
+              break;
+            }
+          if (hit >= 0) {
+            double x, y, z;
+            load_point(b, s, i, n_head, x, y, z);
+            double r = sqrt(x * x + y * y + z * z);
+            if (pass == 0) atomicMin(&fmin[hit], depth_key(r));
+            else if (key_depth(__hip_atomic_load(&fmin[hit], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > R3D_EMPTY_DEPTH) {
+              kill = true;
+              double q = z / r;
+              if (q == q_min || q == q_max) H[H_REBASE] = 1;
+            }
+          }
+        }
+        if (pass == 1) {
+          unsigned long long mask = __ballot(kill);
+          if (lane == 0 && mask) {
+            atomicAnd(&alive[(i0 + tid) >> 6], ~mask);
+            atomicSub(&tile_alive[(i0 + tid) / kTile], __popcll(mask));
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+};
+
+
+// The slot's inputs for scene s; false when the slot has nothing to evaluate there.
+template <int NT>
+__device__ __forceinline__ bool load_slot(Ins<NT> &I, const r3d_batch_t &b, const ChainSlots &slots, int k, int s,
+                                          int first_step) {
+  const int64_t off = slots.sample_off[k][s];
+  const int64_t m64 = slots.sample_off[k][s + 1] - off;
+  const bool act = !slots.active[k] || slots.active[k][s];
+  I.rows5 = slots.samples5[k] + off * 5;
+  I.m = uni((int)m64);
+  I.need = uni(slots.min_points[k][s]);
+  I.step = first_step + k;
+  if (act && m64 > kKeyCap && threadIdx.x == 0) atomicOr(&b.status[s], R3D_S_SAMPLE_TOO_LARGE);
+  return act && m64 > 0 && m64 <= kKeyCap;
+}
+
+// Did one of the slots [j0, k) of this launch change a pixel the evaluation read (or the bounds, or
+// the far list)?  bit 0: yes; bit 1: the bounds moved (the sample must be projected again).
+__device__ __forceinline__ int conflict_with(const BatchWs &w, int s, int j0, int k, const int *H, int rows, int cols) {
+  int out = 0;
+  const int r_lo = H[H_RMIN] - 6, r_hi = H[H_RMAX] + 6;
+  for (int j = j0; j < k; ++j) {
+    const int *rec = w.recs + ((int64_t)s * kMaxChain + j) * kRecInts;
+    int fl = rec[REC_FLAGS];
+    if (!(fl & kRecAccepted)) continue;
+    if (fl & kRecRebased) out |= 3;
+    if (fl & kRecFar) out |= 1;
+    if (rec[REC_RHI] < r_lo || rec[REC_RLO] > r_hi) continue;
+    for (int h = 0; h < 2; ++h) {
+      if (H[H_CMAX0 + h] < 0) continue;
+      int lo = H[H_CMIN0 + h] - 3, hi = H[H_CMAX0 + h] + 3;
+      for (int g = 0; g < 2; ++g)
+        if (rec[REC_CHI0 + 2 * g] >= rec[REC_CLO0 + 2 * g] && rec[REC_CLO0 + 2 * g] <= hi && rec[REC_CHI0 + 2 * g] >= lo)
+          out |= 1;
+    }
+  }
+  return out;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT, NT == 1024 ? 1 : 4)
+k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int chunks, int lds_cap,
+               long long timeout_ticks, int B8) {
+  extern __shared__ __align__(16) unsigned char smem[];     // no static __shared__ here: one LDS array
+  const int k = (int)blockIdx.x / B8, s = (int)blockIdx.x % B8;
+  if (s >= b.B) return;
+  const int tid = threadIdx.x, slot_no = k;
+  (void)slot_no;
+  int *H = reinterpret_cast<int *>(smem);
+  Ins<NT> I(b, w, smem, lds_cap, s, chunks, k);
+
+  // wait until `want` slots of the scene are done (or the chain is abandoned); ONE lane polls relaxed,
+  // then ONE agent-scope acquire; the scalar cache is dropped as well (counters travel through it)
+  auto wait_for = [&](int want) -> int {
+    __syncthreads();
+    if (tid == 0) {
+      int seen = 0;
+      const long long t0 = wall_clock64();
+      for (;;) {
+        seen = __hip_atomic_load(&w.chain_progress[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen < 0 || seen >= want) break;
+        if (wall_clock64() - t0 > timeout_ticks) {
+          seen = kProgTimeout;
+          atomicOr(&b.status[s], R3D_S_CHAIN_TIMEOUT);
+          __hip_atomic_store(&w.chain_progress[s], kProgTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (seen > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      H[H_GO] = seen;
+    }
+    __syncthreads();
+    int seen = uni(H[H_GO]);
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    return seen;
+  };
+  auto publish = [&](int flags, int n_total_after) {
+    // every storing wave drains its stores, the workgroup meets, ONE lane releases (then waits again:
+    // the order fence -> wait -> flag matters) and stores the progress word relaxed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      int *rec = w.recs + ((int64_t)s * kMaxChain + k) * kRecInts;
+      rec[REC_FLAGS] = flags;
+      rec[REC_NTOTAL] = n_total_after;
+      rec[REC_RLO] = H[H_VRMIN];
+      rec[REC_RHI] = H[H_VRMAX];
+      rec[REC_CLO0] = H[H_VCMIN0];
+      rec[REC_CHI0] = H[H_VCMAX0];
+      rec[REC_CLO1] = H[H_VCMIN1];
+      rec[REC_CHI1] = H[H_VCMAX1];
+      if ((b.reserved & kDbgDropPublish) && k == 0 && s == 0 && nk > 1) return;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&w.chain_progress[s], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto outputs = [&](int nv, int acc) {
+    if (tid == 0) {
+      slots.n_visible[k][s] = nv;
+      slots.accepted[k][s] = acc;
+    }
+  };
+
+  // 1. where does the scene stand?  p0 slots are done: the evaluation builds on them
+  int p0 = 0;
+  if (k > 0) {
+    p0 = wait_for(0);
+    if (p0 == kProgDeferred) return;                      // k_insert_big does this slot
+    if (p0 < 0) {
+      outputs(0, 0);
+      return;
+    }
+  }
+  bool waited = p0 >= k;
+  if (!waited && (b.reserved & kDbgSerial)) {
+    p0 = wait_for(k);
+    if (p0 == kProgDeferred) return;
+    if (p0 < 0) {
+      outputs(0, 0);
+      return;
+    }
+    waited = true;
+  }
+  int n_base = p0 > 0 ? w.recs[((int64_t)s * kMaxChain + p0 - 1) * kRecInts + REC_NTOTAL]
+                      : (k > 0 ? w.n_total0[s] : b.n_total[s]);
+  const bool on = load_slot(I, b, slots, k, s, first_step);
+  bool need_sample = true, sample_ok = false;
+  int rc = kOk, attempts = 0;
+  (void)attempts;
+  if (on) {
+    for (;;) {
+      rc = kOk;
+      ++attempts;
+      if (need_sample) {
+        rc = (b.reserved & kDbgDefer) ? kNoFit : I.sample_phase();
+        sample_ok = rc == kOk;
+      }
+      if (rc == kOk) rc = I.scene_phase(n_base, waited);
+      if (rc == kNoFit) break;
+      if (!waited) {
+        int seen = wait_for(k);
+        if (seen == kProgDeferred) return;
+        if (seen < 0) {
+          outputs(0, 0);
+          return;
+        }
+        waited = true;
+        STAMP(13);
+        int cf = rc == kNeedSerial ? 1 : 0;
+        if (sample_ok && I.nvalid > 0) cf |= conflict_with(w, s, p0, k, H, b.rows, b.cols);
+        else {
+          for (int j = p0; j < k; ++j)                     // nothing projected: only new bounds could change that
+            if ((w.recs[((int64_t)s * kMaxChain + j) * kRecInts + REC_FLAGS] & (kRecAccepted | kRecRebased)) ==
+                (kRecAccepted | kRecRebased))
+              cf |= 3;
+        }
+        if (cf) {
+          n_base = b.n_total[s];
+          need_sample = !sample_ok || (cf & 2) != 0;
+          p0 = k;
+          continue;
+        }
+      }
+      break;
+    }
+  } else if (!waited) {
+    int seen = wait_for(k);
+    if (seen == kProgDeferred) return;
+    if (seen < 0) {
+      outputs(0, 0);
+      return;
+    }
+    waited = true;
+  }
+  if (on && rc == kNoFit) {
+    // the rest of this scene's chain goes to k_insert_big; the predecessors must be done first, so
+    // that nobody overwrites the mark
+    if (!waited) {
+      int seen = wait_for(k);
+      if (seen == kProgDeferred) return;
+      if (seen < 0) {
+        outputs(0, 0);
+        return;
+      }
+    }
+    if (tid == 0) {
+      w.defer_from[s] = k;
+      __hip_atomic_store(&w.chain_progress[s], kProgDeferred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  // 2. commit, publish
+  int flags = 0, n_after = waited && !on ? b.n_total[s] : 0;
+  bool rebase = false;
+  if (on) {
+    rebase = I.commit(flags, n_after);
+    outputs(I.nvis, I.accept ? 1 : 0);
+    STAMP(14);
+  } else {
+    outputs(0, 0);
+  }
+  if (rebase) {
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    phase_sync();
+    unsigned long long *s_min = reinterpret_cast<unsigned long long *>(smem + kHdrBytes), *s_max = s_min + NT / 64;
+    rebase_scene<NT>(b, w, chunks, s, s_min, s_max);
+  }
+  if (nk > 1) publish(flags, n_after);
+  STAMP(15);
+#ifdef R3D_STAMPS
+  if (tid == 0)
+    reinterpret_cast<long long *>(b.out_xyzi + (int64_t)s * b.cap * 4)[k * 16 + 12] =
+        (long long)attempts | ((long long)(rc == kOk ? 1 : 0) << 8) | ((long long)I.ww << 16) | ((long long)I.nlist << 32) |
+        ((long long)(I.dt.npx >> 4) << 48);
+#endif
+}
+
+// The pairs the chain kernel could not hold in its LDS, scene by scene, slot after slot.
+template <int NT>
+__global__ void __launch_bounds__(NT)
+k_insert_big(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int chunks, int lds_cap) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int s = (int)blockIdx.x;
+  const int tid = threadIdx.x;
+  const int k0 = w.defer_from[s];
+  for (int k = k0; k < nk; ++k) {
+    Ins<NT> I(b, w, smem, lds_cap, s, chunks, k);
+    const bool on = load_slot(I, b, slots, k, s, first_step);
+    int nv = 0, acc = 0;
+    if (on) {
+      int rc = I.sample_phase();
+      if (rc == kOk) rc = I.scene_phase(b.n_total[s], true);
+      if (rc != kOk) {
+        if (tid == 0) atomicOr(&b.status[s], R3D_S_WINDOW_TOO_LARGE);     // not even a whole CU's LDS holds it
+      } else {
+        int flags, n_after;
+        bool rebase = I.commit(flags, n_after);
+        nv = I.nvis;
+        acc = I.accept ? 1 : 0;
+        if (rebase) {
+          phase_sync();
+          unsigned long long *s_min = reinterpret_cast<unsigned long long *>(smem + kHdrBytes), *s_max = s_min + NT / 64;
+          rebase_scene<NT>(b, w, chunks, s, s_min, s_max);
+        }
+      }
+    }
+    if (tid == 0) {
+      slots.n_visible[k][s] = nv;
+      slots.accepted[k][s] = acc;
+    }
+    phase_sync();                                           // the next slot reads what this one wrote
+  }
+}
+
+__global__ void k_chain_init(r3d_batch_t b, BatchWs w, int nk) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= b.B) return;
+  w.chain_progress[s] = 0;
+  w.n_total0[s] = b.n_total[s];
+  w.defer_from[s] = nk;
+}
+
+constexpr int kSmallNT = 256;
+constexpr int kBigNT = 1024;
+constexpr int kBigLds = 160 * 1024;
+
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+// LDS bytes of a chain workgroup: two 512-thread workgroups per CU by default (measured on config C2:
+// 256 threads x 40 KB leaves most cars to bands / k_insert_big, 1024 x 160 KB leaves the CUs to one pair each).
+static int chain_lds_bytes() {
+  static const int kb = env_int("R3D_INSERT_LDS_KB", 80);
+  int v = kb < 16 ? 16 : (kb > 160 ? 160 : kb);
+  return v * 1024;
+}
+
+template <int NT>
+static int launch_chain(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step, int lds,
+                        long long timeout_ticks, hipStream_t st) {
+  const int B8 = (b.B + 7) & ~7;                              // a scene's slots on one residue of the block id mod 8
+  // per device, every call: the attribute belongs to the current device's copy of the kernel
+  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_chain<NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(k_insert_chain<NT>, dim3(B8 * nk), dim3(NT), lds, st, b, sl, nk, first_step, w, chunks_of(b), lds,
+                     timeout_ticks, B8);
+  R3D_LAUNCHED("k_insert_chain");
+  return R3D_OK;
+}
+
+static int launch_slots(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step,
+                        hipStream_t st) {
+  static const int timeout_ms = env_int("R3D_CHAIN_TIMEOUT_MS", 2000);
+  static const int nt = env_int("R3D_INSERT_NT", 512);
+  const int lds = chain_lds_bytes();
+  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_big<kBigNT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+  hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, nk);
+  int rc = nt == 1024  ? launch_chain<1024>(b, w, sl, nk, first_step, lds, (long long)timeout_ms * 100000ll, st)
+           : nt == 512 ? launch_chain<512>(b, w, sl, nk, first_step, lds, (long long)timeout_ms * 100000ll, st)
+                       : launch_chain<kSmallNT>(b, w, sl, nk, first_step, lds, (long long)timeout_ms * 100000ll, st);
+  if (rc != R3D_OK) return rc;
+  hipLaunchKernelGGL(k_insert_big<kBigNT>, dim3(b.B), dim3(kBigNT), kBigLds, st, b, sl, nk, first_step, w,
+                     chunks_of(b), kBigLds);
+  R3D_LAUNCHED("k_insert_big");
+  return R3D_OK;
+}
+
+}  // namespace r3d
+
+using namespace r3d;
+
+extern "C" {
+
+int r3d_batch_insert(const r3d_batch_t *b, const double *samples5, const int64_t *sample_off,
+                     const int32_t *min_points, const int32_t *active, int32_t step,
+                     int32_t *n_visible, int32_t *accepted, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  if (!samples5 || !sample_off || !min_points || !n_visible || !accepted || step < 1)
+    return fail(R3D_E_ARG, "batch_insert: null pointer or step < 1");
+  BatchWs w = carve_batch(*b, b->workspace);
+  ChainSlots sl{};
+  sl.samples5[0] = samples5;
+  sl.sample_off[0] = sample_off;
+  sl.min_points[0] = min_points;
+  sl.active[0] = active;
+  sl.n_visible[0] = n_visible;
+  sl.accepted[0] = accepted;
+  return launch_slots(*b, w, sl, 1, (int)step, (hipStream_t)stream);
+}
+
+int r3d_batch_insert_many(const r3d_batch_t *b, int32_t n_slots, const double *const *samples5,
+                          const int64_t *const *sample_off, const int32_t *const *min_points,
+                          const int32_t *const *active, int32_t first_step, int32_t *const *n_visible,
+                          int32_t *const *accepted, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  if (!samples5 || !sample_off || !min_points || !n_visible || !accepted || n_slots < 1 || first_step < 1)
+    return fail(R3D_E_ARG, "batch_insert_many: null pointer, no slot or first_step < 1");
+  for (int k = 0; k < n_slots; ++k)
+    if (!samples5[k] || !sample_off[k] || !min_points[k] || !n_visible[k] || !accepted[k])
+      return fail(R3D_E_ARG, "batch_insert_many: null pointer in a slot");
+  static const bool no_chain = getenv("R3D_NO_CHAIN") != nullptr;      // escape hatch: always one launch per slot
+  BatchWs w = carve_batch(*b, b->workspace);
+  const int per = no_chain ? 1 : kMaxChain;
+  for (int k0 = 0; k0 < n_slots; k0 += per) {
+    int nk = n_slots - k0 < per ? n_slots - k0 : per;
+    ChainSlots sl{};
+    for (int k = 0; k < nk; ++k) {
+      sl.samples5[k] = samples5[k0 + k];
+      sl.sample_off[k] = sample_off[k0 + k];
+      sl.min_points[k] = min_points[k0 + k];
+      sl.active[k] = active ? active[k0 + k] : nullptr;
+      sl.n_visible[k] = n_visible[k0 + k];
+      sl.accepted[k] = accepted[k0 + k];
+    }
+    rc = launch_slots(*b, w, sl, nk, (int)(first_step + k0), (hipStream_t)stream);
+    if (rc != R3D_OK) return rc;
+  }
+  return R3D_OK;
+}
+
+}  // extern "C"

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = pkg._lib.load()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.r3d_version() == 0x00010000
+    assert lib.r3d_version() == 0x00020000
     assert isinstance(lib.r3d_last_error(), bytes)
 
 
@@ -43,7 +43,7 @@ def test_batch_descriptor_matches_header(pkg):
                                   "void", "size_t")))
         fields += [n.strip(",") for n in names[first:]]
     assert [f for f, _ in pkg._lib.BatchDesc._fields_] == fields
-    assert ctypes.sizeof(pkg._lib.BatchDesc) == 4 * 4 + 2 * 8 + 21 * 8 + 2 * 8
+    assert ctypes.sizeof(pkg._lib.BatchDesc) == 4 * 4 + 2 * 8 + 17 * 8 + 2 * 8
 
 
 def test_place_query_matches_header(pkg):

@@ -56,11 +56,8 @@ def test_begin_matches_golden_pixels_and_bounds(P, synth):
     b.begin()
     assert np.array_equal(b.pix[0, :len(xyzi)].cpu().numpy(), g["scene_pix"])
     assert np.abs(b.bounds[0].cpu().numpy() - g["bounds"]).max() <= 1e-12
-    # the scratch range images are all-empty between calls (the window min-reduce happens per insert)
-    assert bool((b.grid[0] == -1).all()) and bool((b.sgrid[0] == -1).all())
     nv, acc = b.insert([g["sample5"]], [20])
     assert nv[0] == len(g["visible_idx"]) and acc[0] == 1
-    assert bool((b.grid[0] == -1).all()) and bool((b.sgrid[0] == -1).all())
     b.finish()
     out_xyzi, out_label, check = b.results()[0]
     assert np.array_equal(out_xyzi[:len(g["keep_idx"])], xyzi[g["keep_idx"]])
@@ -170,12 +167,12 @@ def test_full_size_properties(P, synth):
         n_in = len(scenes[s][0])
         n_added = len(check)
         # every output row is an input row or a check row; survivors keep their order
-        head = xyzi[:len(xyzi) - 0]
         inp = {r.tobytes(): i for i, r in enumerate(scenes[s][0])}
         idx = [inp[r.tobytes()] for r in xyzi if r.tobytes() in inp]
         assert idx == sorted(idx)
         assert len(xyzi) <= n_in + n_added and len(idx) <= n_in
-        assert all(a == 0 for a in acc[s]) or True
+        assert len(idx) <= len(xyzi) <= len(idx) + n_added     # survivors + the visible points still alive
+        assert all(a in (0, -1) for a in acc[s]) and len(acc[s]) == len(kinds)
     vb, lb, cb, oacc = _oracle_chain(scenes[0][0], scenes[0][1], slots[0], need[0])
     assert acc[0] == oacc
     _check_scene(res[0], vb, lb, cb)
@@ -367,14 +364,21 @@ def test_other_range_image_sizes(P, synth, monkeypatch, rows, cols):
         _check_scene(r, vb, lb, cb)
 
 
-def test_far_pixels_on_a_large_grid_are_reported(P, synth):
-    """A pixel deeper than 500 m makes the whole image the window; on a grid much larger than the
-    reference's that does not fit the insert kernel's LDS and must be reported, not mis-computed."""
+def test_far_pixels_on_a_large_grid(P, synth, monkeypatch):
+    """Pixels deeper than 500 m are visible to any accepted insert (500 < depth, insertion.py:99, :467)
+    wherever they are in the image; on a grid much larger than the reference's too (round 1 reported
+    this case as R3D_S_WINDOW_TOO_LARGE; the far pixels no longer widen the window)."""
+    monkeypatch.setattr(O, "NUMROW", 448)
+    monkeypatch.setattr(O, "NUMCOLUMN", 2880)
     xyzi, label = synth.make_scene(77, 32, 600)
     xyzi[:40, :3] *= 700.0 / np.linalg.norm(xyzi[:40, :3], axis=1, keepdims=True)
-    slots = [[synth.make_insert(78, "car", centre_range=8.0, centre_az=1.0)]]
-    with pytest.raises(ValueError, match="window"):
-        P.augment_batch([(xyzi, label)], [slots], [[5]], rows=448, cols=2880)
+    slots = [[synth.make_insert(78, "car", centre_range=8.0, centre_az=1.0)],
+             [synth.make_insert(79, "pedestrian", centre_range=6.0, centre_az=-2.0)]]
+    res, acc = P.augment_batch([(xyzi, label)], [slots], [[5, 5]], rows=448, cols=2880)
+    vb, lb, cb, oacc = _oracle_chain(xyzi, label, slots, [5, 5])
+    assert acc[0] == oacc == [0, 0]
+    _check_scene(res[0], vb, lb, cb)
+    assert len(res[0][0]) < len(xyzi) + len(res[0][2])          # the far points were culled
 
 
 @pytest.mark.parametrize("n_scenes", [8, 6])
@@ -473,3 +477,74 @@ def test_c5_scan_on_the_proposed_448x2880_grid(P, synth, monkeypatch):
     vb, lb, cb, oacc = _oracle_chain(xyzi, label, sl, nd)
     assert acc[0] == oacc and any(a == 0 for a in oacc)
     _check_scene(res[0], vb, lb, cb)
+
+
+@pytest.mark.parametrize("debug", [2, 4, 8, 6])
+def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
+    """The insert kernel's other routes, forced with the descriptor's diagnostic bits: 2 = never
+    speculate (every slot waits for its predecessor first), 4 = the window's depth tile built and
+    evaluated in bands of at most 3 candidate rows, 8 = every pair left to k_insert_big (one 1024-thread
+    workgroup per scene); all must give the bytes of the oracle chain, through insert_many and slot by slot."""
+    import torch
+    cases = [_random_case(synth, 11), _random_case(synth, 12, 32, 900, shuffle=True), _random_case(synth, 13, 64, 500)]
+    xyzi, label = synth.make_scene(14, 48, 700)
+    cases.append((xyzi, label, [[blob_in_front_of_extreme(xyzi, "max")]] + cases[0][2][:7], [5] + [20] * 7))
+    B, K = len(cases), 8
+    cap = max(len(c[0]) for c in cases) + sum(max(len(c[2][k][0]) for c in cases) for k in range(K)) + 64
+    for many in (True, False):
+        batch = P.SceneBatch(B, cap, cap, debug=debug)
+        batch.load([(c[0], c[1]) for c in cases])
+        batch.begin()
+        packed = [batch.pack_samples([c[2][k][0] for c in cases]) for k in range(K)]
+        needs = [torch.tensor([c[3][k] for c in cases], dtype=torch.int32, device=batch.device) for k in range(K)]
+        if many:
+            _, acc = batch.insert_many_device(packed, needs)
+            acc = acc.cpu().numpy()
+        else:
+            acc = np.stack([batch.insert_device(p[0], p[1], nd)[1].cpu().numpy().copy() for p, nd in zip(packed, needs)])
+        batch.finish()
+        res = batch.results()
+        for i, c in enumerate(cases):
+            vb, lb, cb, oacc = _oracle_chain(*c)
+            assert [0 if acc[k, i] else -1 for k in range(K)] == oacc
+            _check_scene(res[i], vb, lb, cb)
+
+
+def test_large_sample_and_overlapping_chain(P, synth):
+    """A sample near R3D_MAX_SAMPLE (its arrays exceed the chain kernel's LDS: k_insert_big takes the rest
+    of that scene's chain) and a chain whose slots all overlap (every speculative evaluation must be
+    redone after its predecessor)."""
+    xyzi, label = synth.make_scene(21, 64, 900)
+    big = synth.make_insert(31, "car", centre_range=6.0, centre_az=0.5, points=8000)
+    over = [synth.make_insert(40 + k, kind, centre_range=5.0 + 1.5 * k, centre_az=-1.0 + 0.02 * k)
+            for k, kind in enumerate(["car", "cyclist", "pedestrian", "car", "cyclist", "pedestrian"])][::-1]
+    slots = [[x] for x in over[:3]] + [[big]] + [[x] for x in over[3:]]
+    need = [10] * len(slots)
+    res, acc = P.augment_batch([(xyzi, label), (xyzi, label)], [slots, slots[:3]], [need, need[:3]])
+    vb, lb, cb, oacc = _oracle_chain(xyzi, label, slots, need)
+    assert acc[0] == oacc and oacc[3] == 0
+    _check_scene(res[0], vb, lb, cb)
+    vb, lb, cb, oacc = _oracle_chain(xyzi, label, slots[:3], need[:3])
+    assert acc[1] == oacc
+    _check_scene(res[1], vb, lb, cb)
+
+
+def test_chain_timeout_is_reported(P, synth):
+    """A slot whose predecessor never publishes gives up after the wall-clock bound (diagnostic bit 16
+    makes slot 0 of scene 0 skip its publish): R3D_S_CHAIN_TIMEOUT on that scene, its later slots
+    are not run, the other scene is untouched by it, nothing hangs."""
+    import torch
+    scenes = [synth.make_scene(50 + s, 32, 500) for s in range(2)]
+    ins = [[synth.make_insert(500 + 10 * s + k, "pedestrian", rng_range=(5.0, 15.0)) for k in range(3)] for s in range(2)]
+    n = max(len(x) for x, _ in scenes)
+    batch = P.SceneBatch(2, n + 2000, 2000, debug=16)
+    batch.load(scenes)
+    batch.begin()
+    packed = [batch.pack_samples([ins[s][k] for s in range(2)]) for k in range(3)]
+    need = torch.full((2,), 10, dtype=torch.int32, device=batch.device)
+    nv, acc = batch.insert_many_device(packed, [need] * 3)
+    st = batch.status.cpu().numpy()
+    assert st[0] & P._lib.S_CHAIN_TIMEOUT and not st[1]
+    assert acc.cpu().numpy()[:, 1].tolist() == [1, 1, 1] and acc.cpu().numpy()[1:, 0].tolist() == [0, 0]
+    with pytest.raises(ValueError, match="waiting"):
+        batch.raise_on_status()

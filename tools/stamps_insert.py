@@ -3,9 +3,9 @@
 
     R3D_LIB=pcl-augmentation_amd/libreal3daug_hip_stamps.so python tools/stamps_insert.py [out.npz]
 
-Every workgroup leaves a 100 MHz wall-clock stamp per phase in its scene's out_xyzi slab; one launch
-per slot (r3d_batch_insert) so that the stamps of a slot can be read before the next one overwrites
-them.  Prints a table (mean / p50 / max per phase over all pairs) and saves the raw stamps."""
+Every workgroup of k_insert_chain leaves 100 MHz wall-clock stamps at its phase boundaries in its
+scene's out_xyzi slab (16 per slot).  Prints a table (mean / p50 / p95 / max per phase over all
+pairs) and saves the raw stamps."""
 import importlib
 import sys
 
@@ -17,42 +17,47 @@ pkg = importlib.import_module("pcl-augmentation_amd")
 synth = pkg.synth
 B = 256
 KINDS = ["pedestrian", "cyclist", "car", "pedestrian", "cyclist"]
+K = len(KINDS)
 scenes = [synth.make_scene(s) for s in range(B)]
 inserts = [synth.make_inserts(s, KINDS) for s in range(B)]
-grow = sum(max(len(inserts[s][k]) for s in range(B)) for k in range(5))
+grow = sum(max(len(inserts[s][k]) for s in range(B)) for k in range(K))
 batch = pkg.SceneBatch(B, 120000 + grow, grow)
 batch.load(scenes)
 need = torch.full((B,), 20, dtype=torch.int32, device=batch.device)
-packed = [batch.pack_samples([inserts[s][k] for s in range(B)]) for k in range(5)]
-names = ["project", "window", "re-key + sort", "occ+rank+sdepth", "scene tile", "D bits", "closing", "cands",
-         "evaluate", "count", "commit", "cleanup"]
-NS = len(names) + 1
-raw = np.zeros((5, B, 16), dtype=np.int64)
-for rep in range(2):
+packed = [batch.pack_samples([inserts[s][k] for s in range(B)]) for k in range(K)]
+names = ["project sample", "window + re-key", "occupancy + rank", "counting sort + depths", "sample closing + count",
+         "scene set-up", "chunk list", "candidates + gather (first band)", "scene bits + closing", "evaluate (+ further bands)",
+         "visible list + kill masks", "wait for predecessor", "commit", "publish"]
+edges = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10), (10, 11), (11, 13), (13, 14), (14, 15)]
+for rep in range(3):
     batch.begin()
-    for k, (s5, off) in enumerate(packed):
-        batch.insert_device(s5, off, need)
-        torch.cuda.synchronize()
-        raw[k] = batch.out_xyzi.view(B, -1)[:, :32].contiguous().view(torch.int64).cpu().numpy()
-
-d = np.diff(raw[:, :, :NS], axis=2) / 100.0          # us
-tot = (raw[:, :, NS - 1] - raw[:, :, 0]) / 100.0
-ww = raw[:, :, 13] >> 32
-ncand = raw[:, :, 13] & 0xFFFFFFFF
-nlist = raw[:, :, 14] >> 32
-nvalid = raw[:, :, 14] & 0xFFFFFFFF
-print(f"| phase | mean us | p50 | p95 | max | share of mean total |")
+    batch.out_xyzi.view(B, -1)[:, :K * 32].zero_()
+    batch.insert_many_device(packed, [need] * K)
+    torch.cuda.synchronize()
+    raw = batch.out_xyzi.view(B, -1)[:, :K * 32].contiguous().view(torch.int64).cpu().numpy().reshape(B, K, 16)
+raw = raw.transpose(1, 0, 2)                       # [K, B, 16]
+info = raw[:, :, 12]
+attempts, all_lds, ww, nlist = info & 0xFF, (info >> 8) & 1, (info >> 16) & 0xFFFF, (info >> 32) & 0xFFFF
+# a pair that did not have to wait (slot 0, or its predecessor was done) has no stamp 13: use stamp 11
+st = raw.astype(np.float64)
+st[:, :, 13] = np.where(raw[:, :, 13] == 0, raw[:, :, 11], raw[:, :, 13])
+# a redone evaluation overwrites stamps 0..11 with the second attempt's; totals use the kernel's span
+tot = (st[:, :, 15] - st[:, :, 0]) / 100.0
+print("| phase | mean us | p50 | p95 | max | share of mean total |")
 print("|---|---|---|---|---|---|")
-flat = d.reshape(-1, len(names))
-for i, n in enumerate(names):
-    c = flat[:, i]
-    print(f"| {n} | {c.mean():.2f} | {np.percentile(c, 50):.2f} | {np.percentile(c, 95):.2f} | {c.max():.2f} | {100 * c.mean() / tot.mean():.1f} % |")
-print(f"| total | {tot.mean():.2f} | {np.percentile(tot, 50):.2f} | {np.percentile(tot, 95):.2f} | {tot.max():.2f} | |")
-for k in range(5):
+once = attempts == 1
+for n, (a, z) in zip(names, edges):
+    c = ((st[:, :, z] - st[:, :, a]) / 100.0)[once]
+    print(f"| {n} | {c.mean():.2f} | {np.percentile(c, 50):.2f} | {np.percentile(c, 95):.2f} | {c.max():.2f} | {100 * c.mean() / tot[once].mean():.1f} % |")
+print(f"| total (pairs evaluated once) | {tot[once].mean():.2f} | {np.percentile(tot[once], 50):.2f} | {np.percentile(tot[once], 95):.2f} | {tot[once].max():.2f} | |")
+t0 = raw[:, :, 0].min()
+print(f"pairs: {once.sum()} evaluated once, {(attempts == 2).sum()} twice (a predecessor changed their pixels), "
+      f"{(attempts == 0).sum()} not at all; {(all_lds == 0).sum()} left to k_insert_big")
+print(f"launch span: first start -> last publish = {(raw[:, :, 15].max() - t0) / 100.0:.1f} us; "
+      f"slot starts (mean, us after launch): " + ", ".join(f"{(raw[k, :, 0].mean() - t0) / 100.0:.1f}" for k in range(K)))
+for k in range(K):
     print(f"slot {k} ({KINDS[k]}): total mean {tot[k].mean():.1f} max {tot[k].max():.1f} us; window words mean {ww[k].mean():.0f} "
-          f"max {ww[k].max()}; chunks listed mean {nlist[k].mean():.0f} max {nlist[k].max()}; candidates mean {ncand[k].mean():.0f}; "
-          f"valid sample points mean {nvalid[k].mean():.0f}")
-print(f"sum over slots of (max over scenes) = {tot.max(1).sum():.1f} us; max over scenes of (sum over slots) = "
-      f"{tot.sum(0).max():.1f} us; mean scene sum = {tot.sum(0).mean():.1f} us")
+          f"max {ww[k].max()}; chunks listed mean {nlist[k].mean():.0f} max {nlist[k].max()}; end (mean, us after launch) "
+          f"{(raw[k, :, 15].mean() - t0) / 100.0:.1f}")
 if len(sys.argv) > 1:
     np.savez_compressed(sys.argv[1], raw=raw, names=np.array(names))
