@@ -148,8 +148,30 @@ def require_gpu():
 
 
 def stream_ptr():
+    """The current stream of the CURRENT device: callers make the device of their tensors current
+    first (``on(device)``), the C library launches on HIP's current device."""
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def on(device):
+    """Context manager that makes `device` (a torch.device, string, index or CUDA tensor) the current
+    one: every library call must run with the device of its pointers current."""
+    import torch
+    if isinstance(device, torch.Tensor):
+        device = device.device
+    return torch.cuda.device(torch.device(device))
+
+
+def on_own_device(method):
+    """Decorator for methods of objects with a ``.device``: run the method with that device current."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapped(self, *args, **kwargs):
+        with on(self.device):
+            return method(self, *args, **kwargs)
+    return wrapped
 
 
 def raise_status(bits: int, where: str):

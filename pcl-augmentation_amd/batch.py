@@ -32,6 +32,11 @@ class SceneBatch:
         self.torch = torch
         self.lib = _lib.load()
         self.device = torch.device(device)
+        with _lib.on(self.device):
+            self._init(B, cap, log_cap, rows, cols, exact_projection, debug)
+
+    def _init(self, B, cap, log_cap, rows, cols, exact_projection, debug):
+        torch = self.torch
         cap = (int(cap) + 63) // 64 * 64          # whole 64-point chunks per slab (chunk tables of the placement search)
         self.B, self.cap, self.log_cap, self.rows, self.cols = int(B), int(cap), int(log_cap), int(rows), int(cols)
         dev = self.device
@@ -92,6 +97,7 @@ class SceneBatch:
             }
         return self._pin
 
+    @_lib.on_own_device
     def load(self, scenes):
         """scenes: list of (xyzi float32 [n,4], label uint32 [n]) host arrays, one per scene.
         Only the first n rows of every slab are written and uploaded state beyond them is never
@@ -107,6 +113,7 @@ class SceneBatch:
             np.bitwise_and(label, 0xFFFF, out=hl[s, :n], casting="unsafe")
         self.upload_staging()
 
+    @_lib.on_own_device
     def upload_staging(self):
         """Upload what was written into ``_staging()`` (pinned views, e.g. by a reader thread)."""
         pin = self._staging()
@@ -120,6 +127,7 @@ class SceneBatch:
         pin = self._staging()
         return pin["xyzi"].numpy(), pin["label"].numpy().view(np.uint32), pin["n"].numpy()
 
+    @_lib.on_own_device
     def download_views(self):
         """Results as views of pinned host memory (valid until the next download): (xyzi [B,cap,4],
         label [B,cap] uint32, check [B,log_cap,cols] or None, n_out [B], n_log [B])."""
@@ -142,6 +150,7 @@ class SceneBatch:
         torch.cuda.current_stream().synchronize()
         return px.numpy(), pl.numpy().view(np.uint32), ck, n_out, n_log
 
+    @_lib.on_own_device
     def load_device(self, xyzi, label, n_points):
         """Same from tensors already on the device (copied into the batch slabs)."""
         self.xyzi.copy_(xyzi)
@@ -149,11 +158,13 @@ class SceneBatch:
         self.n_points.copy_(n_points)
 
     # -- the three phases -----------------------------------------------------------------------
+    @_lib.on_own_device
     def begin(self):
         self.step = 0
         _lib.check(self.lib.r3d_batch_begin(C.byref(self.desc), C.c_void_p(self.n_points.data_ptr()),
                                             _lib.stream_ptr()), "r3d_batch_begin")
 
+    @_lib.on_own_device
     def insert_device(self, samples5, sample_off, min_points, active=None, new_slot=True):
         """One candidate per scene from device tensors; returns (n_visible, accepted) tensors.
 
@@ -169,14 +180,17 @@ class SceneBatch:
             _lib.stream_ptr()), "r3d_batch_insert")
         return self.n_visible, self.accepted
 
+    @_lib.on_own_device
     def insert_many_device(self, packed, min_points):
         """Several slots with one candidate each in ONE launch (``r3d_batch_insert_many``): packed =
         list of (samples5, sample_off) device tensors per slot, min_points = list of int32 device
         tensors.  Returns (n_visible [K,B], accepted [K,B]) device tensors."""
         torch = self.torch
         K = len(packed)
-        nv = torch.zeros((K, self.B), dtype=torch.int32, device=self.device)
-        acc = torch.zeros((K, self.B), dtype=torch.int32, device=self.device)
+        if getattr(self, "_many_out", None) is None or self._many_out[0].shape[0] < K:
+            self._many_out = (torch.zeros((max(K, 8), self.B), dtype=torch.int32, device=self.device),
+                              torch.zeros((max(K, 8), self.B), dtype=torch.int32, device=self.device))
+        nv, acc = self._many_out[0][:K], self._many_out[1][:K]      # every slot of every scene is written by the call
         ptrs = lambda xs: (C.c_void_p * K)(*[C.c_void_p(x) for x in xs])
         _lib.check(self.lib.r3d_batch_insert_many(
             C.byref(self.desc), K, ptrs([p[0].data_ptr() for p in packed]), ptrs([p[1].data_ptr() for p in packed]),
@@ -185,6 +199,7 @@ class SceneBatch:
         self.step += K
         return nv, acc
 
+    @_lib.on_own_device
     def pack_samples(self, samples):
         """list of (M x 5 float64 | None) per scene -> (samples5, sample_off) device tensors."""
         torch = self.torch
@@ -198,6 +213,7 @@ class SceneBatch:
                 rows[off[s]:off[s + 1]] = smp
         return (torch.from_numpy(rows).to(self.device), torch.from_numpy(off).to(self.device))
 
+    @_lib.on_own_device
     def insert(self, samples, min_points, active=None, new_slot=True):
         torch = self.torch
         s5, off = self.pack_samples(samples)
@@ -207,6 +223,7 @@ class SceneBatch:
         self._keep = (s5, off, mp, act)          # keep the inputs alive until the stream has run
         return nv.cpu().numpy().copy(), acc.cpu().numpy().copy()
 
+    @_lib.on_own_device
     def export_rows(self):
         """The current merged clouds as float64 rows [x y z label] (what the placement search reads,
         insertion.py:433): (rows [B,cap,4], n_rows [B]) device tensors; the batch is left unchanged."""
@@ -219,10 +236,14 @@ class SceneBatch:
                    "r3d_batch_export_rows")
         return self.rows4, self.n_rows
 
+    @_lib.on_own_device
     def finish(self, check_cols=5):
         torch = self.torch
         if check_cols:
-            self.check = torch.zeros((self.B, self.log_cap, check_cols), dtype=torch.float32, device=self.device)
+            # rows beyond n_log[s] are never read: the buffer is kept between calls
+            if getattr(self, "_check_buf", None) is None or self._check_buf.shape[2] != check_cols:
+                self._check_buf = torch.zeros((self.B, self.log_cap, check_cols), dtype=torch.float32, device=self.device)
+            self.check = self._check_buf
             cp = C.c_void_p(self.check.data_ptr())
         else:
             self.check, cp = None, C.c_void_p(0)
@@ -230,17 +251,20 @@ class SceneBatch:
                    "r3d_batch_finish")
 
     # -- results --------------------------------------------------------------------------------
+    @_lib.on_own_device
     def raise_on_status(self):
         st = self.status.cpu().numpy()
         for s in np.nonzero(st)[0]:
             _lib.raise_status(int(st[s]), f"scene {s}")
 
+    @_lib.on_own_device
     def results(self):
         """Per scene: (xyzi float32 [n,4], label uint32 [n], check float32 [m,cols]), copies."""
         ox, ol, ck, n_out, n_log = self.download_views()
         return [(ox[s, :n_out[s]].copy(), ol[s, :n_out[s]].copy(),
                  ck[s, :n_log[s]].copy() if ck is not None else None) for s in range(self.B)]
 
+    @_lib.on_own_device
     def run_inserts(self, candidates, min_points):
         """The candidate loop of insertion.py:449-545 for every scene, after ``begin``: candidates
         of a slot are tried in order, the slot's "still open" mask lives on the device, and the

@@ -38,6 +38,8 @@ struct BatchWs {
   int32_t *n_total0;            // [B] n_total when the running k_insert_chain was launched
   int32_t *defer_from;          // [B] first slot of the launch left to k_insert_big (n_slots: none)
   int32_t *recs;                // [B*kMaxChain*kRecInts] what every finished slot of the launch publishes
+  unsigned char *glist;         // [B*(kMaxChain+1)*chunks*24] chunk lists that exceed a workgroup's LDS: one area per (scene, slot of the
+                                // launch) for k_insert_chain, one per scene for k_insert_big
   int64_t cand_stride;          // uint32 entries of `cand` per scene
   size_t total;
 };
@@ -68,6 +70,7 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.n_total0 = c.take<int32_t>((size_t)b.B);
   w.defer_from = c.take<int32_t>((size_t)b.B);
   w.recs = c.take<int32_t>((size_t)b.B * kMaxChain * kRecInts);
+  w.glist = c.take<unsigned char>((size_t)b.B * (kMaxChain + 1) * chunks_of(b) * 24);
   w.total = c.off;
   return w;
 }

@@ -179,6 +179,7 @@ struct Ins {
   unsigned char *smem;
   const int lds_cap, s, chunks, slot_no;
   const int tid, rows, cols, npix, wpr;
+  const bool force_glist;
   int *H, *scan;
   // the slot's candidate
   const double *rows5;
@@ -196,33 +197,59 @@ struct Ins {
   uint16_t *s_V;
   uint32_t *s_cand;
   unsigned long long *s_dtile;
-  unsigned char *s_list;                 // chunk list, 24-byte entries growing down from the end of the LDS
+  unsigned char *s_list, *g_list;        // chunk list: 24-byte entries growing down from the end of the LDS, or of
+  bool glist;                            // the pair's area in global memory when they do not fit there
   DTile bt;                              // the band of the tile currently in LDS
   int list_cap, nlist, nvis, n_base, n_far;
   bool accept;
 
+  // area: which of the scene's kMaxChain + 1 global list areas this workgroup may use (its slot of the launch;
+  // kMaxChain for k_insert_big, which then uses it for every pair)
   __device__ __forceinline__ Ins(const r3d_batch_t &b_, const BatchWs &w_, unsigned char *smem_, int lds_cap_, int s_,
-                                 int chunks_, int slot_no_)
+                                 int chunks_, int slot_no_, int area, bool force_glist_)
       : b(b_), w(w_), smem(smem_), lds_cap(lds_cap_), s(s_), chunks(chunks_), slot_no(slot_no_), tid(threadIdx.x),
-        rows(b_.rows), cols(b_.cols), npix(b_.rows * b_.cols), wpr(b_.cols >> 5) {
+        rows(b_.rows), cols(b_.cols), npix(b_.rows * b_.cols), wpr(b_.cols >> 5), force_glist(force_glist_) {
     H = reinterpret_cast<int *>(smem);
     scan = H + H_SCAN;
     nvalid = ww = nocc = ncand = nvis = nlist = 0;
     accept = false;
+    glist = false;
+    g_list = w.glist + (((int64_t)s * (kMaxChain + 1) + area) + 1) * chunks * 24;     // entries grow down from the area's end
   }
 
-  // chunk list entry i: { alive word, kill mask, chunk number, rows of its box }
-  __device__ __forceinline__ unsigned long long &l_alive(int i) const {
-    return *reinterpret_cast<unsigned long long *>(s_list - 24 * (i + 1));
+  // chunk list entry i: { alive word, kill mask, chunk number, rows of its box (first | last << 16) }
+  __device__ __forceinline__ unsigned long long l_alive(int i) const {
+    return glist ? *reinterpret_cast<const unsigned long long *>(g_list - 24 * (i + 1))
+                 : *reinterpret_cast<const unsigned long long *>(s_list - 24 * (i + 1));
   }
-  __device__ __forceinline__ unsigned long long &l_kill(int i) const {
-    return *reinterpret_cast<unsigned long long *>(s_list - 24 * (i + 1) + 8);
+  __device__ __forceinline__ unsigned long long l_kill(int i) const {
+    return glist ? *reinterpret_cast<const unsigned long long *>(g_list - 24 * (i + 1) + 8)
+                 : *reinterpret_cast<const unsigned long long *>(s_list - 24 * (i + 1) + 8);
   }
-  __device__ __forceinline__ uint32_t &l_chunk(int i) const {
-    return *reinterpret_cast<uint32_t *>(s_list - 24 * (i + 1) + 16);
+  __device__ __forceinline__ void set_kill(int i, unsigned long long m) const {
+    if (glist) *reinterpret_cast<unsigned long long *>(g_list - 24 * (i + 1) + 8) = m;
+    else *reinterpret_cast<unsigned long long *>(s_list - 24 * (i + 1) + 8) = m;
   }
-  __device__ __forceinline__ uint32_t &l_rows(int i) const {       // first row | last row << 16 of the chunk's box
-    return *reinterpret_cast<uint32_t *>(s_list - 24 * (i + 1) + 20);
+  __device__ __forceinline__ uint32_t l_chunk(int i) const {
+    return glist ? *reinterpret_cast<const uint32_t *>(g_list - 24 * (i + 1) + 16)
+                 : *reinterpret_cast<const uint32_t *>(s_list - 24 * (i + 1) + 16);
+  }
+  __device__ __forceinline__ uint32_t l_rows(int i) const {
+    return glist ? *reinterpret_cast<const uint32_t *>(g_list - 24 * (i + 1) + 20)
+                 : *reinterpret_cast<const uint32_t *>(s_list - 24 * (i + 1) + 20);
+  }
+  __device__ __forceinline__ void set_entry(int i, unsigned long long a, uint32_t c, uint32_t rr) const {
+    unsigned char *e = (glist ? g_list : s_list) - 24 * (i + 1);
+    if (glist) {
+      *reinterpret_cast<unsigned long long *>(g_list - 24 * (i + 1)) = a;
+      *reinterpret_cast<unsigned long long *>(g_list - 24 * (i + 1) + 8) = 0ull;
+      *reinterpret_cast<uint2 *>(g_list - 24 * (i + 1) + 16) = make_uint2(c, rr);
+    } else {
+      *reinterpret_cast<unsigned long long *>(s_list - 24 * (i + 1)) = a;
+      *reinterpret_cast<unsigned long long *>(s_list - 24 * (i + 1) + 8) = 0ull;
+      *reinterpret_cast<uint2 *>(s_list - 24 * (i + 1) + 16) = make_uint2(c, rr);
+    }
+    (void)e;
   }
   __device__ __forceinline__ int rank_of(int lp) const {
     return (int)s_rank[lp >> 5] + __popc(A.w[lp >> 5] & ((1u << (lp & 31)) - 1u));
@@ -530,12 +557,7 @@ struct Ins {
         bool hit = a && rmin <= win.r_hi && rmax >= win.r_lo && win.touches_words(jmin, jmax);
         if (hit) {
           int slot = atomicAdd(&H[H_NLIST], 1);
-          if (slot < list_cap) {
-            l_alive(slot) = a;
-            l_kill(slot) = 0ull;
-            l_chunk(slot) = (uint32_t)c;
-            l_rows(slot) = (uint32_t)rmin | ((uint32_t)rmax << 16);
-          }
+          if (slot < list_cap) set_entry(slot, a, (uint32_t)c, (uint32_t)rmin | ((uint32_t)rmax << 16));
         }
       }
     }
@@ -639,11 +661,15 @@ struct Ins {
     int carve = r1;
     s_V = reinterpret_cast<uint16_t *>(smem + carve);
     carve = (carve + nvalid * 2 + 7) & ~7;
-    s_list = smem + (lds_cap & ~7);
     const int W = dt.W;
     const int min_band = 5 * W * 8 + W * 4;                   // one candidate row: 5 tile rows, W candidates
+    // the chunk list in LDS, behind room for at least one band; in the pair's global area when that
+    // leaves fewer than 64 entries (or when it overflows, below)
+    s_list = smem + (lds_cap & ~7);
+    if ((lds_cap & ~7) - carve - min_band < 0) return kNoFit;
     list_cap = ((lds_cap & ~7) - carve - min_band) / 24;
-    if (list_cap < 8) return kNoFit;
+    glist = force_glist || list_cap < 64;
+    if (glist) list_cap = chunks;
 
     if (tid == 0) {
       H[H_NLIST] = 0;
@@ -660,8 +686,17 @@ struct Ins {
     build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, (n_base + 63) >> 6);
     __syncthreads();
     nlist = uni(H[H_NLIST]);
-    if (nlist > list_cap) return kNoFit;
-    const int band_bytes = (lds_cap & ~7) - 24 * nlist - carve;
+    if (nlist > list_cap) {                                   // does not fit the LDS: once more, into global memory
+      __syncthreads();
+      if (tid == 0) H[H_NLIST] = 0;
+      glist = true;
+      list_cap = chunks;
+      __syncthreads();
+      build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, (n_base + 63) >> 6);
+      __syncthreads();
+      nlist = uni(H[H_NLIST]);
+    }
+    const int band_bytes = (lds_cap & ~7) - (glist ? 0 : 24 * nlist) - carve;
     s_cand = reinterpret_cast<uint32_t *>(smem + carve);
 
     // rows of the candidates (the closed sample lies within 2 rows of a sample pixel); the tile as ONE
@@ -877,7 +912,7 @@ struct Ins {
               kill = lp >= 0 && vis.get_local(lp);
             }
             unsigned long long mask = __ballot(kill);
-            if (lane == 0 && e < nitems) l_kill(e >> 6) = mask;
+            if (lane == 0 && e < nitems) set_kill(e >> 6, mask);
           }
         }
       }
@@ -1093,7 +1128,7 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
   const int tid = threadIdx.x, slot_no = k;
   (void)slot_no;
   int *H = reinterpret_cast<int *>(smem);
-  Ins<NT> I(b, w, smem, lds_cap, s, chunks, k);
+  Ins<NT> I(b, w, smem, lds_cap, s, chunks, k, k, false);
 
   // wait until `want` slots of the scene are done (or the chain is abandoned); ONE lane polls relaxed,
   // then ONE agent-scope acquire; the scalar cache is dropped as well (counters travel through it)
@@ -1276,7 +1311,7 @@ k_insert_big(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w,
   const int tid = threadIdx.x;
   const int k0 = w.defer_from[s];
   for (int k = k0; k < nk; ++k) {
-    Ins<NT> I(b, w, smem, lds_cap, s, chunks, k);
+    Ins<NT> I(b, w, smem, lds_cap, s, chunks, k, kMaxChain, true);
     const bool on = load_slot(I, b, slots, k, s, first_step);
     int nv = 0, acc = 0;
     if (on) {

@@ -40,6 +40,11 @@ def upload_map(rich_map, device):
 
 
 def chunk_ranges(rows):
+    with _lib.on(rows):
+        return _chunk_ranges(rows)
+
+
+def _chunk_ranges(rows):
     """r3d_places_chunk_ranges of a device tensor of rows (x y first): float32 [chunks, 2]."""
     torch = _lib.require_gpu()
     n = rows.shape[0]
@@ -178,6 +183,7 @@ class PlaceBatch:
         self.max_m = max(s.shape[0] for s in self.samples)
         self.first_cand = 0
 
+    @_lib.on_own_device
     def run(self, first_cand=0):
         self.first_cand = int(first_cand)
         _lib.check(self.lib.r3d_find_possible_places(
@@ -187,6 +193,7 @@ class PlaceBatch:
             self.ws.data_ptr(), self.ws_bytes, _lib.stream_ptr()), "r3d_find_possible_places")
         return self
 
+    @_lib.on_own_device
     def results(self):
         import torch
         torch.cuda.synchronize()

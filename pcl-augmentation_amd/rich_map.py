@@ -20,6 +20,11 @@ def _decode(key):
 
 
 def build_rich_map(frames, placement_labels, device="cuda:0", as_uint8=False):
+    with _lib.on(device):
+        return _build_rich_map(frames, placement_labels, device, as_uint8)
+
+
+def _build_rich_map(frames, placement_labels, device, as_uint8):
     """frames: sequence of (xyzi float32 [n,4], label uint32 [n], transform_matrix 4x4) in processing
     order (tools/datasets.py:45-60 per frame); placement_labels: config['insertion']
     ['placement_labels'] ({1: road, 2: sidewalk, 3: parking}).  Returns (map, move) as the

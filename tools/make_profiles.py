@@ -28,7 +28,8 @@ def one(pattern):
 
 
 def short(name):
-    return name.split("(")[0].replace("r3d::", "").replace("(anonymous namespace)::", "").replace("void ", "").strip()
+    base = name.split("(")[0].replace("r3d::", "").replace("(anonymous namespace)::", "").replace("void ", "").strip()
+    return base.split("<")[0]
 
 
 def counter_avgs(directory, counter):
