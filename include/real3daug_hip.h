@@ -350,6 +350,17 @@ int r3d_map_splat(const float *xyzi, const uint32_t *label, int64_t n, const dou
                   int32_t size_y, int64_t frame_no, uint64_t *keys, int32_t *status, void *stream);
 int r3d_map_finish(const uint64_t *keys, int64_t cells, double *map64, uint8_t *map8, void *stream);
 
+/* =====================================================================================
+ * Host-side packer of the file-to-file driver.  HOST pointers: copies B
+ * frames as the reference's __getitem__ reads them (velodyne .bin rows float32 x y z intensity,
+ * .label words; SS tools/datasets.py:51-56) into the slabs of a (pinned) staging buffer laid out
+ * like r3d_batch_t.xyzi / .label ([B][cap]); labels are masked with 0xFFFF (:53-55), or, with
+ * collapse_keep >= 0, collapsed to {collapse_keep, 1} (OD insertion.py:353-355).  `threads` host
+ * threads share the frames.  The copy into HBM is the caller's.
+ * ===================================================================================== */
+int r3d_host_pack_frames(const float *const *xyzi, const uint32_t *const *label, const int32_t *n_points, int32_t B,
+                         int64_t cap, float *dst_xyzi, uint32_t *dst_label, int32_t collapse_keep, int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,3 +108,29 @@ def occlusion_merge(scene_pcl, sample_pcl, scene_train, sample_train):
         if n_vis == 0 and n_cov == 0 and not bool((mt < st).any()):
             return scene_out, np.array([]), np.array([])
     return scene_out, visible, covered
+
+
+def create_annotation_line(original_string, new_annotation_dict, rotation):
+    """OD insertion.py:227-265: the KITTI label_2 line of an inserted object.  The sample's own line
+    gives truncation, 2-D box and dimensions; the class and the centre (LiDAR frame) come from the
+    placement; location is the centre in the camera frame (-y, -z - 0.08, x - 0.27), rotation_y the
+    sample's minus the placement rotation, alpha the viewing angle plus rotation_y, both wrapped once
+    into [-pi, pi]; occlusion is always 3."""
+    items = (original_string.item() if hasattr(original_string, "item") else str(original_string)).split(" ")
+    c = new_annotation_dict["center"]
+    cam_x, cam_y, cam_z = c["y"] * -1, (c["z"] * -1) - 0.08, c["x"] - 0.27
+
+    def wrap(a):
+        if a < -np.pi:
+            a += 2 * np.pi
+        elif a > np.pi:
+            a -= 2 * np.pi
+        return a
+
+    rotation_y = wrap(float(items[14]) - np.deg2rad(rotation))
+    assert -np.pi <= rotation_y <= np.pi, f"Error in range of sample_rotation_y. Sample_rotation_y = {rotation_y}"
+    alpha = wrap((np.arctan2(cam_x, cam_z) * -1) + rotation_y)
+    assert -np.pi <= alpha <= np.pi, f"Error in range of alpha. Alpha = {alpha}"
+    fields = [new_annotation_dict["class"], items[1], "3", f"{alpha:.02f}", items[4], items[5], items[6], items[7],
+              items[8], items[9], items[10], f"{cam_x:.02f}", f"{cam_y:.02f}", f"{cam_z:.02f}", f"{rotation_y:.02f}"]
+    return " ".join(fields) + "\n"

@@ -1,9 +1,11 @@
 """The output-format half of the reference's ``Real3DAug/tools/datasets.py``.
 
 Only what the hot path's drop-in promise needs: reading a frame the way ``__getitem__`` does and
-writing ``velodyne/{f}.bin``, ``labels/{f}.label`` and ``check/{f}.bin`` byte for byte the way
-``save_data`` does (SS tools/datasets.py:45-60, 72-106; OD tools/datasets.py:56-109).  Directory
-creation prompts, pose handling and annotation synthesis stay with the reference's driver.
+writing ``velodyne/{f}.bin``, ``labels/{f}.label``, ``check/{f}.bin`` and (object detection)
+``label_2/{f}.txt`` byte for byte the way ``save_data`` does (SS tools/datasets.py:45-60, 72-106;
+OD tools/datasets.py:20-37, 56-109).  Directory creation prompts and pose handling stay with the
+reference's driver.  Files are written under a temporary name and renamed, so that a killed run never
+leaves a truncated file that a resumed run would take for finished.
 """
 from __future__ import annotations
 
@@ -49,15 +51,34 @@ def read_frame(velodyne_file, label_file):
     return xyzi, labels & 0xFFFF, labels >> 16
 
 
-def write_frame(output_path, folder, name, xyzi, label, check, write_labels=True):
-    """Write the three files of save_data from packed arrays (SS :80-89; OD :86-93 has no labels)."""
+def _commit(path, data):
+    """Write bytes (or an array's bytes) to path.tmp, then rename: the file is whole or absent."""
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as fh:
+        fh.write(data if isinstance(data, (bytes, bytearray, memoryview)) else memoryview(np.ascontiguousarray(data)).cast("B"))
+    os.replace(tmp, path)
+
+
+def create_annotation(old_address, new_address, additional_annotations_lines):
+    """OD tools/datasets.py:20-37: the frame's label_2 file followed by the lines of the inserted objects."""
+    with open(old_address, "r") as fh:
+        text = fh.read()
+    _commit(new_address, (text + "".join(additional_annotations_lines)).encode())
+
+
+def write_frame(output_path, folder, name, xyzi, label, check, write_labels=True, label_2=None):
+    """Write the files of save_data from packed arrays (SS :80-89; OD :81-93: no labels, but
+    label_2 = (path of the frame's label_2 file, lines of the inserted objects)).  check/ is written
+    last: its presence marks the frame as done (``AugmentPipeline`` resumes by it)."""
     base = os.path.join(output_path, folder)
-    for sub in ("velodyne", "check") + (("labels",) if write_labels else ()):
+    for sub in ("velodyne", "check") + (("labels",) if write_labels else ()) + (("label_2",) if label_2 else ()):
         os.makedirs(os.path.join(base, sub), exist_ok=True)
-    np.ascontiguousarray(xyzi, dtype=np.float32).tofile(os.path.join(base, "velodyne", f"{name}.bin"))
+    if label_2:
+        create_annotation(label_2[0], os.path.join(base, "label_2", f"{name}.txt"), label_2[1])
+    _commit(os.path.join(base, "velodyne", f"{name}.bin"), np.ascontiguousarray(xyzi, dtype=np.float32))
     if write_labels:
-        np.ascontiguousarray(label, dtype=np.uint32).tofile(os.path.join(base, "labels", f"{name}.label"))
-    np.ascontiguousarray(check, dtype=np.float32).tofile(os.path.join(base, "check", f"{name}.bin"))
+        _commit(os.path.join(base, "labels", f"{name}.label"), np.ascontiguousarray(label, dtype=np.uint32))
+    _commit(os.path.join(base, "check", f"{name}.bin"), np.ascontiguousarray(check, dtype=np.float32))
 
 
 class SemanticKITTI:
@@ -76,19 +97,24 @@ class SemanticKITTI:
 
 
 class KITTI:
-    """Object-detection variant (OD tools/datasets.py:76-109): no label file, 4-column check."""
+    """Object-detection variant (OD tools/datasets.py:76-109): no label file, 4-column check, and
+    ``label_2/{f}.txt`` = the frame's annotation file plus one line per inserted object."""
 
     def __init__(self, config):
         self.config = config
+        self.data_path = config["path"].get("dataset_path")
         self.save_output_folder = config["path"]["output_path"]
 
     def remove_space_for_spherical(self, point_cloud):
         return remove_space_for_spherical(point_cloud)[0]
 
-    def save_data(self, point_cloud, added_points, folder, name, idx=None, additional_anno_lines=None):
+    def save_data(self, point_cloud, added_points, folder, name, idx=None, additional_anno_lines=()):
         xyzi, _, _ = pack_for_save(point_cloud)
         _, _, check = pack_for_save(added_points, 4)
-        write_frame(self.save_output_folder, folder, name, xyzi, None, check, False)
+        if self.data_path is None:
+            raise KeyError("config['path']['dataset_path'] is needed for label_2 (OD tools/datasets.py:82)")
+        write_frame(self.save_output_folder, folder, name, xyzi, None, check, False,
+                    label_2=(os.path.join(self.data_path, "label_2", f"{name}.txt"), list(additional_anno_lines)))
 
 
 class Waymo:
@@ -115,6 +141,8 @@ class Waymo:
         base = os.path.join(self.config["path"]["output_path"], folder)
         for sub in ("lidar", "labels_v3_2", "check"):
             os.makedirs(os.path.join(base, sub), exist_ok=True)
-        np.save(os.path.join(base, "lidar", f"{name}.npy"), xyzi)                    # :297
-        np.save(os.path.join(base, "labels_v3_2", f"{name}.npy"), label.reshape(-1, 1))   # :299, N x 1 uint32
-        np.save(os.path.join(base, "check", f"{name}.npy"), check)                   # :301
+        import io
+        for sub, arr in (("lidar", xyzi), ("labels_v3_2", label.reshape(-1, 1)), ("check", check)):   # :297-301
+            buf = io.BytesIO()
+            np.save(buf, arr)
+            _commit(os.path.join(base, sub, f"{name}.npy"), buf.getvalue())

@@ -11,9 +11,11 @@ classes.
 
 Reading, computing and writing overlap: a reader thread parses the files of batch i+1 and a
 writer thread stores the results of batch i-1 while batch i is on the GPU; the device descriptor
-(``SceneBatch``) is allocated once and re-used.  Upload and download are not yet overlapped with
-the kernels (one stream).  ``process`` can be injected (the CPU tests pass the oracle there;
-production uses the HIP path and has no fallback).
+(``SceneBatch``) is allocated once and re-used.  ``run`` / ``run_placed`` keep the candidate loop
+(several placements per insert) and use one stream; ``run_streamed`` (one placement per insert) also
+overlaps upload, kernels and download over several lanes with pinned buffers (``streaming.py``).
+``process`` can be injected (the CPU tests pass the oracle there; production uses the HIP path and
+has no fallback).
 """
 from __future__ import annotations
 
@@ -129,11 +131,100 @@ class AugmentPipeline:
         finally:
             self.process = saved
 
-    def run(self, frames, candidates_for):
+    def run_streamed(self, frames, inserts_for, lanes=3, label_2_for=None, pack_threads=16):
+        """Like ``run`` for ONE placement per insert: inserts_for(i) -> (samples, min_points) with
+        samples[k] = M x 5 float64 (or None).  Batches go through ``StreamedAugmenter`` lanes: pinned
+        buffers, native packing, upload / kernels / download of consecutive batches overlapped."""
+        from .streaming import StreamedAugmenter
+        todo = [i for i, f in enumerate(frames)
+                if not (self.resume and _outputs_exist(self.output_path, self.folder, f.name, self.write_labels))]
+        stats = {"frames": len(frames), "skipped_existing": len(frames) - len(todo), "written": 0, "inserted": 0}
+        t_start = time.perf_counter()
+        B = self.batch_size
+        chunks = [todo[i:i + B] for i in range(0, len(todo), B)]
+        read_q, write_q, errors = queue.Queue(maxsize=2), queue.Queue(maxsize=4), []
+
+        def reader():
+            try:
+                for chunk in chunks:
+                    scenes = [read_frame(frames[i].velodyne_file, frames[i].label_file)[:2] for i in chunk]
+                    ins = [inserts_for(i) for i in chunk]
+                    read_q.put((chunk, scenes, ins))
+            except Exception as e:
+                errors.append(e)
+            finally:
+                read_q.put(None)
+
+        def writer():
+            try:
+                while True:
+                    item = write_q.get()
+                    if item is None:
+                        return
+                    chunk, results, accepted = item
+                    for i, (xyzi, label, check), acc in zip(chunk, results, accepted):
+                        write_frame(self.output_path, self.folder, frames[i].name, xyzi, label, check, self.write_labels,
+                                    label_2=label_2_for(i, acc) if label_2_for else None)
+                        stats["written"] += 1
+                        stats["inserted"] += sum(1 for a in acc if a >= 0)
+            except Exception as e:
+                errors.append(e)
+
+        threads = [threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)]
+        for t in threads:
+            t.start()
+        aug, caps = None, (0, 0, 0, 0)
+
+        def consume(tag, results, accepted):
+            chunk = tag
+            # the views die with the lane's next submit: the writer gets copies of the live rows
+            write_q.put((chunk, [(x.copy(), l.copy(), c.copy()) for x, l, c in results[:len(chunk)]], accepted[:len(chunk)]))
+
+        order = []
+        while not errors:
+            item = read_q.get()
+            if item is None:
+                break
+            chunk, scenes, ins = item
+            pad = B - len(chunk)                                   # the last batch: repeat its last frame, drop the copies
+            scenes, ins = scenes + [scenes[-1]] * pad, ins + [ins[-1]] * pad
+            K = max(len(x[0]) for x in ins)
+            n_max = max(len(x) for x, _ in scenes)
+            grow = max(sum(len(s) for s in x[0] if s is not None) for x in ins)
+            srows = max(sum(len(x[0][k]) for x in ins if k < len(x[0]) and x[0][k] is not None) for k in range(K))
+            if aug is None or K != caps[0] or n_max > caps[1] or grow > caps[2] or srows > caps[3]:
+                for lane in order:
+                    consume(*aug.collect(lane))
+                order = []
+                caps = (K, max(n_max, caps[1]), int(max(grow, caps[2]) * 1.25) + 64, int(max(srows, caps[3]) * 1.25) + 64)
+                aug = StreamedAugmenter(B, caps[1], caps[2], K, caps[3], lanes=lanes, device=self.device,
+                                        check_cols=self.check_cols, collapse_keep=-1 if self.road_label is None else self.road_label,
+                                        pack_threads=pack_threads)
+            lane = aug.free_lane()
+            if lane is None:
+                lane = order.pop(0)
+                consume(*aug.collect(lane))
+            aug.submit(lane, scenes, [x[0] for x in ins], [x[1] for x in ins], tag=chunk)
+            order.append(lane)
+        for lane in order:
+            if not errors:
+                consume(*aug.collect(lane))
+        write_q.put(None)
+        threads[1].join(timeout=120)
+        if errors:
+            raise errors[0]
+        stats["t_total"] = time.perf_counter() - t_start
+        stats["frames_per_s"] = stats["written"] / stats["t_total"] if stats["t_total"] > 0 else 0.0
+        return stats
+
+    def run(self, frames, candidates_for, label_2_for=None):
         """Process every frame; returns a dict of counters and timings.
 
         candidates_for(i) -> (slots, min_points): slots[k] = ordered list of M x 5 float64
-        candidates of insert k of frame i, min_points[k] its acceptance threshold."""
+        candidates of insert k of frame i, min_points[k] its acceptance threshold.
+        label_2_for(i, accepted) -> (path of frame i's label_2 file, annotation lines of its inserted
+        objects) for the object-detection flavour (OD tools/datasets.py:81-84; the lines come from
+        ``Real3DAug.insertion.create_annotation_line``); accepted[k] = index of the accepted candidate or -1."""
         todo = [i for i, f in enumerate(frames)
                 if not (self.resume and _outputs_exist(self.output_path, self.folder, f.name, self.write_labels))]
         stats = {"frames": len(frames), "skipped_existing": len(frames) - len(todo), "written": 0,
@@ -162,11 +253,11 @@ class AugmentPipeline:
                     item = write_q.get()
                     if item is None:
                         return
-                    chunk, results = item
+                    chunk, results, accepted = item
                     t0 = time.perf_counter()
-                    for i, (xyzi, label, check) in zip(chunk, results):
+                    for i, (xyzi, label, check), acc in zip(chunk, results, accepted):
                         write_frame(self.output_path, self.folder, frames[i].name, xyzi, label, check,
-                                    self.write_labels)
+                                    self.write_labels, label_2=label_2_for(i, acc) if label_2_for else None)
                         stats["written"] += 1
                     stats["t_write"] += time.perf_counter() - t0
             except Exception as e:
@@ -186,7 +277,7 @@ class AugmentPipeline:
             stats["inserted"] += sum(1 for a in accepted for x in a if x >= 0)
             while not errors:                                   # do not block on a dead writer
                 try:
-                    write_q.put((chunk, results), timeout=0.5)
+                    write_q.put((chunk, results, accepted), timeout=0.5)
                     break
                 except queue.Full:
                     pass

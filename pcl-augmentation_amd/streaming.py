@@ -1,0 +1,160 @@
+"""Frames streamed through the batched hot path with the transfers overlapped.
+
+``StreamedAugmenter`` keeps a few *lanes*.  A lane is one ``SceneBatch`` on the device plus pinned
+host buffers for everything that crosses the PCIe link (frames in, insert samples in, merged clouds /
+labels / check rows / counters out) and its own HIP stream.  ``submit`` packs a batch of frames into
+the lane's pinned input (the native packer ``r3d_host_pack_frames``: threads, no Python loop over
+points), then enqueues, on the lane's stream, upload -> ``begin`` -> ``insert_many`` -> ``finish`` ->
+download, and returns at once; ``collect`` waits for the lane's event and hands out views of its pinned
+outputs.  With two or more lanes in flight the upload of batch i+1 and the download of batch i-1 run
+on the copy engines while the kernels of batch i run on the CUs, and the host packs meanwhile.
+
+One placement candidate per insert slot (what ``r3d_batch_insert_many`` takes); the candidate loop
+with several placements per slot stays with ``AugmentPipeline.run`` / ``run_placed``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .batch import SceneBatch
+
+
+class _Lane:
+    def __init__(self, B, cap, log_cap, K, sample_rows, rows, cols, device, check_cols):
+        torch = _lib.require_gpu()
+        self.torch = torch
+        self.bt = SceneBatch(B, cap, log_cap, rows=rows, cols=cols, device=device)
+        self.B, self.K, self.check_cols = B, K, check_cols
+        cap, log_cap = self.bt.cap, self.bt.log_cap
+        with _lib.on(device):
+            self.stream = torch.cuda.Stream()
+            self.done = torch.cuda.Event()
+            pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
+            self.in_xyzi, self.in_label, self.in_n = pin((B, cap, 4), torch.float32), pin((B, cap), torch.int32), pin((B,), torch.int32)
+            self.in_rows = [pin((sample_rows, 5), torch.float64) for _ in range(K)]
+            self.in_off = pin((K, B + 1), torch.int64)
+            self.in_need = pin((K, B), torch.int32)
+            self.d_rows = [torch.empty((sample_rows, 5), dtype=torch.float64, device=device) for _ in range(K)]
+            self.d_off = torch.zeros((K, B + 1), dtype=torch.int64, device=device)
+            self.d_need = torch.zeros((K, B), dtype=torch.int32, device=device)
+            self.out_xyzi, self.out_label = pin((B, cap, 4), torch.float32), pin((B, cap), torch.int32)
+            self.out_check = pin((B, log_cap, check_cols), torch.float32)
+            self.out_counts = pin((4, B), torch.int32)                  # n_out, n_log, status, rebases
+            self.out_acc = pin((K, B), torch.int32)
+        self.busy = False
+        self.tag = None
+
+
+class StreamedAugmenter:
+    def __init__(self, B, n_max, grow, n_slots, sample_rows, lanes=3, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN,
+                 device="cuda:0", check_cols=5, collapse_keep=-1, pack_threads=16):
+        """B frames per batch, at most n_max points per frame, `grow` inserted points per frame in all
+        (sum over the slots), n_slots insert slots, at most sample_rows sample points per slot and batch."""
+        self.lib = _lib.load()
+        self.B, self.K = int(B), int(n_slots)
+        self.collapse_keep, self.pack_threads = int(collapse_keep), int(pack_threads)
+        self.lanes = [_Lane(B, n_max + grow, max(grow, 1), n_slots, sample_rows, rows, cols, device, check_cols)
+                      for _ in range(lanes)]
+        self.device = device
+        self.bytes_h2d = self.bytes_d2h = 0
+
+    def free_lane(self):
+        for i, ln in enumerate(self.lanes):
+            if not ln.busy:
+                return i
+        return None
+
+    def submit(self, lane_no, scenes, inserts, min_points, tag=None):
+        """scenes: B x (xyzi float32 [n,4], label uint32 [n]) host arrays as read from the files;
+        inserts[s][k]: M x 5 float64 sample of slot k of frame s (or None); min_points[s][k].
+        Returns immediately; the lane is busy until ``collect``."""
+        ln = self.lanes[lane_no]
+        assert not ln.busy and len(scenes) == self.B
+        torch, bt, B, K = ln.torch, ln.bt, self.B, self.K
+        # -- pack on the host (pinned staging); the frames by the native packer
+        xs = [np.ascontiguousarray(x, dtype=np.float32) for x, _ in scenes]
+        ls = [np.ascontiguousarray(l, dtype=np.uint32) for _, l in scenes]
+        n = np.array([len(x) for x in xs], dtype=np.int32)
+        px = (C.c_void_p * B)(*[x.ctypes.data for x in xs])
+        pl = (C.c_void_p * B)(*[l.ctypes.data for l in ls])
+        _lib.check(self.lib.r3d_host_pack_frames(px, pl, n.ctypes.data, B, bt.cap, ln.in_xyzi.data_ptr(), ln.in_label.data_ptr(),
+                                                 self.collapse_keep, self.pack_threads), "r3d_host_pack_frames")
+        ln.in_n.numpy()[:] = n
+        off = ln.in_off.numpy()
+        need = ln.in_need.numpy()
+        used = 0
+        for k in range(K):
+            rows = ln.in_rows[k].numpy()
+            pos = 0
+            off[k, 0] = 0
+            for s in range(B):
+                smp = inserts[s][k] if k < len(inserts[s]) else None
+                if smp is not None and len(smp):
+                    rows[pos:pos + len(smp)] = smp
+                    pos += len(smp)
+                off[k, s + 1] = pos
+                need[k, s] = min_points[s][k] if k < len(min_points[s]) else 0
+            used = max(used, pos)
+        # -- everything else on the lane's stream: upload, kernels, download
+        with _lib.on(self.device), torch.cuda.stream(ln.stream):
+            bt.xyzi.copy_(ln.in_xyzi, non_blocking=True)         # whole slabs: one contiguous copy each
+            bt.label.copy_(ln.in_label, non_blocking=True)
+            bt.n_points.copy_(ln.in_n, non_blocking=True)
+            for k in range(K):
+                m = int(off[k, B])
+                if m:
+                    ln.d_rows[k][:m].copy_(ln.in_rows[k][:m], non_blocking=True)
+                self.bytes_h2d += m * 40
+            ln.d_off.copy_(ln.in_off, non_blocking=True)
+            ln.d_need.copy_(ln.in_need, non_blocking=True)
+            self.bytes_h2d += B * bt.cap * 20
+            bt.begin()
+            _, acc = bt.insert_many_device([(ln.d_rows[k], ln.d_off[k]) for k in range(K)], [ln.d_need[k] for k in range(K)])
+            bt.finish(ln.check_cols)
+            ln.out_xyzi.copy_(bt.out_xyzi, non_blocking=True)
+            ln.out_label.copy_(bt.out_label, non_blocking=True)
+            ln.out_check.copy_(bt.check, non_blocking=True)
+            ln.out_counts[0].copy_(bt.n_out, non_blocking=True)
+            ln.out_counts[1].copy_(bt.n_log, non_blocking=True)
+            ln.out_counts[2].copy_(bt.status, non_blocking=True)
+            ln.out_counts[3].copy_(bt.rebase, non_blocking=True)
+            ln.out_acc.copy_(acc, non_blocking=True)
+            self.bytes_d2h += B * bt.cap * 20 + ln.out_check.numel() * 4
+            ln.done.record(ln.stream)
+        ln.busy, ln.tag = True, tag
+        return lane_no
+
+    def collect(self, lane_no):
+        """Wait for the lane; (tag, results, accepted): results[s] = (xyzi [n,4] float32, label [n] uint32,
+        check [m,cols] float32) as VIEWS of the lane's pinned buffers (valid until the lane's next submit),
+        accepted[s][k] = 0 (accepted) or -1."""
+        ln = self.lanes[lane_no]
+        assert ln.busy
+        ln.done.synchronize()
+        counts = ln.out_counts.numpy()
+        for s in np.nonzero(counts[2])[0]:
+            ln.busy = False
+            _lib.raise_status(int(counts[2][s]), f"scene {s}")
+        ox, ol, ck = ln.out_xyzi.numpy(), ln.out_label.numpy().view(np.uint32), ln.out_check.numpy()
+        acc = ln.out_acc.numpy()
+        results = [(ox[s, :counts[0][s]], ol[s, :counts[0][s]], ck[s, :counts[1][s]]) for s in range(self.B)]
+        accepted = [[0 if acc[k, s] else -1 for k in range(self.K)] for s in range(self.B)]
+        ln.busy = False
+        return ln.tag, results, accepted
+
+    def run(self, batches, consume):
+        """batches: iterable of (scenes, inserts, min_points, tag); consume(tag, results, accepted) is
+        called in submission order while later batches are in flight."""
+        order = []
+        for scenes, inserts, min_points, tag in batches:
+            lane = self.free_lane()
+            if lane is None:
+                lane = order.pop(0)
+                consume(*self.collect(lane))
+            self.submit(lane, scenes, inserts, min_points, tag)
+            order.append(lane)
+        for lane in order:
+            consume(*self.collect(lane))

@@ -191,9 +191,14 @@ def test_save_bytes(R, tmp_path):
     merged[:, [0, 1, 2, 6, 7]] = g["merged"]
     added = np.full((len(g["all_visible"]), 9), -1.0)
     added[:, [0, 1, 2, 6, 7]] = g["all_visible"]
-    ds.KITTI({"path": {"output_path": str(tmp_path)}}).save_data(merged, added, "od", "000001", 0, [])
+    (tmp_path / "kitti" / "label_2").mkdir(parents=True)
+    (tmp_path / "kitti" / "label_2" / "000001.txt").write_text("Car 0 0 0 1 2 3 4 1.5 1.6 3.9 1 2 30 0.1\n")
+    ds.KITTI({"path": {"output_path": str(tmp_path), "dataset_path": str(tmp_path / "kitti")}}).save_data(merged, added, "od", "000001", 0, [])
     assert (tmp_path / "od/velodyne/000001.bin").read_bytes() == g["velodyne_bin"].tobytes()
     assert (tmp_path / "od/check/000001.bin").read_bytes() == g["check_bin"].tobytes()
+    assert (tmp_path / "od/label_2/000001.txt").read_text() == "Car 0 0 0 1 2 3 4 1.5 1.6 3.9 1 2 30 0.1\n"
+    with pytest.raises(KeyError):                           # the reference's constructor needs dataset_path as well
+        ds.KITTI({"path": {"output_path": str(tmp_path)}}).save_data(merged, added, "od", "000002", 0, [])
 
 
 def test_save_data_waymo(R, tmp_path):
@@ -220,3 +225,28 @@ def test_save_data_waymo(R, tmp_path):
     assert labels.dtype == np.uint32 and labels.shape == (len(want), 1)
     assert np.array_equal(labels[:, 0], want[:, 7].astype(np.uint32))
     assert check.dtype == np.float32 and np.array_equal(check, wadd[:, [0, 1, 2, 6, 7]].astype(np.float32))
+
+
+def test_save_data_writes_the_references_bytes(R, tmp_path):
+    """Row a9: the three dataset flavours of ``save_data`` write, from the merged N x 9 cloud, the
+    bytes the REFERENCE's own ``save_data`` wrote (fixture from tests/golden/make_golden_save.py):
+    SemanticKITTI .bin/.label/check, Waymo .npy files, KITTI .bin/check + label_2 with the annotation
+    lines of the inserted objects appended."""
+    g = load_golden("save_data.npz")
+    ds = R.tools.datasets
+    merged9, allvis9 = g["merged9"], g["allvis9"]
+    out = str(tmp_path)
+    ds.SemanticKITTI({"path": {"output_path": out}}).save_data(merged9.copy(), allvis9.copy(), "ss", "000000", 0)
+    for sub, ext, key in (("velodyne", "bin", "semantic_0"), ("labels", "label", "semantic_1"), ("check", "bin", "semantic_2")):
+        assert (tmp_path / "ss" / sub / f"000000.{ext}").read_bytes() == g[key].tobytes()
+    ds.Waymo({"path": {"output_path": out}}).save_data(merged9.copy(), allvis9.copy(), "wy", "000000", 0)
+    for sub, key in (("lidar", "waymo_0"), ("labels_v3_2", "waymo_1"), ("check", "waymo_2")):
+        assert (tmp_path / "wy" / sub / "000000.npy").read_bytes() == g[key].tobytes()
+    (tmp_path / "in" / "label_2").mkdir(parents=True)
+    (tmp_path / "in" / "label_2" / "000000.txt").write_bytes(g["label_2_in"].tobytes())
+    kitti = ds.KITTI({"path": {"output_path": out, "dataset_path": str(tmp_path / "in")}})
+    kitti.save_data(merged9.copy(), allvis9.copy(), "od", "000000", 0, [str(x) for x in g["anno_lines"]])
+    assert (tmp_path / "od" / "velodyne" / "000000.bin").read_bytes() == g["kitti_0"].tobytes()
+    assert (tmp_path / "od" / "check" / "000000.bin").read_bytes() == g["kitti_1"].tobytes()
+    assert (tmp_path / "od" / "label_2" / "000000.txt").read_bytes() == g["kitti_label_2"].tobytes()
+    assert not list(tmp_path.rglob("*.tmp"))

@@ -174,3 +174,24 @@ def test_closing_matches_scipy_definition():
     assert np.array_equal(O.class_closing(lab), want)
     want2 = ndi.binary_erosion(ndi.binary_dilation(img > 0, structure=fp), structure=fp, border_value=1)
     assert np.array_equal(O.class_closing(lab) == 255, want2)
+
+
+def test_annotation_lines_and_label_2_match_the_reference(pkg, tmp_path):
+    """Row a9, object detection: ``create_annotation_line`` (OD insertion.py:227-265) and
+    ``create_annotation`` (OD tools/datasets.py:20-37) restated on the host give the strings / bytes
+    the reference's functions produced (tests/golden/make_golden_save.py)."""
+    g = load_golden("save_data.npz")
+    ins, ds = pkg.Real3DAug.insertion, pkg.Real3DAug.tools.datasets
+    lines = []
+    for o, c, r, cl, want in zip(g["anno_originals"], g["anno_centres"], g["anno_rotations"], g["anno_classes"], g["anno_lines"]):
+        anno = {"center": {"x": float(c[0]), "y": float(c[1]), "z": float(c[2])}, "class": str(cl)}
+        line = ins.create_annotation_line(np.array(str(o)), anno, int(r))
+        assert line == str(want)
+        lines.append(line)
+    old = tmp_path / "000000.txt"
+    old.write_bytes(g["label_2_in"].tobytes())
+    ds.create_annotation(str(old), str(tmp_path / "new.txt"), lines)
+    assert (tmp_path / "new.txt").read_bytes() == g["kitti_label_2"].tobytes()
+    # wrap-around of the two angles
+    far = ins.create_annotation_line(np.array("Car 0 0 0 1 2 3 4 1.5 1.6 3.9 0 0 0 -3.0"), {"center": {"x": -5.0, "y": 0.1, "z": -1.0}, "class": "Car"}, 90)
+    assert far.split(" ")[14].strip() == f"{-3.0 - np.pi / 2 + 2 * np.pi:.02f}"

@@ -93,3 +93,30 @@ def test_pipeline_on_gpu(pkg, synth, tmp_path, od):
     stats = pipe.run(fr, lambda i: _candidates(synth, i))
     assert stats["written"] == 7 and stats["inserted"] > 0
     _check_outputs(synth, frames, tmp_path / "out", "gpu", od)
+
+
+@pytest.mark.gpu
+def test_streamed_pipeline_on_gpu(pkg, synth, tmp_path):
+    """run_streamed: pinned lanes, native packer, overlapped transfers -- every written file equals the
+    oracle's bytes (SemanticKITTI and KITTI flavour, a last batch that is not full, label_2 files)."""
+    frames = _make_dataset(synth, tmp_path / "in", 7)
+    for od in (False, True):
+        pipe = pkg.AugmentPipeline(str(tmp_path / "out"), "od" if od else "ss", dataset="kitti" if od else "semantic", batch_size=3)
+        fr = [pkg.Frame(v, l) for v, l in frames]
+        (tmp_path / "in" / "label_2").mkdir(exist_ok=True)
+        for f in fr:
+            (tmp_path / "in" / "label_2" / f"{f.name}.txt").write_text("Car 0 0 0 1 2 3 4 1.5 1.6 3.9 1 2 30 0.1\n")
+
+        def inserts_for(i):
+            slots, need = _candidates(synth, i)
+            return [s[0] for s in slots], need
+
+        def label_2_for(i, acc):
+            return str(tmp_path / "in" / "label_2" / f"{fr[i].name}.txt"), [f"Pedestrian 0 3 0 0 0 0 0 1 1 1 0 0 {k} 0\n" for k, a in enumerate(acc) if a >= 0]
+
+        st = pipe.run_streamed(fr, inserts_for, lanes=2, label_2_for=label_2_for if od else None)
+        assert st["written"] == 7
+        _check_outputs(synth, frames, tmp_path / "out", "od" if od else "ss", od)
+        if od:
+            txt = (tmp_path / "out" / "od" / "label_2" / "000003.txt").read_text()
+            assert txt.startswith("Car 0 0 0") and txt.count("\n") >= 2
