@@ -548,3 +548,86 @@ def test_chain_timeout_is_reported(P, synth):
     assert acc.cpu().numpy()[:, 1].tolist() == [1, 1, 1] and acc.cpu().numpy()[1:, 0].tolist() == [0, 0]
     with pytest.raises(ValueError, match="waiting"):
         batch.raise_on_status()
+
+
+def test_bench_scenes_against_the_oracle(P, synth):
+    """Short form of tests/crosscheck_bench.py: 12 scenes of the bench workload (config C2, the seeds the
+    bench times) through one batch, byte for byte against the oracle; 4 more with blobs in front of the
+    extreme-elevation points so that the chain re-bases in the middle."""
+    from conftest import blob_in_front_of_extreme
+    kinds = synth.CONFIG_INSERTS["C2"]
+    seeds = list(range(12)) + [100, 101, 102, 103]
+    scenes = [synth.make_scene(s) for s in seeds]
+    slots = []
+    for i, s in enumerate(seeds):
+        ins = synth.make_inserts(s, kinds)
+        if s >= 100:
+            ins = [blob_in_front_of_extreme(scenes[i][0], "max", seed=s)] + ins[:3] + [blob_in_front_of_extreme(scenes[i][0], "min", seed=s)] + ins[3:]
+        slots.append([[x] for x in ins])
+    need = [[20] * len(sl) for sl in slots]
+    res, acc = P.augment_batch(scenes, slots, need)
+    assert P.batch.SceneBatch.last_rebases >= 4
+    for (xyzi, label), sl, nd, r, a in zip(scenes, slots, need, res, acc):
+        vb, lb, cb, oacc = _oracle_chain(xyzi, label, sl, nd)
+        assert a == oacc
+        _check_scene(r, vb, lb, cb)
+
+
+def test_chain_soak_two_batches_in_flight(P, synth):
+    """Short form of tools/soak_chain.py: the one-launch insert of a 64-scene batch 40 times with a second
+    batch in flight on another stream (a batch size that is not a multiple of 8 as well): every iteration
+    gives the same survivors, labels, counts, accept flags and status."""
+    import torch
+    kinds = synth.CONFIG_INSERTS["C2"]
+    for B in (64, 61):
+        scenes = [synth.make_scene(200 + s, 48, 900) for s in range(B)]
+        inserts = [synth.make_inserts(200 + s, kinds) for s in range(B)]
+        grow = sum(max(len(inserts[s][k]) for s in range(B)) for k in range(len(kinds)))
+        lanes = []
+        for _ in range(2):
+            bt = P.SceneBatch(B, 48 * 900 + grow, grow)
+            bt.load(scenes)
+            pk = [bt.pack_samples([inserts[s][k] for s in range(B)]) for k in range(len(kinds))]
+            nd = torch.full((B,), 20, dtype=torch.int32, device=bt.device)
+            lanes.append((bt, pk, nd, torch.cuda.Stream()))
+
+        def step(lane):
+            bt, pk, nd, st = lanes[lane]
+            with torch.cuda.stream(st):
+                bt.begin()
+                acc = bt.insert_many_device(pk, [nd] * len(pk))[1].clone()
+                bt.finish(check_cols=5)
+            return acc
+
+        def fingerprint(lane, acc):
+            bt = lanes[lane][0]
+            return [int(v.item()) for v in (bt.out_xyzi.view(torch.int32).sum(dtype=torch.int64),
+                                            bt.out_label.view(torch.int32).sum(dtype=torch.int64),
+                                            bt.n_out.sum(dtype=torch.int64), bt.n_log.sum(dtype=torch.int64),
+                                            acc.sum(dtype=torch.int64), bt.status.sum(dtype=torch.int64))]
+
+        torch.cuda.synchronize()
+        first = step(0)
+        torch.cuda.synchronize()
+        ref = fingerprint(0, first)
+        assert ref[-1] == 0 and ref[-2] > 0
+        for _ in range(40):
+            a, b = step(0), step(1)
+            torch.cuda.synchronize()
+            assert fingerprint(0, a) == ref and fingerprint(1, b) == ref
+
+
+def test_c5_full_size_chain(P, synth, monkeypatch):
+    """BASELINE config C5 at full size: one 256-beam 1M-point scan, 50 inserts, range image 448 x 2880,
+    all slots through r3d_batch_insert_many (two launches of the chain kernel: 32 + 18 slots), against
+    the oracle's chain byte for byte."""
+    monkeypatch.setattr(O, "NUMROW", 448)
+    monkeypatch.setattr(O, "NUMCOLUMN", 2880)
+    xyzi, label = synth.make_scene(502, n_beams=256, n_az=3906)
+    kinds = ["car", "pedestrian", "cyclist", "pedestrian", "cyclist"] * 10
+    sl = [[x] for x in synth.make_inserts(502, kinds)]
+    nd = [20] * len(sl)
+    res, acc = P.augment_batch([(xyzi, label)], [sl], [nd], rows=448, cols=2880)
+    vb, lb, cb, oacc = _oracle_chain(xyzi, label, sl, nd)
+    assert acc[0] == oacc and sum(1 for a in oacc if a == 0) >= 40
+    _check_scene(res[0], vb, lb, cb)
