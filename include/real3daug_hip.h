@@ -350,6 +350,16 @@ int r3d_map_splat(const float *xyzi, const uint32_t *label, int64_t n, const dou
                   int32_t size_y, int64_t frame_no, uint64_t *keys, int32_t *status, void *stream);
 int r3d_map_finish(const uint64_t *keys, int64_t cells, double *map64, uint8_t *map8, void *stream);
 
+/* The object-detection flavour, object_detection/rich_map/single_drivable_area_map.py:113-194, for ONE frame
+ * (KITTI has no poses: a map per frame, in the frame's own coordinates).  min_x / min_y = int(min x), int(min y)
+ * of the frame's points and size_x / size_y = int(max) + 1 - min (:118-127; r3d_map_bounds with the identity
+ * pose gives the extremes).  road_map [size_x][size_y] uint8 = cells under points of label road_label (:129-139),
+ * closed with disk(4) (:145-151; {0, 1} as np.savez stores it, :157); pedestrian_map = the cells that are not road
+ * but touch it (:160-178), dilated with disk(2) (:180-188, saved :193).  scratch: 2*size_x*size_y bytes. */
+int r3d_od_maps(const float *xyzi, const uint32_t *label, int64_t n, int32_t road_label, int32_t min_x, int32_t min_y,
+                int32_t size_x, int32_t size_y, uint8_t *road_map, uint8_t *pedestrian_map, uint8_t *scratch,
+                void *stream);
+
 /* =====================================================================================
  * Host-side packer of the file-to-file driver.  HOST pointers: copies B
  * frames as the reference's __getitem__ reads them (velodyne .bin rows float32 x y z intensity,

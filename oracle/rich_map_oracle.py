@@ -46,3 +46,41 @@ def build_rich_map(frames, labels_road, labels_sidewalk, labels_parking):
             elif area[px][py] != 3:
                 area[px][py] = 2
     return area, np.array([[min_x], [min_y], [0], [1]])
+
+
+# ---- object-detection flavour (object_detection/rich_map/single_drivable_area_map.py:113-194) ---------------------
+def _disk_offsets(radius):
+    return [(dr, dc) for dr in range(-radius, radius + 1) for dc in range(-radius, radius + 1) if dr * dr + dc * dc <= radius * radius]
+
+
+def _morph(img, radius, erode):
+    """Binary dilation / erosion with disk(radius), windows clipped at the borders (scikit-image's grey
+    closing / dilation with a symmetric convex footprint and reflecting borders)."""
+    sx, sy = img.shape
+    out = np.ones_like(img) if erode else np.zeros_like(img)
+    for dr, dc in _disk_offsets(radius):
+        r0, r1, c0, c1 = max(0, -dr), min(sx, sx - dr), max(0, -dc), min(sy, sy - dc)
+        if r0 >= r1 or c0 >= c1:
+            continue
+        src = img[r0 + dr:r1 + dr, c0 + dc:c1 + dc]
+        if erode:
+            out[r0:r1, c0:c1] &= src
+        else:
+            out[r0:r1, c0:c1] |= src
+    return out
+
+
+def od_maps(xyzi, label, road_label):
+    """One frame: (road_map uint8, pedestrian_map uint8, min_x, min_y) as the script saves them (:157, :193)."""
+    pc = xyzi[:, :3].astype(np.float64)
+    sem = (label & 0xFFFF).astype(np.int64)
+    min_x, min_y = int(pc[:, 0].min()), int(pc[:, 1].min())                               # :118-119
+    size_x, size_y = int(pc[:, 0].max()) + 1 - min_x, int(pc[:, 1].max()) + 1 - min_y      # :121-127
+    raster = np.zeros((size_x, size_y), dtype=np.uint8)
+    road = pc[sem == road_label]
+    raster[(road[:, 0] - min_x).astype(np.int64), (road[:, 1] - min_y).astype(np.int64)] = 1   # :129-139 (int() truncates)
+    closed = _morph(_morph(raster, 4, False), 4, True)                                     # :145-151
+    ring = np.zeros_like(closed)
+    near = _morph(closed, 1, False) | np.pad(closed, 1)[:-2, :-2] | np.pad(closed, 1)[:-2, 2:] | np.pad(closed, 1)[2:, :-2] | np.pad(closed, 1)[2:, 2:]
+    ring[(closed == 0) & (near == 1)] = 1                                                  # :160-178 (8-neighbourhood)
+    return closed, _morph(ring, 2, False), min_x, min_y                                    # :180-188

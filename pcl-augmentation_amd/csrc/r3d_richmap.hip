@@ -103,6 +103,54 @@ __global__ void k_map_finish(const unsigned long long *keys, int64_t cells, doub
   if (map8) map8[i] = (uint8_t)code;
 }
 
+// ---- object-detection flavour: object_detection/rich_map/single_drivable_area_map.py:113-194, one frame ----
+// :129-139 the cells under the frame's Road points (frame coordinates, int() truncation).
+__global__ __launch_bounds__(256) void k_od_splat(const float4 *xyzi, const uint32_t *label, int64_t n, int road_label,
+                                                 int min_x, int min_y, int size_x, int size_y, uint8_t *raster) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if ((int)(label[i] & 0xFFFFu) != road_label) continue;                  // tools/datasets.py:60-61, :130
+    float4 v = xyzi[i];
+    int px = (int)((double)v.x - (double)min_x), py = (int)((double)v.y - (double)min_y);   // :133-134, :138
+    if (px >= 0 && py >= 0 && px < size_x && py < size_y) raster[(size_t)px * size_y + py] = 1;
+  }
+}
+
+// Binary dilation (erode = 0) or erosion (erode = 1) with disk(radius) -- the cells (dr, dc) with
+// dr*dr + dc*dc <= radius*radius -- windows clipped at the borders (what scikit-image's reflecting grey
+// morphology amounts to for a symmetric convex footprint).  :145-151 closing = erosion of the dilation
+// with disk(4); :182-188 dilation with disk(2).
+__global__ __launch_bounds__(256) void k_od_morph(const uint8_t *src, uint8_t *dst, int size_x, int size_y, int radius,
+                                                 int erode) {
+  int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= size_x * size_y) return;
+  int r = cell / size_y, c = cell - r * size_y;
+  int acc = erode ? 1 : 0;
+  for (int dr = -radius; dr <= radius; ++dr)
+    for (int dc = -radius; dc <= radius; ++dc) {
+      if (dr * dr + dc * dc > radius * radius) continue;
+      int rr = r + dr, cc = c + dc;
+      if (rr < 0 || rr >= size_x || cc < 0 || cc >= size_y) continue;
+      int v = src[(size_t)rr * size_y + cc] != 0;
+      acc = erode ? (acc & v) : (acc | v);
+    }
+  dst[cell] = (uint8_t)acc;
+}
+
+// :160-178 cells that are not road but touch a road cell (8-neighbourhood, clipped).
+__global__ __launch_bounds__(256) void k_od_ring(const uint8_t *road, uint8_t *ring, int size_x, int size_y) {
+  int cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= size_x * size_y) return;
+  int r = cell / size_y, c = cell - r * size_y;
+  int near = 0;
+  if (road[cell] == 0)
+    for (int dr = -1; dr <= 1; ++dr)
+      for (int dc = -1; dc <= 1; ++dc) {
+        int rr = r + dr, cc = c + dc;
+        if (rr >= 0 && rr < size_x && cc >= 0 && cc < size_y && road[(size_t)rr * size_y + cc] == 1) near = 1;
+      }
+  ring[cell] = (uint8_t)near;
+}
+
 int fill_pose(const double *pose16, Pose &p) {
   if (!pose16) return fail(R3D_E_ARG, "rich map: null pose");
   for (int i = 0; i < 16; ++i) p.t[i] = pose16[i];
@@ -154,5 +202,28 @@ extern "C" int r3d_map_finish(const uint64_t *keys, int64_t cells, double *map64
   hipLaunchKernelGGL(k_map_finish, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const unsigned long long *>(keys), cells, map64, map8);
   R3D_LAUNCHED("k_map_finish");
+  return R3D_OK;
+}
+
+extern "C" int r3d_od_maps(const float *xyzi, const uint32_t *label, int64_t n, int32_t road_label, int32_t min_x,
+                           int32_t min_y, int32_t size_x, int32_t size_y, uint8_t *road_map, uint8_t *pedestrian_map,
+                           uint8_t *scratch, void *stream) {
+  if (!xyzi || !label || !road_map || !pedestrian_map || !scratch || n < 0 || size_x <= 0 || size_y <= 0 ||
+      (int64_t)size_x * size_y > (1ll << 30))
+    return fail(R3D_E_ARG, "od_maps: bad argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int cells = size_x * size_y;
+  uint8_t *a = scratch, *b = scratch + cells;
+  R3D_HIP(hipMemsetAsync(a, 0, (size_t)cells, st));
+  if (n > 0)
+    hipLaunchKernelGGL(k_od_splat, dim3(blocks_for(n, 256 * 4, 4096)), dim3(256), 0, st,
+                       reinterpret_cast<const float4 *>(xyzi), label, n, (int)road_label, (int)min_x, (int)min_y, (int)size_x,
+                       (int)size_y, a);
+  const dim3 grid((cells + 255) / 256), block(256);
+  hipLaunchKernelGGL(k_od_morph, grid, block, 0, st, a, b, (int)size_x, (int)size_y, 4, 0);
+  hipLaunchKernelGGL(k_od_morph, grid, block, 0, st, b, road_map, (int)size_x, (int)size_y, 4, 1);
+  hipLaunchKernelGGL(k_od_ring, grid, block, 0, st, road_map, a, (int)size_x, (int)size_y);
+  hipLaunchKernelGGL(k_od_morph, grid, block, 0, st, a, pedestrian_map, (int)size_x, (int)size_y, 2, 0);
+  R3D_LAUNCHED("od_maps kernels");
   return R3D_OK;
 }

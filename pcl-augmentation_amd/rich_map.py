@@ -56,3 +56,26 @@ def _build_rich_map(frames, placement_labels, device, as_uint8):
     if int(status.item()):
         raise AssertionError("Indexing error: a surface point outside the map (drivable_area_map.py:180)")
     return out.cpu().numpy(), np.array([[min_x], [min_y], [0], [1]])
+
+
+def build_od_maps(xyzi, label, road_label, device="cuda:0"):
+    """One frame of object_detection/rich_map/single_drivable_area_map.py:113-194: (road_map uint8
+    [size_x, size_y], pedestrian_map uint8, min_x, min_y) as its two np.savez calls store them (:157, :193).
+    xyzi float32 [n,4], label uint32 [n] as read from the frame's files (tools/datasets.py:56-62)."""
+    with _lib.on(device):
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        x = torch.from_numpy(np.ascontiguousarray(xyzi, dtype=np.float32)).to(device)
+        lab = torch.from_numpy(np.ascontiguousarray(label, dtype=np.uint32).view(np.int32)).to(device)
+        ident = (C.c_double * 16)(*np.eye(4).reshape(16))
+        minmax = torch.tensor([-1, 0, -1, 0], dtype=torch.int64, device=device)
+        _lib.check(lib.r3d_map_bounds(x.data_ptr(), x.shape[0], ident, minmax.data_ptr(), _lib.stream_ptr()), "r3d_map_bounds")
+        mm = [_decode(int(v) & 0xFFFFFFFFFFFFFFFF) for v in minmax.cpu().numpy()]
+        min_x, min_y = int(mm[0]), int(mm[2])                                           # :118-119 (truncation)
+        size_x, size_y = int(mm[1]) + 1 - min_x, int(mm[3]) + 1 - min_y                 # :121-127
+        road = torch.empty((size_x, size_y), dtype=torch.uint8, device=device)
+        ped = torch.empty((size_x, size_y), dtype=torch.uint8, device=device)
+        scratch = torch.empty(2 * size_x * size_y, dtype=torch.uint8, device=device)
+        _lib.check(lib.r3d_od_maps(x.data_ptr(), lab.data_ptr(), x.shape[0], int(road_label), min_x, min_y, size_x, size_y,
+                                   road.data_ptr(), ped.data_ptr(), scratch.data_ptr(), _lib.stream_ptr()), "r3d_od_maps")
+        return road.cpu().numpy(), ped.cpu().numpy(), min_x, min_y

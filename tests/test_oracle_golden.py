@@ -195,3 +195,15 @@ def test_annotation_lines_and_label_2_match_the_reference(pkg, tmp_path):
     # wrap-around of the two angles
     far = ins.create_annotation_line(np.array("Car 0 0 0 1 2 3 4 1.5 1.6 3.9 0 0 0 -3.0"), {"center": {"x": -5.0, "y": 0.1, "z": -1.0}, "class": "Car"}, 90)
     assert far.split(" ")[14].strip() == f"{-3.0 - np.pi / 2 + 2 * np.pi:.02f}"
+
+
+def test_od_rich_map_oracle_matches_the_reference_script():
+    """Row f-4, object detection: the oracle's per-frame road / pedestrian maps equal the maps the reference's
+    single_drivable_area_map.py saved (tests/golden/make_golden_map_od.py)."""
+    from oracle import rich_map_oracle as M
+    g = load_golden("rich_map_od.npz")
+    for f in range(3):
+        road, ped, mx, my = M.od_maps(g[f"xyzi{f}"], g[f"label{f}"], int(g["road_label"]))
+        assert (mx, my) == tuple(g[f"min{f}"])
+        assert road.dtype == g[f"road{f}"].dtype and np.array_equal(road, g[f"road{f}"])
+        assert np.array_equal(ped, g[f"ped{f}"])
