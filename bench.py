@@ -7,9 +7,9 @@
 One "step" is one pass of the hot path over one batch: r3d_batch_begin (elevation bounds,
 spherical projection), the insert slots (r3d_batch_insert_many: sample projection, closing / hole
 fill on the candidate pixels, visibility mask, cull, append) and r3d_batch_finish (compaction into
-the velodyne/.bin + labels/.label byte layout, plus the check/.bin rows).  By default two steps are
-in flight: consecutive steps alternate between two HBM-resident copies of the batch on two HIP
-streams, as consecutive batches of a real run would, so that the streaming kernels of one step fill
+the velodyne/.bin + labels/.label byte layout, plus the check/.bin rows).  By default three steps are
+in flight: consecutive steps rotate over three HBM-resident copies of the batch on three HIP
+streams, as consecutive batches of a real run do (streaming.py), so that the streaming kernels of one step fill
 the CUs that the latency-bound insert kernel of the other leaves idle (`--overlap 1`: one step at a
 time; that rate is also reported, as config.scenes_per_s_one_step_in_flight).
 
@@ -203,7 +203,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2",
                     help="C2 = the configuration the metric is quoted on (default); C5 = the 1M-point stress run")
     ap.add_argument("--scenes", type=int, default=0, help="scenes per GPU batch (default: the config's)")
-    ap.add_argument("--overlap", type=int, default=2,
+    ap.add_argument("--overlap", type=int, default=3,
                     help="consecutive steps alternate between this many full-size batches, each on its own HIP stream "
                          "(1 = every step on the same batch and stream)")
     ap.add_argument("--per-slot-launches", action="store_true",

@@ -44,6 +44,7 @@
 #include "r3d_batch.hpp"
 
 #include <cstdlib>
+#include <string>
 
 namespace r3d {
 
@@ -257,12 +258,19 @@ struct Ins {
   __device__ __forceinline__ int global_pix(int lp) const {
     return win.row_of(lp >> 5) * cols + (win.word_of(lp >> 5) << 5) + (lp & 31);
   }
-  __device__ __forceinline__ unsigned long long sample_key(int lp) const {   // lp = window-local pixel
-    return A.get_local(lp) ? s_sdepth[rank_of(lp)] : R3D_SENT;
+  // Depth keys without branches (lp: window-local pixel, -1 = outside): the loads of the 15 neighbours of a
+  // hole can then be in flight together -- two independent LDS reads, one dependent, instead of 15 chains.
+  __device__ __forceinline__ unsigned long long sample_key(int lp) const {
+    const int wd = lp >= 0 ? lp >> 5 : 0;
+    const uint32_t aw = A.w[wd], rk = s_rank[wd], bit = 1u << (lp & 31);
+    const bool occ = lp >= 0 && (aw & bit);
+    const unsigned long long key = s_sdepth[occ ? (int)rk + __popc(aw & (bit - 1u)) : 0];
+    return occ ? key : R3D_SENT;
   }
   __device__ __forceinline__ unsigned long long scene_key(int r, int c) const {
-    int dl = bt.index(r, c);
-    return dl < 0 ? R3D_SENT : s_dtile[dl];
+    const int dl = bt.index(r, c);
+    const unsigned long long key = s_dtile[dl < 0 ? 0 : dl];
+    return dl < 0 ? R3D_SENT : key;
   }
 
   // ================================================================================================
@@ -788,18 +796,16 @@ struct Ins {
           if (a) sd = key_depth(sample_key(lp));
           if (d) cd = key_depth(scene_key(r, c));
           // hole means (closing.py:44-57): the 15 neighbour keys are gathered first, one image at a time
-          // (one register array), then summed in the reference's order
+          // (one register array, every load issued before the first is used), then summed in the reference's order
           if (!a) {                                            // a candidate is closed: a hole of the sample
             unsigned long long v[15];
 #pragma unroll
             for (int dr = -2; dr <= 2; ++dr)
 #pragma unroll
               for (int dc = -1; dc <= 1; ++dc) {
-                int rr = r + dr, cc = c + dc, k = (dr + 2) * 3 + (dc + 1);
-                v[k] = R3D_SENT;
-                if (rr < 0 || rr >= rows || cc < 0 || cc >= cols) continue;
-                int lp2 = win.lpix_rc(rr, cc);                 // inside the window: holes are >= 2 rows in
-                if (lp2 >= 0) v[k] = sample_key(lp2);
+                int rr = r + dr, cc = c + dc;
+                const bool in = rr >= 0 && rr < rows && cc >= 0 && cc < cols;
+                v[(dr + 2) * 3 + (dc + 1)] = sample_key(in ? win.lpix_rc(rr, cc) : -1);   // inside the window: holes are >= 2 rows in
               }
             sd = mean_of_keys(v);
           }
@@ -809,10 +815,9 @@ struct Ins {
             for (int dr = -2; dr <= 2; ++dr)
 #pragma unroll
               for (int dc = -1; dc <= 1; ++dc) {
-                int rr = r + dr, cc = c + dc, k = (dr + 2) * 3 + (dc + 1);
-                v[k] = R3D_SENT;
-                if (rr < 0 || rr >= rows || cc < 0 || cc >= cols) continue;
-                v[k] = scene_key(rr, cc);
+                int rr = r + dr, cc = c + dc;
+                const bool in = rr >= 0 && rr < rows && cc >= 0 && cc < cols;
+                v[(dr + 2) * 3 + (dc + 1)] = scene_key(in ? rr : -1, cc);
               }
             cd = mean_of_keys(v);
           }
@@ -1123,7 +1128,9 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 1 : 4)
 k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int chunks, int lds_cap,
                long long timeout_ticks, int B8) {
   extern __shared__ __align__(16) unsigned char smem[];     // no static __shared__ here: one LDS array
-  const int k = (int)blockIdx.x / B8, s = (int)blockIdx.x % B8;
+  // B8 > 0: slot-major numbering (slot k of every scene, then slot k + 1; a scene's slots on one residue of the
+  // block id mod 8); B8 == 0: scene-major (the slots of scene 0, then those of scene 1, ...)
+  const int k = B8 ? (int)blockIdx.x / B8 : (int)blockIdx.x % nk, s = B8 ? (int)blockIdx.x % B8 : (int)blockIdx.x / nk;
   if (s >= b.B) return;
   const int tid = threadIdx.x, slot_no = k;
   (void)slot_no;
@@ -1367,11 +1374,13 @@ static int chain_lds_bytes() {
 template <int NT>
 static int launch_chain(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step, int lds,
                         long long timeout_ticks, hipStream_t st) {
-  const int B8 = (b.B + 7) & ~7;                              // a scene's slots on one residue of the block id mod 8
+  // measured on config C2: scene-major numbering is 10-40 % slower (the big pairs of all scenes no longer start together)
+  static const bool scene_major = getenv("R3D_CHAIN_ORDER") && std::string(getenv("R3D_CHAIN_ORDER")) == "scene";
+  const int B8 = scene_major ? 0 : (b.B + 7) & ~7;            // a scene's slots on one residue of the block id mod 8
   // per device, every call: the attribute belongs to the current device's copy of the kernel
   R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_chain<NT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(k_insert_chain<NT>, dim3(B8 * nk), dim3(NT), lds, st, b, sl, nk, first_step, w, chunks_of(b), lds,
+  hipLaunchKernelGGL(k_insert_chain<NT>, dim3((B8 ? B8 : b.B) * nk), dim3(NT), lds, st, b, sl, nk, first_step, w, chunks_of(b), lds,
                      timeout_ticks, B8);
   R3D_LAUNCHED("k_insert_chain");
   return R3D_OK;
