@@ -52,12 +52,21 @@ k_bounds(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
     if (t0 >= n) continue;
     unsigned long long lmin = ~0ull, lmax = 0ull;
     int bad = 0;
+    // the thread's 8 float32 points are requested together (inserted float64 points, which only exist when a
+    // re-based scene comes through here, are fetched from the log below)
+    const float4 *src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
+    float4 pt[kPerThread];
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+      int i = t0 + k * kPT + threadIdx.x;
+      pt[k] = src[i < n ? i : n - 1];
+    }
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
       int i = t0 + k * kPT + threadIdx.x;
       if (i < n) {
-        double x, y, z;
-        load_point(b, s, i, n_head, x, y, z);
+        double x = (double)pt[k].x, y = (double)pt[k].y, z = (double)pt[k].z;
+        if (i >= n_head) load_point(b, s, i, n_head, x, y, z);
         double r = sqrt(x * x + y * y + z * z);
         double q = z / r;
         if (!(q >= -1.0 && q <= 1.0) || !isfinite(x) || !isfinite(y)) {
@@ -355,6 +364,8 @@ k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
           row[0] = make_double2(x, y);
           row[1] = make_double2(z, (double)(b.label[(int64_t)s * b.cap + i] & 0xFFFFu));
         } else {
+          // (measured and dropped: requesting the thread's 8 points and labels before the first store, 0.32 ms
+          // against 0.28 ms; a shifted plain copy for the tiles in which nobody died, 0.30 ms)
           dst[o] = src[i];
           b.out_label[(int64_t)s * b.cap + o] = b.label[(int64_t)s * b.cap + i];
         }

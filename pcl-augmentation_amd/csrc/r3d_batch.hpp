@@ -40,6 +40,9 @@ struct BatchWs {
   int32_t *recs;                // [B*kMaxChain*kRecInts] what every finished slot of the launch publishes
   unsigned char *glist;         // [B*(kMaxChain+1)*chunks*24] chunk lists that exceed a workgroup's LDS: one area per (scene, slot of the
                                 // launch) for k_insert_chain, one per scene for k_insert_big
+  unsigned char *tile_pool;     // [pool_bytes] depth tiles / candidate lists of the pairs whose window exceeds a workgroup's LDS
+  unsigned long long *pool_head; // [1] bytes handed out in the running launch
+  int64_t pool_bytes;
   int64_t cand_stride;          // uint32 entries of `cand` per scene
   size_t total;
 };
@@ -71,6 +74,10 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.defer_from = c.take<int32_t>((size_t)b.B);
   w.recs = c.take<int32_t>((size_t)b.B * kMaxChain * kRecInts);
   w.glist = c.take<unsigned char>((size_t)b.B * (kMaxChain + 1) * chunks_of(b) * 24);
+  w.pool_bytes = (int64_t)b.B * (4 << 20);                  // 4 MB per scene, between 256 MB and 1 GB
+  w.pool_bytes = w.pool_bytes < (256ll << 20) ? (256ll << 20) : (w.pool_bytes > (1ll << 30) ? (1ll << 30) : w.pool_bytes);
+  w.tile_pool = c.take<unsigned char>((size_t)w.pool_bytes);
+  w.pool_head = c.take<unsigned long long>(1);
   w.total = c.off;
   return w;
 }

@@ -53,6 +53,7 @@ constexpr int kDbgSerial = 2;        // never speculate
 constexpr int kDbgBands = 4;         // the depth tile in bands of at most 3 candidate rows
 constexpr int kDbgDefer = 8;         // every pair is left to k_insert_big
 constexpr int kDbgDropPublish = 16;  // slot 0 of scene 0 does not publish: its successors time out
+constexpr int kDbgPoolTile = 32;     // every pair's depth tile and candidate list in the global pool
 
 struct ChainSlots {
   const double *samples5[kMaxChain];
@@ -198,6 +199,9 @@ struct Ins {
   uint16_t *s_V;
   uint32_t *s_cand;
   unsigned long long *s_dtile;
+  unsigned long long *g_dtile;           // the tile in the global pool (the window does not fit the LDS), or null
+  uint32_t *g_cand;
+  long long pool_off;                    // this pair's piece of the pool (-1: none yet, -2: the pool was exhausted)
   unsigned char *s_list, *g_list;        // chunk list: 24-byte entries growing down from the end of the LDS, or of
   bool glist;                            // the pair's area in global memory when they do not fit there
   DTile bt;                              // the band of the tile currently in LDS
@@ -215,6 +219,9 @@ struct Ins {
     nvalid = ww = nocc = ncand = nvis = nlist = 0;
     accept = false;
     glist = false;
+    g_dtile = nullptr;
+    g_cand = nullptr;
+    pool_off = -1;
     g_list = w.glist + (((int64_t)s * (kMaxChain + 1) + area) + 1) * chunks * 24;     // entries grow down from the area's end
   }
 
@@ -269,7 +276,8 @@ struct Ins {
   }
   __device__ __forceinline__ unsigned long long scene_key(int r, int c) const {
     const int dl = bt.index(r, c);
-    const unsigned long long key = s_dtile[dl < 0 ? 0 : dl];
+    const unsigned long long key = g_dtile ? __hip_atomic_load(&g_dtile[dl < 0 ? 0 : dl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : s_dtile[dl < 0 ? 0 : dl];
     return dl < 0 ? R3D_SENT : key;
   }
 
@@ -620,7 +628,8 @@ struct Ins {
           double x = (double)f[u].x, y = (double)f[u].y, z = (double)f[u].z;
           if (idx[h + u] >= n_head) load_point(b, s, idx[h + u], n_head, x, y, z);   // an inserted point: float64, from the log
           double r = sqrt(x * x + y * y + z * z);
-          atomicMin(&s_dtile[dl[h + u]], depth_key(r));
+          if (g_dtile) atomicMin(&g_dtile[dl[h + u]], depth_key(r));
+          else atomicMin(&s_dtile[dl[h + u]], depth_key(r));
           // the points that hold the elevation bounds (max elevation = acos(min z/r)): if the pixel of
           // one of them turns out visible it is culled and the bounds may move (any holder will do).
           // z/r is only evaluated for the points that can be one (|z - q r| tiny).
@@ -712,7 +721,29 @@ struct Ins {
     // in bands of `per` candidate rows with 2 rows of halo on either side
     const int cr0 = uni(H[H_RMIN]) - 2 < 0 ? 0 : uni(H[H_RMIN]) - 2;
     const int cr1 = uni(H[H_RMAX]) + 2 > rows - 1 ? rows - 1 : uni(H[H_RMAX]) + 2;
-    const bool single = !(b.reserved & kDbgBands) && (int64_t)ncand * 4 + (int64_t)dt.npx * 8 + 8 <= band_bytes;
+    bool single = !(b.reserved & (kDbgBands | kDbgPoolTile)) && (int64_t)ncand * 4 + (int64_t)dt.npx * 8 + 8 <= band_bytes;
+    // a window that does not fit the LDS: its tile and candidate list in a piece of the global pool (one
+    // band, the evaluation reads the tile through L2); in row bands in LDS only when the pool is exhausted
+    g_dtile = nullptr;
+    g_cand = nullptr;
+    if (!single && !(b.reserved & kDbgBands) && pool_off != -2) {
+      const long long want = (((long long)dt.npx * 8 + 255) & ~255ll) + (((long long)ncand * 4 + 255) & ~255ll);
+      if (pool_off == -1) {
+        if (tid == 0) {
+          unsigned long long o = atomicAdd(w.pool_head, (unsigned long long)want);
+          H[H_FILL] = o + want <= (unsigned long long)w.pool_bytes ? (int)(o >> 8) : -2;
+        }
+        __syncthreads();
+        const int got = uni(H[H_FILL]);
+        pool_off = got < 0 ? -2 : (long long)got << 8;
+        __syncthreads();
+      }
+      if (pool_off >= 0) {
+        g_dtile = reinterpret_cast<unsigned long long *>(w.tile_pool + pool_off);
+        g_cand = reinterpret_cast<uint32_t *>(w.tile_pool + pool_off + (((long long)dt.npx * 8 + 255) & ~255ll));
+        single = true;
+      }
+    }
     int per = cr1 - cr0 + 1;
     if (!single) {
       per = (band_bytes - 4 * W * 8 - 8) / (12 * W);
@@ -742,7 +773,8 @@ struct Ins {
         while (bits) {
           int bit = __ffs(bits) - 1;
           bits &= bits - 1;
-          s_cand[pos++] = (uint32_t)((e << 5) + bit);
+          if (g_cand) g_cand[pos++] = (uint32_t)((e << 5) + bit);
+          else s_cand[pos++] = (uint32_t)((e << 5) + bit);
         }
       }
       const bool first = a0 == cr0;
@@ -756,7 +788,10 @@ struct Ins {
       __syncthreads();
       const int nc = uni(H[H_FILL]), nsub = uni(H[H_CARRY]);
       s_dtile = reinterpret_cast<unsigned long long *>(smem + ((carve + nc * 4 + 7) & ~7));
-      for (int i = tid; i < bt.npx; i += NT) s_dtile[i] = R3D_SENT;
+      if (g_dtile)
+        for (int i = tid; i < bt.npx; i += NT) g_dtile[i] = R3D_SENT;
+      else
+        for (int i = tid; i < bt.npx; i += NT) s_dtile[i] = R3D_SENT;
       if (first && !single)
         for (int e = tid; e < ww; e += NT) D.w[e] = 0u;
       __syncthreads();
@@ -769,7 +804,7 @@ struct Ins {
           for (int e = tid; e < ww; e += NT) D.w[e] = 0u;
           __syncthreads();
           for (int i = tid; i < bt.npx; i += NT) {
-            if (s_dtile[i] == R3D_SENT) continue;
+            if ((g_dtile ? __hip_atomic_load(&g_dtile[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s_dtile[i]) == R3D_SENT) continue;
             int r = bt.r0 + i / W, k = i % W;
             int c = k < dt.w0 ? dt.c00 + k : dt.c01 + (k - dt.w0);
             D.set_local(win.lpix_rc(r, c));
@@ -788,7 +823,7 @@ struct Ins {
         const int half = cols >> 1;
         int v_n = 0, v_rmin = 0x7FFFFFFF, v_rmax = -1, v_cmin0 = 0x7FFFFFFF, v_cmax0 = -1, v_cmin1 = 0x7FFFFFFF, v_cmax1 = -1;
         for (int ci = tid; ci < nc; ci += NT) {
-          int lp = (int)s_cand[ci];
+          int lp = (int)(g_cand ? g_cand[ci] : s_cand[ci]);
           int r = win.row_of(lp >> 5), c = (win.word_of(lp >> 5) << 5) + (lp & 31);
           double sd = R3D_EMPTY_DEPTH, cd = R3D_EMPTY_DEPTH;
           const bool a = A.get_local(lp), d = D.get_local(lp);
@@ -1349,6 +1384,7 @@ k_insert_big(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w,
 __global__ void k_chain_init(r3d_batch_t b, BatchWs w, int nk) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= b.B) return;
+  if (s == 0) *w.pool_head = 0ull;
   w.chain_progress[s] = 0;
   w.n_total0[s] = b.n_total[s];
   w.defer_from[s] = nk;

@@ -479,11 +479,11 @@ def test_c5_scan_on_the_proposed_448x2880_grid(P, synth, monkeypatch):
     _check_scene(res[0], vb, lb, cb)
 
 
-@pytest.mark.parametrize("debug", [2, 4, 8, 6])
+@pytest.mark.parametrize("debug", [2, 4, 8, 6, 32])
 def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
     """The insert kernel's other routes, forced with the descriptor's diagnostic bits: 2 = never
     speculate (every slot waits for its predecessor first), 4 = the window's depth tile built and
-    evaluated in bands of at most 3 candidate rows, 8 = every pair left to k_insert_big (one 1024-thread
+    evaluated in bands of at most 3 candidate rows, 32 = tile and candidate list in the global pool, 8 = every pair left to k_insert_big (one 1024-thread
     workgroup per scene); all must give the bytes of the oracle chain, through insert_many and slot by slot."""
     import torch
     cases = [_random_case(synth, 11), _random_case(synth, 12, 32, 900, shuffle=True), _random_case(synth, 13, 64, 500)]
