@@ -46,6 +46,10 @@
 #include <cstdlib>
 #include <string>
 
+#ifndef R3D_CHAIN_WAVES
+#define R3D_CHAIN_WAVES 4
+#endif
+
 namespace r3d {
 
 // diagnostic bits of r3d_batch_t.reserved (tests force every path with them)
@@ -1159,7 +1163,7 @@ __device__ __forceinline__ int conflict_with(const BatchWs &w, int s, int j0, in
 }
 
 template <int NT>
-__global__ void __launch_bounds__(NT, NT == 1024 ? 1 : 4)
+__global__ void __launch_bounds__(NT, NT == 1024 ? 1 : R3D_CHAIN_WAVES)
 k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int chunks, int lds_cap,
                long long timeout_ticks, int B8) {
   extern __shared__ __align__(16) unsigned char smem[];     // no static __shared__ here: one LDS array
