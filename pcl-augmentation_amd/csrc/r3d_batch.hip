@@ -105,9 +105,9 @@ k_bounds(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
 // every compaction tile (all points of the frame are alive at step 0).
 //
 // Tables of the fast projection: a bin guessed in float32 is accepted only if the point lies
-// strictly inside that bin's edges, tested in float64 on monotone images of the edges -- cos of
-// the row edges against z/r, and the sign of the cross product with the unit vector of the column
-// edges -- with a margin far above the rounding of either side.
+// strictly inside that bin's edges, tested on monotone images of the edges -- cos of the row edges
+// against z/r, and the sign of the cross product with the unit vector of the column edges -- with a
+// margin far above the rounding of either side (float32 screen, float64 for what it leaves open).
 __global__ void __launch_bounds__(kPT)
 k_prepare(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles) {
   __shared__ double s_b[2];
@@ -138,6 +138,16 @@ k_prepare(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
       edge = edge < 0.0 ? 0.0 : (edge > kPi ? kPi : edge);
       double c = cos(edge);
       w.row_q[(int64_t)s * (b.rows + 2) + k] = c * fabs(c);   // compared with z*|z| / (x*x+y*y+z*z)
+      // float32 screen of k_project: z/r (float32, error < 4e-7) strictly inside (c + m, c' - m) implies the
+      // float64 test above with room to spare.  m = 4e-7 + d, where moving c by d moves c*|c| by more than
+      // twice the float64 test's margin 4e-12: d = 1e-7 for |c| >= 1e-4 (2*|c|*d >= 2e-11), else d = 4e-6
+      // (d*d/2 = 8e-12, the worst case c = d/2).  Thresholds are rounded away from the edge.
+      double m = 4e-7 + (fabs(c) >= 1e-4 ? 1e-7 : 4e-6);
+      float below = (float)(c - m), above = (float)(c + m);
+      if ((double)below > c - m) below = nextafterf(below, -2.f);
+      if ((double)above < c + m) above = nextafterf(above, 2.f);
+      w.row_qf[((int64_t)s * (b.rows + 2) + k) * 2 + 0] = below;   // upper limit of z/r for the row below edge k-1
+      w.row_qf[((int64_t)s * (b.rows + 2) + k) * 2 + 1] = above;   // lower limit of z/r for the row above it
     }
     const int n = b.n_total[s];
     for (int t = threadIdx.x; t < tiles; t += kPT) {
@@ -154,6 +164,8 @@ __global__ void k_col_table(r3d_batch_t b, BatchWs w) {
   double alpha = (double)c * (kTwoPi / (double)b.cols) - kPi;   // direction angle of column edge c
   w.col_dir[2 * c + 0] = cos(alpha);
   w.col_dir[2 * c + 1] = sin(alpha);
+  w.col_dirf[2 * c + 0] = (float)cos(alpha);
+  w.col_dirf[2 * c + 1] = (float)sin(alpha);
 }
 
 // ---- step 0 / rebase: spherical projection -> pixel ids ------------------------------------------
@@ -163,19 +175,18 @@ __global__ void k_col_table(r3d_batch_t b, BatchWs w) {
 // window from the points.  To find those points without scanning the cloud,
 // every 64 consecutive points (one wave) leave their row / column bounding box; LiDAR files are
 // ring-ordered, so a box is about one row by 50 columns.
-// Verified float32 guess of (row, col); returns false when the float64 check cannot confirm the
-// guessed bin (the caller then queues the point for the reference formula).
+// The bin (row, col) of a point is guessed in float32 and confirmed on monotone images of the bin's
+// edges; a point that cannot be confirmed is queued for the reference formula (k_project_slow).
 //   rows: elevation in [edge_k, edge_k+1)  <=>  cos(edge_k+1) < z/r <= cos(edge_k); both sides are
 //         mapped through t -> t*|t| (strictly increasing) and multiplied by r*r = ss, which needs
 //         neither the square root nor the division: z*|z| against c*|c| * ss.  Row 0 also takes
 //         the truncated interval below edge_0 (int() rounds toward zero).
 //   cols: the point lies counter-clockwise of column edge k and clockwise of edge k+1 (sign of
 //         the cross product with the edges' unit vectors).
-// Margins are relative 4e-12 resp. 1e-12 (the L1 norm bounds r from above), three orders of
-// magnitude above the rounding of the products and of the reference's own float64 evaluation.
-// Cheap float32 angle guesses for fast_bin (about 1e-5 rad, a few per mille of a bin): whatever they
-// get wrong the float64 confirmation rejects, so their accuracy only decides how many points take the
-// slow path, never a result.
+// Margins of the float64 confirmation are relative 4e-12 resp. 1e-12 (the L1 norm bounds r from above),
+// three orders of magnitude above the rounding of the products and of the reference's own float64 evaluation.
+// Cheap float32 angle guesses (about 1e-5 rad, a few per mille of a bin): whatever they get wrong the
+// confirmation rejects, so their accuracy only decides how many points take the slow path, never a result.
 __device__ __forceinline__ float guess_acosf(float q) {
   if (fabsf(q) > 0.5f) return acosf(q);                       // steep beams: the library routine
   float q2 = q * q;                                           // asin series, error < 3e-6 for |q| <= 0.5
@@ -188,7 +199,7 @@ __device__ __forceinline__ float guess_acosf(float q) {
 __device__ __forceinline__ float guess_atan2f(float y, float x) {
   float ax = fabsf(x), ay = fabsf(y);
   float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-  float t = mn * __frcp_rn(mx), t2 = t * t;                   // atan on [0, 1], odd polynomial, error ~1e-5
+  float t = mn * __builtin_amdgcn_rcpf(mx), t2 = t * t;       // atan on [0, 1], odd polynomial, error ~1e-5 (v_rcp_f32: 1 ulp)
   float p = fmaf(-0.01172120f, t2, 0.05265332f);
   p = fmaf(p, t2, -0.11643287f);
   p = fmaf(p, t2, 0.19354346f);
@@ -200,18 +211,9 @@ __device__ __forceinline__ float guess_atan2f(float y, float x) {
   return y < 0.f ? -a : a;
 }
 
-__device__ __forceinline__ bool fast_bin(const Binning &bn, const double *__restrict__ row_cc,
-                                         const double *__restrict__ col_dir, float inv_del, float inv_daz,
-                                         float elo, float xf, float yf, float zf, double x, double y, double z,
-                                         double ss, int &row, int &col) {
-  float qf = zf * __frsqrt_rn(xf * xf + yf * yf + zf * zf);
-  qf = qf < -1.f ? -1.f : (qf > 1.f ? 1.f : qf);
-  int rg = (int)floorf((guess_acosf(qf) - elo) * inv_del);
-  int cg = (int)((guess_atan2f(yf, xf) + 3.14159274f) * inv_daz);
-  rg = rg < 0 ? 0 : (rg > bn.rows - 1 ? bn.rows - 1 : rg);
-  cg = cg < 0 ? 0 : (cg > bn.cols - 1 ? bn.cols - 1 : cg);
-  row = rg;
-  col = cg;
+// Float64 confirmation of a guessed bin (rg, cg) against the edge tables.
+__device__ __forceinline__ bool confirm_bin(const double *__restrict__ row_cc, const double *__restrict__ col_dir,
+                                            int rg, int cg, double x, double y, double z, double ss) {
   const double zz = z * fabs(z);
   const double hi = row_cc[rg == 0 ? 0 : rg + 1], lo = row_cc[rg + 2];
   const double ax = col_dir[2 * cg], ay = col_dir[2 * cg + 1], bx = col_dir[2 * cg + 2], by = col_dir[2 * cg + 3];
@@ -222,44 +224,82 @@ __device__ __forceinline__ bool fast_bin(const Binning &bn, const double *__rest
          (int)(bx * y - by * x < -mc);
 }
 
+// k_project screens in float32 first; the float64 confirmation above runs only for the points the screen
+// cannot decide (a few per mille, those within ~1e-6 of a bin edge).  The screen is a sufficient condition
+// for confirm_bin() on the same (rg, cg), so it never changes a result:
+//   rows: qf = z * rsq(x*x + y*y + z*z) in float32 is within 2.7e-7 of z/r (three roundings of the sum,
+//         halved by the root; one ulp of v_rsq_f32; one of the product; all relative, |z/r| <= 1); the
+//         thresholds row_qf keep qf 4e-7 + d away from the cosine of either edge, d chosen in k_prepare so
+//         that z*|z|/ss clears the float64 margin; |qf| < 0.9999 covers the pole test.
+//   cols: fmaf(ax, y, -(ay * x)) with float32 table entries is within 2.4e-7 * (|x| + |y|) of the float64
+//         cross product; it has to clear 1e-6 * (|x| + |y|), the float64 test needs 1e-12 * (|x|+|y|+|z|)
+//         and |z| < 71 * hypot(x, y) away from the poles.
+//   ss must be a normal float32 far from overflow / flush-to-zero (1e-30 < ss < 1e30).
 __global__ void __launch_bounds__(kPT)
 k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int chunks) {
-  extern __shared__ __align__(16) double s_tab[];          // [(cols+1)*2] column edges, [rows+2] row edges
-  double *s_col = s_tab, *s_row = s_tab + (b.cols + 1) * 2;
-  for (int e = threadIdx.x; e < (b.cols + 1) * 2; e += kPT) s_col[e] = w.col_dir[e];
+  extern __shared__ __align__(16) float s_tabf[];          // [(cols+1)*2] column edges, [(rows+2)*2] row limits
+  float2 *s_col = reinterpret_cast<float2 *>(s_tabf), *s_row = s_col + (b.cols + 1);
+  for (int e = threadIdx.x; e < b.cols + 1; e += kPT) s_col[e] = reinterpret_cast<const float2 *>(w.col_dirf)[e];
   int cnt = *count;
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
     int n = b.n_total[s], n_head = b.n_head[s];
     __syncthreads();                                       // previous scene's row table is no longer read
-    for (int e = threadIdx.x; e < b.rows + 2; e += kPT) s_row[e] = w.row_q[(int64_t)s * (b.rows + 2) + e];
+    for (int e = threadIdx.x; e < b.rows + 2; e += kPT)
+      s_row[e] = reinterpret_cast<const float2 *>(w.row_qf)[(int64_t)s * (b.rows + 2) + e];
     __syncthreads();
     Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
     const bool exact = b.reserved & 1;                       // diagnostic: reference formula only
     const float inv_del = (float)(1.0 / bn.d_el), inv_daz = (float)(1.0 / bn.d_az);
     const float elo = (float)(bn.min_el + 0.00001);
+    const double *row_cc = w.row_q + (int64_t)s * (b.rows + 2);
     uint32_t *queue = w.cand + (int64_t)s * w.cand_stride;  // insert scratch, free during step 0
     int flags = 0;
-    // verified float32 guess, 8 points per thread and tile; unconfirmed points are queued for
-    // k_project_slow.  A block walks several tiles so that the tables are staged once.
-    for (int t0 = blockIdx.x * kTile; t0 < n; t0 += gridDim.x * kTile)
-#pragma unroll 2
+    // 8 points per thread and tile; unconfirmed points are queued for k_project_slow.  A block walks
+    // several tiles so that the tables are staged once.  Points are requested two rounds ahead of their use
+    // (indices clamped to the scene: no branch around a load).
+    const float4 *__restrict__ src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
+    const unsigned int last = (unsigned int)(n_head > 0 ? n_head - 1 : 0);
+    auto fetch = [&](int i) {
+      unsigned int j = (unsigned int)i < last ? (unsigned int)i : last;
+      return src[j];
+    };
+    for (int t0 = blockIdx.x * kTile; t0 < n; t0 += gridDim.x * kTile) {
+    float4 pt = fetch(t0 + threadIdx.x), pt1 = fetch(t0 + kPT + threadIdx.x);
+#pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
       int i = t0 + k * kPT + threadIdx.x;
+      float4 pt2 = pt1;
+      if (k + 2 < kPerThread) pt2 = fetch(t0 + (k + 2) * kPT + threadIdx.x);
       BoxAcc box;
       if (i < n) {
-        // float32 points straight from the slab; inserted (float64) points, which only exist when a
-        // re-based scene is projected by this kernel, take the queue
-        float4 pt = i < n_head ? reinterpret_cast<const float4 *>(b.xyzi)[(int64_t)s * b.cap + i]
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-        double x = (double)pt.x, y = (double)pt.y, z = (double)pt.z;
-        double ss = x * x + y * y + z * z;
-        int row, col;
-        if ((int)(!exact) & (int)(i < n_head) &
-            (int)fast_bin(bn, s_row, s_col, inv_del, inv_daz, elo, pt.x, pt.y, pt.z, x, y, z, ss, row, col)) {
+        // (inserted float64 points, which only exist when a re-based scene is projected by this kernel,
+        // take the queue)
+        // bin guess (about 1e-5 rad off at worst, a few per mille of a bin)
+        float ssf = fmaf(pt.x, pt.x, fmaf(pt.y, pt.y, pt.z * pt.z));
+        float qf = pt.z * __frsqrt_rn(ssf);
+        qf = qf < -1.f ? -1.f : (qf > 1.f ? 1.f : qf);
+        int row = (int)floorf((guess_acosf(qf) - elo) * inv_del);
+        int col = (int)((guess_atan2f(pt.y, pt.x) + 3.14159274f) * inv_daz);
+        row = row < 0 ? 0 : (row > bn.rows - 1 ? bn.rows - 1 : row);
+        col = col < 0 ? 0 : (col > bn.cols - 1 ? bn.cols - 1 : col);
+        // float32 screen
+        float2 ea = s_col[col], eb = s_col[col + 1];
+        float mcf = 1e-6f * (fabsf(pt.x) + fabsf(pt.y));
+        int ok = (int)(ssf > 1e-30f) & (int)(ssf < 1e30f) & (int)(fabsf(qf) < 0.9999f) &
+                 (int)(qf < s_row[row == 0 ? 0 : row + 1].x) & (int)(qf > s_row[row + 2].y) &
+                 (int)(fmaf(ea.x, pt.y, -(ea.y * pt.x)) > mcf) & (int)(fmaf(eb.x, pt.y, -(eb.y * pt.x)) < -mcf);
+        bool far = false;
+        if (!ok | (ssf > 249000.f)) {                        // undecided in float32, or r near / above 500
+          double x = (double)pt.x, y = (double)pt.y, z = (double)pt.z;
+          double ss = x * x + y * y + z * z;
+          if (!ok) ok = confirm_bin(row_cc, w.col_dir, row, col, x, y, z, ss);
+          far = ss > R3D_EMPTY_DEPTH * R3D_EMPTY_DEPTH;      // r > 500 (or rounds to it): far list
+        }
+        if (ok & (int)(!exact) & (int)(i < n_head)) {
           int p = row * b.cols + col;
           box.add(row, col);
-          if (ss > R3D_EMPTY_DEPTH * R3D_EMPTY_DEPTH) {      // r > 500 (or rounds to it): far list
+          if (far) {
             int f = atomicAdd(&b.n_far[s], 1);
             if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
             else flags |= R3D_S_FAR_OVERFLOW;
@@ -271,6 +311,8 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
           box.add(b.rows - 1, b.cols - 1);                   // the whole image
         }
       }
+      pt = pt1;
+      pt1 = pt2;
       unsigned long long packed = box.wave_pack();
       unsigned long long living = __ballot(i < n);           // every point of the frame is alive at step 0
       int i0 = t0 + k * kPT + (threadIdx.x & ~63);
@@ -278,6 +320,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
         w.chunk_box[(int64_t)s * chunks + (i0 >> 6)] = packed;
         w.alive[(int64_t)s * chunks + (i0 >> 6)] = living;
       }
+    }
     }
     flags = wave_or_i32(flags);
     if ((threadIdx.x & 63) == 0 && flags) atomicOr(&b.status[s], flags);
@@ -307,71 +350,98 @@ k_project_slow(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs
 }
 
 // Survivors in original order (insertion.py:472-473 applied once for all steps), float4 + label
-// straight into the output arrays.  The 8 alive tests of a thread are issued together, ranks come
-// from wave ballots and one small LDS table: a single barrier per tile.
+// straight into the output arrays.  A wave owns 8 consecutive chunks (512 points) of its block's tile and
+// needs nobody else: its output offset is the sum of the living counts of the scene's preceding tiles
+// (tile_alive, kept by the inserts) and of the preceding chunks of its own tile (popcounts of their alive
+// words); the 8 alive words travel through SGPRs (v_readlane), ranks are v_mbcnt of the word, the 8 points
+// and labels of a lane are requested together.  No LDS, no barrier, 32-bit offsets from scalar bases.
+// (Measured and dropped: the block-wide form with ranks through an LDS table -- 93 VGPRs, 0.28 ms.)
+constexpr int kWaveChunks = kTile / 64 / (kPT / 64);    // chunks of a tile per wave
+
+template <bool ROWS4, bool NONTEMP>
 __global__ void __launch_bounds__(kPT)
 k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles, int chunks,
               double *rows4, int32_t *n_rows) {
-  __shared__ int s_cnt[kPerThread][kPT / 64];           // survivors of (row k, wave)
-  __shared__ int s_pre[kPT / 64];
+  static_assert(kWaveChunks == 8 && kTile / 64 <= 64, "a wave reads its tile's alive words with one load");
   int cnt = *count;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
-    int s = list[li];
-    int n = b.n_total[s];
-    int t0 = blockIdx.x * kTile;
+    const int s = list[li];
+    const int n = b.n_total[s];
+    const int t0 = blockIdx.x * kTile;
     if (t0 >= n) continue;
-    // survivors of the preceding tiles of this scene (at most a few dozen counts): the tile's offset
     int pre = 0;
-    for (int t = threadIdx.x; t < (int)blockIdx.x; t += kPT) pre += w.tile_alive[(int64_t)s * tiles + t];
-    pre = wave_sum_i32(pre);
-    if (lane == 0) s_pre[wave] = pre;
-    __syncthreads();
-    int tile_base = 0;
-#pragma unroll
-    for (int v = 0; v < kPT / 64; ++v) tile_base += s_pre[v];
-    if (threadIdx.x == 0 && t0 + kTile >= n)                   // the scene's last tile publishes the total
-      (rows4 ? n_rows : b.n_out)[s] = tile_base + w.tile_alive[(int64_t)s * tiles + blockIdx.x];
+    for (int t = lane; t < (int)blockIdx.x; t += 64) pre += w.tile_alive[(int64_t)s * tiles + t];
+    const int first = wave * kWaveChunks;                    // my first chunk within the tile
+    unsigned long long m = 0ull;                             // lane c: alive word of chunk c of the tile
+    if (lane < first + kWaveChunks && t0 + lane * 64 < n) m = w.alive[(int64_t)s * chunks + (t0 >> 6) + lane];
+    if (lane < first) pre += __popcll(m);
+    int run = wave_sum_i32(pre);
+    if (threadIdx.x == 0 && t0 + kTile >= n)                 // the scene's last tile publishes the total
+      (ROWS4 ? n_rows : b.n_out)[s] = run + w.tile_alive[(int64_t)s * tiles + blockIdx.x];
     const int n_head = b.n_head[s];
-    const float4 *src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
-    float4 *dst = reinterpret_cast<float4 *>(b.out_xyzi) + (int64_t)s * b.cap;
-    bool flag[kPerThread];
-    int rank[kPerThread];
+    const float4 *__restrict__ src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
+    float4 *__restrict__ dst = reinterpret_cast<float4 *>(b.out_xyzi) + (int64_t)s * b.cap;
+    const uint32_t *__restrict__ lsrc = b.label + (int64_t)s * b.cap;
+    uint32_t *__restrict__ ldst = b.out_label + (int64_t)s * b.cap;
+    const unsigned int ibase = (unsigned int)(t0 + first * 64 + lane);
+    unsigned int mlo[kWaveChunks], mhi[kWaveChunks];
 #pragma unroll
-    for (int k = 0; k < kPerThread; ++k) {                  // the alive bits the inserts left
-      int i0 = t0 + k * kPT + (threadIdx.x & ~63);
-      unsigned long long m = i0 < n ? w.alive[(int64_t)s * chunks + (i0 >> 6)] : 0ull;
-      flag[k] = (m >> lane) & 1ull;
-      rank[k] = __popcll(m & ((1ull << lane) - 1ull));
-      if (lane == 0) s_cnt[k][wave] = __popcll(m);
+    for (int k = 0; k < kWaveChunks; ++k) {
+      mlo[k] = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)m, first + k);
+      mhi[k] = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(m >> 32), first + k);
     }
-    __syncthreads();
-    int run = tile_base;
-#pragma unroll
-    for (int k = 0; k < kPerThread; ++k) {
-      int mine = 0;
-#pragma unroll
-      for (int v = 0; v < kPT / 64; ++v) {
-        if (v == wave) mine = run;
-        run += s_cnt[k][v];
-      }
-      if (flag[k]) {
-        int i = t0 + k * kPT + threadIdx.x, o = mine + rank[k];
-        if (rows4) {                                        // r3d_batch_export_rows: x y z label as float64
+    if (ROWS4) {                                             // r3d_batch_export_rows: x y z label as float64
+#pragma unroll 1
+      for (int k = 0; k < kWaveChunks; ++k) {
+        unsigned long long mk = ((unsigned long long)mhi[k] << 32) | mlo[k];
+        if ((mk >> lane) & 1ull) {
+          int i = (int)(ibase + k * 64), o = run + (int)__builtin_amdgcn_mbcnt_hi(mhi[k], __builtin_amdgcn_mbcnt_lo(mlo[k], 0u));
           double x, y, z;
           load_point(b, s, i, n_head, x, y, z);
           double2 *row = reinterpret_cast<double2 *>(rows4 + ((int64_t)s * b.cap + o) * 4);
           row[0] = make_double2(x, y);
-          row[1] = make_double2(z, (double)(b.label[(int64_t)s * b.cap + i] & 0xFFFFu));
-        } else {
-          // (measured and dropped: requesting the thread's 8 points and labels before the first store, 0.32 ms
-          // against 0.28 ms; a shifted plain copy for the tiles in which nobody died, 0.30 ms)
-          dst[o] = src[i];
-          b.out_label[(int64_t)s * b.cap + o] = b.label[(int64_t)s * b.cap + i];
+          row[1] = make_double2(z, (double)(lsrc[i] & 0xFFFFu));
         }
+        run += __popcll(mk);
       }
+    } else {
+      // (named scalars, not arrays: the compiler keeps arrays of float4 filled under a branch in scratch)
+#define R3D_LOAD(K)                                                                                     \
+  unsigned int i##K = ibase + K * 64;                                                                      \
+  i##K = i##K < (unsigned int)n ? i##K : (unsigned int)n - 1u; /* dead points are few: every lane loads */ \
+  float4 p##K;                                                                                          \
+  uint32_t l##K;                                                                                        \
+  if (NONTEMP) {                                                                                        \
+    const float *f = reinterpret_cast<const float *>(src + i##K);                                       \
+    p##K = make_float4(__builtin_nontemporal_load(f), __builtin_nontemporal_load(f + 1),                \
+                       __builtin_nontemporal_load(f + 2), __builtin_nontemporal_load(f + 3));           \
+    l##K = __builtin_nontemporal_load(lsrc + i##K);                                                     \
+  } else {                                                                                              \
+    p##K = src[i##K];                                                                                   \
+    l##K = lsrc[i##K];                                                                                  \
+  }
+#define R3D_STORE(K)                                                                                    \
+  if ((((unsigned long long)mhi[K] << 32 | mlo[K]) >> lane) & 1ull) {                                   \
+    unsigned int o = (unsigned int)run + __builtin_amdgcn_mbcnt_hi(mhi[K], __builtin_amdgcn_mbcnt_lo(mlo[K], 0u)); \
+    if (NONTEMP) {                                                                                      \
+      float *f = reinterpret_cast<float *>(dst + o);                                                    \
+      __builtin_nontemporal_store(p##K.x, f);                                                           \
+      __builtin_nontemporal_store(p##K.y, f + 1);                                                       \
+      __builtin_nontemporal_store(p##K.z, f + 2);                                                       \
+      __builtin_nontemporal_store(p##K.w, f + 3);                                                       \
+      __builtin_nontemporal_store(l##K, ldst + o);                                                      \
+    } else {                                                                                            \
+      dst[o] = p##K;                                                                                    \
+      ldst[o] = l##K;                                                                                   \
+    }                                                                                                   \
+  }                                                                                                     \
+  run += __popc(mlo[K]) + __popc(mhi[K]);
+      R3D_LOAD(0) R3D_LOAD(1) R3D_LOAD(2) R3D_LOAD(3) R3D_LOAD(4) R3D_LOAD(5) R3D_LOAD(6) R3D_LOAD(7)
+      R3D_STORE(0) R3D_STORE(1) R3D_STORE(2) R3D_STORE(3) R3D_STORE(4) R3D_STORE(5) R3D_STORE(6) R3D_STORE(7)
+#undef R3D_LOAD
+#undef R3D_STORE
     }
-    __syncthreads();                                      // s_cnt is reused by the next scene
   }
 }
 
@@ -403,7 +473,7 @@ int check_batch(const r3d_batch_t *b) {
     return fail(R3D_E_ARG, "batch: null array");
   if (b->cols % 32 != 0)
     return fail(R3D_E_ARG, "batch: cols must be a multiple of 32 (row-aligned bit images)");
-  if (((size_t)(b->cols + 1) * 2 + b->rows + 2) * sizeof(double) > 64 * 1024)
+  if (((size_t)(b->cols + 1) + b->rows + 2) * 2 * sizeof(float) > 64 * 1024)
     return fail(R3D_E_ARG, "batch: range image too large for the projection kernel's LDS edge tables");
   if (b->workspace_bytes < carve_batch(*b, nullptr).total)
     return fail(R3D_E_WORKSPACE, "batch: workspace smaller than r3d_batch_workspace_bytes()");
@@ -418,7 +488,7 @@ static int project_blocks(const r3d_batch_t &b) {
 }
 
 static size_t project_lds_bytes(const r3d_batch_t &b) {
-  return ((size_t)(b.cols + 1) * 2 + b.rows + 2) * sizeof(double);
+  return ((size_t)(b.cols + 1) + b.rows + 2) * 2 * sizeof(float);
 }
 
 // bounds -> tables -> project for the scenes of (list, count); rows = block rows of the launches.
@@ -438,8 +508,12 @@ static int launch_compact(const r3d_batch_t &b, const BatchWs &w, const int32_t 
                           const int32_t *count, int rows, hipStream_t st, double *rows4 = nullptr,
                           int32_t *n_rows = nullptr) {
   int tiles = tiles_of(b);
-  hipLaunchKernelGGL(k_alive_write, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, tiles, chunks_of(b),
-                     rows4, n_rows);
+  dim3 grid(tiles, rows), blk(kPT);
+  // non-temporal loads and stores: nothing of the cloud is read again before r3d_batch_begin overwrites the state
+  if (rows4)
+    hipLaunchKernelGGL((k_alive_write<true, false>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b), rows4, n_rows);
+  else
+    hipLaunchKernelGGL((k_alive_write<false, true>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b), rows4, n_rows);
   R3D_LAUNCHED("compaction kernel");
   return R3D_OK;
 }
@@ -493,9 +567,7 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream) {
                          w.all_list, w.all_count, w, chunks_of(*b));
       break;
     case R3D_K_ALIVE_WRITE:
-      hipLaunchKernelGGL(k_alive_write, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w, tiles,
-                         chunks_of(*b), (double *)nullptr, (int32_t *)nullptr);
-      break;
+      return launch_compact(*b, w, w.all_list, w.all_count, b->B, st);
     default:
       return fail(R3D_E_ARG, "batch_launch_one: unknown kernel id");
   }

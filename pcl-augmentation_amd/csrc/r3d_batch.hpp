@@ -32,6 +32,8 @@ struct BatchWs {
   unsigned long long *alive;    // [B*chunks] alive bit of every point
   double *row_q;                // [B*(rows+2)] c*|c|, c = cos of the row edges (entry k: edge k-1)
   double *col_dir;              // [(cols+1)*2] unit vector of every column edge
+  float *row_qf;                // [B*(rows+2)*2] float32 limits of z/r either side of every row edge (k_project's screen)
+  float *col_dirf;              // [(cols+1)*2] col_dir in float32
   double *q_ext;                // [B*2] min and max of z/r (the points that hold the elevation bounds)
   int32_t *n_slow;              // [B] points queued for k_project_slow
   int32_t *chain_progress;      // [B] slots of the scene completed by the running k_insert_chain (< 0: see r3d_insert.hip)
@@ -67,6 +69,8 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.alive = c.take<unsigned long long>((size_t)b.B * chunks_of(b));
   w.row_q = c.take<double>((size_t)b.B * (b.rows + 2));
   w.col_dir = c.take<double>((size_t)(b.cols + 1) * 2);
+  w.row_qf = c.take<float>((size_t)b.B * (b.rows + 2) * 2);
+  w.col_dirf = c.take<float>((size_t)(b.cols + 1) * 2);
   w.q_ext = c.take<double>((size_t)b.B * 2);
   w.n_slow = c.take<int32_t>((size_t)b.B);
   w.chain_progress = c.take<int32_t>((size_t)b.B);
@@ -126,14 +130,14 @@ struct BoxAcc {
     add(rmin, (int)((bx >> 32) & 0xFFFF));
     add(rmax, (int)((bx >> 48) & 0xFFFF));
   }
-  __device__ __forceinline__ unsigned long long wave_pack() {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {                 // two packed 16-bit reductions per step
-      int tl = __shfl_xor(__builtin_bit_cast(int, lo), o, 64);
-      int th = __shfl_xor(__builtin_bit_cast(int, hi), o, 64);
-      lo = __builtin_elementwise_min(lo, __builtin_bit_cast(u16x2, tl));
-      hi = __builtin_elementwise_max(hi, __builtin_bit_cast(u16x2, th));
-    }
+  __device__ __forceinline__ unsigned long long wave_pack() {          // uniform: the box of the wave's 64 lanes
+#define R3D_STEP(C, M)                                                                                              \
+  lo = __builtin_elementwise_min(lo, __builtin_bit_cast(u16x2, dpp_take<C, M>(-1, __builtin_bit_cast(int, lo))));  \
+  hi = __builtin_elementwise_max(hi, __builtin_bit_cast(u16x2, dpp_take<C, M>(0, __builtin_bit_cast(int, hi))));
+    R3D_DPP_STEPS(R3D_STEP)                              // two packed 16-bit reductions per step
+#undef R3D_STEP
+    lo = __builtin_bit_cast(u16x2, wave_last_i32(__builtin_bit_cast(int, lo)));
+    hi = __builtin_bit_cast(u16x2, wave_last_i32(__builtin_bit_cast(int, hi)));
     return pack_box(lo.x, hi.x, lo.y, hi.y);           // rmin > rmax: empty box
   }
 };

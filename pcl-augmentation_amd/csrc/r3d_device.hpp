@@ -94,42 +94,82 @@ __device__ __forceinline__ double ordered_key_inv(unsigned long long k) {
 }
 
 // ---- wave / block reductions and scans (wave = 64 lanes) ------------------------------------
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    unsigned long long w = __shfl_xor(v, o, 64);
-    v = w < v ? w : v;
-  }
-  return v;
+// Cross-lane steps are DPP row shifts and row broadcasts (VALU, a few cycles each), not ds_bpermute
+// (an LDS-pipe round trip per step): lane i takes lane i-1, i-2, i-4, i-8 of its row of 16, then
+// lane 15 of the previous row, then lane 31.  Lanes without a source keep the identity, so after the
+// six steps lane i holds the combination of lanes 0..i (an inclusive scan) and lane 63 the total.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_take(int identity, int v) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xF, false);
 }
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    unsigned long long w = __shfl_xor(v, o, 64);
-    v = w > v ? w : v;
-  }
-  return v;
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ int wave_or_i32(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
-  return v;
-}
+#define R3D_DPP_STEPS(STEP) \
+  STEP(0x111, 0xF) STEP(0x112, 0xF) STEP(0x114, 0xF) STEP(0x118, 0xF) STEP(0x142, 0xA) STEP(0x143, 0xC)
+
+__device__ __forceinline__ int wave_last_i32(int v) { return __builtin_amdgcn_readlane(v, 63); }
 
 // Inclusive wave scan of ints.
 __device__ __forceinline__ int wave_iscan_i32(int v) {
-  int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int w = __shfl_up(v, o, 64);
-    if (lane >= o) v += w;
-  }
+#define R3D_STEP(C, M) v += dpp_take<C, M>(0, v);
+  R3D_DPP_STEPS(R3D_STEP)
+#undef R3D_STEP
   return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) { return wave_last_i32(wave_iscan_i32(v)); }
+__device__ __forceinline__ int wave_or_i32(int v) {
+#define R3D_STEP(C, M) v |= dpp_take<C, M>(0, v);
+  R3D_DPP_STEPS(R3D_STEP)
+#undef R3D_STEP
+  return wave_last_i32(v);
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#define R3D_STEP(C, M) { int t = dpp_take<C, M>(0x7FFFFFFF, v); v = t < v ? t : v; }
+  R3D_DPP_STEPS(R3D_STEP)
+#undef R3D_STEP
+  return wave_last_i32(v);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#define R3D_STEP(C, M) { int t = dpp_take<C, M>((int)0x80000000, v); v = t > v ? t : v; }
+  R3D_DPP_STEPS(R3D_STEP)
+#undef R3D_STEP
+  return wave_last_i32(v);
+}
+__device__ __forceinline__ float wave_min_f32(float v) {           // NaN-free inputs
+#define R3D_STEP(C, M) v = fminf(v, __int_as_float(dpp_take<C, M>(0x7F800000, __float_as_int(v))));
+  R3D_DPP_STEPS(R3D_STEP)
+#undef R3D_STEP
+  return __int_as_float(wave_last_i32(__float_as_int(v)));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#define R3D_STEP(C, M) v = fmaxf(v, __int_as_float(dpp_take<C, M>((int)0xFF800000, __float_as_int(v))));
+  R3D_DPP_STEPS(R3D_STEP)
+#undef R3D_STEP
+  return __int_as_float(wave_last_i32(__float_as_int(v)));
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#define R3D_STEP(C, M)                                                                                    \
+  {                                                                                                       \
+    unsigned int lo = (unsigned int)dpp_take<C, M>(-1, (int)(unsigned int)v);                             \
+    unsigned int hi = (unsigned int)dpp_take<C, M>(-1, (int)(unsigned int)(v >> 32));                     \
+    unsigned long long t = ((unsigned long long)hi << 32) | lo;                                           \
+    v = t < v ? t : v;                                                                                    \
+  }
+  R3D_DPP_STEPS(R3D_STEP)
+#undef R3D_STEP
+  return ((unsigned long long)(unsigned int)wave_last_i32((int)(unsigned int)(v >> 32)) << 32) |
+         (unsigned int)wave_last_i32((int)(unsigned int)v);
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#define R3D_STEP(C, M)                                                                                    \
+  {                                                                                                       \
+    unsigned int lo = (unsigned int)dpp_take<C, M>(0, (int)(unsigned int)v);                              \
+    unsigned int hi = (unsigned int)dpp_take<C, M>(0, (int)(unsigned int)(v >> 32));                      \
+    unsigned long long t = ((unsigned long long)hi << 32) | lo;                                           \
+    v = t > v ? t : v;                                                                                    \
+  }
+  R3D_DPP_STEPS(R3D_STEP)
+#undef R3D_STEP
+  return ((unsigned long long)(unsigned int)wave_last_i32((int)(unsigned int)(v >> 32)) << 32) |
+         (unsigned int)wave_last_i32((int)(unsigned int)v);
 }
 
 // Exclusive block scan; `sm` needs blockDim.x/64 + 1 ints.  Returns the exclusive prefix of v and

@@ -348,16 +348,9 @@ struct Ins {
       }
       nval = wave_sum_i32(nval);
       flags = wave_or_i32(flags);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        int t;
-        t = __shfl_xor(rmin, o, 64); rmin = t < rmin ? t : rmin;
-        t = __shfl_xor(rmax, o, 64); rmax = t > rmax ? t : rmax;
-        t = __shfl_xor(cmin0, o, 64); cmin0 = t < cmin0 ? t : cmin0;
-        t = __shfl_xor(cmax0, o, 64); cmax0 = t > cmax0 ? t : cmax0;
-        t = __shfl_xor(cmin1, o, 64); cmin1 = t < cmin1 ? t : cmin1;
-        t = __shfl_xor(cmax1, o, 64); cmax1 = t > cmax1 ? t : cmax1;
-      }
+      rmin = wave_min_i32(rmin); rmax = wave_max_i32(rmax);
+      cmin0 = wave_min_i32(cmin0); cmax0 = wave_max_i32(cmax0);
+      cmin1 = wave_min_i32(cmin1); cmax1 = wave_max_i32(cmax1);
       if ((tid & 63) == 0) {
         atomicAdd(&H[H_NVALID], nval);
         if (flags) atomicOr(&H[H_FLAGS], flags);
@@ -883,16 +876,9 @@ struct Ins {
           }
         }
         v_n = wave_sum_i32(v_n);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          int t;
-          t = __shfl_xor(v_rmin, o, 64); v_rmin = t < v_rmin ? t : v_rmin;
-          t = __shfl_xor(v_rmax, o, 64); v_rmax = t > v_rmax ? t : v_rmax;
-          t = __shfl_xor(v_cmin0, o, 64); v_cmin0 = t < v_cmin0 ? t : v_cmin0;
-          t = __shfl_xor(v_cmax0, o, 64); v_cmax0 = t > v_cmax0 ? t : v_cmax0;
-          t = __shfl_xor(v_cmin1, o, 64); v_cmin1 = t < v_cmin1 ? t : v_cmin1;
-          t = __shfl_xor(v_cmax1, o, 64); v_cmax1 = t > v_cmax1 ? t : v_cmax1;
-        }
+        v_rmin = wave_min_i32(v_rmin); v_rmax = wave_max_i32(v_rmax);
+        v_cmin0 = wave_min_i32(v_cmin0); v_cmax0 = wave_max_i32(v_cmax0);
+        v_cmin1 = wave_min_i32(v_cmin1); v_cmax1 = wave_max_i32(v_cmax1);
         if ((tid & 63) == 0 && v_rmax >= 0) {
           atomicAdd(&H[H_NVIS], v_n);
           atomicMin(&H[H_VRMIN], v_rmin);
