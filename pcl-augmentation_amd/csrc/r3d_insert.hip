@@ -75,8 +75,34 @@ constexpr int kProgTimeout = -1, kProgDeferred = -2;
 
 // ---- window of the range image: rows [r_lo, r_hi] x one or two column intervals of whole 32-pixel
 // words (two when the object straddles the azimuth seam) ---------------------------------------------
+// Quotient and remainder of 0 <= p < 2^24 by a divisor fixed for the workgroup: one float multiply and a
+// correction step instead of the ~40 instructions of an integer division by a run-time value.  (float)p is
+// exact, the reciprocal and the product round by 2^-24 each: the truncated product is within 1 of the quotient.
+struct FastDiv {
+  int d;
+  float inv;
+  __device__ __forceinline__ void set(int d_) {
+    d = d_;
+    inv = 1.0f / (float)(d_ > 0 ? d_ : 1);
+  }
+  __device__ __forceinline__ int div(int p, int &rem) const {
+    int q = (int)((float)p * inv);
+    int r = p - q * d;
+    if (r < 0) {
+      --q;
+      r += d;
+    } else if (r >= d) {
+      ++q;
+      r -= d;
+    }
+    rem = r;
+    return q;
+  }
+};
+
 struct Window {
   int r_lo, r_hi, n_iv, jl0, jh0, jl1, jh1, nj0, njw, nrw, cols;
+  FastDiv by_njw;
   // window-local word index of image word (row r, word j), -1 outside the window
   __device__ __forceinline__ int lword(int r, int j) const {
     if (r < r_lo || r > r_hi) return -1;
@@ -86,10 +112,10 @@ struct Window {
     else return -1;
     return (r - r_lo) * njw + k;
   }
-  __device__ __forceinline__ int row_of(int e) const { return r_lo + e / njw; }      // e: local word
-  __device__ __forceinline__ int word_of(int e) const {
-    int k = e % njw;
-    return k < nj0 ? jl0 + k : jl1 + (k - nj0);
+  __device__ __forceinline__ void row_word(int e, int &r, int &j) const {            // e: local word
+    int k;
+    r = r_lo + by_njw.div(e, k);
+    j = k < nj0 ? jl0 + k : jl1 + (k - nj0);
   }
   __device__ __forceinline__ int lpix_rc(int r, int c) const {  // window-local pixel, -1 outside
     int lw = lword(r, c >> 5);
@@ -123,19 +149,6 @@ struct WinImage {
   }
 };
 
-// OR of a word with its horizontal neighbours' bits (columns c-1, c, c+1), clipped at the row ends.
-__device__ __forceinline__ uint32_t hor3(const WinImage &m, const Window &win, int r, int j) {
-  uint32_t c = m.word(win, r, j), l = m.word(win, r, j - 1), rr = m.word(win, r, j + 1);
-  return c | (c << 1) | (l >> 31) | (c >> 1) | (rr << 31);
-}
-// AND of the same three columns; a neighbour outside the IMAGE does not constrain (erosion border).
-__device__ __forceinline__ uint32_t hand3(const WinImage &m, const Window &win, int r, int j, int wpr) {
-  uint32_t c = m.word(win, r, j);
-  uint32_t l = j > 0 ? (m.word(win, r, j - 1) >> 31) : 1u;
-  uint32_t rr = j < wpr - 1 ? (m.word(win, r, j + 1) << 31) : 0x80000000u;
-  return c & ((c << 1) | l) & ((c >> 1) | rr);
-}
-
 // closing.py:44-57 on up to 15 already loaded keys (R3D_SENT = empty): sum over the occupied ones,
 // drow outer / dcolumn inner, divided by their count.
 __device__ __forceinline__ double mean_of_keys(const unsigned long long (&v)[15]) {
@@ -151,16 +164,34 @@ __device__ __forceinline__ double mean_of_keys(const unsigned long long (&v)[15]
 }
 
 // Diagnostic builds (make STAMPS=1) record a 100 MHz wall-clock stamp per phase in the first bytes
-// of the scene's out_xyzi slab (scratch until r3d_batch_finish), 16 stamps per slot;
+// of the scene's out_xyzi slab (scratch until r3d_batch_finish), 32 words per slot;
 // tools/stamps_insert.py reads them.
 #ifdef R3D_STAMPS
 #define STAMP(i)                                                                                         \
   do {                                                                                                   \
     __syncthreads();                                                                                     \
-    if (tid == 0) reinterpret_cast<long long *>(b.out_xyzi + (int64_t)s * b.cap * 4)[slot_no * 16 + (i)] = wall_clock64(); \
+    if (tid == 0) reinterpret_cast<long long *>(b.out_xyzi + (int64_t)s * b.cap * 4)[slot_no * 32 + (i)] = wall_clock64(); \
+  } while (0)
+// inside the gather loop: thread 0's own time between the marks, loads drained at every mark
+#define GSTAMP_DECL long long g_acc[5] = {0, 0, 0, 0, 0}, g_last = 0
+#define GSTAMP(i)                                                   \
+  do {                                                              \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+    long long g_now = wall_clock64();                               \
+    if ((i) > 0) g_acc[i] += g_now - g_last;                        \
+    g_last = g_now;                                                 \
+  } while (0)
+#define GSTAMP_END                                                                                              \
+  do {                                                                                                          \
+    if (tid == 0)                                                                                               \
+      for (int gi = 1; gi < 5; ++gi)                                                                            \
+        reinterpret_cast<long long *>(b.out_xyzi + (int64_t)s * b.cap * 4)[slot_no * 32 + 16 + gi] += g_acc[gi]; \
   } while (0)
 #else
 #define STAMP(i)
+#define GSTAMP_DECL
+#define GSTAMP(i)
+#define GSTAMP_END
 #endif
 
 // header of a workgroup's LDS (ints)
@@ -211,6 +242,7 @@ struct Ins {
   DTile bt;                              // the band of the tile currently in LDS
   int list_cap, nlist, nvis, n_base, n_far;
   bool accept;
+  FastDiv by_cols, by_W;
 
   // area: which of the scene's kMaxChain + 1 global list areas this workgroup may use (its slot of the launch;
   // kMaxChain for k_insert_big, which then uses it for every pair)
@@ -226,6 +258,7 @@ struct Ins {
     g_dtile = nullptr;
     g_cand = nullptr;
     pool_off = -1;
+    by_cols.set(cols);
     g_list = w.glist + (((int64_t)s * (kMaxChain + 1) + area) + 1) * chunks * 24;     // entries grow down from the area's end
   }
 
@@ -267,7 +300,9 @@ struct Ins {
     return (int)s_rank[lp >> 5] + __popc(A.w[lp >> 5] & ((1u << (lp & 31)) - 1u));
   }
   __device__ __forceinline__ int global_pix(int lp) const {
-    return win.row_of(lp >> 5) * cols + (win.word_of(lp >> 5) << 5) + (lp & 31);
+    int r, j;
+    win.row_word(lp >> 5, r, j);
+    return r * cols + (j << 5) + (lp & 31);
   }
   // Depth keys without branches (lp: window-local pixel, -1 = outside): the loads of the 15 neighbours of a
   // hole can then be in flight together -- two independent LDS reads, one dependent, instead of 15 chains.
@@ -278,11 +313,8 @@ struct Ins {
     const unsigned long long key = s_sdepth[occ ? (int)rk + __popc(aw & (bit - 1u)) : 0];
     return occ ? key : R3D_SENT;
   }
-  __device__ __forceinline__ unsigned long long scene_key(int r, int c) const {
-    const int dl = bt.index(r, c);
-    const unsigned long long key = g_dtile ? __hip_atomic_load(&g_dtile[dl < 0 ? 0 : dl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                           : s_dtile[dl < 0 ? 0 : dl];
-    return dl < 0 ? R3D_SENT : key;
+  __device__ __forceinline__ unsigned long long tile_key(int dl) const {      // dl: pixel of the band in LDS / the pool
+    return g_dtile ? __hip_atomic_load(&g_dtile[dl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s_dtile[dl];
   }
 
   // ================================================================================================
@@ -410,12 +442,14 @@ struct Ins {
     win.nj0 = win.jh0 - win.jl0 + 1;
     win.njw = win.nj0 + (win.n_iv > 1 ? win.jh1 - win.jl1 + 1 : 0);
     win.nrw = win.r_hi - win.r_lo + 1;
+    win.by_njw.set(win.njw);
     ww = win.nrw * win.njw;                                 // window words
     dt.r0 = win.r_lo;
     dt.r1 = win.r_hi;
     dt.w0 = dt.c10 - dt.c00 + 1;
     dt.W = dt.n_iv == 0 ? 0 : dt.w0 + (dt.n_iv > 1 ? dt.c11 - dt.c01 + 1 : 0);
     dt.npx = win.nrw * dt.W;
+    by_W.set(dt.W);
 
     // bit images: sample occupancy | scratch (dilations, then visible pixels) | sample closed |
     // scene occupancy | scene closed | occupied sample pixels before each window word
@@ -518,22 +552,7 @@ struct Ins {
     STAMP(4);
     // -- 5. closing of the sample's occupancy (closing.py:9-23) by word-parallel dilate / erode; exact
     // on every row at least 2 inside the window (or at the image border): candidates are ------------
-    for (int pass = 0; pass < 2; ++pass) {
-      const WinImage &src = pass == 0 ? A : T;
-      WinImage &dst = pass == 0 ? T : Cs;
-      for (int e = tid; e < ww; e += NT) {
-        int r = win.row_of(e), j = win.word_of(e);
-        uint32_t acc = pass ? 0xFFFFFFFFu : 0u;
-        for (int dr = -2; dr <= 2; ++dr) {
-          int rr = r + dr;
-          if (rr < 0 || rr >= rows) continue;
-          if (pass) acc &= hand3(src, win, rr, j, wpr);
-          else acc |= hor3(src, win, rr, j);
-        }
-        dst.w[e] = acc;
-      }
-      __syncthreads();
-    }
+    closing(A, T, Cs);
     // candidate pixels: where the sample is closed
     {
       int c = 0;
@@ -588,8 +607,10 @@ struct Ins {
     const int32_t *pixs = b.pix + (int64_t)s * b.cap;
     const float4 *xyzi = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
     const int nitems = (sub ? nsub : nlist) << 6;           // sub: the entries whose rows reach the band
+    GSTAMP_DECL;
     for (int e0 = tid; e0 < nitems; e0 += kPer * NT) {
       int idx[kPer], p[kPer], dl[kPer];
+      GSTAMP(0);
 #pragma unroll
       for (int u = 0; u < kPer; ++u) {
         int e = e0 + u * NT;
@@ -601,15 +622,17 @@ struct Ins {
       }
 #pragma unroll
       for (int u = 0; u < kPer; ++u) p[u] = idx[u] >= 0 ? pixs[idx[u]] : 0;
+      GSTAMP(1);
 #pragma unroll
       for (int u = 0; u < kPer; ++u) {
         dl[u] = -1;
         if (idx[u] >= 0) {
-          int r = p[u] / cols, c = p[u] - r * cols;
+          int c, r = by_cols.div(p[u], c);
           dl[u] = bt.index(r, c);
           if (all_rows_bits && dt.index(r, c) >= 0) D.set_local(win.lpix_rc(r, c));
         }
       }
+      GSTAMP(2);
       // coordinates: four float32 points in flight at a time
 #pragma unroll
       for (int h = 0; h < kPer; h += 4) {
@@ -619,6 +642,7 @@ struct Ins {
           f[u] = make_float4(1.f, 0.f, 0.f, 0.f);
           if (dl[h + u] >= 0 && idx[h + u] < n_head) f[u] = xyzi[idx[h + u]];
         }
+        GSTAMP(3);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (dl[h + u] < 0) continue;
@@ -634,25 +658,44 @@ struct Ins {
           if (fabs(z - q_min * r) <= tol && z / r == q_min) H[H_EXT0] = p[h + u];
           if (fabs(z - q_max * r) <= tol && z / r == q_max) H[H_EXT1] = p[h + u];
         }
+        GSTAMP(4);
       }
     }
+    GSTAMP_END;
   }
 
-  // 5-row x 3-column closing (closing.py:9-23) of one bit image of the window: src -> tmp -> dst.
+  // 5-row x 3-column closing (closing.py:9-23) of one bit image of the window: src -> tmp -> dst, dilation
+  // then erosion, 32 pixels per word.  In the window-local numbering the word above / below is njw words
+  // away and the horizontal neighbours are e - 1 / e + 1 unless the row (or the column interval) ends there.
+  // A word outside the window reads as 0; a row or column outside the IMAGE does not take part (no
+  // contribution to the dilation, no constraint on the erosion).
   __device__ __forceinline__ void closing(const WinImage &src, WinImage &tmp, WinImage &dst) {
     for (int pass = 0; pass < 2; ++pass) {
-      const WinImage &from = pass == 0 ? src : tmp;
-      WinImage &to = pass == 0 ? tmp : dst;
+      const uint32_t *from = pass == 0 ? src.w : tmp.w;
+      uint32_t *to = pass == 0 ? tmp.w : dst.w;
       for (int e = tid; e < ww; e += NT) {
-        int r = win.row_of(e), j = win.word_of(e);
+        int k, r = win.r_lo + win.by_njw.div(e, k);
+        const int j = k < win.nj0 ? win.jl0 + k : win.jl1 + (k - win.nj0);
+        const bool has_l = k > 0 && k != win.nj0, has_r = k < win.njw - 1 && k != win.nj0 - 1;
+        // what stands in for a neighbour word that is not in the window: nothing, except beyond the image's
+        // first / last column during the erosion
+        const uint32_t l_out = pass && j == 0 ? 1u : 0u, r_out = pass && j == wpr - 1 ? 0x80000000u : 0u;
         uint32_t acc = pass ? 0xFFFFFFFFu : 0u;
+#pragma unroll
         for (int dr = -2; dr <= 2; ++dr) {
-          int rr = r + dr;
+          const int rr = r + dr;
           if (rr < 0 || rr >= rows) continue;
-          if (pass) acc &= hand3(from, win, rr, j, wpr);
-          else acc |= hor3(from, win, rr, j);
+          uint32_t c = 0u, l = l_out, rw = r_out;
+          if (rr >= win.r_lo && rr <= win.r_hi) {
+            const int q = e + dr * win.njw;
+            c = from[q];
+            if (has_l) l = from[q - 1] >> 31;
+            if (has_r) rw = from[q + 1] << 31;
+          }
+          if (pass) acc &= c & ((c << 1) | l) & ((c >> 1) | rw);
+          else acc |= c | (c << 1) | l | (c >> 1) | rw;
         }
-        to.w[e] = acc;
+        to[e] = acc;
       }
       __syncthreads();
     }
@@ -802,7 +845,7 @@ struct Ins {
           __syncthreads();
           for (int i = tid; i < bt.npx; i += NT) {
             if ((g_dtile ? __hip_atomic_load(&g_dtile[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s_dtile[i]) == R3D_SENT) continue;
-            int r = bt.r0 + i / W, k = i % W;
+            int k, r = bt.r0 + by_W.div(i, k);
             int c = k < dt.w0 ? dt.c00 + k : dt.c01 + (k - dt.w0);
             D.set_local(win.lpix_rc(r, c));
           }
@@ -821,12 +864,18 @@ struct Ins {
         int v_n = 0, v_rmin = 0x7FFFFFFF, v_rmax = -1, v_cmin0 = 0x7FFFFFFF, v_cmax0 = -1, v_cmin1 = 0x7FFFFFFF, v_cmax1 = -1;
         for (int ci = tid; ci < nc; ci += NT) {
           int lp = (int)(g_cand ? g_cand[ci] : s_cand[ci]);
-          int r = win.row_of(lp >> 5), c = (win.word_of(lp >> 5) << 5) + (lp & 31);
+          int r, c;
+          win.row_word(lp >> 5, r, c);
+          c = (c << 5) + (lp & 31);
           double sd = R3D_EMPTY_DEPTH, cd = R3D_EMPTY_DEPTH;
           const bool a = A.get_local(lp), d = D.get_local(lp);
           const bool c_hole = !d && E.get_local(lp);
+          // A candidate lies at least 4 rows / 2 columns inside the window unless the image ends there, so the
+          // neighbours of its 5 x 3 footprint are plain offsets in the window-local and tile-local numbering
+          // (rows `rstride` resp. W apart); what leaves the image counts as empty.
+          const int rstride = win.njw << 5, dl0 = bt.index(r, c);
           if (a) sd = key_depth(sample_key(lp));
-          if (d) cd = key_depth(scene_key(r, c));
+          if (d) cd = key_depth(dl0 < 0 ? R3D_SENT : tile_key(dl0));
           // hole means (closing.py:44-57): the 15 neighbour keys are gathered first, one image at a time
           // (one register array, every load issued before the first is used), then summed in the reference's order
           if (!a) {                                            // a candidate is closed: a hole of the sample
@@ -837,7 +886,8 @@ struct Ins {
               for (int dc = -1; dc <= 1; ++dc) {
                 int rr = r + dr, cc = c + dc;
                 const bool in = rr >= 0 && rr < rows && cc >= 0 && cc < cols;
-                v[(dr + 2) * 3 + (dc + 1)] = sample_key(in ? win.lpix_rc(rr, cc) : -1);   // inside the window: holes are >= 2 rows in
+                int lq = lp + dr * rstride + dc;
+                v[(dr + 2) * 3 + (dc + 1)] = sample_key(in && (unsigned)lq < (unsigned)(ww << 5) ? lq : -1);
               }
             sd = mean_of_keys(v);
           }
@@ -849,7 +899,10 @@ struct Ins {
               for (int dc = -1; dc <= 1; ++dc) {
                 int rr = r + dr, cc = c + dc;
                 const bool in = rr >= 0 && rr < rows && cc >= 0 && cc < cols;
-                v[(dr + 2) * 3 + (dc + 1)] = scene_key(in ? rr : -1, cc);
+                int dq = dl0 + dr * W + dc;
+                const bool ok = in && dl0 >= 0 && (unsigned)dq < (unsigned)bt.npx;
+                unsigned long long key = tile_key(ok ? dq : 0);
+                v[(dr + 2) * 3 + (dc + 1)] = ok ? key : R3D_SENT;
               }
             cd = mean_of_keys(v);
           }
@@ -907,42 +960,62 @@ struct Ins {
           }
         }
       }
-      int base = 0;
-      for (int k0 = 0; k0 < nvalid; k0 += NT) {
-        int k = k0 + tid;
-        int flag = (k < nvalid && vis.get_local((int)s_lp[s_F[k]])) ? 1 : 0;
+      // the visible points in sorted order: thread t takes the sorted points [t*L, t*L + L), one block scan
+      {
+        const int L = (nvalid + NT - 1) / NT;
+        const int k_lo = tid * L < nvalid ? tid * L : nvalid, k_hi = k_lo + L < nvalid ? k_lo + L : nvalid;
+        int cnt = 0;
+        for (int k = k_lo; k < k_hi; ++k) cnt += vis.get_local((int)s_lp[s_F[k]]) ? 1 : 0;
         int tot;
-        int ex = block_escan_i32(flag, scan, tot);
-        if (flag) s_V[base + ex] = (uint16_t)k;
-        base += tot;
+        int o = block_escan_i32(cnt, scan, tot);
+        for (int k = k_lo; k < k_hi; ++k)
+          if (vis.get_local((int)s_lp[s_F[k]])) s_V[o++] = (uint16_t)k;
       }
       // every living scene point in a visible pixel dies (:470-473): one mask per listed chunk, so that
-      // the commit is a handful of atomics
+      // the commit is a handful of atomics.  Only the chunks whose rows reach a visible row are looked at:
+      // their entry numbers are compacted into the room the candidates and the tile no longer need.
       {
         constexpr int kPer = 8;
         const int lane = tid & 63;
         const int32_t *pixs = b.pix + (int64_t)s * b.cap;
-        const int nitems = nlist << 6;
+        const int vr0 = uni(H[H_VRMIN]), vr1 = uni(H[H_VRMAX]);
+        uint16_t *s_kl = reinterpret_cast<uint16_t *>(smem + carve);
+        const int room = ((lds_cap & ~7) - (glist ? 0 : 24 * nlist) - carve) / 2;
+        int nkl = nlist;
+        if (nlist <= room && nlist <= 0xFFFF) {
+          if (tid == 0) H[H_CARRY] = 0;
+          __syncthreads();
+          for (int i = tid; i < nlist; i += NT) {
+            uint32_t rr = l_rows(i);
+            if ((int)(rr & 0xFFFF) <= vr1 && (int)(rr >> 16) >= vr0) s_kl[atomicAdd(&H[H_CARRY], 1)] = (uint16_t)i;
+          }
+          __syncthreads();
+          nkl = uni(H[H_CARRY]);
+        } else {
+          s_kl = nullptr;
+        }
+        const int nitems = nkl << 6;
         for (int e0 = tid; e0 < nitems; e0 += kPer * NT) {
-          int p[kPer];
+          int p[kPer], ent[kPer];
           bool on[kPer];
 #pragma unroll
           for (int u = 0; u < kPer; ++u) {
             int e = e0 + u * NT;
-            on[u] = e < nitems && ((l_alive(e >> 6) >> (e & 63)) & 1ull);
-            p[u] = on[u] ? pixs[(int)(l_chunk(e >> 6) << 6) + (e & 63)] : 0;
+            ent[u] = e < nitems ? (s_kl ? (int)s_kl[e >> 6] : (e >> 6)) : 0;
+            on[u] = e < nitems && ((l_alive(ent[u]) >> (e & 63)) & 1ull);
+            p[u] = on[u] ? pixs[(int)(l_chunk(ent[u]) << 6) + (e & 63)] : 0;
           }
 #pragma unroll
           for (int u = 0; u < kPer; ++u) {
             int e = e0 + u * NT;
             bool kill = false;
             if (on[u]) {
-              int r = p[u] / cols;
-              int lp = win.lpix_rc(r, p[u] - r * cols);
+              int c, r = by_cols.div(p[u], c);
+              int lp = win.lpix_rc(r, c);
               kill = lp >= 0 && vis.get_local(lp);
             }
             unsigned long long mask = __ballot(kill);
-            if (lane == 0 && e < nitems) set_kill(e >> 6, mask);
+            if (lane == 0 && e < nitems && mask) set_kill(ent[u], mask);
           }
         }
       }
@@ -980,7 +1053,9 @@ struct Ins {
         if (valid) {
           int j = s_F[s_V[o]];
           int lp = (int)s_lp[j];
-          int row = win.row_of(lp >> 5), col = (win.word_of(lp >> 5) << 5) + (lp & 31);
+          int row, col;
+          win.row_word(lp >> 5, row, col);
+          col = (col << 5) + (lp & 31);
           const double *q = rows5 + (int64_t)j * 5;
           double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
           int lr = n_log + o;
@@ -1328,7 +1403,7 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
   STAMP(15);
 #ifdef R3D_STAMPS
   if (tid == 0)
-    reinterpret_cast<long long *>(b.out_xyzi + (int64_t)s * b.cap * 4)[k * 16 + 12] =
+    reinterpret_cast<long long *>(b.out_xyzi + (int64_t)s * b.cap * 4)[k * 32 + 12] =
         (long long)attempts | ((long long)(rc == kOk ? 1 : 0) << 8) | ((long long)I.ww << 16) | ((long long)I.nlist << 32) |
         ((long long)(I.dt.npx >> 4) << 48);
 #endif

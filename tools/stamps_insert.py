@@ -4,7 +4,7 @@
     R3D_LIB=pcl-augmentation_amd/libreal3daug_hip_stamps.so python tools/stamps_insert.py [out.npz]
 
 Every workgroup of k_insert_chain leaves 100 MHz wall-clock stamps at its phase boundaries in its
-scene's out_xyzi slab (16 per slot).  Prints a table (mean / p50 / p95 / max per phase over all
+scene's out_xyzi slab (32 words per slot).  Prints a table (mean / p50 / p95 / max per phase over all
 pairs) and saves the raw stamps."""
 import importlib
 import sys
@@ -31,10 +31,10 @@ names = ["project sample", "window + re-key", "occupancy + rank", "counting sort
 edges = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10), (10, 11), (11, 13), (13, 14), (14, 15)]
 for rep in range(3):
     batch.begin()
-    batch.out_xyzi.view(B, -1)[:, :K * 32].zero_()
+    batch.out_xyzi.view(B, -1)[:, :K * 64].zero_()
     batch.insert_many_device(packed, [need] * K)
     torch.cuda.synchronize()
-    raw = batch.out_xyzi.view(B, -1)[:, :K * 32].contiguous().view(torch.int64).cpu().numpy().reshape(B, K, 16)
+    raw = batch.out_xyzi.view(B, -1)[:, :K * 64].contiguous().view(torch.int64).cpu().numpy().reshape(B, K, 32)
 raw = raw.transpose(1, 0, 2)                       # [K, B, 16]
 info = raw[:, :, 12]
 attempts, all_lds, ww, nlist = info & 0xFF, (info >> 8) & 1, (info >> 16) & 0xFFFF, (info >> 32) & 0xFFFF
@@ -59,5 +59,8 @@ for k in range(K):
     print(f"slot {k} ({KINDS[k]}): total mean {tot[k].mean():.1f} max {tot[k].max():.1f} us; window words mean {ww[k].mean():.0f} "
           f"max {ww[k].max()}; chunks listed mean {nlist[k].mean():.0f} max {nlist[k].max()}; end (mean, us after launch) "
           f"{(raw[k, :, 15].mean() - t0) / 100.0:.1f}")
+g = raw[:, :, 17:21].astype(np.float64) / 100.0                  # thread 0 inside the gather loop (loads drained at every mark)
+print("gather loop, thread 0, us per pair (mean / max): " + "; ".join(
+    f"{n} {g[:, :, i].mean():.2f} / {g[:, :, i].max():.2f}" for i, n in enumerate(["list + pixel ids", "place in tile", "coordinates", "sqrt + min"])))
 if len(sys.argv) > 1:
     np.savez_compressed(sys.argv[1], raw=raw, names=np.array(names))
