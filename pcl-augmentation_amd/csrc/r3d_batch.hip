@@ -41,6 +41,56 @@ __global__ void k_begin_init(r3d_batch_t b, const int32_t *n_points, BatchWs w) 
 
 // elevation = acos(z/r) is monotone in q = z/r, so the bounds of insertion.py:78-79 are acos of
 // the extreme q: reduce q here (sqrt + divide per point), take acos twice per scene afterwards.
+//
+// The float64 square root and division (~60 instructions) are only spent on points that can be an
+// extreme.  k_bounds_sample first reduces the exact q of one wave-row in 16 (two rows of every
+// 2048-point tile) into qkeys: the q of two real points, so the true extremes lie at or beyond them.
+// k_bounds then screens every point in float32: qf = z * rsq(x*x + y*y + z*z) is within 3e-7 of z/r
+// (see k_project), so a point with  lo + 2e-6 < qf < hi - 2e-6  lies strictly between two points of the
+// scene and is neither extreme; it is also finite and inside [-1, 1], so it raises no flag.  Whatever
+// the screen cannot exclude (the top and bottom ring of a scan; inserted float64 points; anything not
+// a normal float32) takes the exact evaluation as before.
+__device__ __forceinline__ void exact_q(const r3d_batch_t &b, int s, int i, int n_head, float4 pt,
+                                        unsigned long long &lmin, unsigned long long &lmax, int &bad) {
+  double x = (double)pt.x, y = (double)pt.y, z = (double)pt.z;
+  if (i >= n_head) load_point(b, s, i, n_head, x, y, z);
+  double r = sqrt(x * x + y * y + z * z);
+  double q = z / r;
+  if (!(q >= -1.0 && q <= 1.0) || !isfinite(x) || !isfinite(y)) {
+    bad = 1;
+  } else {
+    unsigned long long kq = ordered_key(q);
+    lmin = kq < lmin ? kq : lmin;
+    lmax = kq > lmax ? kq : lmax;
+  }
+}
+
+__global__ void __launch_bounds__(kPT)
+k_bounds_sample(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
+  int cnt = *count;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    int s = list[li];
+    int n = b.n_total[s], n_head = b.n_head[s];
+    int t0 = (blockIdx.x * (kPT / 64) + wave) * kTile;          // one tile per wave: its rows 0 and 16
+    if (t0 >= n) continue;
+    const float4 *src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
+    unsigned long long lmin = ~0ull, lmax = 0ull;
+    int bad = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int i = t0 + h * (kTile / 2) + lane;
+      if (i < n) exact_q(b, s, i, n_head, src[i], lmin, lmax, bad);
+    }
+    lmin = wave_min_u64(lmin);
+    lmax = wave_max_u64(lmax);
+    if (lane == 0 && lmin != ~0ull) {
+      atomicMin(&w.qkeys[2 * s + 0], lmin);
+      atomicMax(&w.qkeys[2 * s + 1], lmax);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(kPT)
 k_bounds(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
   __shared__ unsigned long long s_min[kPT / 64], s_max[kPT / 64];
@@ -52,8 +102,16 @@ k_bounds(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
     if (t0 >= n) continue;
     unsigned long long lmin = ~0ull, lmax = 0ull;
     int bad = 0;
+    // what the sample (or the tiles that finished before this one) found: every later value is only more extreme
+    const unsigned long long k_lo = __hip_atomic_load(&w.qkeys[2 * s + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long k_hi = __hip_atomic_load(&w.qkeys[2 * s + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float lo_t = __builtin_inff(), hi_t = -__builtin_inff();    // no sample: nothing is excluded
+    if (k_lo != ~0ull) {
+      lo_t = (float)(ordered_key_inv(k_lo) + 2.5e-6);            // 2e-6 and the rounding of the conversion
+      hi_t = (float)(ordered_key_inv(k_hi) - 2.5e-6);
+    }
     // the thread's 8 float32 points are requested together (inserted float64 points, which only exist when a
-    // re-based scene comes through here, are fetched from the log below)
+    // re-based scene comes through here, are fetched from the log by exact_q)
     const float4 *src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
     float4 pt[kPerThread];
 #pragma unroll
@@ -64,19 +122,10 @@ k_bounds(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
       int i = t0 + k * kPT + threadIdx.x;
-      if (i < n) {
-        double x = (double)pt[k].x, y = (double)pt[k].y, z = (double)pt[k].z;
-        if (i >= n_head) load_point(b, s, i, n_head, x, y, z);
-        double r = sqrt(x * x + y * y + z * z);
-        double q = z / r;
-        if (!(q >= -1.0 && q <= 1.0) || !isfinite(x) || !isfinite(y)) {
-          bad = 1;
-        } else {
-          unsigned long long kq = ordered_key(q);
-          lmin = kq < lmin ? kq : lmin;
-          lmax = kq > lmax ? kq : lmax;
-        }
-      }
+      float ssf = fmaf(pt[k].x, pt[k].x, fmaf(pt[k].y, pt[k].y, pt[k].z * pt[k].z));
+      float qf = pt[k].z * __frsqrt_rn(ssf);
+      const bool inside = (ssf > 1e-30f) & (ssf < 1e30f) & (qf > lo_t) & (qf < hi_t) & (i < n_head);
+      if (i < n && !inside) exact_q(b, s, i, n_head, pt[k], lmin, lmax, bad);
     }
     lmin = wave_min_u64(lmin);
     lmax = wave_max_u64(lmax);
@@ -93,8 +142,10 @@ k_bounds(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
         lmin = s_min[v] < lmin ? s_min[v] : lmin;
         lmax = s_max[v] > lmax ? s_max[v] : lmax;
       }
-      atomicMin(&w.qkeys[2 * s + 0], lmin);
-      atomicMax(&w.qkeys[2 * s + 1], lmax);
+      if (lmin != ~0ull) {
+        atomicMin(&w.qkeys[2 * s + 0], lmin);
+        atomicMax(&w.qkeys[2 * s + 1], lmax);
+      }
     }
     __syncthreads();
   }
@@ -278,11 +329,11 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
         // bin guess (about 1e-5 rad off at worst, a few per mille of a bin)
         float ssf = fmaf(pt.x, pt.x, fmaf(pt.y, pt.y, pt.z * pt.z));
         float qf = pt.z * __frsqrt_rn(ssf);
-        qf = qf < -1.f ? -1.f : (qf > 1.f ? 1.f : qf);
+        qf = __builtin_amdgcn_fmed3f(qf, -1.f, 1.f);
         int row = (int)floorf((guess_acosf(qf) - elo) * inv_del);
         int col = (int)((guess_atan2f(pt.y, pt.x) + 3.14159274f) * inv_daz);
-        row = row < 0 ? 0 : (row > bn.rows - 1 ? bn.rows - 1 : row);
-        col = col < 0 ? 0 : (col > bn.cols - 1 ? bn.cols - 1 : col);
+        row = max(0, min(row, bn.rows - 1));
+        col = max(0, min(col, bn.cols - 1));
         // float32 screen
         float2 ea = s_col[col], eb = s_col[col + 1];
         float mcf = 1e-6f * (fabsf(pt.x) + fabsf(pt.y));
@@ -497,6 +548,7 @@ static size_t project_lds_bytes(const r3d_batch_t &b) {
 static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_t *list,
                             const int32_t *count, int rows, hipStream_t st) {
   int tiles = tiles_of(b);
+  hipLaunchKernelGGL(k_bounds_sample, dim3((tiles + kPT / 64 - 1) / (kPT / 64), rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_bounds, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_prepare, dim3(1, rows), dim3(kPT), 0, st, b, list, count, w, tiles);
   hipLaunchKernelGGL(k_project, dim3(project_blocks(b), rows), dim3(kPT), project_lds_bytes(b), st, b, list,

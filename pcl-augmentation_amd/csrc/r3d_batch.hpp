@@ -114,15 +114,16 @@ __device__ __forceinline__ unsigned long long pack_box(int rmin, int rmax, int c
          ((unsigned long long)(cmin & 0xFFFF) << 32) | ((unsigned long long)(cmax & 0xFFFF) << 48);
 }
 
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
-// Row / column bounding box of the pixels of one wave's 64 points.
+// Row / column bounding box of the pixels of one wave's 64 points.  Four 32-bit minima / maxima: with the
+// identity as the DPP `old` operand every step of their reduction is ONE instruction (v_min_u32_dpp ...);
+// the packed 16-bit form needs a move per step because VOP3P takes no DPP.
 struct BoxAcc {
-  u16x2 lo = {0xFFFF, 0xFFFF}, hi = {0, 0};        // (row, col) minima and maxima
+  unsigned int rlo = 0xFFFFu, rhi = 0u, clo = 0xFFFFu, chi = 0u;
   __device__ __forceinline__ void add(int row, int col) {
-    u16x2 v = {(unsigned short)row, (unsigned short)col};
-    lo = __builtin_elementwise_min(lo, v);
-    hi = __builtin_elementwise_max(hi, v);
+    rlo = (unsigned)row < rlo ? (unsigned)row : rlo;
+    rhi = (unsigned)row > rhi ? (unsigned)row : rhi;
+    clo = (unsigned)col < clo ? (unsigned)col : clo;
+    chi = (unsigned)col > chi ? (unsigned)col : chi;
   }
   __device__ __forceinline__ void add_box(unsigned long long bx) {      // union with a packed box
     int rmin = (int)(bx & 0xFFFF), rmax = (int)((bx >> 16) & 0xFFFF);
@@ -131,14 +132,18 @@ struct BoxAcc {
     add(rmax, (int)((bx >> 48) & 0xFFFF));
   }
   __device__ __forceinline__ unsigned long long wave_pack() {          // uniform: the box of the wave's 64 lanes
-#define R3D_STEP(C, M)                                                                                              \
-  lo = __builtin_elementwise_min(lo, __builtin_bit_cast(u16x2, dpp_take<C, M>(-1, __builtin_bit_cast(int, lo))));  \
-  hi = __builtin_elementwise_max(hi, __builtin_bit_cast(u16x2, dpp_take<C, M>(0, __builtin_bit_cast(int, hi))));
-    R3D_DPP_STEPS(R3D_STEP)                              // two packed 16-bit reductions per step
+#define R3D_STEP(C, M)                                                                       \
+  {                                                                                          \
+    unsigned int t0 = (unsigned int)dpp_take<C, M>(-1, (int)rlo), t1 = (unsigned int)dpp_take<C, M>(0, (int)rhi); \
+    unsigned int t2 = (unsigned int)dpp_take<C, M>(-1, (int)clo), t3 = (unsigned int)dpp_take<C, M>(0, (int)chi); \
+    rlo = t0 < rlo ? t0 : rlo;                                                               \
+    rhi = t1 > rhi ? t1 : rhi;                                                               \
+    clo = t2 < clo ? t2 : clo;                                                               \
+    chi = t3 > chi ? t3 : chi;                                                               \
+  }
+    R3D_DPP_STEPS(R3D_STEP)
 #undef R3D_STEP
-    lo = __builtin_bit_cast(u16x2, wave_last_i32(__builtin_bit_cast(int, lo)));
-    hi = __builtin_bit_cast(u16x2, wave_last_i32(__builtin_bit_cast(int, hi)));
-    return pack_box(lo.x, hi.x, lo.y, hi.y);           // rmin > rmax: empty box
+    return pack_box(wave_last_i32((int)rlo), wave_last_i32((int)rhi), wave_last_i32((int)clo), wave_last_i32((int)chi));   // rmin > rmax: empty box
   }
 };
 

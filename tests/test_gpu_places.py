@@ -494,3 +494,41 @@ def test_object_database_equals_the_reference_scripts(P, tmp_path):
     removed = co.filter_objects(save, config)
     left = sorted(os.path.relpath(p, save) for p in glob.glob(os.path.join(save, "*", "*.npz")))
     assert left == sorted(str(x) for x in g["after_filter"]) and len(removed) == n - len(left) > 0
+
+
+def test_object_database_od_equals_the_reference_script(P, tmp_path):
+    """Row f-3, object-detection flavour: object_cut_out.py:83-168 on the fixture's KITTI frames -- unoccluded
+    objects of the inserted classes whose enlarged box is entirely in the camera image, ground-labelled points
+    dropped, min_points; same files, annotation lines and rows as the reference script left
+    (tests/golden/make_golden_cut_od.py)."""
+    from PIL import Image
+    co = importlib.import_module("pcl-augmentation_amd.cut_object")
+    g = load_golden("cut_objects_od.npz")
+    classes = [str(c) for c in g["classes"]]
+    config = {"insertion": {"classes": classes, "min_points": dict(zip(classes, (int(x) for x in g["min_points"]))),
+                            "labels_shortcut": dict(zip(classes, (str(x) for x in g["shortcuts"])))},
+              "labels": dict(zip(("Road", "Parking", "Sidewalk"), (int(x) for x in g["ground_labels"])))}
+    save = str(tmp_path / "objects")
+    (tmp_path / "calib.txt").write_text(str(g["calib"]))
+    Image.new("RGB", tuple(int(x) for x in g["img_size"])).save(tmp_path / "img.png")
+    assert tuple(co.image_shape(str(tmp_path / "img.png"))) == (int(g["img_size"][1]), int(g["img_size"][0]))
+    written = []
+    for f in range(int(g["n_frames"])):
+        (tmp_path / f"{f:06d}.txt").write_text(str(g[f"label_2_{f}"]))
+        written += co.cut_frame_objects_od(g[f"points{f}"], str(tmp_path / f"{f:06d}.txt"), str(tmp_path / "calib.txt"),
+                                           str(tmp_path / "img.png"), config, save)
+    n = int(g["n_files"])
+    assert n >= 4 and sorted(os.path.relpath(p, save) for p in written) == sorted(str(g[f"name{i}"]) for i in range(n))
+    for i in range(n):
+        d = np.load(os.path.join(save, str(g[f"name{i}"])), allow_pickle=True)
+        assert str(d["anno"]) == str(g[f"anno{i}"])
+        assert d["pcl"].dtype == g[f"pcl{i}"].dtype and np.array_equal(d["pcl"], g[f"pcl{i}"])
+    # every reason to skip an object occurs in the fixture: out of view (beside / behind), occluded, another class, too sparse
+    lines = str(g["label_2_0"]).splitlines()
+    shape = co.image_shape(str(tmp_path / "img.png"))
+    views = []
+    for ln in lines:
+        a = co.kitti_box_from_label_line(ln.split(" "))
+        c = np.array([[a["center"]["x"], a["center"]["y"], a["center"]["z"]]])
+        views.append(bool(co.camera_fov_flags(c, str(tmp_path / "calib.txt"), shape)[0]))
+    assert views.count(False) == 2 and sum(int(ln.split(" ")[2]) != 0 for ln in lines) == 1
