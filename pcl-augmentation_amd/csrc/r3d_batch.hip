@@ -65,29 +65,44 @@ __device__ __forceinline__ void exact_q(const r3d_batch_t &b, int s, int i, int 
   }
 }
 
+constexpr int kSampleBlocks = 8;      // workgroups per scene of k_bounds_sample (one pair of atomics each)
+
 __global__ void __launch_bounds__(kPT)
 k_bounds_sample(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
+  __shared__ unsigned long long s_min[kPT / 64], s_max[kPT / 64];
   int cnt = *count;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
     int n = b.n_total[s], n_head = b.n_head[s];
-    int t0 = (blockIdx.x * (kPT / 64) + wave) * kTile;          // one tile per wave: its rows 0 and 16
-    if (t0 >= n) continue;
     const float4 *src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
     unsigned long long lmin = ~0ull, lmax = 0ull;
     int bad = 0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int i = t0 + h * (kTile / 2) + lane;
-      if (i < n) exact_q(b, s, i, n_head, src[i], lmin, lmax, bad);
+    // a wave takes every (gridDim.x * waves)-th tile: its rows 0 and 16
+    for (int t0 = (blockIdx.x * (kPT / 64) + wave) * kTile; t0 < n; t0 += gridDim.x * (kPT / 64) * kTile) {
+      int i0 = t0 + lane, i1 = t0 + kTile / 2 + lane;
+      float4 p0 = src[i0 < n ? i0 : n - 1], p1 = src[i1 < n ? i1 : n - 1];
+      if (i0 < n) exact_q(b, s, i0, n_head, p0, lmin, lmax, bad);
+      if (i1 < n) exact_q(b, s, i1, n_head, p1, lmin, lmax, bad);
     }
     lmin = wave_min_u64(lmin);
     lmax = wave_max_u64(lmax);
-    if (lane == 0 && lmin != ~0ull) {
-      atomicMin(&w.qkeys[2 * s + 0], lmin);
-      atomicMax(&w.qkeys[2 * s + 1], lmax);
+    if (lane == 0) {
+      s_min[wave] = lmin;
+      s_max[wave] = lmax;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int v = 1; v < kPT / 64; ++v) {
+        lmin = s_min[v] < lmin ? s_min[v] : lmin;
+        lmax = s_max[v] > lmax ? s_max[v] : lmax;
+      }
+      if (lmin != ~0ull) {
+        atomicMin(&w.qkeys[2 * s + 0], lmin);
+        atomicMax(&w.qkeys[2 * s + 1], lmax);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -548,7 +563,7 @@ static size_t project_lds_bytes(const r3d_batch_t &b) {
 static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_t *list,
                             const int32_t *count, int rows, hipStream_t st) {
   int tiles = tiles_of(b);
-  hipLaunchKernelGGL(k_bounds_sample, dim3((tiles + kPT / 64 - 1) / (kPT / 64), rows), dim3(kPT), 0, st, b, list, count, w);
+  hipLaunchKernelGGL(k_bounds_sample, dim3(kSampleBlocks, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_bounds, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_prepare, dim3(1, rows), dim3(kPT), 0, st, b, list, count, w, tiles);
   hipLaunchKernelGGL(k_project, dim3(project_blocks(b), rows), dim3(kPT), project_lds_bytes(b), st, b, list,
