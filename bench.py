@@ -285,7 +285,7 @@ def main():
             accs = [bt.insert_device(s5, off, nd)[1].clone() for s5, off in pk]
             bt.last_acc = torch.stack(accs)
         else:
-            bt.last_acc = bt.insert_many_device(pk, [nd] * len(pk))[1]
+            bt.last_vis, bt.last_acc = bt.insert_many_device(pk, [nd] * len(pk))
         bt.finish(check_cols=5)
 
     def enqueue_serial():
@@ -350,6 +350,7 @@ def main():
         serial_elapsed = elapsed
     n_out = batch.n_out.cpu().numpy()
     n_accepted = int(batch.last_acc.sum().item())
+    n_appended = int((batch.last_vis * batch.last_acc).sum().item()) if hasattr(batch, "last_vis") else None
     rebases = int(batch.rebase.sum().item())        # informational: a rebase leaves the inputs intact
 
     if rank == 0:
@@ -453,6 +454,7 @@ def main():
             "config": {"workload": cfg["workload"],
                        "scenes_per_gpu": B, "points_per_scene": int(n_pts / B), "inserts_per_scene": K,
                        "range_image": [batch.rows, batch.cols], "inserts_accepted": n_accepted, "inserts_tried": B * K,
+                       "points_appended": n_appended, "points_culled": None if n_appended is None else int(n_pts + n_appended - n_out.sum()),
                        "steps_in_flight": depth, "check_rows_in_timed_region": True,
                        "scenes_per_s_one_step_in_flight": round(B * world * args.steps / serial_elapsed, 1),
                        "ms_per_step_one_step_in_flight": round(step_ms_serial, 3),
