@@ -338,6 +338,8 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
       float4 pt2 = pt1;
       if (k + 2 < kPerThread) pt2 = fetch(t0 + (k + 2) * kPT + threadIdx.x);
       BoxAcc box;
+      int row = 0, col = 0;
+      bool placed = false;
       if (i < n) {
         // (inserted float64 points, which only exist when a re-based scene is projected by this kernel,
         // take the queue)
@@ -345,8 +347,8 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
         float ssf = fmaf(pt.x, pt.x, fmaf(pt.y, pt.y, pt.z * pt.z));
         float qf = pt.z * __frsqrt_rn(ssf);
         qf = __builtin_amdgcn_fmed3f(qf, -1.f, 1.f);
-        int row = (int)floorf((guess_acosf(qf) - elo) * inv_del);
-        int col = (int)((guess_atan2f(pt.y, pt.x) + 3.14159274f) * inv_daz);
+        row = (int)floorf((guess_acosf(qf) - elo) * inv_del);
+        col = (int)((guess_atan2f(pt.y, pt.x) + 3.14159274f) * inv_daz);
         row = max(0, min(row, bn.rows - 1));
         col = max(0, min(col, bn.cols - 1));
         // float32 screen
@@ -365,6 +367,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
         if (ok & (int)(!exact) & (int)(i < n_head)) {
           int p = row * b.cols + col;
           box.add(row, col);
+          placed = true;
           if (far) {
             int f = atomicAdd(&b.n_far[s], 1);
             if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
@@ -379,7 +382,18 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
       }
       pt = pt1;
       pt1 = pt2;
-      unsigned long long packed = box.wave_pack();
+      // the chunk's box.  A scan in ring order gives 64 points of one row whose columns rise with the lane:
+      // then the box is lane 0's and lane 63's pixel (checked, not assumed); anything else takes the reduction.
+      unsigned long long packed;
+      {
+        const int before = __builtin_amdgcn_update_dpp(col, col, 0x138, 0xF, 0xF, false);   // wave_shr:1; lane 0 keeps its own
+        const int row0 = __builtin_amdgcn_readfirstlane(row);
+        const bool in_order = placed & (row == row0) & (col >= before);
+        if (__ballot(in_order) == ~0ull)
+          packed = pack_box(row0, row0, __builtin_amdgcn_readfirstlane(col), __builtin_amdgcn_readlane(col, 63));
+        else
+          packed = box.wave_pack();
+      }
       unsigned long long living = __ballot(i < n);           // every point of the frame is alive at step 0
       int i0 = t0 + k * kPT + (threadIdx.x & ~63);
       if ((threadIdx.x & 63) == 0 && i0 < n) {
