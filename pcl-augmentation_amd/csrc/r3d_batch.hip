@@ -43,7 +43,7 @@ __global__ void k_begin_init(r3d_batch_t b, const int32_t *n_points, BatchWs w) 
 // the extreme q: reduce q here (sqrt + divide per point), take acos twice per scene afterwards.
 //
 // The float64 square root and division (~60 instructions) are only spent on points that can be an
-// extreme.  k_bounds_sample first reduces the exact q of one wave-row in 16 (two rows of every
+// extreme.  k_bounds_sample first reduces the exact q of one wave-row in 32 (the first row of every
 // 2048-point tile) into qkeys: the q of two real points, so the true extremes lie at or beyond them.
 // k_bounds then screens every point in float32: qf = z * rsq(x*x + y*y + z*z) is within 3e-7 of z/r
 // (see k_project), so a point with  lo + 2e-6 < qf < hi - 2e-6  lies strictly between two points of the
@@ -65,8 +65,9 @@ __device__ __forceinline__ void exact_q(const r3d_batch_t &b, int s, int i, int 
   }
 }
 
-constexpr int kSampleBlocks = 8;      // workgroups per scene of k_bounds_sample (one pair of atomics each)
-
+// One wave per 2048-point tile reads the tile's first row (64 points: one row in 32); a workgroup (4 tiles)
+// leaves one pair of atomics.  (Per-wave atomics serialise: 15 000 waves on 2 x 32 addresses took 0.13 ms in
+// config C5; a few workgroups per scene looping over the tiles are latency-bound, 0.024 ms.)
 __global__ void __launch_bounds__(kPT)
 k_bounds_sample(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
   __shared__ unsigned long long s_min[kPT / 64], s_max[kPT / 64];
@@ -75,16 +76,12 @@ k_bounds_sample(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchW
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
     int n = b.n_total[s], n_head = b.n_head[s];
+    if ((int)blockIdx.x * (kPT / 64) * kTile >= n) continue;
     const float4 *src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
     unsigned long long lmin = ~0ull, lmax = 0ull;
     int bad = 0;
-    // a wave takes every (gridDim.x * waves)-th tile: its rows 0 and 16
-    for (int t0 = (blockIdx.x * (kPT / 64) + wave) * kTile; t0 < n; t0 += gridDim.x * (kPT / 64) * kTile) {
-      int i0 = t0 + lane, i1 = t0 + kTile / 2 + lane;
-      float4 p0 = src[i0 < n ? i0 : n - 1], p1 = src[i1 < n ? i1 : n - 1];
-      if (i0 < n) exact_q(b, s, i0, n_head, p0, lmin, lmax, bad);
-      if (i1 < n) exact_q(b, s, i1, n_head, p1, lmin, lmax, bad);
-    }
+    const int i = (blockIdx.x * (kPT / 64) + wave) * kTile + lane;
+    if (i < n) exact_q(b, s, i, n_head, src[i], lmin, lmax, bad);
     lmin = wave_min_u64(lmin);
     lmax = wave_max_u64(lmax);
     if (lane == 0) {
@@ -577,7 +574,7 @@ static size_t project_lds_bytes(const r3d_batch_t &b) {
 static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_t *list,
                             const int32_t *count, int rows, hipStream_t st) {
   int tiles = tiles_of(b);
-  hipLaunchKernelGGL(k_bounds_sample, dim3(kSampleBlocks, rows), dim3(kPT), 0, st, b, list, count, w);
+  hipLaunchKernelGGL(k_bounds_sample, dim3((tiles + kPT / 64 - 1) / (kPT / 64), rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_bounds, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_prepare, dim3(1, rows), dim3(kPT), 0, st, b, list, count, w, tiles);
   hipLaunchKernelGGL(k_project, dim3(project_blocks(b), rows), dim3(kPT), project_lds_bytes(b), st, b, list,

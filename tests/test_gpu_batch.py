@@ -227,6 +227,40 @@ def test_fast_projection_equals_reference_formula(P, synth):
     assert np.array_equal(pix[1][0][0, :len(sc)], sc[:, 8].astype(np.int32))
 
 
+def test_screened_bounds_equal_numpy(P, synth):
+    """k_bounds screens in float32 against a sampled pre-pass and evaluates z/r exactly only where a point can
+    be an extreme: the elevation bounds must be those of the plain formula (insertion.py:74-79) whatever the
+    order of the points, wherever the extreme point sits, and for clouds shorter than a wave or a tile."""
+    rng = np.random.default_rng(11)
+    base, lab = synth.make_scene(90)
+    scenes = [(base, lab), synth.make_scene(91, shuffle=True)]
+    for n in (2, 63, 65, 2047, 2049, 40000):
+        idx = np.linspace(0, len(base) - 1, n).astype(np.int64)          # from the first ring to the last
+        scenes.append((base[idx], lab[idx]))
+    # the extreme points at places the sample (the first 64 points of every 2048-point tile) does not read
+    hi, lo = base.copy(), base.copy()
+    hi[5000 + 70] = [3.0, 0.5, 2.9, 0.1]
+    lo[len(lo) - 1] = [2.0, -0.5, -6.0, 0.1]
+    both = hi.copy()
+    both[len(both) - 1] = lo[len(lo) - 1]
+    scenes += [(hi, lab), (lo, lab), (both, lab)]
+    # two points whose z/r differ by a few ulp: the exact evaluation has to pick the right one
+    tie = base.copy()
+    tie[1000] = [10.0, 0.0, 5.0, 0.0]
+    tie[99000] = [np.float32(10.000001), 0.0, 5.0, 0.0]
+    scenes.append((tie, lab))
+    cap = max(len(x) for x, _ in scenes) + 64
+    b = P.SceneBatch(len(scenes), cap, 64)
+    b.load(scenes)
+    b.begin()
+    got = b.bounds.cpu().numpy()
+    assert (b.status.cpu().numpy() == 0).all()
+    for s, (xyzi, _) in enumerate(scenes):
+        x, y, z = (xyzi[:, k].astype(np.float64) for k in range(3))
+        el = np.arccos(z / np.sqrt(x * x + y * y + z * z))
+        assert abs(got[s, 0] - el.max()) <= 4.5e-16 and abs(got[s, 1] - el.min()) <= 4.5e-16, s
+
+
 def test_baseline_config_shapes(P, synth):
     """BASELINE.json configs as parity cases (full size, few scenes): C3 = object-detection path
     (labels collapsed to {40, 1}, 10 mixed inserts, 4-column check file), C4 = 8 inserts per frame,
