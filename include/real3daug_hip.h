@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define R3D_VERSION 0x00020000
+#define R3D_VERSION 0x00020001
 
 #define R3D_NUMROW 112        /* insertion.py:22 */
 #define R3D_NUMCOLUMN 1440    /* insertion.py:23; the pixel id always multiplies by THIS (:116,:127) */
@@ -174,6 +174,16 @@ int r3d_batch_create(const r3d_batch_t *b, void *stream);
  * point and resets all per-scene state.  (The min-reduce of :118-125 is done per insert, on the
  * window of the range image that the insert can see -- DESIGN.md par.3.) */
 int r3d_batch_begin(const r3d_batch_t *b, const int32_t *n_points, void *stream);
+
+/* Step 0 for clouds whose coordinates are genuine float64 (the Waymo flavour: tools/datasets.py:240-262 hands
+ * the driver x y z intensity label as float64 after subtracting the LiDAR offset).  rows5: device double
+ * [B][cap][5], n_points[s] rows used.  The points are kept like inserted points are -- exact coordinates in the
+ * log (rows 0 .. n_points[s]-1, birth step 0), their float32 rounding in xyzi --, so every later step works on
+ * the float64 values; r3d_batch_export_rows returns them, and b->log5 rows from n_points[s] on are the accepted
+ * visible points (all_visible_parts).  Needs log_cap >= n_points[s] + the points to be inserted
+ * (else R3D_S_CAPACITY).  The projection of step 0 uses the reference formula for every point (no float32
+ * shortcut: the screen of the fast path assumes float32-exact inputs). */
+int r3d_batch_begin_f64(const r3d_batch_t *b, const double *rows5, const int32_t *n_points, void *stream);
 
 /* One placement candidate per scene (insertion.py:453-526).  samples5: rows of [x y z intensity
  * label] float64, scene s owns rows sample_off[s] .. sample_off[s+1] (device int64[B+1]).

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "r3d_batch_workspace_bytes": (C.c_size_t, [C.POINTER(BatchDesc)]),
     "r3d_batch_create": (C.c_int, [C.POINTER(BatchDesc), _P]),
     "r3d_batch_begin": (C.c_int, [C.POINTER(BatchDesc), _P, _P]),
+    "r3d_batch_begin_f64": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P]),
     "r3d_batch_insert": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "r3d_batch_finish": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int32, _P]),
     "r3d_batch_launch_one": (C.c_int, [C.POINTER(BatchDesc), C.c_int32, _P]),

@@ -165,6 +165,51 @@ class SceneBatch:
                                             _lib.stream_ptr()), "r3d_batch_begin")
 
     @_lib.on_own_device
+    def begin_f64(self, scenes5):
+        """Step 0 for clouds with genuine float64 coordinates (the Waymo flavour, SS tools/datasets.py:240-262):
+        scenes5[s] = N x 5 float64 rows [x y z intensity label].  The frame's points are kept in the log next
+        to the inserted ones (``log_cap`` >= N + inserted points), every later step works on the float64 values;
+        read the result with ``results_f64``."""
+        torch = self.torch
+        assert len(scenes5) == self.B
+        if getattr(self, "_rows5", None) is None:
+            self._rows5 = torch.zeros((self.B, self.cap, 5), dtype=torch.float64, device=self.device)
+            self._rows5_pin = torch.zeros((self.B, self.cap, 5), dtype=torch.float64).pin_memory()
+        host, n = self._rows5_pin.numpy(), np.zeros(self.B, dtype=np.int32)
+        for s, rows in enumerate(scenes5):
+            rows = np.asarray(rows, dtype=np.float64)
+            if len(rows) > self.cap or len(rows) > self.log_cap:
+                raise ValueError(f"scene {s}: {len(rows)} points exceed capacity {min(self.cap, self.log_cap)}")
+            n[s] = len(rows)
+            host[s, :len(rows)] = rows[:, :5]
+        self._rows5.copy_(self._rows5_pin, non_blocking=True)
+        self.n_points.copy_(torch.from_numpy(n))
+        self.n_frame = n.copy()
+        self.step = 0
+        _lib.check(self.lib.r3d_batch_begin_f64(C.byref(self.desc), C.c_void_p(self._rows5.data_ptr()),
+                                                C.c_void_p(self.n_points.data_ptr()), _lib.stream_ptr()),
+                   "r3d_batch_begin_f64")
+
+    @_lib.on_own_device
+    def results_f64(self):
+        """After ``begin_f64`` and the inserts: per scene (merged N' x 5 float64 rows [x y z intensity label] in
+        the reference's order -- surviving frame points, then surviving inserted points --, added M x 5 float64 =
+        all_visible_parts).  Coordinates and labels come from ``r3d_batch_export_rows`` (exact float64), the
+        intensity column from the compaction (``finish``)."""
+        rows4, n_rows = self.export_rows()
+        self.finish(check_cols=0)
+        rows4, n_rows = rows4.cpu().numpy(), n_rows.cpu().numpy()
+        inten, n_out = self.out_xyzi[:, :, 3].cpu().numpy(), self.n_out.cpu().numpy()
+        log5, n_log = self.log5.cpu().numpy(), self.n_log.cpu().numpy()
+        out = []
+        for s in range(self.B):
+            assert n_rows[s] == n_out[s]
+            m = np.empty((n_rows[s], 5))
+            m[:, 0:3], m[:, 3], m[:, 4] = rows4[s, :n_rows[s], 0:3], inten[s, :n_out[s]], rows4[s, :n_rows[s], 3]
+            out.append((m, log5[s, self.n_frame[s]:n_log[s]].copy()))
+        return out
+
+    @_lib.on_own_device
     def insert_device(self, samples5, sample_off, min_points, active=None, new_slot=True):
         """One candidate per scene from device tensors; returns (n_visible, accepted) tensors.
 

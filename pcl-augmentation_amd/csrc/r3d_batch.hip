@@ -15,7 +15,8 @@
 namespace r3d {
 
 // ---- step 0 / rebase: bounds ------------------------------------------------------------------
-__global__ void k_begin_init(r3d_batch_t b, const int32_t *n_points, BatchWs w) {
+// f64: the frame's points live in the log like inserted points do (r3d_batch_begin_f64)
+__global__ void k_begin_init(r3d_batch_t b, const int32_t *n_points, BatchWs w, bool f64) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s == 0) {
     *w.all_count = b.B;
@@ -23,13 +24,13 @@ __global__ void k_begin_init(r3d_batch_t b, const int32_t *n_points, BatchWs w) 
   if (s >= b.B) return;
   int n = n_points[s];
   int st = 0;
-  if (n < 0 || n > b.cap) {
+  if (n < 0 || n > b.cap || (f64 && n > b.log_cap)) {
     n = 0;
     st = R3D_S_CAPACITY;
   }
-  b.n_head[s] = n;
+  b.n_head[s] = f64 ? 0 : n;
   b.n_total[s] = n;
-  b.n_log[s] = 0;
+  b.n_log[s] = f64 ? n : 0;
   b.n_far[s] = 0;
   b.rebase[s] = 0;
   b.status[s] = st;
@@ -37,6 +38,29 @@ __global__ void k_begin_init(r3d_batch_t b, const int32_t *n_points, BatchWs w) 
   w.all_list[s] = s;
   w.qkeys[2 * s + 0] = ~0ull;   // running min of z/r
   w.qkeys[2 * s + 1] = 0ull;    // running max of z/r
+}
+
+// r3d_batch_begin_f64: rows of [x y z intensity label] float64 -> log rows 0..n-1 (exact), their float32
+// rounding in xyzi / label (what the .bin writers and the compaction copy), tail_ref = identity, birth step 0.
+__global__ void __launch_bounds__(kPT)
+k_load_f64(r3d_batch_t b, const double *__restrict__ rows5, const int32_t *n_points) {
+  const int s = blockIdx.y;
+  int n = n_points[s];
+  if (n < 0 || n > b.cap || n > b.log_cap) return;            // k_begin_init flags the scene
+  for (int i = blockIdx.x * kPT + threadIdx.x; i < n; i += gridDim.x * kPT) {
+    const double *q = rows5 + ((int64_t)s * b.cap + i) * 5;
+    double v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4];
+    double *l = b.log5 + ((int64_t)s * b.log_cap + i) * 5;
+    l[0] = v0;
+    l[1] = v1;
+    l[2] = v2;
+    l[3] = v3;
+    l[4] = v4;
+    b.log_birth[(int64_t)s * b.log_cap + i] = 0;
+    b.tail_ref[(int64_t)s * b.log_cap + i] = i;
+    reinterpret_cast<float4 *>(b.xyzi)[(int64_t)s * b.cap + i] = make_float4((float)v0, (float)v1, (float)v2, (float)v3);
+    b.label[(int64_t)s * b.cap + i] = (uint32_t)(int64_t)v4;
+  }
 }
 
 // elevation = acos(z/r) is monotone in q = z/r, so the bounds of insertion.py:78-79 are acos of
@@ -572,14 +596,14 @@ static size_t project_lds_bytes(const r3d_batch_t &b) {
 
 // bounds -> tables -> project for the scenes of (list, count); rows = block rows of the launches.
 static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_t *list,
-                            const int32_t *count, int rows, hipStream_t st) {
+                            const int32_t *count, int rows, hipStream_t st, int slow_blocks = 4) {
   int tiles = tiles_of(b);
   hipLaunchKernelGGL(k_bounds_sample, dim3((tiles + kPT / 64 - 1) / (kPT / 64), rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_bounds, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_prepare, dim3(1, rows), dim3(kPT), 0, st, b, list, count, w, tiles);
   hipLaunchKernelGGL(k_project, dim3(project_blocks(b), rows), dim3(kPT), project_lds_bytes(b), st, b, list,
                      count, w, chunks_of(b));
-  hipLaunchKernelGGL(k_project_slow, dim3(4, rows), dim3(kPT), 0, st, b, list, count, w);
+  hipLaunchKernelGGL(k_project_slow, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w);
   R3D_LAUNCHED("reproject kernels");
   return R3D_OK;
 }
@@ -625,8 +649,20 @@ int r3d_batch_begin(const r3d_batch_t *b, const int32_t *n_points, void *stream)
   if (!n_points) return fail(R3D_E_ARG, "batch_begin: null n_points");
   hipStream_t st = (hipStream_t)stream;
   BatchWs w = carve_batch(*b, b->workspace);
-  hipLaunchKernelGGL(k_begin_init, dim3((b->B + 255) / 256), dim3(256), 0, st, *b, n_points, w);
+  hipLaunchKernelGGL(k_begin_init, dim3((b->B + 255) / 256), dim3(256), 0, st, *b, n_points, w, false);
   return launch_reproject(*b, w, w.all_list, w.all_count, b->B, st);
+}
+
+int r3d_batch_begin_f64(const r3d_batch_t *b, const double *rows5, const int32_t *n_points, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  if (!n_points || !rows5) return fail(R3D_E_ARG, "batch_begin_f64: null rows5 or n_points");
+  hipStream_t st = (hipStream_t)stream;
+  BatchWs w = carve_batch(*b, b->workspace);
+  hipLaunchKernelGGL(k_load_f64, dim3(32, b->B), dim3(kPT), 0, st, *b, rows5, n_points);
+  hipLaunchKernelGGL(k_begin_init, dim3((b->B + 255) / 256), dim3(256), 0, st, *b, n_points, w, true);
+  // every point takes the reference formula: more workgroups per scene for k_project_slow
+  return launch_reproject(*b, w, w.all_list, w.all_count, b->B, st, 32);
 }
 
 int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream) {

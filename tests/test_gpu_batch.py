@@ -48,6 +48,33 @@ def test_golden_chains(P, name, od):
     assert np.array_equal(label, g["merged"][:, 4].astype(np.uint32))
 
 
+def test_float64_clouds_waymo_flavour(P, tmp_path):
+    """r3d_batch_begin_f64: a frame whose coordinates are genuine float64 (what Waymo.__getitem__ hands the driver,
+    SS tools/datasets.py:240-262) through the batched path: merged cloud, added points and accepts equal the
+    reference's chain on the same float64 input, and Waymo.save_data writes the reference's three .npy files
+    (tests/golden/make_golden_waymo.py): the merged coordinates are the float64 ones, bit for bit."""
+    import importlib
+    g = load_golden("chain_waymo_f64.npz")
+    scene5 = g["scene5"]
+    assert not np.array_equal(scene5[:, :3], scene5[:, :3].astype(np.float32))
+    samples = np.split(g["samples"], np.cumsum(g["sample_sizes"])[:-1])
+    n, grow = len(scene5), int(g["sample_sizes"].sum())
+    b = P.SceneBatch(1, n + grow, n + grow)
+    b.begin_f64([scene5])
+    acc = [int(b.insert([smp], [int(need)])[1][0]) for smp, need in zip(samples, g["min_points"])]
+    b.raise_on_status()
+    assert acc == list(g["accepted"])
+    (merged, added), = b.results_f64()
+    assert np.array_equal(merged, g["merged"]) and np.array_equal(added, g["all_visible"])
+    # the reference's files: lidar / labels_v3_2 / check .npy, the LiDAR offset added back in float64 first
+    ds = importlib.import_module("pcl-augmentation_amd.Real3DAug.tools.datasets")
+    nine = lambda r5: np.column_stack([r5[:, 0:3], -np.ones((len(r5), 3)), r5[:, 3:5], -np.ones(len(r5))])
+    w = ds.Waymo({"path": {"output_path": str(tmp_path)}})
+    w.save_data(nine(merged), nine(added), "f", "000000")
+    for sub, key in (("lidar", "lidar_npy"), ("labels_v3_2", "labels_npy"), ("check", "check_npy")):
+        assert open(tmp_path / "f" / sub / "000000.npy", "rb").read() == g[key].tobytes(), sub
+
+
 def test_begin_matches_golden_pixels_and_bounds(P, synth):
     g = load_golden("c1_120k.npz")
     xyzi, label = synth.make_scene(int(g["scene_seed"]))

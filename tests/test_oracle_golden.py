@@ -121,6 +121,18 @@ def test_chain_and_bytes(name, od):
     assert vb == g["velodyne_bin"].tobytes() and cb == g["check_bin"].tobytes()
 
 
+def test_chain_on_float64_cloud():
+    """The oracle on a frame with genuine float64 coordinates (the Waymo flavour) equals the reference's chain
+    (tests/golden/make_golden_waymo.py)."""
+    g = load_golden("chain_waymo_f64.npz")
+    samples = np.split(g["samples"], np.cumsum(g["sample_sizes"])[:-1])
+    merged, allvis, acc = O.augment_scene(g["scene5"], [[s] for s in samples], list(g["min_points"]))
+    assert np.array_equal(np.array([a >= 0 for a in acc], dtype=np.int32), g["accepted"]) and 0 in g["accepted"]
+    assert np.array_equal(merged[:, [0, 1, 2, 6, 7]], g["merged"])
+    assert np.array_equal(allvis[:, [0, 1, 2, 6, 7]], g["all_visible"])
+    assert not np.array_equal(g["scene5"][:, :3], g["scene5"][:, :3].astype(np.float32))
+
+
 def test_c1_120k(synth):
     g = load_golden("c1_120k.npz")
     xyzi, label = synth.make_scene(int(g["scene_seed"]))
