@@ -204,7 +204,7 @@ enum {
 };
 constexpr int kHdrBytes = 512;
 
-enum { kOk = 0, kNoFit = 1, kNeedSerial = 2 };
+enum { kOk = 0, kNoFit = 1, kNeedSerial = 2, kStale = 3 };
 
 // A value every lane holds (read from LDS or global memory): into a scalar register.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -707,7 +707,10 @@ struct Ins {
   // cannot hold the chunk list plus one band of the tile, or kNeedSerial when the scene has pixels
   // beyond 500 m and `serial` is false (their culling is not a matter of the window).
   // ================================================================================================
-  __device__ __forceinline__ int scene_phase(int n_base_, bool serial) {
+  // `stale()`: called by the whole workgroup at two points of a speculative evaluation (after the chunk list, after
+  // the gather); true = a slot that finished meanwhile changed a pixel this evaluation reads, give up now (kStale).
+  template <class Stale>
+  __device__ __forceinline__ int scene_phase(int n_base_, bool serial, Stale &&stale) {
     n_base = uni(n_base_);
     n_far = uni(b.n_far[s] < R3D_FAR_CAP ? b.n_far[s] : R3D_FAR_CAP);
     nvis = 0;
@@ -791,6 +794,7 @@ struct Ins {
       if (per < 1) return kNoFit;
     }
 
+    if (!serial && stale()) return kStale;
     STAMP(7);
     WinImage &vis = T;
     for (int a0 = cr0; a0 <= cr1; a0 += per) {
@@ -839,6 +843,7 @@ struct Ins {
       __syncthreads();
 
       if (first) {
+        if (!serial && stale()) return kStale;
         STAMP(8);
         if (single) {                                          // scene occupancy bits, from the tile's pixels
           for (int e = tid; e < ww; e += NT) D.w[e] = 0u;
@@ -1327,8 +1332,62 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
       if (need_sample) {
         rc = (b.reserved & kDbgDefer) ? kNoFit : I.sample_phase();
         sample_ok = rc == kOk;
+        // The scene may have moved on while the sample was prepared: build on the freshest state, so that fewer
+        // slots remain that can invalidate the evaluation (a big pair that has to evaluate twice is the tail
+        // of the launch).  New bounds in between: the sample is projected again.
+        if (rc == kOk && !waited) {
+          const int p1 = wait_for(0);
+          if (p1 == kProgDeferred) return;
+          if (p1 < 0) {
+            outputs(0, 0);
+            return;
+          }
+          if (p1 > p0) {
+            bool moved = false;
+            for (int j = p0; j < p1; ++j)
+              if ((w.recs[((int64_t)s * kMaxChain + j) * kRecInts + REC_FLAGS] & (kRecAccepted | kRecRebased)) ==
+                  (kRecAccepted | kRecRebased))
+                moved = true;
+            p0 = p1;
+            n_base = w.recs[((int64_t)s * kMaxChain + p0 - 1) * kRecInts + REC_NTOTAL];
+            waited = p0 >= k;
+            if (moved) continue;
+          }
+        }
       }
-      if (rc == kOk) rc = I.scene_phase(n_base, waited);
+      // while it speculates, the evaluation looks twice whether a slot that finished meanwhile has already
+      // invalidated it: a doomed evaluation of a big pair is given up early and restarted on the fresher state
+      int gone = 0, stale_cf = 0;
+      if (rc == kOk)
+        rc = I.scene_phase(n_base, waited, [&]() -> bool {
+          const int p1 = wait_for(0);
+          if (p1 < 0) {
+            gone = p1;
+            return true;
+          }
+          if (p1 > p0) {
+            stale_cf = I.nvalid > 0 ? conflict_with(w, s, p0, p1, H, b.rows, b.cols) : 0;
+            if (I.nvalid == 0)
+              for (int j = p0; j < p1; ++j)
+                if ((w.recs[((int64_t)s * kMaxChain + j) * kRecInts + REC_FLAGS] & (kRecAccepted | kRecRebased)) ==
+                    (kRecAccepted | kRecRebased))
+                  stale_cf |= 3;
+            p0 = p1;                                         // slots below p1 are accounted for from here on
+            if (stale_cf) return true;
+          }
+          return false;
+        });
+      if (rc == kStale) {
+        if (gone == kProgDeferred) return;
+        if (gone < 0) {
+          outputs(0, 0);
+          return;
+        }
+        n_base = w.recs[((int64_t)s * kMaxChain + p0 - 1) * kRecInts + REC_NTOTAL];
+        waited = p0 >= k;
+        need_sample = (stale_cf & 2) != 0;
+        continue;
+      }
       if (rc == kNoFit) break;
       if (!waited) {
         int seen = wait_for(k);
@@ -1423,7 +1482,7 @@ k_insert_big(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w,
     int nv = 0, acc = 0;
     if (on) {
       int rc = I.sample_phase();
-      if (rc == kOk) rc = I.scene_phase(b.n_total[s], true);
+      if (rc == kOk) rc = I.scene_phase(b.n_total[s], true, [] { return false; });
       if (rc != kOk) {
         if (tid == 0) atomicOr(&b.status[s], R3D_S_WINDOW_TOO_LARGE);     // not even a whole CU's LDS holds it
       } else {
