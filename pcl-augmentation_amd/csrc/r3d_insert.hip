@@ -313,9 +313,9 @@ struct Ins {
     const unsigned long long key = s_sdepth[occ ? (int)rk + __popc(aw & (bit - 1u)) : 0];
     return occ ? key : R3D_SENT;
   }
-  __device__ __forceinline__ unsigned long long tile_key(int dl) const {      // dl: pixel of the band in LDS / the pool
-    return g_dtile ? __hip_atomic_load(&g_dtile[dl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s_dtile[dl];
-  }
+  // dl: pixel of the band in LDS / the pool (plain loads: after the gather the pooled tile is read-only, and the
+  // workgroup has dropped its stale cache lines)
+  __device__ __forceinline__ unsigned long long tile_key(int dl) const { return g_dtile ? g_dtile[dl] : s_dtile[dl]; }
 
   // ================================================================================================
   // sample phase.  kOk, or kNoFit when the per-point / per-pixel arrays exceed this kernel's LDS.
@@ -629,7 +629,7 @@ struct Ins {
         if (idx[u] >= 0) {
           int c, r = by_cols.div(p[u], c);
           dl[u] = bt.index(r, c);
-          if (all_rows_bits && dt.index(r, c) >= 0) D.set_local(win.lpix_rc(r, c));
+          if (all_rows_bits && (bt.npx == dt.npx ? dl[u] >= 0 : dt.index(r, c) >= 0)) D.set_local(win.lpix_rc(r, c));
         }
       }
       GSTAMP(2);
@@ -836,20 +836,24 @@ struct Ins {
         for (int i = tid; i < bt.npx; i += NT) g_dtile[i] = R3D_SENT;
       else
         for (int i = tid; i < bt.npx; i += NT) s_dtile[i] = R3D_SENT;
-      if (first && !single)
+      // the scene's occupancy bits: set by the gather when the tile is banded or lives in the pool (reading a
+      // pooled tile back costs a trip through L2 per pixel), else read off the finished tile in LDS below
+      const bool bits_in_gather = first && (!single || g_dtile);
+      if (bits_in_gather)
         for (int e = tid; e < ww; e += NT) D.w[e] = 0u;
       __syncthreads();
-      gather(first && !single, use_sub ? s_sub : nullptr, nsub);
+      gather(bits_in_gather, use_sub ? s_sub : nullptr, nsub);
+      if (g_dtile) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the minima were formed in L2: drop this CU's copies
       __syncthreads();
 
       if (first) {
         if (!serial && stale()) return kStale;
         STAMP(8);
-        if (single) {                                          // scene occupancy bits, from the tile's pixels
+        if (single && !g_dtile) {                              // scene occupancy bits, from the tile's pixels
           for (int e = tid; e < ww; e += NT) D.w[e] = 0u;
           __syncthreads();
           for (int i = tid; i < bt.npx; i += NT) {
-            if ((g_dtile ? __hip_atomic_load(&g_dtile[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s_dtile[i]) == R3D_SENT) continue;
+            if (s_dtile[i] == R3D_SENT) continue;
             int k, r = bt.r0 + by_W.div(i, k);
             int c = k < dt.w0 ? dt.c00 + k : dt.c01 + (k - dt.w0);
             D.set_local(win.lpix_rc(r, c));
