@@ -1527,12 +1527,18 @@ static int env_int(const char *name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
-// LDS bytes of a chain workgroup: two 512-thread workgroups per CU by default (measured on config C2:
-// 256 threads x 40 KB leaves most cars to bands / k_insert_big, 1024 x 160 KB leaves the CUs to one pair each).
-static int chain_lds_bytes() {
-  static const int kb = env_int("R3D_INSERT_LDS_KB", 80);
-  int v = kb < 16 ? 16 : (kb > 160 ? 160 : kb);
-  return v * 1024;
+// Shape of a chain workgroup.  Range images of KITTI's size (112 x 1440): two 512-thread workgroups with 80 KB each per
+// CU (measured on config C2: 256 threads x 40 KB leaves most cars to the pool / k_insert_big, 1024 x 160 KB leaves
+// the CUs to one pair each and no room for the other steps in flight).  Large range images (config C5, 448 x 2880:
+// a car's window is ~16x the pixels): one 1024-thread workgroup with the CU's whole LDS -- 2.5 ms per step against
+// 5.9 ms, nearly every pair then fits the chain kernel.  R3D_INSERT_NT / R3D_INSERT_LDS_KB override.
+static void chain_shape(const r3d_batch_t &b, int &nt, int &lds) {
+  static const int env_nt = env_int("R3D_INSERT_NT", 0), env_kb = env_int("R3D_INSERT_LDS_KB", 0);
+  const bool large = (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN;
+  nt = env_nt ? env_nt : (large ? 1024 : 512);
+  int kb = env_kb ? env_kb : (nt == 1024 ? 160 : 80);
+  kb = kb < 16 ? 16 : (kb > 160 ? 160 : kb);
+  lds = kb * 1024;
 }
 
 template <int NT>
@@ -1553,8 +1559,8 @@ static int launch_chain(const r3d_batch_t &b, const BatchWs &w, const ChainSlots
 static int launch_slots(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step,
                         hipStream_t st) {
   static const int timeout_ms = env_int("R3D_CHAIN_TIMEOUT_MS", 2000);
-  static const int nt = env_int("R3D_INSERT_NT", 512);
-  const int lds = chain_lds_bytes();
+  int nt, lds;
+  chain_shape(b, nt, lds);
   R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_big<kBigNT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
   hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, nk);
