@@ -75,6 +75,37 @@ def test_float64_clouds_waymo_flavour(P, tmp_path):
         assert open(tmp_path / "f" / sub / "000000.npy", "rb").read() == g[key].tobytes(), sub
 
 
+def test_float64_begin_ragged_batch_and_capacity(P, synth):
+    """begin_f64 on a ragged batch equals the oracle scene by scene; a frame that does not fit the log is refused
+    on the host, and one that leaves no room for an accepted insert raises the capacity status."""
+    rng = np.random.default_rng(5)
+    frames = []
+    for s, (beams, naz) in enumerate([(16, 400), (24, 300), (8, 250)]):
+        xyzi, label = synth.make_scene(300 + s, beams, naz)
+        f5 = synth.scene5_from_packed(xyzi, label)
+        f5[:, 0:3] += rng.normal(0.0, 1e-3, (len(f5), 3))
+        frames.append(f5)
+    inserts = [synth.make_insert(3100 + s, kind, rng_range=(5.0, 12.0)) for s, kind in enumerate(["pedestrian", "cyclist", "car"])]
+    n_max = max(len(f) for f in frames)
+    grow = max(len(i) for i in inserts)
+    b = P.SceneBatch(3, n_max + grow, n_max + grow)
+    b.begin_f64(frames)
+    nv, acc = b.insert(inserts, [20, 20, 20])
+    b.raise_on_status()
+    for s, ((merged, added), f5, smp) in enumerate(zip(b.results_f64(), frames, inserts)):
+        m9, a9, ok = O.augment_scene(f5, [[smp]], [20])
+        assert (ok[0] >= 0) == bool(acc[s]) and len(added) == (nv[s] if acc[s] else 0)
+        assert np.array_equal(merged, m9[:, [0, 1, 2, 6, 7]]) and np.array_equal(added, a9[:, [0, 1, 2, 6, 7]])
+    big = max(frames, key=len)
+    with pytest.raises(ValueError):
+        P.SceneBatch(1, len(big) + grow, len(big) - 1).begin_f64([big])
+    tight = P.SceneBatch(1, len(frames[2]) + 8, len(frames[2]) + 8)          # room for 8 inserted points only
+    tight.begin_f64([frames[2]])
+    tight.insert([inserts[2]], [20])
+    with pytest.raises(Exception):
+        tight.raise_on_status()
+
+
 def test_begin_matches_golden_pixels_and_bounds(P, synth):
     g = load_golden("c1_120k.npz")
     xyzi, label = synth.make_scene(int(g["scene_seed"]))
