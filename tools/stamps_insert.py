@@ -15,13 +15,19 @@ import torch
 sys.path.insert(0, '.')
 pkg = importlib.import_module("pcl-augmentation_amd")
 synth = pkg.synth
-B = 256
-KINDS = ["pedestrian", "cyclist", "car", "pedestrian", "cyclist"]
+import os
+if os.environ.get("R3D_STAMPS_CONFIG") == "C5":            # the first launch (32 slots) of config C5's 50 inserts
+    B, KINDS = 32, (["car", "pedestrian", "cyclist", "pedestrian", "cyclist"] * 10)[:32]
+    scenes = [synth.make_scene(s, n_beams=256, n_az=3906) for s in range(B)]
+    shape = dict(rows=448, cols=2880)
+else:
+    B, KINDS = 256, ["pedestrian", "cyclist", "car", "pedestrian", "cyclist"]
+    scenes = [synth.make_scene(s) for s in range(B)]
+    shape = {}
 K = len(KINDS)
-scenes = [synth.make_scene(s) for s in range(B)]
 inserts = [synth.make_inserts(s, KINDS) for s in range(B)]
 grow = sum(max(len(inserts[s][k]) for s in range(B)) for k in range(K))
-batch = pkg.SceneBatch(B, 120000 + grow, grow)
+batch = pkg.SceneBatch(B, max(len(x) for x, _ in scenes) + grow, grow, **shape)
 batch.load(scenes)
 need = torch.full((B,), 20, dtype=torch.int32, device=batch.device)
 packed = [batch.pack_samples([inserts[s][k] for s in range(B)]) for k in range(K)]
