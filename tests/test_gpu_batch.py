@@ -625,7 +625,10 @@ def test_chain_timeout_is_reported(P, synth):
     """A slot whose predecessor never publishes gives up after the wall-clock bound (diagnostic bit 16
     makes slot 0 of scene 0 skip its publish): R3D_S_CHAIN_TIMEOUT on that scene, its later slots
     are not run, the other scene is untouched by it, nothing hangs."""
+    import os
     import torch
+    if os.environ.get("R3D_NO_CHAIN"):
+        pytest.skip("R3D_NO_CHAIN: one launch per slot, nothing waits inside a kernel")
     scenes = [synth.make_scene(50 + s, 32, 500) for s in range(2)]
     ins = [[synth.make_insert(500 + 10 * s + k, "pedestrian", rng_range=(5.0, 15.0)) for k in range(3)] for s in range(2)]
     n = max(len(x) for x, _ in scenes)
