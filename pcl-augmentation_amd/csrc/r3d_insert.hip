@@ -1038,9 +1038,13 @@ struct Ins {
   // commit of an accepted candidate: append (insertion.py:526), cull (:470-473).  Returns true when
   // the scene must be re-based (the elevation bounds may have moved).  `flags_out`: kRec* bits.
   // ================================================================================================
-  __device__ __forceinline__ bool commit(int &flags_out, int &n_total_after) {
+  // n_total_in / n_head_in: the scene's counts when the caller already holds them (the chain kernel: from the
+  // predecessor's record), -1 = read them here.  The log holds one row per appended point: n_log = n_total - n_head.
+  __device__ __forceinline__ bool commit(int &flags_out, int &n_total_after, int n_total_in = -1, int n_head_in = -1) {
     const int lane = tid & 63, wave = tid >> 6;
-    const int n_total = uni(b.n_total[s]), n_log = uni(b.n_log[s]), n_head = uni(b.n_head[s]);
+    const int n_head = n_head_in >= 0 ? n_head_in : uni(b.n_head[s]);
+    const int n_total = n_total_in >= 0 ? n_total_in : uni(b.n_total[s]);
+    const int n_log = n_total - n_head;
     const int tiles = (int)((b.cap + kTile - 1) / kTile);
     n_total_after = n_total;
     flags_out = 0;
@@ -1052,6 +1056,7 @@ struct Ins {
     if (!accept) return false;
     unsigned long long *alive = w.alive + (int64_t)s * chunks;
     int32_t *tile_alive = w.tile_alive + (int64_t)s * tiles;
+    STAMP(22);
     // -- the visible points, in (pixel, index) order, behind the cloud; one 64-point chunk per wave step
     {
       const int c_first = n_total >> 6, c_last = (n_total + nvis - 1) >> 6;
@@ -1098,6 +1103,7 @@ struct Ins {
         }
       }
     }
+    STAMP(23);
     // -- the scene points in visible pixels die
     for (int i = tid; i < nlist; i += NT) {
       unsigned long long mask = l_kill(i);
@@ -1106,6 +1112,7 @@ struct Ins {
       atomicAnd(&alive[c], ~mask);
       atomicSub(&tile_alive[(c << 6) / kTile], __popcll(mask));
     }
+    STAMP(24);
     // -- pixels that now hold a return beyond 500 m join the far list
     for (int o = tid; o < nvis; o += NT) {
       int k = s_V[o];
@@ -1123,6 +1130,7 @@ struct Ins {
     // (500 < depth, insertion.py:99,:467): not a matter of the window.  Rare: two passes over the cloud.
     if (n_far > 0) far_pass(n_total);
     __syncthreads();
+    STAMP(25);
     const bool rebase = uni(H[H_REBASE]) != 0;
     flags_out = kRecAccepted | (rebase ? kRecRebased : 0) | ((H[H_FARADD] || n_far > 0) ? kRecFar : 0);
     n_total_after = n_total + nvis;
@@ -1211,25 +1219,31 @@ __device__ __forceinline__ bool load_slot(Ins<NT> &I, const r3d_batch_t &b, cons
 
 // Did one of the slots [j0, k) of this launch change a pixel the evaluation read (or the bounds, or
 // the far list)?  bit 0: yes; bit 1: the bounds moved (the sample must be projected again).
+// Lane L of every wave looks at slot j0 + L (a launch has at most kMaxChain = 32 slots): one trip to the records
+// however many slots there are.  Must be called by whole waves.
 __device__ __forceinline__ int conflict_with(const BatchWs &w, int s, int j0, int k, const int *H, int rows, int cols) {
+  static_assert(kMaxChain <= 64, "one lane per slot of the launch");
   int out = 0;
-  const int r_lo = H[H_RMIN] - 6, r_hi = H[H_RMAX] + 6;
-  for (int j = j0; j < k; ++j) {
-    const int *rec = w.recs + ((int64_t)s * kMaxChain + j) * kRecInts;
-    int fl = rec[REC_FLAGS];
-    if (!(fl & kRecAccepted)) continue;
-    if (fl & kRecRebased) out |= 3;
-    if (fl & kRecFar) out |= 1;
-    if (rec[REC_RHI] < r_lo || rec[REC_RLO] > r_hi) continue;
-    for (int h = 0; h < 2; ++h) {
-      if (H[H_CMAX0 + h] < 0) continue;
-      int lo = H[H_CMIN0 + h] - 3, hi = H[H_CMAX0 + h] + 3;
-      for (int g = 0; g < 2; ++g)
-        if (rec[REC_CHI0 + 2 * g] >= rec[REC_CLO0 + 2 * g] && rec[REC_CLO0 + 2 * g] <= hi && rec[REC_CHI0 + 2 * g] >= lo)
-          out |= 1;
+  const int j = j0 + (int)(threadIdx.x & 63);
+  if (j < k) {
+    const int4 *rec = reinterpret_cast<const int4 *>(w.recs + ((int64_t)s * kMaxChain + j) * kRecInts);
+    const int4 a = rec[0], c = rec[1];            // flags, n_total, rows lo / hi | columns lo0 hi0 lo1 hi1
+    if (a.x & kRecAccepted) {
+      if (a.x & kRecRebased) out |= 3;
+      if (a.x & kRecFar) out |= 1;
+      const int r_lo = H[H_RMIN] - 6, r_hi = H[H_RMAX] + 6;
+      if (!(a.w < r_lo || a.z > r_hi)) {
+        const int clo[2] = {c.x, c.z}, chi[2] = {c.y, c.w};
+        for (int h = 0; h < 2; ++h) {
+          if (H[H_CMAX0 + h] < 0) continue;
+          int lo = H[H_CMIN0 + h] - 3, hi = H[H_CMAX0 + h] + 3;
+          for (int g = 0; g < 2; ++g)
+            if (chi[g] >= clo[g] && clo[g] <= hi && chi[g] >= lo) out |= 1;
+        }
+      }
     }
   }
-  return out;
+  return wave_or_i32(out);
 }
 
 template <int NT>
@@ -1303,6 +1317,11 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
     }
   };
 
+  const int n_head0 = uni(b.n_head[s]);                     // fixed for the launch
+  // the scene's point count when this pair commits: what its predecessor published (read once the wait is over)
+  auto count_now = [&]() -> int {
+    return k > 0 ? uni(w.recs[((int64_t)s * kMaxChain + k - 1) * kRecInts + REC_NTOTAL]) : uni(w.n_total0[s]);
+  };
   // 1. where does the scene stand?  p0 slots are done: the evaluation builds on them
   int p0 = 0;
   if (k > 0) {
@@ -1446,10 +1465,11 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
     return;
   }
   // 2. commit, publish
-  int flags = 0, n_after = waited && !on ? b.n_total[s] : 0;
+  const int n_now = count_now();
+  int flags = 0, n_after = waited && !on ? n_now : 0;
   bool rebase = false;
   if (on) {
-    rebase = I.commit(flags, n_after);
+    rebase = I.commit(flags, n_after, n_now, n_head0);
     outputs(I.nvis, I.accept ? 1 : 0);
     STAMP(14);
   } else {

@@ -68,5 +68,12 @@ for k in range(K):
 g = raw[:, :, 17:21].astype(np.float64) / 100.0                  # thread 0 inside the gather loop (loads drained at every mark)
 print("gather loop, thread 0, us per pair (mean / max): " + "; ".join(
     f"{n} {g[:, :, i].mean():.2f} / {g[:, :, i].max():.2f}" for i, n in enumerate(["list + pixel ids", "place in tile", "coordinates", "sqrt + min"])))
+c = raw.astype(np.float64)
+if (raw[:, :, 22] > 0).any():
+    m = raw[:, :, 22] > 0
+    print("commit (accepted pairs), us: header %.2f; append %.2f; kills %.2f; far list + barrier %.2f; tail %.2f" % (
+        ((c[:, :, 22] - st[:, :, 13]) / 100)[m].mean(), ((c[:, :, 23] - c[:, :, 22]) / 100)[m].mean(),
+        ((c[:, :, 24] - c[:, :, 23]) / 100)[m].mean(), ((c[:, :, 25] - c[:, :, 24]) / 100)[m].mean(),
+        ((c[:, :, 14] - c[:, :, 25]) / 100)[m].mean()))
 if len(sys.argv) > 1:
     np.savez_compressed(sys.argv[1], raw=raw, names=np.array(names))
