@@ -348,6 +348,9 @@ def main():
         serial_elapsed = time.perf_counter() - t1
     else:
         serial_elapsed = elapsed
+    batch.debug_counters(reset=True)
+    enqueue_serial()
+    insert_paths = batch.debug_counters(reset=True)       # which way every pair of one step went
     n_out = batch.n_out.cpu().numpy()
     n_accepted = int(batch.last_acc.sum().item())
     n_appended = int((batch.last_vis * batch.last_acc).sum().item()) if hasattr(batch, "last_vis") else None
@@ -460,7 +463,7 @@ def main():
                        "ms_per_step_one_step_in_flight": round(step_ms_serial, 3),
                        "insert_api": f"r3d_batch_insert x{K}" if args.per_slot_launches else f"r3d_batch_insert_many({K})",
                        "rebases_in_timed_steps": rebases, "settle_steps_in_setup": settle,
-                       "mean_points_out": float(n_out.mean())},
+                       "mean_points_out": float(n_out.mean()), "insert_paths_one_step": insert_paths},
             "roofline": roofline,
             "pipeline_alg_GBps_per_gpu": round(pipe_gbs, 1),
             "pipeline_frac_of_hbm_peak": round(pipe_gbs / HBM_PEAK_GBS, 4),

@@ -231,6 +231,19 @@ int r3d_batch_export_rows(const r3d_batch_t *b, double *rows4, int32_t *n_rows, 
 #define R3D_K_ALIVE_WRITE 5   /* k_alive_write: survivors, original order, into out_xyzi / out_label */
 int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream);
 
+/* Diagnostic: the 16 counters the insert kernels keep in the workspace since r3d_batch_create (or the last
+ * call with reset != 0), copied to HOST memory; synchronises the stream.  [0..3] pairs k_eval evaluated and
+ * stored / could not store (pool exhausted) / left because the scene has pixels beyond 500 m / left because
+ * they exceed its LDS; [4..7] slots k_commit_chain committed from the stored evaluation / found rejected /
+ * evaluated again after a conflicting predecessor / evaluated because k_eval had not; [8..10] scenes handed
+ * to k_insert_big: sample too large for k_sample_prep, bounds moved, evaluation too large; [11] rebases;
+ * [12] pairs whose sample phase did not fit k_sample_prep. */
+int r3d_batch_debug_counters(const r3d_batch_t *b, int32_t *host_out16, int32_t reset, void *stream);
+/* Diagnostic: per (scene, slot) of the last insert launch, two int64 words [B][32][2] to HOST memory: 100 MHz
+ * ticks k_commit_chain spent on the slot | the counter index (above) of the way it took << 48; the tick at which
+ * it started.  n_words <= B * 64.  Synchronises the stream. */
+int r3d_batch_debug_trace(const r3d_batch_t *b, int64_t *host_out, int64_t n_words, void *stream);
+
 /* =====================================================================================
  * Level 3 -- placement search.
  *

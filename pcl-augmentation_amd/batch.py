@@ -295,6 +295,25 @@ class SceneBatch:
         _lib.check(self.lib.r3d_batch_finish(C.byref(self.desc), cp, int(check_cols or 5), _lib.stream_ptr()),
                    "r3d_batch_finish")
 
+    @_lib.on_own_device
+    def debug_counters(self, reset=True):
+        """The insert kernels' diagnostic counters (r3d_batch_debug_counters) as a dict."""
+        out = (C.c_int32 * 16)()
+        _lib.check(self.lib.r3d_batch_debug_counters(C.byref(self.desc), out, 1 if reset else 0, _lib.stream_ptr()),
+                   "r3d_batch_debug_counters")
+        names = ["eval_stored", "eval_pool_full", "eval_far_scene", "eval_nofit", "chain_stored", "chain_rejected",
+                 "chain_conflict", "chain_unevaluated", "defer_prep", "defer_bounds", "defer_nofit", "rebases", "prep_nofit"]
+        return dict(zip(names, list(out)))
+
+    @_lib.on_own_device
+    def debug_trace(self):
+        """Per (scene, slot) of the last insert launch: (ticks of 10 ns k_commit_chain spent, path id, start tick)
+        as int64 arrays [B, 32] each (r3d_batch_debug_trace)."""
+        out = np.zeros((self.B, 32, 2), dtype=np.int64)
+        _lib.check(self.lib.r3d_batch_debug_trace(C.byref(self.desc), out.ctypes.data, out.size, _lib.stream_ptr()),
+                   "r3d_batch_debug_trace")
+        return out[:, :, 0] & ((1 << 48) - 1), out[:, :, 0] >> 48, out[:, :, 1]
+
     # -- results --------------------------------------------------------------------------------
     @_lib.on_own_device
     def raise_on_status(self):

@@ -21,6 +21,22 @@ constexpr int kTile = kPT * kPerThread;   // points per block tile
 constexpr int kKeyCap = R3D_MAX_SAMPLE;
 constexpr int kMaxChain = 32;        // insert slots of one k_insert_chain launch
 constexpr int kRecInts = 16;         // int32 words of a published slot record
+constexpr int kEvalClasses = 4;      // launch shapes of k_eval (LDS need of the pair)
+
+// One (scene, slot) pair of an insert launch: where its sample record and the results of its evaluation live in
+// the launch's pool, and the few numbers the commit chain decides on (r3d_insert.hip).
+struct PairRec {
+  long long rec_off, res_off;        // byte offsets into tile_pool
+  int32_t rec_bytes, state;          // kPair*
+  int32_t sflags;                    // R3D_S_* bits raised by the sample's projection
+  int32_t rmin, rmax, cmin0, cmin1, cmax0, cmax1;   // rows / columns (per image half) of the sample's pixels
+  int32_t nvis, accept, rebase, nkill;              // of the evaluation against the launch-time scene
+  int32_t vrmin, vrmax, vcmin0, vcmin1, vcmax0, vcmax1;   // rows / columns of its visible pixels
+  int32_t nhits;                     // scene points inside the pair's window at launch time ("hits"), -1: not kept
+  long long hits_off;                // {pixel | holder flags, point, depth key} x nhits in tile_pool
+  int32_t n0, pad;                   // the scene's point count the hits were gathered under
+};
+static_assert(sizeof(PairRec) == 112, "PairRec layout");
 
 struct BatchWs {
   unsigned long long *qkeys;    // [B][2] ordered keys of min / max of z/r
@@ -44,6 +60,11 @@ struct BatchWs {
                                 // launch) for k_insert_chain, one per scene for k_insert_big
   unsigned char *tile_pool;     // [pool_bytes] depth tiles / candidate lists of the pairs whose window exceeds a workgroup's LDS
   unsigned long long *pool_head; // [1] bytes handed out in the running launch
+  PairRec *pairs;               // [B*kMaxChain] the pairs of the running launch
+  int32_t *cls_list;            // [kEvalClasses][B*kMaxChain] pair ids (scene * kMaxChain + slot) per launch shape of k_eval
+  int32_t *cls_count;           // [kEvalClasses]
+  int32_t *dbg;                 // [16] diagnostic counters of the insert kernels (r3d_batch_debug_counters)
+  long long *trace;             // [B*kMaxChain*2] per slot of the last launch: 100 MHz ticks k_commit_chain spent on it | path << 48
   int64_t pool_bytes;
   int64_t cand_stride;          // uint32 entries of `cand` per scene
   size_t total;
@@ -82,6 +103,11 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.pool_bytes = w.pool_bytes < (256ll << 20) ? (256ll << 20) : (w.pool_bytes > (1ll << 30) ? (1ll << 30) : w.pool_bytes);
   w.tile_pool = c.take<unsigned char>((size_t)w.pool_bytes);
   w.pool_head = c.take<unsigned long long>(1);
+  w.pairs = c.take<PairRec>((size_t)b.B * kMaxChain);
+  w.cls_list = c.take<int32_t>((size_t)kEvalClasses * b.B * kMaxChain);
+  w.cls_count = c.take<int32_t>(kEvalClasses);
+  w.dbg = c.take<int32_t>(16);
+  w.trace = c.take<long long>((size_t)b.B * kMaxChain * 2);
   w.total = c.off;
   return w;
 }

@@ -44,6 +44,9 @@
 #include "r3d_batch.hpp"
 
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 
 #ifndef R3D_CHAIN_WAVES
@@ -198,13 +201,19 @@ __device__ __forceinline__ double mean_of_keys(const unsigned long long (&v)[15]
 enum {
   H_NVALID = 0, H_NCAND, H_REBASE, H_FLAGS, H_RMIN, H_RMAX, H_CMIN0, H_CMIN1, H_CMAX0, H_CMAX1,
   H_NLIST, H_CARRY, H_EXT0, H_EXT1, H_NOCC, H_NVIS, H_VRMIN, H_VRMAX, H_VCMIN0, H_VCMIN1, H_VCMAX0,
-  H_VCMAX1, H_FARADD, H_FILL,
-  H_GO = 28,          // chain logic: broadcast cell (not touched by the phases)
+  H_VCMAX1, H_FARADD, H_FILL, H_HITCAP, H_NHITS,
+  H_GO = 30,          // chain logic: broadcast cell (not touched by the phases)
   H_SCAN = 32         // block scan cells [NT/64 + 1]
 };
 constexpr int kHdrBytes = 512;
 
 enum { kOk = 0, kNoFit = 1, kNeedSerial = 2, kStale = 3 };
+// PairRec.state: nothing to do | the sample's record is in the pool | ... and the results of its evaluation
+// against the launch-time scene | the pair does not fit the kernels' LDS (k_insert_big takes the scene from here)
+enum { kPairIdle = 0, kPairSampled = 1, kPairEvaluated = 2, kPairNoFit = 3 };
+// diagnostic counters (BatchWs::dbg): what k_eval did with its pairs, which way k_commit_chain took per slot
+enum { D_EVAL_STORED = 0, D_EVAL_POOL, D_EVAL_SERIAL, D_EVAL_NOFIT, D_CHAIN_STORED, D_CHAIN_REJECTED, D_CHAIN_CONFLICT,
+       D_CHAIN_UNEVAL, D_DEFER_PREP, D_DEFER_BOUNDS, D_DEFER_NOFIT, D_REBASE, D_PREP_NOFIT };
 
 // A value every lane holds (read from LDS or global memory): into a scalar register.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -225,7 +234,7 @@ struct Ins {
   Binning bn;
   Window win;
   DTile dt;
-  int nvalid, ww, nocc, ncand, r1;
+  int nvalid, ww, nocc, ncand, r1, rec_end;
   uint32_t *s_oob, *s_lp, *s_img, *s_rank;
   uint16_t *s_F, *s_start;
   unsigned long long *s_sdepth;
@@ -241,6 +250,14 @@ struct Ins {
   bool glist;                            // the pair's area in global memory when they do not fit there
   DTile bt;                              // the band of the tile currently in LDS
   int list_cap, nlist, nvis, n_base, n_far;
+  // the hits: the living points inside the window as the first evaluation found them.  k_eval stores them (g_hits,
+  // counted in H_NHITS); an evaluation of the same pair after its predecessors (k_commit_chain) replays them -- alive
+  // bit re-read -- instead of listing and gathering the scene again, and gathers only the points appended since.
+  uint4 *g_hits;                         // where this evaluation stores its hits, or null
+  const uint4 *r_hits;                   // hits to replay, or null
+  int r_nhits, r_n0;
+  bool keep_hits;
+  long long hits_off;
   bool accept;
   FastDiv by_cols, by_W;
 
@@ -257,6 +274,11 @@ struct Ins {
     glist = false;
     g_dtile = nullptr;
     g_cand = nullptr;
+    g_hits = nullptr;
+    r_hits = nullptr;
+    r_nhits = r_n0 = 0;
+    keep_hits = false;
+    hits_off = -1;
     pool_off = -1;
     by_cols.set(cols);
     g_list = w.glist + (((int64_t)s * (kMaxChain + 1) + area) + 1) * chunks * 24;     // entries grow down from the area's end
@@ -317,12 +339,12 @@ struct Ins {
   // workgroup has dropped its stale cache lines)
   __device__ __forceinline__ unsigned long long tile_key(int dl) const { return g_dtile ? g_dtile[dl] : s_dtile[dl]; }
 
-  // ================================================================================================
-  // sample phase.  kOk, or kNoFit when the per-point / per-pixel arrays exceed this kernel's LDS.
-  // ================================================================================================
-  __device__ __forceinline__ int sample_phase() {
-    accept = false;
-    nvis = 0;
+  // LDS layout of a pair.  The sample's RECORD -- everything the sample phase leaves behind -- is one contiguous
+  // image [0, rec_end): header | out-of-bounds bits | window pixel per point | sorted order | occupancy, closed,
+  // rank images | first sorted point and min depth per occupied pixel.  k_sample_prep stores that image in the
+  // launch's pool, k_eval and k_commit_chain load it back.  Behind it: the three scratch images, then (from r1)
+  // whatever the scene phase carves.
+  __device__ __forceinline__ int carve_head() {
     int carve = kHdrBytes;
     s_oob = reinterpret_cast<uint32_t *>(smem + carve);
     carve += ((m + 31) >> 5) * 4;
@@ -330,6 +352,114 @@ struct Ins {
     carve += m * 4;
     s_F = reinterpret_cast<uint16_t *>(smem + carve);
     carve = (carve + m * 2 + 7) & ~7;
+    return carve;
+  }
+  __device__ __forceinline__ int carve_images(int carve) {
+    s_img = reinterpret_cast<uint32_t *>(smem + carve);
+    carve = (carve + 3 * ww * 4 + 7) & ~7;
+    A.w = s_img;
+    Cs.w = s_img + ww;
+    s_rank = s_img + 2 * ww;
+    return carve;
+  }
+  __device__ __forceinline__ void carve_tail(int carve) {   // needs nocc
+    s_start = reinterpret_cast<uint16_t *>(smem + carve);
+    carve = (carve + (nocc + 1) * 2 + 7) & ~7;
+    s_sdepth = reinterpret_cast<unsigned long long *>(smem + carve);
+    carve += nocc * 8;
+    rec_end = (carve + 15) & ~15;
+    uint32_t *scr = reinterpret_cast<uint32_t *>(smem + rec_end);
+    T.w = scr;
+    D.w = scr + ww;
+    E.w = scr + 2 * ww;
+    r1 = (rec_end + 3 * ww * 4 + 7) & ~7;                   // scratch from here on
+  }
+  __device__ __forceinline__ void store_record(unsigned char *dst) const {       // dst: 16-byte aligned, rec_end bytes
+    const uint4 *from = reinterpret_cast<const uint4 *>(smem);
+    uint4 *to = reinterpret_cast<uint4 *>(dst);
+    for (int i = tid; i < (rec_end >> 4); i += NT) to[i] = from[i];
+  }
+  // kOk, or kNoFit when this kernel's LDS cannot hold the record plus the scratch images
+  __device__ __forceinline__ int load_record(const unsigned char *src, int bytes) {
+    accept = false;
+    nvis = 0;
+    if (bytes + 64 > lds_cap) return kNoFit;
+    __syncthreads();                                         // the previous use of this LDS is over
+    const uint4 *from = reinterpret_cast<const uint4 *>(src);
+    uint4 *to = reinterpret_cast<uint4 *>(smem);
+    for (int i = tid; i < (bytes >> 4); i += NT) to[i] = from[i];
+    __syncthreads();
+    nvalid = uni(H[H_NVALID]);
+    nocc = uni(H[H_NOCC]);
+    ncand = uni(H[H_NCAND]);
+    compute_window();
+    carve_tail(carve_images(carve_head()));
+    if ((int64_t)r1 + 64 > lds_cap) return kNoFit;
+    return kOk;
+  }
+
+  // -- the window of a projected sample (H_RMIN .. H_CMAX1, H_NVALID in the header): candidates lie within 2 rows /
+  // 1 column of a sample pixel, their hole means look 2 / 1 further, their closing 4 / 2 further.  Sets win, dt, ww.
+  __device__ __forceinline__ void compute_window() {
+    win.cols = cols;
+    win.n_iv = 1;
+    win.jl0 = win.jl1 = win.jh1 = 0;
+    win.jh0 = -1;
+    win.r_lo = 0;
+    win.r_hi = -1;                                          // nothing valid: empty window
+    dt.n_iv = 0;
+    dt.c00 = dt.c01 = dt.c11 = 0;
+    dt.c10 = -1;
+    if (nvalid > 0) {
+      const int rmin = uni(H[H_RMIN]), rmax = uni(H[H_RMAX]);
+      const int cmin0 = uni(H[H_CMIN0]), cmax0 = uni(H[H_CMAX0]), cmin1 = uni(H[H_CMIN1]), cmax1 = uni(H[H_CMAX1]);
+      win.r_lo = rmin - 6 < 0 ? 0 : rmin - 6;
+      win.r_hi = rmax + 6 > rows - 1 ? rows - 1 : rmax + 6;
+      const bool h0 = cmax0 >= 0, h1 = cmax1 >= 0;
+      // exact column interval of either image half, and the whole words that hold it
+      const int lo0 = cmin0 - 3 < 0 ? 0 : cmin0 - 3, hi0 = cmax0 + 3 > cols - 1 ? cols - 1 : cmax0 + 3;
+      const int lo1 = cmin1 - 3 < 0 ? 0 : cmin1 - 3, hi1 = cmax1 + 3 > cols - 1 ? cols - 1 : cmax1 + 3;
+      if (h0 && h1) {
+        const bool merge_w = (lo1 >> 5) <= (hi0 >> 5) + 1, merge_c = lo1 <= hi0 + 1;
+        win.n_iv = merge_w ? 1 : 2;
+        win.jl0 = lo0 >> 5;
+        win.jh0 = merge_w ? ((hi1 >> 5) > (hi0 >> 5) ? (hi1 >> 5) : (hi0 >> 5)) : (hi0 >> 5);
+        win.jl1 = merge_w ? 0 : (lo1 >> 5);
+        win.jh1 = merge_w ? 0 : (hi1 >> 5);
+        dt.n_iv = merge_c ? 1 : 2;
+        dt.c00 = lo0;
+        dt.c10 = merge_c ? (hi1 > hi0 ? hi1 : hi0) : hi0;
+        dt.c01 = merge_c ? 0 : lo1;
+        dt.c11 = merge_c ? 0 : hi1;
+      } else {
+        const int lo = h0 ? lo0 : lo1, hi = h0 ? hi0 : hi1;
+        win.jl0 = lo >> 5;
+        win.jh0 = hi >> 5;
+        dt.n_iv = 1;
+        dt.c00 = lo;
+        dt.c10 = hi;
+      }
+  }
+  win.nj0 = win.jh0 - win.jl0 + 1;
+  win.njw = win.nj0 + (win.n_iv > 1 ? win.jh1 - win.jl1 + 1 : 0);
+  win.nrw = win.r_hi - win.r_lo + 1;
+  win.by_njw.set(win.njw);
+  ww = win.nrw * win.njw;                                 // window words
+  dt.r0 = win.r_lo;
+  dt.r1 = win.r_hi;
+  dt.w0 = dt.c10 - dt.c00 + 1;
+  dt.W = dt.n_iv == 0 ? 0 : dt.w0 + (dt.n_iv > 1 ? dt.c11 - dt.c01 + 1 : 0);
+  dt.npx = win.nrw * dt.W;
+  by_W.set(dt.W);
+  }
+
+  // ================================================================================================
+  // sample phase.  kOk, or kNoFit when the per-point / per-pixel arrays exceed this kernel's LDS.
+  // ================================================================================================
+  __device__ __forceinline__ int sample_phase() {
+    accept = false;
+    nvis = 0;
+    int carve = carve_head();
     if (carve > lds_cap) return kNoFit;
     __syncthreads();                                         // the previous use of this LDS is over
     for (int i = tid; i < ((m + 31) >> 5); i += NT) s_oob[i] = 0u;
@@ -398,71 +528,13 @@ struct Ins {
     nvalid = uni(H[H_NVALID]);
 
     STAMP(1);
-    // -- 2. the window: candidates lie within 2 rows / 1 column of a sample pixel, their closing
-    // looks 4 rows / 2 columns further ---------------------------------------------------------------
-    win.cols = cols;
-    win.n_iv = 1;
-    win.jl0 = win.jl1 = win.jh1 = 0;
-    win.jh0 = -1;
-    win.r_lo = 0;
-    win.r_hi = -1;                                          // nothing valid: empty window
-    dt.n_iv = 0;
-    dt.c00 = dt.c01 = dt.c11 = 0;
-    dt.c10 = -1;
-    if (nvalid > 0) {
-      const int rmin = uni(H[H_RMIN]), rmax = uni(H[H_RMAX]);
-      const int cmin0 = uni(H[H_CMIN0]), cmax0 = uni(H[H_CMAX0]), cmin1 = uni(H[H_CMIN1]), cmax1 = uni(H[H_CMAX1]);
-      win.r_lo = rmin - 6 < 0 ? 0 : rmin - 6;
-      win.r_hi = rmax + 6 > rows - 1 ? rows - 1 : rmax + 6;
-      const bool h0 = cmax0 >= 0, h1 = cmax1 >= 0;
-      // exact column interval of either image half, and the whole words that hold it
-      const int lo0 = cmin0 - 3 < 0 ? 0 : cmin0 - 3, hi0 = cmax0 + 3 > cols - 1 ? cols - 1 : cmax0 + 3;
-      const int lo1 = cmin1 - 3 < 0 ? 0 : cmin1 - 3, hi1 = cmax1 + 3 > cols - 1 ? cols - 1 : cmax1 + 3;
-      if (h0 && h1) {
-        const bool merge_w = (lo1 >> 5) <= (hi0 >> 5) + 1, merge_c = lo1 <= hi0 + 1;
-        win.n_iv = merge_w ? 1 : 2;
-        win.jl0 = lo0 >> 5;
-        win.jh0 = merge_w ? ((hi1 >> 5) > (hi0 >> 5) ? (hi1 >> 5) : (hi0 >> 5)) : (hi0 >> 5);
-        win.jl1 = merge_w ? 0 : (lo1 >> 5);
-        win.jh1 = merge_w ? 0 : (hi1 >> 5);
-        dt.n_iv = merge_c ? 1 : 2;
-        dt.c00 = lo0;
-        dt.c10 = merge_c ? (hi1 > hi0 ? hi1 : hi0) : hi0;
-        dt.c01 = merge_c ? 0 : lo1;
-        dt.c11 = merge_c ? 0 : hi1;
-      } else {
-        const int lo = h0 ? lo0 : lo1, hi = h0 ? hi0 : hi1;
-        win.jl0 = lo >> 5;
-        win.jh0 = hi >> 5;
-        dt.n_iv = 1;
-        dt.c00 = lo;
-        dt.c10 = hi;
-      }
-    }
-    win.nj0 = win.jh0 - win.jl0 + 1;
-    win.njw = win.nj0 + (win.n_iv > 1 ? win.jh1 - win.jl1 + 1 : 0);
-    win.nrw = win.r_hi - win.r_lo + 1;
-    win.by_njw.set(win.njw);
-    ww = win.nrw * win.njw;                                 // window words
-    dt.r0 = win.r_lo;
-    dt.r1 = win.r_hi;
-    dt.w0 = dt.c10 - dt.c00 + 1;
-    dt.W = dt.n_iv == 0 ? 0 : dt.w0 + (dt.n_iv > 1 ? dt.c11 - dt.c01 + 1 : 0);
-    dt.npx = win.nrw * dt.W;
-    by_W.set(dt.W);
+    compute_window();
 
-    // bit images: sample occupancy | scratch (dilations, then visible pixels) | sample closed |
-    // scene occupancy | scene closed | occupied sample pixels before each window word
+    // bit images of the sample: occupancy | closed | occupied sample pixels before each window word.  (The three
+    // scratch images -- dilations / visible pixels, scene occupancy, scene closed -- follow the sample's record.)
     if ((int64_t)carve + 6ll * ww * 4 > lds_cap) return kNoFit;
-    s_img = reinterpret_cast<uint32_t *>(smem + carve);
-    carve = (carve + 6 * ww * 4 + 7) & ~7;
-    A.w = s_img;
-    T.w = s_img + ww;
-    Cs.w = s_img + 2 * ww;
-    D.w = s_img + 3 * ww;
-    E.w = s_img + 4 * ww;
-    s_rank = s_img + 5 * ww;
-    for (int i = tid; i < 6 * ww; i += NT) s_img[i] = 0u;
+    carve = carve_images(carve);
+    for (int i = tid; i < ww; i += NT) A.w[i] = 0u;
     // every valid sample pixel lies inside the window
     for (int j = tid; j < m; j += NT) {
       uint32_t rc = s_lp[j];
@@ -489,16 +561,13 @@ struct Ins {
       __syncthreads();
     }
     nocc = uni(H[H_CARRY]);
+    if (tid == 0) H[H_NOCC] = nocc;
 
     // per occupied pixel: first sorted point, min depth; scratch: counters, unordered placement
-    s_start = reinterpret_cast<uint16_t *>(smem + carve);
-    carve = (carve + (nocc + 1) * 2 + 7) & ~7;
-    s_sdepth = reinterpret_cast<unsigned long long *>(smem + carve);
-    carve += nocc * 8;
-    r1 = carve;                                             // scratch from here on
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + carve);
-    uint16_t *s_U = reinterpret_cast<uint16_t *>(smem + carve + nocc * 4);
-    if (carve + nocc * 4 + nvalid * 2 > lds_cap) return kNoFit;
+    carve_tail(carve);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + r1);
+    uint16_t *s_U = reinterpret_cast<uint16_t *>(smem + r1 + nocc * 4);
+    if ((int64_t)r1 + (int64_t)nocc * 4 + (int64_t)nvalid * 2 > lds_cap) return kNoFit;
     for (int i = tid; i < nocc; i += NT) {
       s_cnt[i] = 0u;
       s_sdepth[i] = R3D_SENT;
@@ -568,9 +637,13 @@ struct Ins {
 
   // The chunks that can hold a point of the window: bounding box touches it, somebody alive (4 chunks
   // per thread in flight).
-  __device__ __forceinline__ void build_list(const unsigned long long *boxes, const unsigned long long *alive, int n_chunks) {
+  // c_first / p_first: with replayed hits only the chunks from c_first on are listed, and of chunk c_first only the
+  // points from p_first on (the earlier ones are among the hits)
+  __device__ __forceinline__ void build_list(const unsigned long long *boxes, const unsigned long long *alive, int n_chunks,
+                                             int c_first = 0, int p_first = 0) {
     constexpr int kU = 4;
-    for (int c0 = tid; c0 < n_chunks; c0 += kU * NT) {
+    int hitcap = 0;
+    for (int c0 = c_first + tid; c0 < n_chunks; c0 += kU * NT) {
       unsigned long long bx[kU], aw[kU];
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
@@ -584,15 +657,19 @@ struct Ins {
         int left = n_base - (c << 6);                       // points of the chunk below the base count
         unsigned long long a = aw[u];
         if (left < 64) a = left > 0 ? a & ((1ull << left) - 1ull) : 0ull;
+        if (c == c_first && (p_first & 63)) a &= ~((1ull << (p_first & 63)) - 1ull);
         int rmin = (int)(bx[u] & 0xFFFF), rmax = (int)((bx[u] >> 16) & 0xFFFF);
         int jmin = (int)((bx[u] >> 32) & 0xFFFF) >> 5, jmax = (int)((bx[u] >> 48) & 0xFFFF) >> 5;
         bool hit = a && rmin <= win.r_hi && rmax >= win.r_lo && win.touches_words(jmin, jmax);
         if (hit) {
           int slot = atomicAdd(&H[H_NLIST], 1);
           if (slot < list_cap) set_entry(slot, a, (uint32_t)c, (uint32_t)rmin | ((uint32_t)rmax << 16));
+          hitcap += __popcll(a);
         }
       }
     }
+    hitcap = wave_sum_i32(hitcap);
+    if ((tid & 63) == 0 && hitcap) atomicAdd(&H[H_HITCAP], hitcap);
   }
 
   // The living points of the listed chunks whose pixel lies in rows [bt.r0, bt.r1] of the tile are
@@ -655,13 +732,57 @@ struct Ins {
           // one of them turns out visible it is culled and the bounds may move (any holder will do).
           // z/r is only evaluated for the points that can be one (|z - q r| tiny).
           double tol = 1e-9 * r;
-          if (fabs(z - q_min * r) <= tol && z / r == q_min) H[H_EXT0] = p[h + u];
-          if (fabs(z - q_max * r) <= tol && z / r == q_max) H[H_EXT1] = p[h + u];
+          uint32_t holder = 0u;
+          if (fabs(z - q_min * r) <= tol && z / r == q_min) {
+            H[H_EXT0] = p[h + u];
+            holder |= 0x40000000u;
+          }
+          if (fabs(z - q_max * r) <= tol && z / r == q_max) {
+            H[H_EXT1] = p[h + u];
+            holder |= 0x80000000u;
+          }
+          if (g_hits) {
+            const unsigned long long key = depth_key(r);
+            g_hits[atomicAdd(&H[H_NHITS], 1)] = make_uint4((uint32_t)p[h + u] | holder, (uint32_t)idx[h + u], (uint32_t)key,
+                                                          (uint32_t)(key >> 32));
+          }
         }
         GSTAMP(4);
       }
     }
     GSTAMP_END;
+  }
+
+  // The stored hits of this pair that are still alive, into the band (what gather() does for listed chunks).
+  __device__ __forceinline__ void replay_hits(bool all_rows_bits) {
+    const unsigned long long *alive = w.alive + (int64_t)s * chunks;
+    constexpr int kPer = 4;
+    for (int h0 = tid; h0 < r_nhits; h0 += kPer * NT) {
+      uint4 e[kPer];
+      unsigned long long aw[kPer];
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        const int h = h0 + u * NT;
+        e[u] = h < r_nhits ? r_hits[h] : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < kPer; ++u)
+        aw[u] = h0 + u * NT < r_nhits ? __hip_atomic_load(&alive[e[u].y >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        if (!((aw[u] >> (e[u].y & 63)) & 1ull)) continue;    // culled by a predecessor (or past the end)
+        const int p = (int)(e[u].x & 0x00FFFFFFu);
+        int c, r = by_cols.div(p, c);
+        const int dl = bt.index(r, c);
+        if (all_rows_bits && (bt.npx == dt.npx ? dl >= 0 : dt.index(r, c) >= 0)) D.set_local(win.lpix_rc(r, c));
+        if (dl < 0) continue;
+        const unsigned long long key = (unsigned long long)e[u].z | ((unsigned long long)e[u].w << 32);
+        if (g_dtile) atomicMin(&g_dtile[dl], key);
+        else atomicMin(&s_dtile[dl], key);
+        if (e[u].x & 0x40000000u) H[H_EXT0] = p;
+        if (e[u].x & 0x80000000u) H[H_EXT1] = p;
+      }
+    }
   }
 
   // 5-row x 3-column closing (closing.py:9-23) of one bit image of the window: src -> tmp -> dst, dilation
@@ -733,6 +854,7 @@ struct Ins {
 
     if (tid == 0) {
       H[H_NLIST] = 0;
+      H[H_HITCAP] = H[H_NHITS] = 0;
       H[H_EXT0] = H[H_EXT1] = -1;
       H[H_NVIS] = 0;
       H[H_REBASE] = 0;
@@ -743,16 +865,17 @@ struct Ins {
 
     STAMP(6);
     // -- 6. the chunks that can hold a point of the window --------------------------------------------
-    build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, (n_base + 63) >> 6);
+    const int c_first = r_hits ? r_n0 >> 6 : 0, p_first = r_hits ? r_n0 : 0;   // replayed hits cover the points below r_n0
+    build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, (n_base + 63) >> 6, c_first, p_first);
     __syncthreads();
     nlist = uni(H[H_NLIST]);
     if (nlist > list_cap) {                                   // does not fit the LDS: once more, into global memory
       __syncthreads();
-      if (tid == 0) H[H_NLIST] = 0;
+      if (tid == 0) H[H_NLIST] = H[H_HITCAP] = 0;
       glist = true;
       list_cap = chunks;
       __syncthreads();
-      build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, (n_base + 63) >> 6);
+      build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, (n_base + 63) >> 6, c_first, p_first);
       __syncthreads();
       nlist = uni(H[H_NLIST]);
     }
@@ -792,6 +915,25 @@ struct Ins {
       per = (band_bytes - 4 * W * 8 - 8) / (12 * W);
       if (b.reserved & kDbgBands) per = per > 3 ? 3 : per;
       if (per < 1) return kNoFit;
+    }
+
+    // room for the hits of this evaluation (at most the living points of the listed chunks), when they are wanted
+    g_hits = nullptr;
+    hits_off = -1;
+    if (keep_hits && single && !r_hits) {
+      const long long want = ((long long)uni(H[H_HITCAP]) * 16 + 255) & ~255ll;
+      __syncthreads();
+      if (tid == 0) {
+        unsigned long long o = atomicAdd(w.pool_head, (unsigned long long)want);
+        H[H_FILL] = o + want <= (unsigned long long)w.pool_bytes ? (int)(o >> 8) : -1;
+      }
+      __syncthreads();
+      const int got = uni(H[H_FILL]);
+      if (got >= 0) {
+        hits_off = (long long)got << 8;
+        g_hits = reinterpret_cast<uint4 *>(w.tile_pool + hits_off);
+      }
+      __syncthreads();
     }
 
     if (!serial && stale()) return kStale;
@@ -843,6 +985,7 @@ struct Ins {
         for (int e = tid; e < ww; e += NT) D.w[e] = 0u;
       __syncthreads();
       gather(bits_in_gather, use_sub ? s_sub : nullptr, nsub);
+      if (r_hits) replay_hits(bits_in_gather);
       if (g_dtile) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the minima were formed in L2: drop this CU's copies
       __syncthreads();
 
@@ -1112,6 +1255,18 @@ struct Ins {
       atomicAnd(&alive[c], ~mask);
       atomicSub(&tile_alive[(c << 6) / kTile], __popcll(mask));
     }
+    if (r_hits) {                                           // ... and among the replayed hits (T: the visible pixels)
+      for (int h = tid; h < r_nhits; h += NT) {
+        const uint4 e = r_hits[h];
+        const int p = (int)(e.x & 0x00FFFFFFu);
+        int c, r = by_cols.div(p, c);
+        const int lp = win.lpix_rc(r, c);
+        if (lp < 0 || !T.get_local(lp)) continue;
+        const unsigned long long bit = 1ull << (e.y & 63);
+        const unsigned long long old = atomicAnd(&alive[e.y >> 6], ~bit);
+        if (old & bit) atomicSub(&tile_alive[(int)e.y / kTile], 1);
+      }
+    }
     STAMP(24);
     // -- pixels that now hold a return beyond 500 m join the far list
     for (int o = tid; o < nvis; o += NT) {
@@ -1140,6 +1295,96 @@ struct Ins {
       if (rebase) b.rebase[s] += 1;                           // single writer per scene
     }
     return rebase;
+  }
+
+  // What an evaluation leaves for the commit chain (k_eval -> k_commit_chain), in the launch's pool:
+  //   [visible list: nvis x u16 | kill entries {u64 mask, u32 chunk, u32 0} of the chunks that lose points]
+  // and the numbers of `pr`.  False when the pool is exhausted (the chain then evaluates the pair itself).
+  __device__ __forceinline__ bool store_results(PairRec *pr) {
+    int nkill = 0;
+    long long off = -1;
+    if (accept) {
+      __syncthreads();
+      if (tid == 0) H[H_CARRY] = 0;
+      __syncthreads();
+      int c = 0;
+      for (int i = tid; i < nlist; i += NT) c += l_kill(i) ? 1 : 0;
+      c = wave_sum_i32(c);
+      if ((tid & 63) == 0 && c) atomicAdd(&H[H_CARRY], c);
+      __syncthreads();
+      nkill = uni(H[H_CARRY]);
+      const long long vbytes = ((long long)nvis * 2 + 15) & ~15ll;
+      const long long want = (vbytes + (long long)nkill * 16 + 255) & ~255ll;
+      __syncthreads();
+      if (tid == 0) {
+        unsigned long long o = atomicAdd(w.pool_head, (unsigned long long)want);
+        H[H_FILL] = o + want <= (unsigned long long)w.pool_bytes ? (int)(o >> 8) : -1;
+        H[H_CARRY] = 0;
+      }
+      __syncthreads();
+      const int got = uni(H[H_FILL]);
+      if (got < 0) return false;
+      off = (long long)got << 8;
+      uint16_t *gv = reinterpret_cast<uint16_t *>(w.tile_pool + off);
+      for (int o = tid; o < nvis; o += NT) gv[o] = s_V[o];
+      uint4 *ge = reinterpret_cast<uint4 *>(w.tile_pool + off + vbytes);
+      for (int i = tid; i < nlist; i += NT) {
+        const unsigned long long mask = l_kill(i);
+        if (!mask) continue;
+        const int pos = atomicAdd(&H[H_CARRY], 1);
+        ge[pos] = make_uint4((uint32_t)mask, (uint32_t)(mask >> 32), l_chunk(i), 0u);
+      }
+    }
+    if (tid == 0) {
+      pr->res_off = off;
+      pr->nvis = nvis;
+      pr->accept = accept ? 1 : 0;
+      pr->rebase = H[H_REBASE];
+      pr->nkill = nkill;
+      pr->vrmin = H[H_VRMIN];
+      pr->vrmax = H[H_VRMAX];
+      pr->vcmin0 = H[H_VCMIN0];
+      pr->vcmin1 = H[H_VCMIN1];
+      pr->vcmax0 = H[H_VCMAX0];
+      pr->vcmax1 = H[H_VCMAX1];
+      pr->hits_off = hits_off;
+      pr->nhits = g_hits ? H[H_NHITS] : -1;
+      pr->n0 = n_base;
+      pr->state = kPairEvaluated;
+    }
+    return true;
+  }
+  // The reverse, after load_record: the state commit() reads.  kNoFit when this kernel's LDS cannot hold the lists.
+  __device__ __forceinline__ int load_results(const PairRec &pr) {
+    accept = pr.accept != 0;
+    nvis = pr.nvis;
+    nlist = pr.nkill;
+    n_far = 0;
+    glist = false;
+    s_V = reinterpret_cast<uint16_t *>(smem + r1);
+    s_list = smem + (lds_cap & ~7);
+    const long long vbytes = ((long long)nvis * 2 + 15) & ~15ll;
+    if ((long long)r1 + vbytes + 24ll * nlist + 16 > (lds_cap & ~7)) return kNoFit;
+    const uint16_t *gv = reinterpret_cast<const uint16_t *>(w.tile_pool + pr.res_off);
+    for (int o = tid; o < nvis; o += NT) s_V[o] = gv[o];
+    const uint4 *ge = reinterpret_cast<const uint4 *>(w.tile_pool + pr.res_off + vbytes);
+    for (int i = tid; i < nlist; i += NT) {
+      const uint4 e = ge[i];
+      set_entry(i, 0ull, e.z, 0u);
+      set_kill(i, (unsigned long long)e.x | ((unsigned long long)e.y << 32));
+    }
+    if (tid == 0) {
+      H[H_REBASE] = pr.rebase;
+      H[H_FARADD] = 0;
+      H[H_VRMIN] = pr.vrmin;
+      H[H_VRMAX] = pr.vrmax;
+      H[H_VCMIN0] = pr.vcmin0;
+      H[H_VCMIN1] = pr.vcmin1;
+      H[H_VCMAX0] = pr.vcmax0;
+      H[H_VCMAX1] = pr.vcmax1;
+    }
+    __syncthreads();
+    return kOk;
   }
 
   // The far pixels that are not candidates of this insert: smoothed sample depth 500 there, the scene's
@@ -1492,6 +1737,237 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
 #endif
 }
 
+// ====================================================================================================
+// The insert launch in three kernels without a wait inside any of them:
+//   k_sample_prep   every (slot, scene) pair at once: the sample phase, its record into the launch's pool, the pair
+//                   into the list of the k_eval launch shape whose LDS holds its evaluation
+//   k_eval          every pair at once, against the scene as it stood when the launch began: the scene phase; visible
+//                   list and kill masks into the pool
+//   k_commit_chain  one workgroup per scene walks its slots in order: a pair none of whose accepted predecessors
+//                   touched the pixels it read commits what k_eval found; any other pair is evaluated again right
+//                   there, after its predecessors, and committed.  What no LDS of these kernels holds, and whatever
+//                   follows a rebase, is left to k_insert_big behind them.
+// (The round-2 kernel, k_insert_chain above, did all of this per pair in one workgroup that waited for its scene's
+// previous slot; it stays selectable with R3D_INSERT_LEGACY=1.)
+// ====================================================================================================
+struct EvalShapes {
+  int lds[kEvalClasses];       // LDS bytes of the class's k_eval launch, ascending; 0 = class not used
+};
+
+template <int NT>
+__global__ void __launch_bounds__(NT)
+k_sample_prep(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int chunks, int lds_cap, int B8,
+              EvalShapes shapes) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int k = (int)blockIdx.x / B8, s = (int)blockIdx.x % B8;
+  if (s >= b.B) return;
+  const int tid = threadIdx.x;
+  int *H = reinterpret_cast<int *>(smem);
+  Ins<NT> I(b, w, smem, lds_cap, s, chunks, k, k, false);
+  const int pid = s * kMaxChain + k;
+  PairRec *pr = w.pairs + pid;
+  const bool on = load_slot(I, b, slots, k, s, first_step);
+  if (!on) {
+    if (tid == 0) pr->state = kPairIdle;
+    return;
+  }
+  int rc = (b.reserved & kDbgDefer) ? kNoFit : I.sample_phase();
+  long long off = -1;
+  if (rc == kOk) {
+    const long long want = ((long long)I.rec_end + 255) & ~255ll;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long o = atomicAdd(w.pool_head, (unsigned long long)want);
+      H[H_GO] = o + want <= (unsigned long long)w.pool_bytes ? (int)(o >> 8) : -1;
+    }
+    __syncthreads();
+    const int got = uni(H[H_GO]);
+    if (got < 0) rc = kNoFit;
+    else off = (long long)got << 8;
+  }
+  if (rc != kOk) {
+    if (tid == 0) {
+      pr->state = kPairNoFit;
+      atomicAdd(&w.dbg[D_PREP_NOFIT], 1);
+    }
+    return;
+  }
+  I.store_record(w.tile_pool + off);
+  if (tid == 0) {
+    pr->rec_off = off;
+    pr->rec_bytes = I.rec_end;
+    pr->res_off = -1;
+    pr->sflags = H[H_FLAGS];
+    pr->rmin = H[H_RMIN];
+    pr->rmax = H[H_RMAX];
+    pr->cmin0 = H[H_CMIN0];
+    pr->cmin1 = H[H_CMIN1];
+    pr->cmax0 = H[H_CMAX0];
+    pr->cmax1 = H[H_CMAX1];
+    pr->nvis = 0;
+    pr->accept = 0;
+    pr->rebase = 0;
+    pr->nkill = 0;
+    pr->nhits = -1;
+    pr->hits_off = -1;
+    pr->n0 = 0;
+    pr->vrmin = pr->vcmin0 = pr->vcmin1 = 0x7FFFFFFF;
+    pr->vrmax = pr->vcmax0 = pr->vcmax1 = -1;
+    if (I.nvalid == 0) {
+      pr->state = kPairEvaluated;                           // nothing of the sample is inside the image: rejected
+    } else {
+      pr->state = kPairSampled;
+      // LDS of the evaluation: record, scratch images, visible list, candidates, depth tile, ~160 listed chunks
+      const long long need = (long long)I.r1 + 2ll * I.nvalid + 4ll * I.ncand + 8ll * I.dt.npx + 24 * 160 + 64;
+      int c = 0;
+      while (c + 1 < kEvalClasses && shapes.lds[c + 1] > 0 && need > shapes.lds[c]) ++c;
+      if (!(b.reserved & kDbgSerial)) w.cls_list[(int64_t)c * b.B * kMaxChain + atomicAdd(&w.cls_count[c], 1)] = pid;
+    }
+  }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT, NT == 1024 ? 1 : R3D_CHAIN_WAVES)
+k_eval(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int chunks, int lds_cap, int cls) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  if ((int)blockIdx.x >= w.cls_count[cls]) return;
+  const int pid = w.cls_list[(int64_t)cls * b.B * kMaxChain + blockIdx.x];
+  const int s = pid / kMaxChain, k = pid % kMaxChain;
+  Ins<NT> I(b, w, smem, lds_cap, s, chunks, k, k, false);
+  load_slot(I, b, slots, k, s, first_step);
+  PairRec *pr = w.pairs + pid;
+  int rc = I.load_record(w.tile_pool + pr->rec_off, pr->rec_bytes);
+  I.keep_hits = true;
+  if (rc == kOk) rc = I.scene_phase(w.n_total0[s], false, [] { return false; });
+  bool kept = false;
+  if (rc == kOk) kept = I.store_results(pr);
+  if (threadIdx.x == 0) atomicAdd(&w.dbg[kept ? D_EVAL_STORED : (rc == kOk ? D_EVAL_POOL : (rc == kNeedSerial ? D_EVAL_SERIAL : D_EVAL_NOFIT))], 1);
+  // anything else (the scene has pixels beyond 500 m; the evaluation does not fit this LDS): the chain does it
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT)
+k_commit_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int chunks, int lds_cap) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int s = (int)blockIdx.x;
+  const int tid = threadIdx.x;
+  int *H = reinterpret_cast<int *>(smem);
+  // what the slots so far did to the scene: kRec* flags, count afterwards, rows / columns of the visible pixels;
+  // kept in the last KB of this workgroup's LDS (the Ins below sees the rest)
+  int *recs = reinterpret_cast<int *>(smem + lds_cap - kMaxChain * 8 * 4);
+  const int lds_ins = lds_cap - kMaxChain * 8 * 4;
+  const int n_head0 = uni(b.n_head[s]);
+  int n_now = uni(w.n_total0[s]);
+  int defer = nk;
+  for (int k = 0; k < nk; ++k) {
+    Ins<NT> I(b, w, smem, lds_ins, s, chunks, k, kMaxChain, false);
+    const bool on = load_slot(I, b, slots, k, s, first_step);
+    const long long t_slot = wall_clock64();
+    int path = 0;
+    int flags = 0, n_after = n_now, nv = 0, acc = 0;
+    bool rebase = false;
+    if (on) {
+      const PairRec pr = w.pairs[s * kMaxChain + k];
+      const bool have_rec = pr.state == kPairSampled || pr.state == kPairEvaluated;
+      if (!have_rec && (b.reserved & kDbgDefer)) {
+        if (tid == 0) atomicAdd(&w.dbg[D_DEFER_PREP], 1);
+        defer = k;
+        break;
+      }
+      // did an accepted predecessor change a pixel this pair's evaluation read, the bounds or the far list?
+      int cf = pr.state == kPairEvaluated && !(b.reserved & kDbgSerial) ? 0 : 1;
+      if (have_rec) {
+        int out = 0;
+        const int j = tid & 63;
+        if (j < k) {
+          const int *r = recs + j * 8;
+          if (r[REC_FLAGS] & kRecAccepted) {
+            if (r[REC_FLAGS] & kRecRebased) out |= 3;
+            if (r[REC_FLAGS] & kRecFar) out |= 1;
+            if (!(r[REC_RHI] < pr.rmin - 6 || r[REC_RLO] > pr.rmax + 6)) {
+              const int slo[2] = {pr.cmin0, pr.cmin1}, shi[2] = {pr.cmax0, pr.cmax1};
+              for (int h = 0; h < 2; ++h) {
+                if (shi[h] < 0) continue;
+                for (int g = 0; g < 2; ++g) {
+                  const int clo = r[REC_CLO0 + 2 * g], chi = r[REC_CHI0 + 2 * g];
+                  if (chi >= clo && clo <= shi[h] + 3 && chi >= slo[h] - 3) out |= 1;
+                }
+              }
+            }
+          }
+        }
+        cf |= wave_or_i32(out);
+      }
+      cf = uni(cf);
+      if (cf & 2) {                                         // the bounds moved: the sample is projected again
+        if (tid == 0) atomicAdd(&w.dbg[D_DEFER_BOUNDS], 1);
+        defer = k;
+        break;
+      }
+      int rc = kOk;
+      if (!cf && !pr.accept) {                              // rejected, and nothing has changed that
+        nv = pr.nvis;
+        if (tid == 0 && pr.sflags) atomicOr(&b.status[s], pr.sflags);
+        if (tid == 0) atomicAdd(&w.dbg[D_CHAIN_REJECTED], 1);
+      } else {
+        // (a sample too large for k_sample_prep's LDS is projected here)
+        rc = have_rec ? I.load_record(w.tile_pool + pr.rec_off, pr.rec_bytes) : I.sample_phase();
+        bool stored = rc == kOk && !cf;
+        if (stored && I.load_results(pr) != kOk) stored = false;   // lists too long for this LDS: evaluate here
+        if (rc == kOk && !stored) {
+          if (pr.state == kPairEvaluated && pr.nhits >= 0 && !(b.reserved & kDbgSerial)) {   // replay what k_eval gathered
+            I.r_hits = reinterpret_cast<const uint4 *>(w.tile_pool + pr.hits_off);
+            I.r_nhits = pr.nhits;
+            I.r_n0 = pr.n0;
+          }
+          rc = I.scene_phase(n_now, true, [] { return false; });
+        }
+        path = rc != kOk ? D_DEFER_NOFIT : (stored ? D_CHAIN_STORED : (cf ? D_CHAIN_CONFLICT : D_CHAIN_UNEVAL));
+        if (tid == 0) atomicAdd(&w.dbg[path], 1);
+        if (rc != kOk) {
+          defer = k;
+          break;
+        }
+        rebase = I.commit(flags, n_after, n_now, n_head0);
+        nv = I.nvis;
+        acc = I.accept ? 1 : 0;
+      }
+    } else {
+      // nothing to insert here
+    }
+    if (tid == 0) {
+      slots.n_visible[k][s] = nv;
+      slots.accepted[k][s] = acc;
+      int *r = recs + k * 8;
+      r[REC_FLAGS] = flags;
+      r[REC_NTOTAL] = n_after;
+      r[REC_RLO] = acc ? H[H_VRMIN] : 0x7FFFFFFF;
+      r[REC_RHI] = acc ? H[H_VRMAX] : -1;
+      r[REC_CLO0] = acc ? H[H_VCMIN0] : 0x7FFFFFFF;
+      r[REC_CHI0] = acc ? H[H_VCMAX0] : -1;
+      r[REC_CLO1] = acc ? H[H_VCMIN1] : 0x7FFFFFFF;
+      r[REC_CHI1] = acc ? H[H_VCMAX1] : -1;
+    }
+    n_now = n_after;
+    // The next slot of this workgroup reads what this one wrote: a barrier is all it takes (one CU, one L1; alive bits
+    // and counters are atomics).  An agent-scope fence here writes the whole L2 back -- 50 us per slot while the
+    // L2 is still full of what k_eval stored.
+    __syncthreads();
+    if (tid == 0) {
+      w.trace[((int64_t)s * kMaxChain + k) * 2] = (wall_clock64() - t_slot) | ((long long)path << 48);
+      w.trace[((int64_t)s * kMaxChain + k) * 2 + 1] = t_slot;
+    }
+    if (rebase) {
+      unsigned long long *s_min = reinterpret_cast<unsigned long long *>(smem + kHdrBytes), *s_max = s_min + NT / 64;
+      rebase_scene<NT>(b, w, chunks, s, s_min, s_max);
+      if (tid == 0) atomicAdd(&w.dbg[D_REBASE], 1);
+      defer = k + 1;                                        // the later samples are projected under the new bounds
+      break;
+    }
+  }
+  if (tid == 0 && defer < nk) w.defer_from[s] = defer;
+}
+
 // The pairs the chain kernel could not hold in its LDS, scene by scene, slot after slot.
 template <int NT>
 __global__ void __launch_bounds__(NT)
@@ -1532,7 +2008,10 @@ k_insert_big(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w,
 __global__ void k_chain_init(r3d_batch_t b, BatchWs w, int nk) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= b.B) return;
-  if (s == 0) *w.pool_head = 0ull;
+  if (s == 0) {
+    *w.pool_head = 0ull;
+    for (int c = 0; c < kEvalClasses; ++c) w.cls_count[c] = 0;
+  }
   w.chain_progress[s] = 0;
   w.n_total0[s] = b.n_total[s];
   w.defer_from[s] = nk;
@@ -1576,8 +2055,139 @@ static int launch_chain(const r3d_batch_t &b, const BatchWs &w, const ChainSlots
   return R3D_OK;
 }
 
+// launch shapes of k_eval, smallest first: threads per class, LDS from R3D_EVAL_KB ("24,48,80,160")
+constexpr int kEvalNT[kEvalClasses] = {256, 256, 512, 1024};
+
+// The launch shapes of k_eval run side by side: shape 0 on the caller's stream, the others on helper streams of the
+// device (created on first use, kept for the life of the process) that fork from the caller's stream behind
+// k_sample_prep and join it before k_commit_chain.  Events are made per call, so calls from several host threads
+// and streams do not share any.
+struct Helpers {
+  hipStream_t st[kEvalClasses - 1];
+  bool ok = false;
+};
+static Helpers *device_helpers() {
+  static std::mutex mu;
+  static std::map<int, Helpers> per_device;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  Helpers &h = per_device[dev];
+  if (!h.ok) {
+    for (int i = 0; i < kEvalClasses - 1; ++i)
+      if (hipStreamCreateWithFlags(&h.st[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+    h.ok = true;
+  }
+  return &h;
+}
+
+template <int NT>
+static int launch_eval(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step, int lds, int cls,
+                       hipStream_t st) {
+  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(k_eval<NT>, dim3(b.B * nk), dim3(NT), lds, st, b, sl, nk, first_step, w, chunks_of(b), lds, cls);
+  R3D_LAUNCHED("k_eval");
+  return R3D_OK;
+}
+
+template <int NTP, int NTC>
+static int launch_three(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step, int lds_prep,
+                        int lds_chain, const EvalShapes &sh, hipStream_t st) {
+  const int B8 = (b.B + 7) & ~7;
+  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sample_prep<NTP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              lds_prep));
+  hipLaunchKernelGGL(k_sample_prep<NTP>, dim3(B8 * nk), dim3(NTP), lds_prep, st, b, sl, nk, first_step, w, chunks_of(b), lds_prep,
+                     B8, sh);
+  R3D_LAUNCHED("k_sample_prep");
+  static const bool side_by_side = !getenv("R3D_EVAL_ONE_STREAM");
+  int n_shapes = 0;
+  for (int c = 0; c < kEvalClasses; ++c) n_shapes += sh.lds[c] > 0;
+  Helpers *hp = side_by_side && n_shapes > 1 ? device_helpers() : nullptr;
+  hipEvent_t fork = nullptr, join[kEvalClasses] = {nullptr, nullptr, nullptr, nullptr};
+  if (hp) {
+    R3D_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    R3D_HIP(hipEventRecord(fork, st));
+  }
+  int first = -1;
+  for (int c = kEvalClasses - 1; c >= 0; --c) {             // the big shapes first: they take longest
+    if (sh.lds[c] <= 0) continue;
+    if (first < 0) first = c;
+    hipStream_t on = st;
+    if (hp && c != 0) {
+      on = hp->st[c - 1];
+      R3D_HIP(hipStreamWaitEvent(on, fork, 0));
+    }
+    int rc = kEvalNT[c] == 256   ? launch_eval<256>(b, w, sl, nk, first_step, sh.lds[c], c, on)
+             : kEvalNT[c] == 512 ? launch_eval<512>(b, w, sl, nk, first_step, sh.lds[c], c, on)
+                                 : launch_eval<1024>(b, w, sl, nk, first_step, sh.lds[c], c, on);
+    if (rc != R3D_OK) return rc;
+    if (on != st) {
+      R3D_HIP(hipEventCreateWithFlags(&join[c], hipEventDisableTiming));
+      R3D_HIP(hipEventRecord(join[c], on));
+    }
+  }
+  for (int c = 0; c < kEvalClasses; ++c)
+    if (join[c]) {
+      R3D_HIP(hipStreamWaitEvent(st, join[c], 0));
+      R3D_HIP(hipEventDestroy(join[c]));                    // released once it has completed
+    }
+  if (fork) R3D_HIP(hipEventDestroy(fork));
+  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_chain<NTC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              lds_chain));
+  hipLaunchKernelGGL(k_commit_chain<NTC>, dim3(b.B), dim3(NTC), lds_chain, st, b, sl, nk, first_step, w, chunks_of(b), lds_chain);
+  R3D_LAUNCHED("k_commit_chain");
+  return R3D_OK;
+}
+
+static int launch_slots_legacy(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step,
+                               hipStream_t st);
+
 static int launch_slots(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step,
                         hipStream_t st) {
+  static const bool legacy = getenv("R3D_INSERT_LEGACY") != nullptr;
+  if (legacy || (b.reserved & kDbgDropPublish)) return launch_slots_legacy(b, w, sl, nk, first_step, st);
+  static int kb[kEvalClasses] = {0, 0, 0, 0};
+  static const bool parsed = [] {
+    const char *v = getenv("R3D_EVAL_KB");
+    const int dflt[kEvalClasses] = {24, 48, 80, 160};
+    for (int c = 0; c < kEvalClasses; ++c) kb[c] = dflt[c];
+    if (v && *v) {
+      int c = 0;
+      for (const char *q = v; c < kEvalClasses; ++c) {
+        kb[c] = atoi(q);
+        q = strchr(q, ',');
+        if (!q) {
+          for (++c; c < kEvalClasses; ++c) kb[c] = 0;
+          break;
+        }
+        ++q;
+      }
+    }
+    return true;
+  }();
+  (void)parsed;
+  static const int prep_kb = env_int("R3D_PREP_KB", 40);
+  const bool large = (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN;
+  EvalShapes sh{};
+  for (int c = 0; c < kEvalClasses; ++c) sh.lds[c] = large ? (c == kEvalClasses - 1 ? kBigLds : 0) : kb[c] * 1024;
+  if (large) {                                              // one shape: the whole CU per pair (see chain_shape)
+    sh.lds[0] = kBigLds;
+    for (int c = 1; c < kEvalClasses; ++c) sh.lds[c] = 0;
+  }
+  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_big<kBigNT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+  hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, nk);
+  int rc = large ? launch_three<1024, 1024>(b, w, sl, nk, first_step, kBigLds, kBigLds, sh, st)
+                 : launch_three<256, 512>(b, w, sl, nk, first_step, prep_kb * 1024, 80 * 1024, sh, st);
+  if (rc != R3D_OK) return rc;
+  hipLaunchKernelGGL(k_insert_big<kBigNT>, dim3(b.B), dim3(kBigNT), kBigLds, st, b, sl, nk, first_step, w,
+                     chunks_of(b), kBigLds);
+  R3D_LAUNCHED("k_insert_big");
+  return R3D_OK;
+}
+
+static int launch_slots_legacy(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step,
+                               hipStream_t st) {
   static const int timeout_ms = env_int("R3D_CHAIN_TIMEOUT_MS", 2000);
   int nt, lds;
   chain_shape(b, nt, lds);
@@ -1646,6 +2256,27 @@ int r3d_batch_insert_many(const r3d_batch_t *b, int32_t n_slots, const double *c
     rc = launch_slots(*b, w, sl, nk, (int)(first_step + k0), (hipStream_t)stream);
     if (rc != R3D_OK) return rc;
   }
+  return R3D_OK;
+}
+
+int r3d_batch_debug_trace(const r3d_batch_t *b, int64_t *host_out, int64_t n_words, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  BatchWs w = carve_batch(*b, b->workspace);
+  if (!host_out || n_words < 0 || n_words > (int64_t)b->B * kMaxChain * 2) return fail(R3D_E_ARG, "batch_debug_trace: size");
+  R3D_HIP(hipMemcpyAsync(host_out, w.trace, n_words * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  R3D_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return R3D_OK;
+}
+
+int r3d_batch_debug_counters(const r3d_batch_t *b, int32_t *host_out16, int32_t reset, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  if (!host_out16) return fail(R3D_E_ARG, "batch_debug_counters: null output");
+  BatchWs w = carve_batch(*b, b->workspace);
+  R3D_HIP(hipMemcpyAsync(host_out16, w.dbg, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  if (reset) R3D_HIP(hipMemsetAsync(w.dbg, 0, 16 * sizeof(int32_t), (hipStream_t)stream));
+  R3D_HIP(hipStreamSynchronize((hipStream_t)stream));
   return R3D_OK;
 }
 
