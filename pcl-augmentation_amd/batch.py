@@ -379,7 +379,7 @@ class SceneBatch:
 
 
 def augment_batch(scenes, candidates, min_points, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN, device="cuda:0",
-                  check_cols=5, reuse=None):
+                  check_cols=5, reuse=None, debug=0):
     """Run whole frames through the insert loop on one GPU.
 
     scenes[s] = (xyzi float32 [n,4], label uint32 [n]); candidates[s][k] = ordered list of M x 5
@@ -397,7 +397,7 @@ def augment_batch(scenes, candidates, min_points, rows=_lib.NUMROW, cols=_lib.NU
         # a descriptor is re-usable for any later call that fits (a rebase rewrites only the slabs
         # that load() overwrites anyway); `reuse` is the caller's {B: SceneBatch} cache
         batch = SceneBatch(B, int(cap * 1.05) + 64 if reuse is not None else cap, max(grow, 1) * (2 if reuse is not None else 1),
-                           rows, cols, device)
+                           rows, cols, device, debug=debug)
         if reuse is not None:
             reuse[B] = batch
     batch.load(scenes)

@@ -61,6 +61,7 @@ constexpr int kDbgBands = 4;         // the depth tile in bands of at most 3 can
 constexpr int kDbgDefer = 8;         // every pair is left to k_insert_big
 constexpr int kDbgDropPublish = 16;  // slot 0 of scene 0 does not publish: its successors time out
 constexpr int kDbgPoolTile = 32;     // every pair's depth tile and candidate list in the global pool
+constexpr int kDbgThree = 64;        // the launch as k_sample_prep / k_eval / k_commit_chain (also: R3D_INSERT_THREE=1)
 
 struct ChainSlots {
   const double *samples5[kMaxChain];
@@ -256,7 +257,7 @@ struct Ins {
   uint4 *g_hits;                         // where this evaluation stores its hits, or null
   const uint4 *r_hits;                   // hits to replay, or null
   int r_nhits, r_n0;
-  bool keep_hits;
+  bool keep_hits, hits_done;              // hits_done: the gather that stores them has run to its end
   long long hits_off;
   bool accept;
   FastDiv by_cols, by_W;
@@ -277,7 +278,7 @@ struct Ins {
     g_hits = nullptr;
     r_hits = nullptr;
     r_nhits = r_n0 = 0;
-    keep_hits = false;
+    keep_hits = hits_done = false;
     hits_off = -1;
     pool_off = -1;
     by_cols.set(cols);
@@ -722,6 +723,18 @@ struct Ins {
         GSTAMP(3);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+          // where this lane's hit goes: one LDS atomic per wave (every lane of a wave is in this loop: the listed
+          // items come in multiples of 64)
+          int hpos = 0;
+          if (g_hits) {
+            const unsigned long long hm = __ballot(dl[h + u] >= 0);
+            if (hm) {
+              const int lead = __ffsll((long long)hm) - 1;
+              int base = 0;
+              if ((tid & 63) == lead) base = atomicAdd(&H[H_NHITS], __popcll(hm));
+              hpos = __builtin_amdgcn_readlane(base, lead) + __popcll(hm & ((1ull << (tid & 63)) - 1ull));
+            }
+          }
           if (dl[h + u] < 0) continue;
           double x = (double)f[u].x, y = (double)f[u].y, z = (double)f[u].z;
           if (idx[h + u] >= n_head) load_point(b, s, idx[h + u], n_head, x, y, z);   // an inserted point: float64, from the log
@@ -743,7 +756,7 @@ struct Ins {
           }
           if (g_hits) {
             const unsigned long long key = depth_key(r);
-            g_hits[atomicAdd(&H[H_NHITS], 1)] = make_uint4((uint32_t)p[h + u] | holder, (uint32_t)idx[h + u], (uint32_t)key,
+            g_hits[hpos] = make_uint4((uint32_t)p[h + u] | holder, (uint32_t)idx[h + u], (uint32_t)key,
                                                           (uint32_t)(key >> 32));
           }
         }
@@ -920,6 +933,7 @@ struct Ins {
     // room for the hits of this evaluation (at most the living points of the listed chunks), when they are wanted
     g_hits = nullptr;
     hits_off = -1;
+    hits_done = false;
     if (keep_hits && single && !r_hits) {
       const long long want = ((long long)uni(H[H_HITCAP]) * 16 + 255) & ~255ll;
       __syncthreads();
@@ -985,6 +999,7 @@ struct Ins {
         for (int e = tid; e < ww; e += NT) D.w[e] = 0u;
       __syncthreads();
       gather(bits_in_gather, use_sub ? s_sub : nullptr, nsub);
+      hits_done = g_hits != nullptr;
       if (r_hits) replay_hits(bits_in_gather);
       if (g_dtile) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the minima were formed in L2: drop this CU's copies
       __syncthreads();
@@ -1592,6 +1607,8 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
   const bool on = load_slot(I, b, slots, k, s, first_step);
   bool need_sample = true, sample_ok = false;
   int rc = kOk, attempts = 0;
+  const uint4 *sv_hits = nullptr;                           // the hits of this pair's first evaluation, for a later one
+  int sv_nhits = 0, sv_n0 = 0;
   (void)attempts;
   if (on) {
     for (;;) {
@@ -1626,6 +1643,16 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
       // while it speculates, the evaluation looks twice whether a slot that finished meanwhile has already
       // invalidated it: a doomed evaluation of a big pair is given up early and restarted on the fresher state
       int gone = 0, stale_cf = 0;
+      // the first evaluation keeps its hits; a later one of this pair under the same bounds replays them
+      if (need_sample) sv_hits = nullptr;                   // new bounds: other pixel ids
+      I.r_hits = sv_hits;
+      I.r_nhits = sv_nhits;
+      I.r_n0 = sv_n0;
+      // (kept where evaluating twice is the rule: long chains, large range images; storing them costs the short
+      // chains of config C2 more -- 0.35 against 0.32 ms per launch -- than the 3 % of its pairs that replay gain)
+      I.keep_hits = sv_hits == nullptr && !waited && !(b.reserved & kDbgSerial) &&
+                    (nk >= 8 || (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN);
+      const int n_base_used = n_base;
       if (rc == kOk)
         rc = I.scene_phase(n_base, waited, [&]() -> bool {
           const int p1 = wait_for(0);
@@ -1645,6 +1672,11 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
           }
           return false;
         });
+      if (I.hits_done && !sv_hits) {                        // (the count is in LDS until the next evaluation starts)
+        sv_hits = I.g_hits;
+        sv_nhits = uni(H[H_NHITS]);
+        sv_n0 = n_base_used;
+      }
       if (rc == kStale) {
         if (gone == kProgDeferred) return;
         if (gone < 0) {
@@ -2144,8 +2176,8 @@ static int launch_slots_legacy(const r3d_batch_t &b, const BatchWs &w, const Cha
 
 static int launch_slots(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step,
                         hipStream_t st) {
-  static const bool legacy = getenv("R3D_INSERT_LEGACY") != nullptr;
-  if (legacy || (b.reserved & kDbgDropPublish)) return launch_slots_legacy(b, w, sl, nk, first_step, st);
+  static const bool three = getenv("R3D_INSERT_THREE") != nullptr;
+  if (!(three || (b.reserved & kDbgThree)) || (b.reserved & kDbgDropPublish)) return launch_slots_legacy(b, w, sl, nk, first_step, st);
   static int kb[kEvalClasses] = {0, 0, 0, 0};
   static const bool parsed = [] {
     const char *v = getenv("R3D_EVAL_KB");
@@ -2177,8 +2209,10 @@ static int launch_slots(const r3d_batch_t &b, const BatchWs &w, const ChainSlots
   R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_big<kBigNT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
   hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, nk);
+  static const int chain_nt = env_int("R3D_CHAIN_NT", 1024);
   int rc = large ? launch_three<1024, 1024>(b, w, sl, nk, first_step, kBigLds, kBigLds, sh, st)
-                 : launch_three<256, 512>(b, w, sl, nk, first_step, prep_kb * 1024, 80 * 1024, sh, st);
+           : chain_nt == 1024 ? launch_three<256, 1024>(b, w, sl, nk, first_step, prep_kb * 1024, kBigLds, sh, st)
+                              : launch_three<256, 512>(b, w, sl, nk, first_step, prep_kb * 1024, 80 * 1024, sh, st);
   if (rc != R3D_OK) return rc;
   hipLaunchKernelGGL(k_insert_big<kBigNT>, dim3(b.B), dim3(kBigNT), kBigLds, st, b, sl, nk, first_step, w,
                      chunks_of(b), kBigLds);

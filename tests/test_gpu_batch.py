@@ -571,9 +571,11 @@ def test_c5_scan_on_the_proposed_448x2880_grid(P, synth, monkeypatch):
     _check_scene(res[0], vb, lb, cb)
 
 
-@pytest.mark.parametrize("debug", [2, 4, 8, 6, 32])
+@pytest.mark.parametrize("debug", [2, 4, 8, 6, 32, 64, 66, 72, 96])
 def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
-    """The insert kernel's other routes, forced with the descriptor's diagnostic bits: 2 = never
+    """The insert kernel's other routes, forced with the descriptor's diagnostic bits (64 = the launch as three
+    kernels without a wait: k_sample_prep, k_eval, k_commit_chain -- alone, with every pair evaluated in the chain,
+    with every pair left to k_insert_big, with pooled tiles): 2 = never
     speculate (every slot waits for its predecessor first), 4 = the window's depth tile built and
     evaluated in bands of at most 3 candidate rows, 32 = tile and candidate list in the global pool, 8 = every pair left to k_insert_big (one 1024-thread
     workgroup per scene); all must give the bytes of the oracle chain, through insert_many and slot by slot."""
@@ -645,10 +647,11 @@ def test_chain_timeout_is_reported(P, synth):
         batch.raise_on_status()
 
 
-def test_bench_scenes_against_the_oracle(P, synth):
+@pytest.mark.parametrize("debug", [0, 64])
+def test_bench_scenes_against_the_oracle(P, synth, debug):
     """Short form of tests/crosscheck_bench.py: 12 scenes of the bench workload (config C2, the seeds the
     bench times) through one batch, byte for byte against the oracle; 4 more with blobs in front of the
-    extreme-elevation points so that the chain re-bases in the middle."""
+    extreme-elevation points so that the chain re-bases in the middle.  debug = 64: the launch as three kernels."""
     from conftest import blob_in_front_of_extreme
     kinds = synth.CONFIG_INSERTS["C2"]
     seeds = list(range(12)) + [100, 101, 102, 103]
@@ -660,7 +663,7 @@ def test_bench_scenes_against_the_oracle(P, synth):
             ins = [blob_in_front_of_extreme(scenes[i][0], "max", seed=s)] + ins[:3] + [blob_in_front_of_extreme(scenes[i][0], "min", seed=s)] + ins[3:]
         slots.append([[x] for x in ins])
     need = [[20] * len(sl) for sl in slots]
-    res, acc = P.augment_batch(scenes, slots, need)
+    res, acc = P.augment_batch(scenes, slots, need, debug=debug)
     assert P.batch.SceneBatch.last_rebases >= 4
     for (xyzi, label), sl, nd, r, a in zip(scenes, slots, need, res, acc):
         vb, lb, cb, oacc = _oracle_chain(xyzi, label, sl, nd)
