@@ -14,10 +14,10 @@ from . import _lib, synth  # noqa: F401
 from ._lib import R3DError  # noqa: F401
 from .batch import SceneBatch, augment_batch, run_sharded, shard_indices  # noqa: F401
 from . import Real3DAug  # noqa: F401
-from .pipeline import AugmentPipeline, Frame  # noqa: F401
+from .pipeline import AugmentPipeline, Frame, run_sharded_files  # noqa: F401
 from . import places  # noqa: F401
 from .places import PlaceScene, find_places  # noqa: F401
 from .placed import PlacedInserter  # noqa: F401
 from .rich_map import build_rich_map  # noqa: F401
 
-__all__ = ["SceneBatch", "augment_batch", "run_sharded", "shard_indices", "AugmentPipeline", "Frame", "Real3DAug", "synth", "R3DError", "places", "PlaceScene", "find_places", "PlacedInserter", "build_rich_map"]
+__all__ = ["SceneBatch", "augment_batch", "run_sharded", "shard_indices", "AugmentPipeline", "Frame", "run_sharded_files", "Real3DAug", "synth", "R3DError", "places", "PlaceScene", "find_places", "PlacedInserter", "build_rich_map"]

@@ -294,3 +294,34 @@ class AugmentPipeline:
         stats["t_total"] = time.perf_counter() - t_start
         stats["frames_per_s"] = stats["written"] / stats["t_total"] if stats["t_total"] > 0 else 0.0
         return stats
+
+
+def run_sharded_files(frames, inserts_for, output_path, folder, rank=None, world_size=None, device=None, dataset="semantic",
+                      batch_size=64, lanes=3, label_2_for=None, process=None, resume=True):
+    """BASELINE config C4 ("full sweep, scene-sharded across the GPUs of a node"): rank r of G takes frames r, r + G,
+    r + 2G, ... and runs them file to file through its own GPU; no rank talks to another on the data path, every frame
+    is written by exactly one rank (the reference shards by letting N copies of the script race for claim files,
+    SS insertion.py:339-350; resume is by the existence of a frame's outputs, as there).
+
+    inserts_for(i) -> (samples, min_points) of frame i: one placement per insert (``run_streamed``).  ``process``
+    (tests only): a CPU stand-in for the GPU leg with ``AugmentPipeline.run``'s signature; it gets one candidate per
+    insert.  Returns this rank's counters; `frames` holds the rank's own frame indices."""
+    if rank is None or world_size is None:
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    from .batch import shard_indices
+    mine = shard_indices(len(frames), rank, world_size)
+    pipe = AugmentPipeline(output_path, folder, dataset=dataset, batch_size=batch_size,
+                           device=device or f"cuda:{rank}", resume=resume, process=process)
+    local = [frames[i] for i in mine]
+    if process is not None:
+        def cands(j):
+            smp, need = inserts_for(mine[j])
+            return [[x] for x in smp], need
+        st = pipe.run(local, cands, label_2_for=(lambda j, acc: label_2_for(mine[j], acc)) if label_2_for else None)
+    else:
+        st = pipe.run_streamed(local, lambda j: inserts_for(mine[j]), lanes=lanes,
+                               label_2_for=(lambda j, acc: label_2_for(mine[j], acc)) if label_2_for else None)
+    st.update(rank=rank, world_size=world_size, frame_indices=mine)
+    return st
