@@ -91,7 +91,7 @@ def cpu_worker(args):
     print(json.dumps({"scenes": hi - lo, "seconds": spent}))
 
 
-def cpu_baselines(pkg, cfg, config_name, n_check, budget_s=20.0):
+def cpu_baselines(pkg, cfg, config_name, n_check, budget_s=20.0, all_cores=True):
     """Single core: the first scenes of rank 0's batch (their bytes are kept for the parity check),
     at most budget_s seconds.  All cores: one process per core over disjoint further scenes."""
     done, spent, kept = 0, 0.0, []
@@ -107,6 +107,8 @@ def cpu_baselines(pkg, cfg, config_name, n_check, budget_s=20.0):
               "sample": f"the first {done} scenes of the timed batch ({cfg['workload'].split(':')[0]}: "
                         f"{cfg['beams'] * cfg['az']} points, {len(cfg['kinds'])} inserts) through oracle.augment_scene "
                         "(NumPy port of the reference), one core"}
+    if not all_cores:
+        return single, None, kept
     visible = len(os.sched_getaffinity(0))
     cores = min(visible, 16)            # one GPU's share of the host (the box shows all of its cores to every lease)
     per = max(1, min(8, int(budget_s / max(spent / done, 1e-3) / 2)))
@@ -216,6 +218,14 @@ def main():
     ap.add_argument("--e2e", type=int, default=0, metavar="FRAMES",
                     help="also time the file-to-file pipeline (SURVEY.md par.8 f-2) on FRAMES frames: host frames in, "
                          "pinned double-buffered transfers overlapped with the kernels, host files' bytes out")
+    ap.add_argument("--distinct", type=int, default=0, metavar="N",
+                    help="generate only N distinct scenes and cycle them through the batch (the inserts stay per scene); "
+                         "default: every scene of the batch is its own")
+    ap.add_argument("--cpu-budget", type=float, default=0.0, metavar="SECONDS",
+                    help="seconds of oracle time for the single-core CPU baseline (default 20; 30 for C5); below 20 the "
+                         "one-process-per-core leg is skipped")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="only the headline measurement: no c5 / e2e / placement_search objects in the line")
     ap.add_argument("--cpu-worker", type=int, nargs=2, metavar=("LO", "HI"), help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -232,6 +242,7 @@ def main():
 
     cfg = dict(CONFIGS[args.config])
     B = args.scenes or cfg["scenes"]
+    cfg["workload"] = cfg["workload"].replace(f"batch of {cfg['scenes']} ", f"batch of {B} ")
     kinds = cfg["kinds"]
     pkg = importlib.import_module("pcl-augmentation_amd")
     synth = pkg.synth
@@ -242,8 +253,9 @@ def main():
     oracle_bytes = []
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         n_check = max(0, min(args.parity_scenes if args.config == "C2" else 1, B))   # a C5 scene takes the oracle ~10 s
-        cpu_single, cpu_multi, oracle_bytes = cpu_baselines(pkg, cfg, args.config, n_check,
-                                                            budget_s=20.0 if args.config == "C2" else 30.0)
+        budget = args.cpu_budget or (20.0 if args.config == "C2" else 30.0)
+        cpu_single, cpu_multi, oracle_bytes = cpu_baselines(pkg, cfg, args.config, n_check, budget_s=budget,
+                                                            all_cores=budget >= 20.0)
 
     import torch
     import torch.distributed as dist
@@ -259,7 +271,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    scenes = [build_scene(synth, cfg, scene_seed(rank, s)) for s in range(B)]
+    distinct = min(args.distinct, B) if args.distinct > 0 else B
+    scenes = [build_scene(synth, cfg, scene_seed(rank, s)) for s in range(distinct)]
+    scenes = [scenes[s % distinct] for s in range(B)]
     inserts = [synth.make_inserts(scene_seed(rank, s), kinds) for s in range(B)]
     K = len(kinds)
     n_max = max(len(x) for x, _ in scenes)
@@ -336,9 +350,31 @@ def main():
         elapsed = float(t.item())
     for bt, _, _ in lanes:
         bt.raise_on_status()
-    if depth > 1:                                   # every lane worked on the same input: same output
-        ref_out = lanes[0][0].n_out.cpu().numpy()
-        assert all(np.array_equal(bt.n_out.cpu().numpy(), ref_out) for bt, _, _ in lanes[1:])
+    lanes_checked = 0
+    if depth > 1:
+        # the batches of the timed, overlapped run: every lane worked on the same input, so the lanes must agree byte
+        # for byte (lane 0 is compared with the oracle below, BEFORE anything runs on it again)
+        ref = lanes[0][0]
+        ref_out = ref.n_out.cpu().numpy()
+        for bt, _, _ in lanes[1:]:
+            assert np.array_equal(bt.n_out.cpu().numpy(), ref_out), "lanes of the overlapped run disagree (n_out)"
+            same = bool(torch.equal(bt.out_xyzi.view(torch.int32), ref.out_xyzi.view(torch.int32))) and \
+                bool(torch.equal(bt.out_label, ref.out_label)) and bool(torch.equal(bt.n_log, ref.n_log))
+            m = int(ref.n_log.max().item())
+            same = same and bool(torch.equal(bt.check[:, :m].view(torch.int32), ref.check[:, :m].view(torch.int32)))
+            if not same:
+                raise SystemExit("parity FAILED: lanes of the three-in-flight run disagree")
+            lanes_checked += 1
+        overlapped_bytes = None
+        if rank == 0 and oracle_bytes:
+            n_out_h, n_log_h = ref_out, ref.n_log.cpu().numpy()
+            for s, (vb, lb, cb) in enumerate(oracle_bytes):
+                xyzi = ref.out_xyzi[s, :n_out_h[s]].cpu().numpy()
+                label = ref.out_label[s, :n_out_h[s]].cpu().numpy().view(np.uint32)
+                check = ref.check[s, :n_log_h[s]].cpu().numpy()
+                if xyzi.tobytes() != vb or label.tobytes() != lb or check.tobytes() != cb:
+                    raise SystemExit(f"parity FAILED: scene {s} of the three-in-flight run differs from the oracle")
+            overlapped_bytes = len(oracle_bytes)
         # the same K steps one at a time, for the record (not the headline value)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -448,6 +484,9 @@ def main():
         # inserts + the check rows (40 B read, 20 B written per inserted point)
         step_bytes = 16.0 * n_pts * 2 + 20.0 * n_pts + 20.0 * n_out_pts + 80.0 * m_pts + 60.0 * n_log_pts
         pipe_gbs = step_bytes * args.steps / elapsed / 1e9
+        # SURVEY.md par.8d's floor for the same result: every point read once and written once, 40 B per point
+        floor_bytes = 20.0 * n_pts + 20.0 * n_out_pts
+        floor_gbs = floor_bytes * args.steps / elapsed / 1e9
         out = {
             "metric": "augmented scenes/sec (120k-pt, 64-beam)" if args.config == "C2" else "augmented scenes/sec (1M-pt, 256-beam)",
             "value": round(scenes_per_s, 1),
@@ -468,16 +507,45 @@ def main():
             "pipeline_alg_GBps_per_gpu": round(pipe_gbs, 1),
             "pipeline_frac_of_hbm_peak": round(pipe_gbs / HBM_PEAK_GBS, 4),
             "pipeline_alg_bytes_per_scene": round(step_bytes / B, 1),
+            "pipeline_frac_floor_model": round(floor_gbs / HBM_PEAK_GBS, 4),
+            "pipeline_byte_models": {"passes_made": "16 N (bounds) + 16 N (project) + 20 N + 20 N_out (compaction) + 80 M (inserts) + "
+                                                    "60 M_visible (check rows): what this pipeline's kernels have to move",
+                                     "floor": "20 N + 20 N_out: every point read once and written once (SURVEY.md par.8d)"},
             "parity_checked": parity_checked,
+            "parity_of_overlapped_run": {"scenes_vs_oracle_lane0": overlapped_bytes if depth > 1 else None,
+                                         "lanes_byte_equal_to_lane0": lanes_checked},
         }
         if cpu_single is not None:
             out["cpu_baseline"] = cpu_single
             out["cpu_baseline_all_cores"] = cpu_multi
-        if args.placement > 0 and world == 1:
-            out["placement_search"] = placement_leg(pkg, torch, args.placement, not args.no_cpu_baseline, CONFIGS["C2"]["kinds"])
-        if args.e2e > 0 and world == 1:
+        extra = world == 1 and args.config == "C2" and not args.no_extra_legs
+        t_extra = time.perf_counter()
+        if (args.placement > 0 or extra) and world == 1:
+            out["placement_search"] = placement_leg(pkg, torch, args.placement or 64, not args.no_cpu_baseline, CONFIGS["C2"]["kinds"])
+        if (args.e2e > 0 or extra) and world == 1:
             e2e = importlib.import_module("tools.e2e_pipeline")
-            out["e2e"] = e2e.measure(pkg, n_frames=args.e2e)
+            out["e2e"] = e2e.measure(pkg, n_frames=args.e2e or 2048)
+        if extra:
+            # BASELINE.json's stress configuration in the same line: a child process (its own batches, freed when it ends)
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", "C5", "--scenes", "64", "--distinct", "16", "--steps", "4",
+                   "--warmup", "1", "--no-extra-legs", "--parity-scenes", "1", "--cpu-budget", "8"]
+            if args.no_cpu_baseline:
+                cmd.append("--no-cpu-baseline")
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+                c5 = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                out["c5"] = {"scans_per_s": c5["value"], "ms_per_step": c5["ms_per_step"], "scans_per_batch": c5["config"]["scenes_per_gpu"],
+                             "points_per_scan": c5["config"]["points_per_scene"], "inserts_per_scan": c5["config"]["inserts_per_scene"],
+                             "range_image": c5["config"]["range_image"], "steps_in_flight": c5["config"]["steps_in_flight"],
+                             "ms_per_step_one_step_in_flight": c5["config"]["ms_per_step_one_step_in_flight"],
+                             "pipeline_frac_of_hbm_peak": c5["pipeline_frac_of_hbm_peak"],
+                             "pipeline_frac_floor_model": c5.get("pipeline_frac_floor_model"),
+                             "api_calls_ms": c5["roofline"]["api_calls_ms"], "parity_checked": c5["parity_checked"],
+                             "cpu_baseline": c5.get("cpu_baseline"), "workload": c5["config"]["workload"],
+                             "command": " ".join(cmd[1:])}
+            except Exception as e:                                 # the headline must not depend on this leg
+                out["c5"] = {"error": repr(e)[:300]}
+            out["extra_legs_seconds"] = round(time.perf_counter() - t_extra, 1)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -394,6 +394,26 @@ int r3d_od_maps(const float *xyzi, const uint32_t *label, int64_t n, int32_t roa
 int r3d_host_pack_frames(const float *const *xyzi, const uint32_t *const *label, const int32_t *n_points, int32_t B,
                          int64_t cap, float *dst_xyzi, uint32_t *dst_label, int32_t collapse_keep, int32_t threads);
 
+/* The delta of a batch instead of its merged clouds, for a caller that still holds the frames on the host (the
+ * streamed file-to-file driver): alive [B][chunks] uint64 -- bit i of word c = point 64 c + i of the scene survives
+ * (chunks = (cap + 63) / 64; bits beyond the scene's count are 0) --, the inserted points in insertion order,
+ * tail_xyzi [B][tail_stride][4] float32 (what save_data writes of them, SS tools/datasets.py:81) and tail_label
+ * [B][tail_stride], and counts [2][B] int32 = points of the frame, points after the inserts.  Called after the
+ * inserts INSTEAD of r3d_batch_finish (no compaction runs on the device); does not change the batch.
+ * Not for batches begun with r3d_batch_begin_f64. */
+int r3d_batch_export_delta(const r3d_batch_t *b, uint64_t *alive, float *tail_xyzi, uint32_t *tail_label, int64_t tail_stride,
+                           int32_t *counts, void *stream);
+
+/* HOST pointers: the merged clouds from the frames as packed by r3d_host_pack_frames (in_xyzi / in_label, [B][cap])
+ * and the delta above (copied to the host): out_xyzi [B][out_cap][4], out_label [B][out_cap], n_out [B] -- the bytes
+ * of velodyne/{f}.bin and labels/{f}.label (insertion.py:472-473, :526; SS tools/datasets.py:80-84) -- and, when
+ * check != NULL, check [B][check_stride][check_cols] = every inserted point, x y z intensity (label) as float32
+ * (the bytes of check/{f}.bin, :73-75, :86-88).  `threads` host threads share the frames. */
+int r3d_host_merge_frames(const float *in_xyzi, const uint32_t *in_label, int64_t cap, const uint64_t *alive, int64_t chunks,
+                          const float *tail_xyzi, const uint32_t *tail_label, int64_t tail_stride, const int32_t *counts,
+                          int32_t B, float *out_xyzi, uint32_t *out_label, int64_t out_cap, int32_t *n_out, float *check,
+                          int64_t check_stride, int32_t check_cols, int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

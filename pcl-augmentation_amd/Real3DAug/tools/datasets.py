@@ -54,8 +54,11 @@ def read_frame(velodyne_file, label_file):
 def _commit(path, data):
     """Write bytes (or an array's bytes) to path.tmp, then rename: the file is whole or absent."""
     tmp = path + ".tmp"
+    if not isinstance(data, (bytes, bytearray, memoryview)):
+        data = np.ascontiguousarray(data)
+        data = memoryview(data).cast("B") if data.size else b""      # (a view with a zero in its shape cannot be cast)
     with open(tmp, "wb") as fh:
-        fh.write(data if isinstance(data, (bytes, bytearray, memoryview)) else memoryview(np.ascontiguousarray(data)).cast("B"))
+        fh.write(data)
     os.replace(tmp, path)
 
 

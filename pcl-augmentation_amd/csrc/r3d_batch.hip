@@ -563,6 +563,34 @@ __global__ void k_pack_log(r3d_batch_t b, float *__restrict__ check, int check_c
   }
 }
 
+// r3d_batch_export_delta: what a host that still holds the frames needs to write the merged files -- the alive word
+// of every 64-point chunk and the inserted points (float32 rounding + label) in insertion order, at a fixed stride.
+__global__ void k_export_delta(r3d_batch_t b, BatchWs w, int chunks, unsigned long long *alive_out, float *tail_xyzi,
+                               uint32_t *tail_label, int64_t tail_stride, int32_t *counts) {
+  const int s = blockIdx.y;
+  const int n_head = b.n_head[s], n_total = b.n_total[s];
+  const int n_tail = n_total - n_head;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    counts[s] = n_head;
+    counts[b.B + s] = n_total;
+    if (n_tail > tail_stride) atomicOr(&b.status[s], R3D_S_CAPACITY);
+  }
+  const int n_words = (n_total + 63) >> 6;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += gridDim.x * blockDim.x) {
+    unsigned long long a = c < n_words ? w.alive[(int64_t)s * chunks + c] : 0ull;
+    const int left = n_total - (c << 6);
+    if (left < 64) a = left > 0 ? a & ((1ull << left) - 1ull) : 0ull;
+    alive_out[(int64_t)s * chunks + c] = a;
+  }
+  const float4 *src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap + n_head;
+  float4 *dst = reinterpret_cast<float4 *>(tail_xyzi) + (int64_t)s * tail_stride;
+  const int n_copy = n_tail < tail_stride ? n_tail : (int)tail_stride;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_copy; i += gridDim.x * blockDim.x) {
+    dst[i] = src[i];
+    tail_label[(int64_t)s * tail_stride + i] = b.label[(int64_t)s * b.cap + n_head + i];
+  }
+}
+
 int check_batch(const r3d_batch_t *b) {
   if (!b) return fail(R3D_E_ARG, "batch: null descriptor");
   if (b->B <= 0 || b->rows <= 0 || b->cols <= 0 || b->cap <= 0 || b->log_cap <= 0)
@@ -700,6 +728,18 @@ int r3d_batch_export_rows(const r3d_batch_t *b, double *rows4, int32_t *n_rows, 
   if (!rows4 || !n_rows) return fail(R3D_E_ARG, "batch_export_rows: null output");
   BatchWs w = carve_batch(*b, b->workspace);
   return launch_compact(*b, w, w.all_list, w.all_count, b->B, (hipStream_t)stream, rows4, n_rows);
+}
+
+int r3d_batch_export_delta(const r3d_batch_t *b, uint64_t *alive, float *tail_xyzi, uint32_t *tail_label, int64_t tail_stride,
+                           int32_t *counts, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  if (!alive || !tail_xyzi || !tail_label || !counts || tail_stride <= 0) return fail(R3D_E_ARG, "batch_export_delta: null output or stride");
+  BatchWs w = carve_batch(*b, b->workspace);
+  hipLaunchKernelGGL(k_export_delta, dim3(8, b->B), dim3(256), 0, (hipStream_t)stream, *b, w, chunks_of(*b),
+                     reinterpret_cast<unsigned long long *>(alive), tail_xyzi, tail_label, tail_stride, counts);
+  R3D_LAUNCHED("k_export_delta");
+  return R3D_OK;
 }
 
 int r3d_batch_finish(const r3d_batch_t *b, float *check, int32_t check_cols, void *stream) {

@@ -37,4 +37,76 @@ int r3d_host_pack_frames(const float *const *xyzi, const uint32_t *const *label,
   return R3D_OK;
 }
 
+// The merged cloud of every frame from the frame itself (still in the host's staging slab) and the delta the device
+// exported (r3d_batch_export_delta): surviving frame points in their order, then the surviving inserted points
+// (insertion.py:472-473, :526), and the check rows = every inserted point (SS tools/datasets.py:73-75, :86-88).
+int r3d_host_merge_frames(const float *in_xyzi, const uint32_t *in_label, int64_t cap, const uint64_t *alive, int64_t chunks,
+                          const float *tail_xyzi, const uint32_t *tail_label, int64_t tail_stride, const int32_t *counts,
+                          int32_t B, float *out_xyzi, uint32_t *out_label, int64_t out_cap, int32_t *n_out, float *check,
+                          int64_t check_stride, int32_t check_cols, int32_t threads) {
+  if (!in_xyzi || !in_label || !alive || !tail_xyzi || !tail_label || !counts || !out_xyzi || !out_label || !n_out || B <= 0)
+    return r3d::fail(R3D_E_ARG, "host_merge_frames: null pointer or no frame");
+  if (check && check_cols != 4 && check_cols != 5) return r3d::fail(R3D_E_ARG, "host_merge_frames: check_cols");
+  for (int s = 0; s < B; ++s) {
+    const int64_t n_head = counts[s], n_total = counts[B + s];
+    if (n_head < 0 || n_total < n_head || n_total > cap || n_total - n_head > tail_stride || (n_total + 63) / 64 > chunks ||
+        (check && n_total - n_head > check_stride))
+      return r3d::fail(R3D_E_ARG, "host_merge_frames: counts exceed the buffers");
+  }
+  if (threads < 1) threads = 1;
+  if (threads > B) threads = B;
+  std::vector<int> bad(threads, 0);
+  auto work = [&](int t) {
+    for (int s = t; s < B; s += threads) {
+      const int64_t n_head = counts[s], n_total = counts[B + s], n_tail = n_total - n_head;
+      const uint64_t *aw = alive + (int64_t)s * chunks;
+      const float *hx = in_xyzi + (int64_t)s * cap * 4, *tx = tail_xyzi + (int64_t)s * tail_stride * 4;
+      const uint32_t *hl = in_label + (int64_t)s * cap, *tl = tail_label + (int64_t)s * tail_stride;
+      float *ox = out_xyzi + (int64_t)s * out_cap * 4;
+      uint32_t *ol = out_label + (int64_t)s * out_cap;
+      int64_t o = 0;
+      for (int64_t c = 0; c * 64 < n_total; ++c) {
+        uint64_t m = aw[c];
+        const int64_t base = c * 64;
+        if (m == ~0ull && base + 64 <= n_head) {                                   // the usual chunk: everybody lives
+          if (o + 64 > out_cap) { bad[t] = 1; break; }
+          std::memcpy(ox + o * 4, hx + base * 4, 64 * 4 * sizeof(float));
+          std::memcpy(ol + o, hl + base, 64 * sizeof(uint32_t));
+          o += 64;
+          continue;
+        }
+        while (m) {
+          const int bit = __builtin_ctzll(m);
+          m &= m - 1;
+          const int64_t i = base + bit;
+          if (o >= out_cap) { bad[t] = 1; break; }
+          if (i < n_head) {
+            std::memcpy(ox + o * 4, hx + i * 4, 4 * sizeof(float));
+            ol[o] = hl[i];
+          } else {
+            std::memcpy(ox + o * 4, tx + (i - n_head) * 4, 4 * sizeof(float));
+            ol[o] = tl[i - n_head];
+          }
+          ++o;
+        }
+      }
+      n_out[s] = (int32_t)o;
+      if (check) {
+        float *ck = check + (int64_t)s * check_stride * check_cols;
+        for (int64_t j = 0; j < n_tail; ++j) {
+          std::memcpy(ck + j * check_cols, tx + j * 4, 4 * sizeof(float));
+          if (check_cols == 5) ck[j * 5 + 4] = (float)tl[j];
+        }
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+  work(0);
+  for (auto &th : pool) th.join();
+  for (int t = 0; t < threads; ++t)
+    if (bad[t]) return r3d::fail(R3D_E_ARG, "host_merge_frames: a merged cloud exceeds out_cap");
+  return R3D_OK;
+}
+
 }  // extern "C"

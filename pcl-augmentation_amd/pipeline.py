@@ -131,10 +131,16 @@ class AugmentPipeline:
         finally:
             self.process = saved
 
-    def run_streamed(self, frames, inserts_for, lanes=3, label_2_for=None, pack_threads=16):
+    def run_streamed(self, frames, inserts_for, lanes=3, label_2_for=None, pack_threads=16, io_threads=16, delta=True):
         """Like ``run`` for ONE placement per insert: inserts_for(i) -> (samples, min_points) with
         samples[k] = M x 5 float64 (or None).  Batches go through ``StreamedAugmenter`` lanes: pinned
-        buffers, native packing, upload / kernels / download of consecutive batches overlapped."""
+        buffers, native packing, upload / kernels / download of consecutive batches overlapped; only the delta
+        of a batch comes back from the device, the merged clouds are put together on the host.
+
+        ``io_threads`` threads read the frames of the next batches ahead of the GPU (a reader thread keeps two
+        batches in flight) and write the files of a finished batch straight from the lane's buffers -- the lane
+        is handed back when its files are on disk, the other lanes keep the GPU busy meanwhile."""
+        from concurrent.futures import ThreadPoolExecutor
         from .streaming import StreamedAugmenter
         todo = [i for i, f in enumerate(frames)
                 if not (self.resume and _outputs_exist(self.output_path, self.folder, f.name, self.write_labels))]
@@ -142,75 +148,96 @@ class AugmentPipeline:
         t_start = time.perf_counter()
         B = self.batch_size
         chunks = [todo[i:i + B] for i in range(0, len(todo), B)]
-        read_q, write_q, errors = queue.Queue(maxsize=2), queue.Queue(maxsize=4), []
+        read_q, errors, stop = queue.Queue(maxsize=2), [], threading.Event()
+        pool = ThreadPoolExecutor(max_workers=max(1, int(io_threads)))
+
+        def read_one(i):
+            return read_frame(frames[i].velodyne_file, frames[i].label_file)[:2], inserts_for(i)
 
         def reader():
             try:
                 for chunk in chunks:
-                    scenes = [read_frame(frames[i].velodyne_file, frames[i].label_file)[:2] for i in chunk]
-                    ins = [inserts_for(i) for i in chunk]
-                    read_q.put((chunk, scenes, ins))
+                    got = list(pool.map(read_one, chunk))
+                    got += [got[-1]] * (B - len(chunk))             # the last batch: repeat its last frame, drop the copies
+                    item = (chunk, [g[0] for g in got], [g[1] for g in got])
+                    while not stop.is_set():                       # do not block for ever on a consumer that has failed
+                        try:
+                            read_q.put(item, timeout=0.5)
+                            break
+                        except queue.Full:
+                            pass
+                    if stop.is_set():
+                        return
             except Exception as e:
                 errors.append(e)
             finally:
-                read_q.put(None)
+                while not stop.is_set():
+                    try:
+                        read_q.put(None, timeout=0.5)
+                        break
+                    except queue.Full:
+                        pass
 
-        def writer():
-            try:
-                while True:
-                    item = write_q.get()
-                    if item is None:
-                        return
-                    chunk, results, accepted = item
-                    for i, (xyzi, label, check), acc in zip(chunk, results, accepted):
-                        write_frame(self.output_path, self.folder, frames[i].name, xyzi, label, check, self.write_labels,
-                                    label_2=label_2_for(i, acc) if label_2_for else None)
-                        stats["written"] += 1
-                        stats["inserted"] += sum(1 for a in acc if a >= 0)
-            except Exception as e:
-                errors.append(e)
+        rt = threading.Thread(target=reader, daemon=True)
+        rt.start()
 
-        threads = [threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)]
-        for t in threads:
-            t.start()
-        aug, caps = None, (0, 0, 0, 0)
+        def write_one(args):
+            i, (xyzi, label, check), acc = args
+            write_frame(self.output_path, self.folder, frames[i].name, xyzi, label, check, self.write_labels,
+                        label_2=label_2_for(i, acc) if label_2_for else None)
+            return sum(1 for a in acc if a >= 0)
 
         def consume(tag, results, accepted):
             chunk = tag
-            # the views die with the lane's next submit: the writer gets copies of the live rows
-            write_q.put((chunk, [(x.copy(), l.copy(), c.copy()) for x, l, c in results[:len(chunk)]], accepted[:len(chunk)]))
+            # straight from the lane's buffers: the lane is not submitted again before these writes are done
+            for n_ins in pool.map(write_one, zip(chunk, results[:len(chunk)], accepted[:len(chunk)])):
+                stats["written"] += 1
+                stats["inserted"] += n_ins
 
-        order = []
-        while not errors:
-            item = read_q.get()
-            if item is None:
-                break
+        def shape_of(item):
             chunk, scenes, ins = item
-            pad = B - len(chunk)                                   # the last batch: repeat its last frame, drop the copies
-            scenes, ins = scenes + [scenes[-1]] * pad, ins + [ins[-1]] * pad
             K = max(len(x[0]) for x in ins)
             n_max = max(len(x) for x, _ in scenes)
             grow = max(sum(len(s) for s in x[0] if s is not None) for x in ins)
-            srows = max(sum(len(x[0][k]) for x in ins if k < len(x[0]) and x[0][k] is not None) for k in range(K))
-            if aug is None or K != caps[0] or n_max > caps[1] or grow > caps[2] or srows > caps[3]:
-                for lane in order:
-                    consume(*aug.collect(lane))
-                order = []
-                caps = (K, max(n_max, caps[1]), int(max(grow, caps[2]) * 1.25) + 64, int(max(srows, caps[3]) * 1.25) + 64)
-                aug = StreamedAugmenter(B, caps[1], caps[2], K, caps[3], lanes=lanes, device=self.device,
+            srows = max((sum(len(x[0][k]) for x in ins if k < len(x[0]) and x[0][k] is not None) for k in range(K)), default=0)
+            return K, n_max, grow, srows
+
+        pending, caps, done = [None], (0, 0, 0, 0), [False]
+
+        def segment():
+            """Batches for the current lanes; stops (leaving the batch in `pending`) at one that needs larger lanes."""
+            while not errors:
+                item = pending[0] if pending[0] is not None else read_q.get()
+                pending[0] = None
+                if item is None:
+                    done[0] = True
+                    return
+                K, n_max, grow, srows = shape_of(item)
+                if K > caps[0] or n_max > caps[1] or grow > caps[2] or srows > caps[3]:
+                    pending[0] = item
+                    return
+                chunk, scenes, ins = item
+                yield scenes, [x[0] for x in ins], [x[1] for x in ins], chunk
+
+        try:
+            aug = None
+            while not done[0] and not errors:
+                if pending[0] is None:
+                    pending[0] = read_q.get()
+                    if pending[0] is None:
+                        break
+                K, n_max, grow, srows = shape_of(pending[0])       # (larger) lanes with 25 % headroom
+                caps = (max(K, caps[0]), max(int(n_max * 1.25) + 64, caps[1]), max(int(grow * 1.25) + 64, caps[2]),
+                        max(int(srows * 1.25) + 64, caps[3]))
+                aug = None                                         # free the old lanes first
+                aug = StreamedAugmenter(B, caps[1], caps[2], caps[0], caps[3], lanes=lanes, device=self.device,
                                         check_cols=self.check_cols, collapse_keep=-1 if self.road_label is None else self.road_label,
-                                        pack_threads=pack_threads)
-            lane = aug.free_lane()
-            if lane is None:
-                lane = order.pop(0)
-                consume(*aug.collect(lane))
-            aug.submit(lane, scenes, [x[0] for x in ins], [x[1] for x in ins], tag=chunk)
-            order.append(lane)
-        for lane in order:
-            if not errors:
-                consume(*aug.collect(lane))
-        write_q.put(None)
-        threads[1].join(timeout=120)
+                                        pack_threads=pack_threads, delta=delta)
+                aug.run(segment(), consume)
+        finally:
+            stop.set()
+            rt.join(timeout=30)
+            pool.shutdown(wait=True)
         if errors:
             raise errors[0]
         stats["t_total"] = time.perf_counter() - t_start

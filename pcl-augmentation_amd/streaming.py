@@ -1,13 +1,19 @@
 """Frames streamed through the batched hot path with the transfers overlapped.
 
 ``StreamedAugmenter`` keeps a few *lanes*.  A lane is one ``SceneBatch`` on the device plus pinned
-host buffers for everything that crosses the PCIe link (frames in, insert samples in, merged clouds /
-labels / check rows / counters out) and its own HIP stream.  ``submit`` packs a batch of frames into
-the lane's pinned input (the native packer ``r3d_host_pack_frames``: threads, no Python loop over
-points), then enqueues, on the lane's stream, upload -> ``begin`` -> ``insert_many`` -> ``finish`` ->
-download, and returns at once; ``collect`` waits for the lane's event and hands out views of its pinned
-outputs.  With two or more lanes in flight the upload of batch i+1 and the download of batch i-1 run
-on the copy engines while the kernels of batch i run on the CUs, and the host packs meanwhile.
+host buffers for everything that crosses the PCIe link and its own HIP stream.  ``submit`` packs a batch
+of frames into the lane's pinned input (the native packer ``r3d_host_pack_frames``: threads, no Python loop
+over points), then enqueues, on the lane's stream, upload -> ``begin`` -> ``insert_many`` -> export of the
+DELTA -> download, and returns at once; ``collect`` waits for the lane's event, merges on the host and hands
+out views of the lane's output buffers.  With two or more lanes in flight the upload of batch i+1 and the
+download of batch i-1 run on the copy engines while the kernels of batch i run on the CUs, and the host packs
+and merges meanwhile.
+
+What comes back from the device is the delta, not the merged cloud (99.4 % of which is the frame the host
+still holds in the lane's pinned input): one alive bit per point, the inserted points, four counters per
+frame -- 0.1 MB per frame instead of 2.5 MB.  ``r3d_host_merge_frames`` (C++ threads) writes the merged cloud,
+the labels and the check rows from that: the bytes of ``velodyne/ labels/ check/`` (SS tools/datasets.py:72-91).
+``delta=False`` keeps the round-2 behaviour (``r3d_batch_finish`` on the device, whole clouds downloaded).
 
 One placement candidate per insert slot (what ``r3d_batch_insert_many`` takes); the candidate loop
 with several placements per slot stays with ``AugmentPipeline.run`` / ``run_placed``.
@@ -23,41 +29,61 @@ from .batch import SceneBatch
 
 
 class _Lane:
-    def __init__(self, B, cap, log_cap, K, sample_rows, rows, cols, device, check_cols):
+    def __init__(self, B, cap, log_cap, K, sample_rows, rows, cols, device, check_cols, delta):
         torch = _lib.require_gpu()
         self.torch = torch
         self.bt = SceneBatch(B, cap, log_cap, rows=rows, cols=cols, device=device)
         self.B, self.K, self.check_cols = B, K, check_cols
         cap, log_cap = self.bt.cap, self.bt.log_cap
+        self.chunks = (cap + 63) // 64
         with _lib.on(device):
             self.stream = torch.cuda.Stream()
+            self.copy_streams = [torch.cuda.Stream() for _ in range(4)]
             self.done = torch.cuda.Event()
             pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
             self.in_xyzi, self.in_label, self.in_n = pin((B, cap, 4), torch.float32), pin((B, cap), torch.int32), pin((B,), torch.int32)
             self.in_rows = [pin((sample_rows, 5), torch.float64) for _ in range(K)]
-            self.in_off = pin((K, B + 1), torch.int64)
-            self.in_need = pin((K, B), torch.int32)
+            self.in_off = pin((max(K, 1), B + 1), torch.int64)
+            self.in_need = pin((max(K, 1), B), torch.int32)
             self.d_rows = [torch.empty((sample_rows, 5), dtype=torch.float64, device=device) for _ in range(K)]
-            self.d_off = torch.zeros((K, B + 1), dtype=torch.int64, device=device)
-            self.d_need = torch.zeros((K, B), dtype=torch.int32, device=device)
-            self.out_xyzi, self.out_label = pin((B, cap, 4), torch.float32), pin((B, cap), torch.int32)
-            self.out_check = pin((B, log_cap, check_cols), torch.float32)
+            self.d_off = torch.zeros((max(K, 1), B + 1), dtype=torch.int64, device=device)
+            self.d_need = torch.zeros((max(K, 1), B), dtype=torch.int32, device=device)
             self.out_counts = pin((4, B), torch.int32)                  # n_out, n_log, status, rebases
-            self.out_acc = pin((K, B), torch.int32)
+            self.out_acc = pin((max(K, 1), B), torch.int32)
+            if delta:
+                # the delta on the device and in pinned memory; the merged results in plain host memory
+                self.d_alive = torch.zeros((B, self.chunks), dtype=torch.int64, device=device)
+                self.d_tail_xyzi = torch.zeros((B, log_cap, 4), dtype=torch.float32, device=device)
+                self.d_tail_label = torch.zeros((B, log_cap), dtype=torch.int32, device=device)
+                self.d_dcounts = torch.zeros((2, B), dtype=torch.int32, device=device)
+                self.h_alive, self.h_tail_xyzi = pin((B, self.chunks), torch.int64), pin((B, log_cap, 4), torch.float32)
+                self.h_tail_label, self.h_dcounts = pin((B, log_cap), torch.int32), pin((2, B), torch.int32)
+                self.out_xyzi = torch.empty((B, cap, 4), dtype=torch.float32)
+                self.out_label = torch.empty((B, cap), dtype=torch.int32)
+                self.out_check = torch.empty((B, log_cap, max(check_cols, 4)), dtype=torch.float32)
+                self.h_n_out = torch.zeros((B,), dtype=torch.int32)
+            else:
+                self.out_xyzi, self.out_label = pin((B, cap, 4), torch.float32), pin((B, cap), torch.int32)
+                self.out_check = pin((B, log_cap, max(check_cols, 4)), torch.float32)
+            # the batch was built on the device's current stream: this lane's stream starts behind it
+            self.stream.wait_stream(torch.cuda.current_stream())
         self.busy = False
         self.tag = None
 
 
 class StreamedAugmenter:
     def __init__(self, B, n_max, grow, n_slots, sample_rows, lanes=3, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN,
-                 device="cuda:0", check_cols=5, collapse_keep=-1, pack_threads=16):
+                 device="cuda:0", check_cols=5, collapse_keep=-1, pack_threads=16, delta=True):
         """B frames per batch, at most n_max points per frame, `grow` inserted points per frame in all
         (sum over the slots), n_slots insert slots, at most sample_rows sample points per slot and batch."""
         self.lib = _lib.load()
         self.B, self.K = int(B), int(n_slots)
-        self.collapse_keep, self.pack_threads = int(collapse_keep), int(pack_threads)
-        self.lanes = [_Lane(B, n_max + grow, max(grow, 1), n_slots, sample_rows, rows, cols, device, check_cols)
-                      for _ in range(lanes)]
+        self.collapse_keep, self.pack_threads, self.delta = int(collapse_keep), int(pack_threads), bool(delta)
+        self.check_cols = int(check_cols)
+        import os
+        self.copy_streams = max(1, min(4, int(os.environ.get("R3D_COPY_STREAMS", "1"))))
+        self.lanes = [_Lane(B, n_max + grow, max(grow, 1), self.K, max(int(sample_rows), 1), rows, cols, device, self.check_cols,
+                            self.delta) for _ in range(lanes)]
         self.device = device
         self.bytes_h2d = self.bytes_d2h = 0
 
@@ -69,8 +95,8 @@ class StreamedAugmenter:
 
     def submit(self, lane_no, scenes, inserts, min_points, tag=None):
         """scenes: B x (xyzi float32 [n,4], label uint32 [n]) host arrays as read from the files;
-        inserts[s][k]: M x 5 float64 sample of slot k of frame s (or None); min_points[s][k].
-        Returns immediately; the lane is busy until ``collect``."""
+        inserts[s][k]: M x 5 float64 sample of slot k of frame s (or None; a frame may have fewer than n_slots
+        inserts); min_points[s][k].  Returns immediately; the lane is busy until ``collect``."""
         ln = self.lanes[lane_no]
         assert not ln.busy and len(scenes) == self.B
         torch, bt, B, K = ln.torch, ln.bt, self.B, self.K
@@ -85,7 +111,6 @@ class StreamedAugmenter:
         ln.in_n.numpy()[:] = n
         off = ln.in_off.numpy()
         need = ln.in_need.numpy()
-        used = 0
         for k in range(K):
             rows = ln.in_rows[k].numpy()
             pos = 0
@@ -97,11 +122,27 @@ class StreamedAugmenter:
                     pos += len(smp)
                 off[k, s + 1] = pos
                 need[k, s] = min_points[s][k] if k < len(min_points[s]) else 0
-            used = max(used, pos)
         # -- everything else on the lane's stream: upload, kernels, download
         with _lib.on(self.device), torch.cuda.stream(ln.stream):
-            bt.xyzi.copy_(ln.in_xyzi, non_blocking=True)         # whole slabs: one contiguous copy each
-            bt.label.copy_(ln.in_label, non_blocking=True)
+            if self.copy_streams > 1:
+                # the frames in pieces on several streams: one hipMemcpyAsync keeps ONE copy engine busy
+                # (~36 GB/s on this box), pieces on several streams are taken by several engines
+                ev = torch.cuda.Event()
+                ev.record(ln.stream)
+                n_piece = self.copy_streams
+                step = (B + n_piece - 1) // n_piece
+                for j, cs in enumerate(ln.copy_streams[:n_piece]):
+                    lo, hi = j * step, min(B, (j + 1) * step)
+                    if lo >= hi:
+                        continue
+                    cs.wait_event(ev)
+                    with torch.cuda.stream(cs):
+                        bt.xyzi[lo:hi].copy_(ln.in_xyzi[lo:hi], non_blocking=True)
+                        bt.label[lo:hi].copy_(ln.in_label[lo:hi], non_blocking=True)
+                    ln.stream.wait_stream(cs)
+            else:
+                bt.xyzi.copy_(ln.in_xyzi, non_blocking=True)     # whole slabs: one contiguous copy each
+                bt.label.copy_(ln.in_label, non_blocking=True)
             bt.n_points.copy_(ln.in_n, non_blocking=True)
             for k in range(K):
                 m = int(off[k, B])
@@ -112,24 +153,36 @@ class StreamedAugmenter:
             ln.d_need.copy_(ln.in_need, non_blocking=True)
             self.bytes_h2d += B * bt.cap * 20
             bt.begin()
-            _, acc = bt.insert_many_device([(ln.d_rows[k], ln.d_off[k]) for k in range(K)], [ln.d_need[k] for k in range(K)])
-            bt.finish(ln.check_cols)
-            ln.out_xyzi.copy_(bt.out_xyzi, non_blocking=True)
-            ln.out_label.copy_(bt.out_label, non_blocking=True)
-            ln.out_check.copy_(bt.check, non_blocking=True)
-            ln.out_counts[0].copy_(bt.n_out, non_blocking=True)
+            if K:
+                _, acc = bt.insert_many_device([(ln.d_rows[k], ln.d_off[k]) for k in range(K)], [ln.d_need[k] for k in range(K)])
+                ln.out_acc.copy_(acc, non_blocking=True)
+            if self.delta:
+                _lib.check(self.lib.r3d_batch_export_delta(C.byref(bt.desc), ln.d_alive.data_ptr(), ln.d_tail_xyzi.data_ptr(),
+                                                           ln.d_tail_label.data_ptr(), bt.log_cap, ln.d_dcounts.data_ptr(),
+                                                           _lib.stream_ptr()), "r3d_batch_export_delta")
+                ln.h_alive.copy_(ln.d_alive, non_blocking=True)
+                ln.h_tail_xyzi.copy_(ln.d_tail_xyzi, non_blocking=True)
+                ln.h_tail_label.copy_(ln.d_tail_label, non_blocking=True)
+                ln.h_dcounts.copy_(ln.d_dcounts, non_blocking=True)
+                self.bytes_d2h += ln.h_alive.numel() * 8 + ln.h_tail_xyzi.numel() * 4 + ln.h_tail_label.numel() * 4
+            else:
+                bt.finish(ln.check_cols)
+                ln.out_xyzi.copy_(bt.out_xyzi, non_blocking=True)
+                ln.out_label.copy_(bt.out_label, non_blocking=True)
+                if bt.check is not None:
+                    ln.out_check[:, :, :ln.check_cols].copy_(bt.check, non_blocking=True)
+                ln.out_counts[0].copy_(bt.n_out, non_blocking=True)
+                self.bytes_d2h += B * bt.cap * 20 + ln.out_check.numel() * 4
             ln.out_counts[1].copy_(bt.n_log, non_blocking=True)
             ln.out_counts[2].copy_(bt.status, non_blocking=True)
             ln.out_counts[3].copy_(bt.rebase, non_blocking=True)
-            ln.out_acc.copy_(acc, non_blocking=True)
-            self.bytes_d2h += B * bt.cap * 20 + ln.out_check.numel() * 4
             ln.done.record(ln.stream)
         ln.busy, ln.tag = True, tag
         return lane_no
 
     def collect(self, lane_no):
         """Wait for the lane; (tag, results, accepted): results[s] = (xyzi [n,4] float32, label [n] uint32,
-        check [m,cols] float32) as VIEWS of the lane's pinned buffers (valid until the lane's next submit),
+        check [m,cols] float32) as VIEWS of the lane's buffers (valid until the lane's next submit),
         accepted[s][k] = 0 (accepted) or -1."""
         ln = self.lanes[lane_no]
         assert ln.busy
@@ -138,23 +191,66 @@ class StreamedAugmenter:
         for s in np.nonzero(counts[2])[0]:
             ln.busy = False
             _lib.raise_status(int(counts[2][s]), f"scene {s}")
+        cc = max(ln.check_cols, 4)
+        if self.delta:
+            bt = ln.bt
+            _lib.check(self.lib.r3d_host_merge_frames(
+                ln.in_xyzi.data_ptr(), ln.in_label.data_ptr(), bt.cap, ln.h_alive.data_ptr(), ln.chunks, ln.h_tail_xyzi.data_ptr(),
+                ln.h_tail_label.data_ptr(), bt.log_cap, ln.h_dcounts.data_ptr(), self.B, ln.out_xyzi.data_ptr(),
+                ln.out_label.data_ptr(), bt.cap, ln.h_n_out.data_ptr(), ln.out_check.data_ptr() if ln.check_cols else None,
+                bt.log_cap, cc, self.pack_threads), "r3d_host_merge_frames")
+            n_out = ln.h_n_out.numpy()
+        else:
+            n_out = counts[0]
         ox, ol, ck = ln.out_xyzi.numpy(), ln.out_label.numpy().view(np.uint32), ln.out_check.numpy()
         acc = ln.out_acc.numpy()
-        results = [(ox[s, :counts[0][s]], ol[s, :counts[0][s]], ck[s, :counts[1][s]]) for s in range(self.B)]
+        results = [(ox[s, :n_out[s]], ol[s, :n_out[s]], ck[s, :counts[1][s], :ln.check_cols] if ln.check_cols else None)
+                   for s in range(self.B)]
         accepted = [[0 if acc[k, s] else -1 for k in range(self.K)] for s in range(self.B)]
         ln.busy = False
         return ln.tag, results, accepted
 
     def run(self, batches, consume):
         """batches: iterable of (scenes, inserts, min_points, tag); consume(tag, results, accepted) is
-        called in submission order while later batches are in flight."""
-        order = []
-        for scenes, inserts, min_points, tag in batches:
-            lane = self.free_lane()
-            if lane is None:
-                lane = order.pop(0)
-                consume(*self.collect(lane))
-            self.submit(lane, scenes, inserts, min_points, tag)
-            order.append(lane)
-        for lane in order:
-            consume(*self.collect(lane))
+        called in submission order while later batches are in flight.  This thread packs and submits; a second
+        one waits for the lanes in order, merges (delta mode) and calls ``consume`` -- so the host's packing of
+        batch i+1 and its merging / consuming of batch i-1 overlap as well."""
+        import queue
+        import threading
+        submitted, freed, errors = queue.Queue(), queue.Queue(), []
+
+        def drain():
+            while True:
+                lane = submitted.get()
+                if lane is None:
+                    return
+                try:
+                    if not errors:
+                        consume(*self.collect(lane))
+                except Exception as e:                             # surfaces in the submitting thread
+                    errors.append(e)
+                    self.lanes[lane].busy = False
+                freed.put(lane)
+
+        th = threading.Thread(target=drain, daemon=True)
+        th.start()
+        in_flight = 0
+        try:
+            for scenes, inserts, min_points, tag in batches:
+                if errors:
+                    break
+                lane = self.free_lane() if in_flight < len(self.lanes) else None
+                if lane is None:
+                    freed.get()
+                    in_flight -= 1
+                    if errors:
+                        break
+                    lane = self.free_lane()
+                self.submit(lane, scenes, inserts, min_points, tag)
+                in_flight += 1
+                submitted.put(lane)
+        finally:
+            submitted.put(None)
+            th.join()
+        if errors:
+            raise errors[0]

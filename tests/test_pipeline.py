@@ -117,6 +117,37 @@ def test_streamed_pipeline_on_gpu(pkg, synth, tmp_path):
         st = pipe.run_streamed(fr, inserts_for, lanes=2, label_2_for=label_2_for if od else None)
         assert st["written"] == 7
         _check_outputs(synth, frames, tmp_path / "out", "od" if od else "ss", od)
+        # once more with whole clouds downloaded instead of the delta (delta=False), and frames without any insert
+        import shutil
+        shutil.rmtree(tmp_path / "out" / ("od" if od else "ss"))
+        st = pipe.run_streamed(fr, inserts_for, lanes=2, label_2_for=label_2_for if od else None, delta=False, io_threads=3)
+        assert st["written"] == 7
+        _check_outputs(synth, frames, tmp_path / "out", "od" if od else "ss", od)
         if od:
             txt = (tmp_path / "out" / "od" / "label_2" / "000003.txt").read_text()
             assert txt.startswith("Car 0 0 0") and txt.count("\n") >= 2
+
+
+@pytest.mark.gpu
+def test_streamed_pipeline_without_inserts_and_growing_shapes(pkg, synth, tmp_path):
+    """Batches whose frames have no insert at all (K = 0) come back unchanged; a later batch with more slots and
+    larger frames makes the driver build larger lanes and carry on."""
+    frames = _make_dataset(synth, tmp_path / "in", 6)
+    fr = [pkg.Frame(v, l) for v, l in frames]
+
+    def inserts_for(i):
+        if i < 3:
+            return [], []
+        slots, need = _candidates(synth, i)
+        return [s[0] for s in slots], need
+
+    pipe = pkg.AugmentPipeline(str(tmp_path / "out"), "k0", batch_size=3)
+    st = pipe.run_streamed(fr, inserts_for, lanes=2)
+    assert st["written"] == 6
+    for i in range(3):
+        assert (tmp_path / "out" / "k0" / "velodyne" / f"{i:06d}.bin").read_bytes() == open(frames[i][0], "rb").read()
+        assert (tmp_path / "out" / "k0" / "check" / f"{i:06d}.bin").read_bytes() == b""
+    for i in range(3, 6):
+        exp = _expected(synth, frames, i, False)
+        assert (tmp_path / "out" / "k0" / "velodyne" / f"{i:06d}.bin").read_bytes() == exp[0]
+        assert (tmp_path / "out" / "k0" / "check" / f"{i:06d}.bin").read_bytes() == exp[2]

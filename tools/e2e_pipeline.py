@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def measure(pkg, n_frames=1024, B=256, lanes=3, pack_threads=16):
+def measure(pkg, n_frames=1024, B=256, lanes=3, pack_threads=16, delta=True):
     synth = pkg.synth
     kinds = synth.CONFIG_INSERTS["C2"]
     n_distinct = min(n_frames, B)                     # B distinct frames, cycled: the generator is not what is measured
@@ -34,7 +34,7 @@ def measure(pkg, n_frames=1024, B=256, lanes=3, pack_threads=16):
     srows = max(sum(len(ins[k]) for ins in inserts) for k in range(len(kinds))) * (B // n_distinct + 1)
     from importlib import import_module
     streaming = import_module("pcl-augmentation_amd.streaming")
-    aug = streaming.StreamedAugmenter(B, n_max, grow, len(kinds), srows, lanes=lanes, pack_threads=pack_threads)
+    aug = streaming.StreamedAugmenter(B, n_max, grow, len(kinds), srows, lanes=lanes, pack_threads=pack_threads, delta=delta)
     batch = [scenes[s % n_distinct] for s in range(B)], [inserts[s % n_distinct] for s in range(B)]
     n_batches = max(2, n_frames // B)
     got = {"frames": 0, "points": 0}
@@ -51,13 +51,14 @@ def measure(pkg, n_frames=1024, B=256, lanes=3, pack_threads=16):
     dt = time.perf_counter() - t0
     return {"frames_per_s": round(got["frames"] / dt, 1), "frames": got["frames"], "batch": B, "lanes": lanes,
             "h2d_GBps": round(aug.bytes_h2d / dt / 1e9, 2), "d2h_GBps": round(aug.bytes_d2h / dt / 1e9, 2),
-            "pack_threads": pack_threads,
+            "pack_threads": pack_threads, "delta": delta,
             "what": "config C2 frames (120k points, 5 inserts) resident in host memory -> native packer -> pinned staging -> "
-                    "upload / begin / insert_many / finish / download on three lanes -> merged cloud, labels, check rows in "
-                    "pinned host memory; disk excluded"}
+                    "upload / begin / insert_many / " + ("delta export / download (alive bits + inserted points) -> host merge"
+                                                         if delta else "finish / download of the whole clouds") +
+                    " on three lanes -> merged cloud, labels, check rows in host memory; disk excluded"}
 
 
-def measure_disk(pkg, n_frames=512, B=64):
+def measure_disk(pkg, n_frames=512, B=64, io_threads=16):
     synth = pkg.synth
     kinds = synth.CONFIG_INSERTS["C2"]
     root = tempfile.mkdtemp(prefix="r3d_e2e_")
@@ -71,10 +72,11 @@ def measure_disk(pkg, n_frames=512, B=64):
             frames.append(pkg.Frame(f"{root}/in/velodyne/{i:06d}.bin", f"{root}/in/labels/{i:06d}.label"))
             ins[i] = (synth.make_inserts(i % 64, kinds), [20] * len(kinds))
         pipe = pkg.AugmentPipeline(f"{root}/out", "run", batch_size=B)
-        pipe.run_streamed(frames[:B], lambda i: ins[i])               # warm-up
+        pipe.run_streamed(frames[:B], lambda i: ins[i], io_threads=io_threads)   # warm-up
         shutil.rmtree(f"{root}/out")
-        st = pipe.run_streamed(frames, lambda i: ins[i])
+        st = pipe.run_streamed(frames, lambda i: ins[i], io_threads=io_threads)
         return {"frames_per_s": round(st["frames_per_s"], 1), "frames": st["written"], "batch": B,
+                "io_threads": io_threads,
                 "what": "the same frames as .bin / .label files on local disk, read, processed and written back (velodyne, labels, check)"}
     finally:
         shutil.rmtree(root, ignore_errors=True)
@@ -85,4 +87,5 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     bs = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     print("in memory:", measure(pkg, n, bs))
+    print("in memory, whole clouds downloaded:", measure(pkg, n, bs, delta=False))
     print("disk     :", measure_disk(pkg, min(n, 512), min(bs, 64)))
