@@ -51,6 +51,56 @@ def read_frame(velodyne_file, label_file):
     return xyzi, labels & 0xFFFF, labels >> 16
 
 
+LIDAR_LOCATION = np.array([1.22, 0, 2])               # SS tools/datasets.py:226
+
+
+def read_frame_waymo(lidar_file, label_file=None, pose_file=None):
+    """SS tools/datasets.py:239-270 (Waymo.__getitem__): ``lidar/{f}.npy`` rows of 6 -> x y z intensity, the semantic
+    column of ``labels_v3_2/{f}.npy`` (rows: instance, semantic) appended (float64 by NumPy's promotion, :257), the
+    LiDAR offset subtracted in float64 (:259).  Returns (pcl N x 5 float64, pose @ correction 4 x 4 or None,
+    instances N x 1).  The other two files sit beside the scan (``labels_v3_2/``, ``poses/``) unless given."""
+    parts = lidar_file.split("/")
+    if label_file is None:
+        label_file = "/".join(parts[:-2] + ["labels_v3_2", parts[-1]])
+    if pose_file is None:
+        pose_file = "/".join(parts[:-2] + ["poses", parts[-1]])
+    pcl = np.load(lidar_file).reshape(-1, 6)
+    pcl = pcl[:, :4]
+    semantic_labels = np.load(label_file).reshape(-1, 2)
+    instances = semantic_labels[:, 0].reshape(-1, 1)
+    semantic_labels = semantic_labels[:, 1].reshape(-1, 1)
+    pcl = np.hstack((pcl, semantic_labels))
+    pcl[:, 0:3] -= LIDAR_LOCATION
+    matrix = None
+    if os.path.exists(pose_file):
+        correction_matrix = np.eye(4)
+        correction_matrix[0:3, 3] = LIDAR_LOCATION.T
+        matrix = np.load(pose_file).reshape(4, 4) @ correction_matrix
+    return pcl, matrix, instances
+
+
+def save_arrays_waymo(merged5, added5):
+    """The three arrays Waymo.save_data stores (SS tools/datasets.py:287-301) from N x 5 float64 rows
+    [x y z intensity label]: the offset added back in float64, then the casts."""
+    m, a = np.array(merged5, dtype=np.float64, copy=True), np.array(added5, dtype=np.float64, copy=True).reshape(-1, 5)
+    m[:, 0:3] += LIDAR_LOCATION
+    a[:, 0:3] += LIDAR_LOCATION
+    # (C order whatever the layout of the arrays that came in: np.save records the order in the file's header)
+    return m[:, 0:4].astype(np.float32, order="C"), m[:, 4:5].astype(np.uint32, order="C"), a.astype(np.float32, order="C")
+
+
+def write_frame_waymo(output_path, folder, name, merged5, added5):
+    """``lidar/ labels_v3_2/ check/{name}.npy`` as Waymo.save_data writes them; check/ last (its presence marks the
+    frame as done)."""
+    import io
+    base = os.path.join(output_path, folder)
+    for sub, arr in zip(("lidar", "labels_v3_2", "check"), save_arrays_waymo(merged5, added5)):
+        os.makedirs(os.path.join(base, sub), exist_ok=True)
+        buf = io.BytesIO()
+        np.save(buf, arr)
+        _commit(os.path.join(base, sub, f"{name}.npy"), buf.getvalue())
+
+
 def _commit(path, data):
     """Write bytes (or an array's bytes) to path.tmp, then rename: the file is whole or absent."""
     tmp = path + ".tmp"

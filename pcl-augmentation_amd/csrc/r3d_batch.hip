@@ -348,7 +348,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
     // several tiles so that the tables are staged once.  Points are requested two rounds ahead of their use
     // (indices clamped to the scene: no branch around a load).
     const float4 *__restrict__ src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
-    const unsigned int last = (unsigned int)(n_head > 0 ? n_head - 1 : 0);
+    const unsigned int last = (unsigned int)(n > 0 ? n - 1 : 0);   // (the slab holds the float32 rounding of float64 points)
     auto fetch = [&](int i) {
       unsigned int j = (unsigned int)i < last ? (unsigned int)i : last;
       return src[j];
@@ -381,13 +381,19 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
                  (int)(qf < s_row[row == 0 ? 0 : row + 1].x) & (int)(qf > s_row[row + 2].y) &
                  (int)(fmaf(ea.x, pt.y, -(ea.y * pt.x)) > mcf) & (int)(fmaf(eb.x, pt.y, -(eb.y * pt.x)) < -mcf);
         bool far = false;
+        // A point with genuine float64 coordinates (r3d_batch_begin_f64; an inserted point of a re-projected scene):
+        // the float32 slab gave the guess, the float64 confirmation decides on the exact coordinates from the log
+        // (the float32 screen is a statement about float32-exact inputs).
+        const bool is64 = i >= n_head;
+        if (is64) ok = 0;
         if (!ok | (ssf > 249000.f)) {                        // undecided in float32, or r near / above 500
           double x = (double)pt.x, y = (double)pt.y, z = (double)pt.z;
+          if (is64) load_point(b, s, i, n_head, x, y, z);
           double ss = x * x + y * y + z * z;
           if (!ok) ok = confirm_bin(row_cc, w.col_dir, row, col, x, y, z, ss);
           far = ss > R3D_EMPTY_DEPTH * R3D_EMPTY_DEPTH;      // r > 500 (or rounds to it): far list
         }
-        if (ok & (int)(!exact) & (int)(i < n_head)) {
+        if (ok & (int)(!exact)) {
           int p = row * b.cols + col;
           box.add(row, col);
           placed = true;

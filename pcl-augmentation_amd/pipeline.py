@@ -26,7 +26,7 @@ import time
 
 import numpy as np
 
-from .Real3DAug.tools.datasets import read_frame, write_frame
+from .Real3DAug.tools.datasets import read_frame, read_frame_waymo, write_frame, write_frame_waymo
 
 
 class Frame:
@@ -37,7 +37,9 @@ class Frame:
         self.name = name or os.path.splitext(os.path.basename(velodyne_file))[0]
 
 
-def _outputs_exist(output_path, folder, name, write_labels):
+def _outputs_exist(output_path, folder, name, write_labels, waymo=False):
+    if waymo:
+        return all(os.path.exists(os.path.join(output_path, folder, sub, f"{name}.npy")) for sub in ("lidar", "labels_v3_2", "check"))
     subs = ("velodyne", "check") + (("labels",) if write_labels else ())
     ext = {"velodyne": "bin", "check": "bin", "labels": "label"}
     return all(os.path.exists(os.path.join(output_path, folder, sub, f"{name}.{ext[sub]}")) for sub in subs)
@@ -49,13 +51,16 @@ class AugmentPipeline:
         """dataset: "semantic" (SemanticKITTI: labels written, 5-column check file) or "kitti"
         (object detection: labels collapsed to {Road, 1} before use, OD insertion.py:353-355,
         no label file, 4-column check file)."""
-        assert dataset in ("semantic", "kitti")
+        assert dataset in ("semantic", "kitti", "waymo")
+        # "waymo": frames are lidar/{f}.npy (+ labels_v3_2/, SS tools/datasets.py:239-270), clouds are float64 after the
+        # LiDAR offset is subtracted and go through r3d_batch_begin_f64; outputs are the three .npy files of :287-301
         self.output_path, self.folder, self.dataset = output_path, folder, dataset
         self.batch_size, self.device, self.resume = int(batch_size), device, resume
         self.check_cols = 5 if dataset == "semantic" else 4
         self.write_labels = dataset == "semantic"
         self.road_label = 40 if collapse_labels_to_road is None and dataset == "kitti" else collapse_labels_to_road
-        self.process = process or self._process_hip
+        self.waymo = dataset == "waymo"
+        self.process = process or (self._process_waymo if self.waymo else self._process_hip)
         self._batches = {}
 
     # -- the GPU leg ------------------------------------------------------------------------------
@@ -64,8 +69,25 @@ class AugmentPipeline:
         return augment_batch(scenes, candidates, min_points, device=self.device, check_cols=self.check_cols,
                              reuse=self._batches)
 
+    def _process_waymo(self, scenes5, candidates, min_points):
+        """Float64 frames (N x 5 rows) through ``SceneBatch.begin_f64``; results = (merged N' x 5, added M x 5, None)."""
+        from .batch import SceneBatch
+        B = len(scenes5)
+        grow = max(sum(max((len(x) for x in slot), default=0) for slot in c) for c in candidates)
+        n_max = max(len(x) for x in scenes5)
+        batch = self._batches.get(("waymo", B))
+        if batch is None or batch.cap < n_max + grow or batch.log_cap < n_max + grow:
+            batch = SceneBatch(B, int((n_max + grow) * 1.05) + 64, int((n_max + grow) * 1.05) + 64, device=self.device)
+            self._batches[("waymo", B)] = batch
+        batch.begin_f64(scenes5)
+        accepted = batch.run_inserts(candidates, min_points)
+        batch.raise_on_status()
+        return [(m, a, None) for m, a in batch.results_f64()], accepted
+
     # -- reading / writing -------------------------------------------------------------------------
     def _read(self, frame):
+        if self.waymo:
+            return read_frame_waymo(frame.velodyne_file, frame.label_file)[0]
         xyzi, label, _ = read_frame(frame.velodyne_file, frame.label_file)
         if self.road_label is not None:                       # OD insertion.py:353-355
             label = np.where(label == self.road_label, self.road_label, 1).astype(np.uint32)
@@ -253,7 +275,7 @@ class AugmentPipeline:
         objects) for the object-detection flavour (OD tools/datasets.py:81-84; the lines come from
         ``Real3DAug.insertion.create_annotation_line``); accepted[k] = index of the accepted candidate or -1."""
         todo = [i for i, f in enumerate(frames)
-                if not (self.resume and _outputs_exist(self.output_path, self.folder, f.name, self.write_labels))]
+                if not (self.resume and _outputs_exist(self.output_path, self.folder, f.name, self.write_labels, self.waymo))]
         stats = {"frames": len(frames), "skipped_existing": len(frames) - len(todo), "written": 0,
                  "inserted": 0, "t_read": 0.0, "t_process": 0.0, "t_write": 0.0}
         t_start = time.perf_counter()
@@ -283,8 +305,11 @@ class AugmentPipeline:
                     chunk, results, accepted = item
                     t0 = time.perf_counter()
                     for i, (xyzi, label, check), acc in zip(chunk, results, accepted):
-                        write_frame(self.output_path, self.folder, frames[i].name, xyzi, label, check,
-                                    self.write_labels, label_2=label_2_for(i, acc) if label_2_for else None)
+                        if self.waymo:
+                            write_frame_waymo(self.output_path, self.folder, frames[i].name, xyzi, label)   # merged5, added5
+                        else:
+                            write_frame(self.output_path, self.folder, frames[i].name, xyzi, label, check,
+                                        self.write_labels, label_2=label_2_for(i, acc) if label_2_for else None)
                         stats["written"] += 1
                     stats["t_write"] += time.perf_counter() - t0
             except Exception as e:
