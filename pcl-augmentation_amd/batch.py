@@ -348,6 +348,15 @@ class SceneBatch:
             self._keep = (packed, needs)
             acc_h = acc.cpu().numpy()                                        # the one synchronisation
             bad = int((self.status & _lib.S_CHAIN_TIMEOUT).sum().item())
+            if bad and self.step == k_max:
+                # a slot gave up waiting for its scene's previous slot (the chain kernel leans on the order in which
+                # workgroups are dispatched): do the batch again right here, one launch per slot -- the frames are
+                # still in the slabs, step 0 restores everything the inserts changed
+                self.chain_timeouts = getattr(self, "chain_timeouts", 0) + bad
+                self.begin()
+                accs = [self.insert_device(p[0], p[1], nd)[1].clone() for p, nd in zip(packed, needs)]
+                acc_h = torch.stack(accs).cpu().numpy()
+                bad = int((self.status & _lib.S_CHAIN_TIMEOUT).sum().item())
             if bad:
                 raise _lib.R3DError("r3d_batch_insert_many could not order the slots of a scene on this device "
                                     "(status R3D_S_CHAIN_TIMEOUT); set R3D_NO_CHAIN=1 to insert slot by slot")

@@ -1567,7 +1567,11 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
       if ((b.reserved & kDbgDropPublish) && k == 0 && s == 0 && nk > 1) return;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&w.chain_progress[s], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // k -> k + 1 and nothing else: a successor that gave up has left a negative mark there, which stays (a late
+      // publish must not revive the chain: the later slots would then wait their full time-out one after the other)
+      int expect = k;
+      __hip_atomic_compare_exchange_strong(&w.chain_progress[s], &expect, k + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
     }
   };
   auto outputs = [&](int nv, int acc) {

@@ -729,3 +729,18 @@ def test_c5_full_size_chain(P, synth, monkeypatch):
     vb, lb, cb, oacc = _oracle_chain(xyzi, label, sl, nd)
     assert acc[0] == oacc and sum(1 for a in oacc if a == 0) >= 40
     _check_scene(res[0], vb, lb, cb)
+
+
+def test_chain_timeout_is_recovered_in_process(P, synth):
+    """augment_batch / run_inserts after a chain time-out (diagnostic bit 16: slot 0 of scene 0 never publishes): the
+    batch is done again slot by slot in the same process -- no environment variable, no restart -- and equals the oracle."""
+    scenes = [synth.make_scene(70 + s, 32, 500) for s in range(2)]
+    slots = [[[synth.make_insert(700 + 10 * s + k, "pedestrian", rng_range=(5.0, 15.0))] for k in range(3)] for s in range(2)]
+    need = [[10] * 3] * 2
+    keep = {}
+    res, acc = P.augment_batch(scenes, slots, need, reuse=keep, debug=16)
+    assert keep[2].chain_timeouts >= 1
+    for (xyzi, label), sl, nd, r, a in zip(scenes, slots, need, res, acc):
+        vb, lb, cb, oacc = _oracle_chain(xyzi, label, sl, nd)
+        assert a == oacc
+        _check_scene(r, vb, lb, cb)
