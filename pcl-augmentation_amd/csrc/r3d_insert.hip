@@ -219,7 +219,7 @@ enum { D_EVAL_STORED = 0, D_EVAL_POOL, D_EVAL_SERIAL, D_EVAL_NOFIT, D_CHAIN_STOR
 // A value every lane holds (read from LDS or global memory): into a scalar register.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <int NT>
+template <int NT, bool HITS>
 struct Ins {
   const r3d_batch_t &b;
   const BatchWs &w;
@@ -236,6 +236,7 @@ struct Ins {
   Window win;
   DTile dt;
   int nvalid, ww, nocc, ncand, r1, rec_end;
+  bool planes_pooled;
   uint32_t *s_oob, *s_lp, *s_img, *s_rank;
   uint16_t *s_F, *s_start;
   unsigned long long *s_sdepth;
@@ -369,11 +370,37 @@ struct Ins {
     s_sdepth = reinterpret_cast<unsigned long long *>(smem + carve);
     carve += nocc * 8;
     rec_end = (carve + 15) & ~15;
+    // the three scratch images behind the record -- or, for a window so large that they would leave the scene phase
+    // less than its minimum (a car a few metres from the sensor on a 448 x 2880 image: 5 000 words per image), in
+    // the launch's pool: place_scratch_images() below.  (Only then: the evaluation reads these bits far more often
+    // than the depth tile, which goes to the pool first.)
+    const long long after_sort = 4ll * nocc + 2ll * nvalid + 64;                 // the sample phase's sort scratch
+    const long long after_scene = 2ll * nvalid + 44ll * dt.W + 4 * 1024;           // visible list, one band of the tile, slack
+    planes_pooled = (int64_t)rec_end + 3ll * ww * 4 + (after_sort > after_scene ? after_sort : after_scene) > lds_cap;
     uint32_t *scr = reinterpret_cast<uint32_t *>(smem + rec_end);
     T.w = scr;
     D.w = scr + ww;
     E.w = scr + 2 * ww;
-    r1 = (rec_end + 3 * ww * 4 + 7) & ~7;                   // scratch from here on
+    r1 = planes_pooled ? rec_end : (rec_end + 3 * ww * 4 + 7) & ~7;   // scratch from here on
+  }
+  // kOk, or kNoFit when the pool is exhausted.  Called by the whole workgroup after carve_tail().
+  __device__ __forceinline__ int place_scratch_images() {
+    if (!planes_pooled) return kOk;
+    const long long want = (3ll * ww * 4 + 255) & ~255ll;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long o = atomicAdd(w.pool_head, (unsigned long long)want);
+      H[H_FILL] = o + want <= (unsigned long long)w.pool_bytes ? (int)(o >> 8) : -1;
+    }
+    __syncthreads();
+    const int got = uni(H[H_FILL]);
+    __syncthreads();
+    if (got < 0) return kNoFit;
+    uint32_t *scr = reinterpret_cast<uint32_t *>(w.tile_pool + ((long long)got << 8));
+    T.w = scr;
+    D.w = scr + ww;
+    E.w = scr + 2 * ww;
+    return kOk;
   }
   __device__ __forceinline__ void store_record(unsigned char *dst) const {       // dst: 16-byte aligned, rec_end bytes
     const uint4 *from = reinterpret_cast<const uint4 *>(smem);
@@ -396,7 +423,7 @@ struct Ins {
     compute_window();
     carve_tail(carve_images(carve_head()));
     if ((int64_t)r1 + 64 > lds_cap) return kNoFit;
-    return kOk;
+    return place_scratch_images();
   }
 
   // -- the window of a projected sample (H_RMIN .. H_CMAX1, H_NVALID in the header): candidates lie within 2 rows /
@@ -533,7 +560,7 @@ struct Ins {
 
     // bit images of the sample: occupancy | closed | occupied sample pixels before each window word.  (The three
     // scratch images -- dilations / visible pixels, scene occupancy, scene closed -- follow the sample's record.)
-    if ((int64_t)carve + 6ll * ww * 4 > lds_cap) return kNoFit;
+    if ((int64_t)carve + 3ll * ww * 4 + 64 > lds_cap) return kNoFit;
     carve = carve_images(carve);
     for (int i = tid; i < ww; i += NT) A.w[i] = 0u;
     // every valid sample pixel lies inside the window
@@ -569,6 +596,7 @@ struct Ins {
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(smem + r1);
     uint16_t *s_U = reinterpret_cast<uint16_t *>(smem + r1 + nocc * 4);
     if ((int64_t)r1 + (int64_t)nocc * 4 + (int64_t)nvalid * 2 > lds_cap) return kNoFit;
+    if (place_scratch_images() != kOk) return kNoFit;
     for (int i = tid; i < nocc; i += NT) {
       s_cnt[i] = 0u;
       s_sdepth[i] = R3D_SENT;
@@ -679,7 +707,7 @@ struct Ins {
   // loaded only for the points inside the band.  all_rows_bits: also set the scene occupancy bit of
   // every point of the window (banded tiles: the occupancy of the whole window is needed up front).
   __device__ __forceinline__ void gather(bool all_rows_bits, const uint16_t *sub, int nsub) {
-    constexpr int kPer = 8;
+    constexpr int kPer = HITS ? 4 : 8;                      // (the kernels that keep hits sit on their register budget)
     const int n_head = uni(b.n_head[s]);
     const double q_min = w.q_ext[2 * s + 0], q_max = w.q_ext[2 * s + 1];
     const int32_t *pixs = b.pix + (int64_t)s * b.cap;
@@ -726,7 +754,7 @@ struct Ins {
           // where this lane's hit goes: one LDS atomic per wave (every lane of a wave is in this loop: the listed
           // items come in multiples of 64)
           int hpos = 0;
-          if (g_hits) {
+          if (HITS && g_hits) {
             const unsigned long long hm = __ballot(dl[h + u] >= 0);
             if (hm) {
               const int lead = __ffsll((long long)hm) - 1;
@@ -754,7 +782,7 @@ struct Ins {
             H[H_EXT1] = p[h + u];
             holder |= 0x80000000u;
           }
-          if (g_hits) {
+          if (HITS && g_hits) {
             const unsigned long long key = depth_key(r);
             g_hits[hpos] = make_uint4((uint32_t)p[h + u] | holder, (uint32_t)idx[h + u], (uint32_t)key,
                                                           (uint32_t)(key >> 32));
@@ -878,7 +906,7 @@ struct Ins {
 
     STAMP(6);
     // -- 6. the chunks that can hold a point of the window --------------------------------------------
-    const int c_first = r_hits ? r_n0 >> 6 : 0, p_first = r_hits ? r_n0 : 0;   // replayed hits cover the points below r_n0
+    const int c_first = HITS && r_hits ? r_n0 >> 6 : 0, p_first = HITS && r_hits ? r_n0 : 0;   // replayed hits cover the points below r_n0
     build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, (n_base + 63) >> 6, c_first, p_first);
     __syncthreads();
     nlist = uni(H[H_NLIST]);
@@ -934,7 +962,7 @@ struct Ins {
     g_hits = nullptr;
     hits_off = -1;
     hits_done = false;
-    if (keep_hits && single && !r_hits) {
+    if (HITS && keep_hits && single && !r_hits) {
       const long long want = ((long long)uni(H[H_HITCAP]) * 16 + 255) & ~255ll;
       __syncthreads();
       if (tid == 0) {
@@ -1000,7 +1028,7 @@ struct Ins {
       __syncthreads();
       gather(bits_in_gather, use_sub ? s_sub : nullptr, nsub);
       hits_done = g_hits != nullptr;
-      if (r_hits) replay_hits(bits_in_gather);
+      if (HITS && r_hits) replay_hits(bits_in_gather);
       if (g_dtile) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the minima were formed in L2: drop this CU's copies
       __syncthreads();
 
@@ -1270,7 +1298,7 @@ struct Ins {
       atomicAnd(&alive[c], ~mask);
       atomicSub(&tile_alive[(c << 6) / kTile], __popcll(mask));
     }
-    if (r_hits) {                                           // ... and among the replayed hits (T: the visible pixels)
+    if (HITS && r_hits) {                                   // ... and among the replayed hits (T: the visible pixels)
       for (int h = tid; h < r_nhits; h += NT) {
         const uint4 e = r_hits[h];
         const int p = (int)(e.x & 0x00FFFFFFu);
@@ -1463,8 +1491,8 @@ struct Ins {
 
 
 // The slot's inputs for scene s; false when the slot has nothing to evaluate there.
-template <int NT>
-__device__ __forceinline__ bool load_slot(Ins<NT> &I, const r3d_batch_t &b, const ChainSlots &slots, int k, int s,
+template <class INS>
+__device__ __forceinline__ bool load_slot(INS &I, const r3d_batch_t &b, const ChainSlots &slots, int k, int s,
                                           int first_step) {
   const int64_t off = slots.sample_off[k][s];
   const int64_t m64 = slots.sample_off[k][s + 1] - off;
@@ -1506,7 +1534,7 @@ __device__ __forceinline__ int conflict_with(const BatchWs &w, int s, int j0, in
   return wave_or_i32(out);
 }
 
-template <int NT>
+template <int NT, bool HITS>
 __global__ void __launch_bounds__(NT, NT == 1024 ? 1 : R3D_CHAIN_WAVES)
 k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int chunks, int lds_cap,
                long long timeout_ticks, int B8) {
@@ -1518,7 +1546,7 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
   const int tid = threadIdx.x, slot_no = k;
   (void)slot_no;
   int *H = reinterpret_cast<int *>(smem);
-  Ins<NT> I(b, w, smem, lds_cap, s, chunks, k, k, false);
+  Ins<NT, HITS> I(b, w, smem, lds_cap, s, chunks, k, k, false);
 
   // wait until `want` slots of the scene are done (or the chain is abandoned); ONE lane polls relaxed,
   // then ONE agent-scope acquire; the scalar cache is dropped as well (counters travel through it)
@@ -1597,15 +1625,8 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
     }
   }
   bool waited = p0 >= k;
-  if (!waited && (b.reserved & kDbgSerial)) {
-    p0 = wait_for(k);
-    if (p0 == kProgDeferred) return;
-    if (p0 < 0) {
-      outputs(0, 0);
-      return;
-    }
-    waited = true;
-  }
+  // (diagnostic bit 2: never evaluate ahead of the predecessors -- the sample is prepared, then the pair waits)
+  const bool speculate = !(b.reserved & kDbgSerial);
   int n_base = p0 > 0 ? w.recs[((int64_t)s * kMaxChain + p0 - 1) * kRecInts + REC_NTOTAL]
                       : (k > 0 ? w.n_total0[s] : b.n_total[s]);
   const bool on = load_slot(I, b, slots, k, s, first_step);
@@ -1625,7 +1646,7 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
         // slots remain that can invalidate the evaluation (a big pair that has to evaluate twice is the tail
         // of the launch).  New bounds in between: the sample is projected again.
         if (rc == kOk && !waited) {
-          const int p1 = wait_for(0);
+          const int p1 = wait_for(speculate ? 0 : k);         // not speculating: the sample is ready, now the predecessors
           if (p1 == kProgDeferred) return;
           if (p1 < 0) {
             outputs(0, 0);
@@ -1652,10 +1673,7 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
       I.r_hits = sv_hits;
       I.r_nhits = sv_nhits;
       I.r_n0 = sv_n0;
-      // (kept where evaluating twice is the rule: long chains, large range images; storing them costs the short
-      // chains of config C2 more -- 0.35 against 0.32 ms per launch -- than the 3 % of its pairs that replay gain)
-      I.keep_hits = sv_hits == nullptr && !waited && !(b.reserved & kDbgSerial) &&
-                    (nk >= 8 || (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN);
+      I.keep_hits = HITS && sv_hits == nullptr && !waited && speculate;
       const int n_base_used = n_base;
       if (rc == kOk)
         rc = I.scene_phase(n_base, waited, [&]() -> bool {
@@ -1799,7 +1817,7 @@ k_sample_prep(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w
   if (s >= b.B) return;
   const int tid = threadIdx.x;
   int *H = reinterpret_cast<int *>(smem);
-  Ins<NT> I(b, w, smem, lds_cap, s, chunks, k, k, false);
+  Ins<NT, false> I(b, w, smem, lds_cap, s, chunks, k, k, false);
   const int pid = s * kMaxChain + k;
   PairRec *pr = w.pairs + pid;
   const bool on = load_slot(I, b, slots, k, s, first_step);
@@ -1869,7 +1887,7 @@ k_eval(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int c
   if ((int)blockIdx.x >= w.cls_count[cls]) return;
   const int pid = w.cls_list[(int64_t)cls * b.B * kMaxChain + blockIdx.x];
   const int s = pid / kMaxChain, k = pid % kMaxChain;
-  Ins<NT> I(b, w, smem, lds_cap, s, chunks, k, k, false);
+  Ins<NT, true> I(b, w, smem, lds_cap, s, chunks, k, k, false);
   load_slot(I, b, slots, k, s, first_step);
   PairRec *pr = w.pairs + pid;
   int rc = I.load_record(w.tile_pool + pr->rec_off, pr->rec_bytes);
@@ -1896,7 +1914,7 @@ k_commit_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
   int n_now = uni(w.n_total0[s]);
   int defer = nk;
   for (int k = 0; k < nk; ++k) {
-    Ins<NT> I(b, w, smem, lds_ins, s, chunks, k, kMaxChain, false);
+    Ins<NT, true> I(b, w, smem, lds_ins, s, chunks, k, kMaxChain, false);
     const bool on = load_slot(I, b, slots, k, s, first_step);
     const long long t_slot = wall_clock64();
     int path = 0;
@@ -2013,7 +2031,7 @@ k_insert_big(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w,
   const int tid = threadIdx.x;
   const int k0 = w.defer_from[s];
   for (int k = k0; k < nk; ++k) {
-    Ins<NT> I(b, w, smem, lds_cap, s, chunks, k, kMaxChain, true);
+    Ins<NT, false> I(b, w, smem, lds_cap, s, chunks, k, kMaxChain, true);
     const bool on = load_slot(I, b, slots, k, s, first_step);
     int nv = 0, acc = 0;
     if (on) {
@@ -2041,7 +2059,7 @@ k_insert_big(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w,
   }
 }
 
-__global__ void k_chain_init(r3d_batch_t b, BatchWs w, int nk) {
+__global__ void k_chain_init(r3d_batch_t b, BatchWs w, int nk, int defer0 = -1) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= b.B) return;
   if (s == 0) {
@@ -2050,7 +2068,7 @@ __global__ void k_chain_init(r3d_batch_t b, BatchWs w, int nk) {
   }
   w.chain_progress[s] = 0;
   w.n_total0[s] = b.n_total[s];
-  w.defer_from[s] = nk;
+  w.defer_from[s] = defer0 >= 0 ? defer0 : nk;
 }
 
 constexpr int kSmallNT = 256;
@@ -2076,16 +2094,16 @@ static void chain_shape(const r3d_batch_t &b, int &nt, int &lds) {
   lds = kb * 1024;
 }
 
-template <int NT>
+template <int NT, bool HITS>
 static int launch_chain(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step, int lds,
                         long long timeout_ticks, hipStream_t st) {
   // measured on config C2: scene-major numbering is 10-40 % slower (the big pairs of all scenes no longer start together)
   static const bool scene_major = getenv("R3D_CHAIN_ORDER") && std::string(getenv("R3D_CHAIN_ORDER")) == "scene";
   const int B8 = scene_major ? 0 : (b.B + 7) & ~7;            // a scene's slots on one residue of the block id mod 8
   // per device, every call: the attribute belongs to the current device's copy of the kernel
-  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_chain<NT>),
+  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_chain<NT, HITS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(k_insert_chain<NT>, dim3((B8 ? B8 : b.B) * nk), dim3(NT), lds, st, b, sl, nk, first_step, w, chunks_of(b), lds,
+  hipLaunchKernelGGL((k_insert_chain<NT, HITS>), dim3((B8 ? B8 : b.B) * nk), dim3(NT), lds, st, b, sl, nk, first_step, w, chunks_of(b), lds,
                      timeout_ticks, B8);
   R3D_LAUNCHED("k_insert_chain");
   return R3D_OK;
@@ -2231,10 +2249,24 @@ static int launch_slots_legacy(const r3d_batch_t &b, const BatchWs &w, const Cha
   chain_shape(b, nt, lds);
   R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_big<kBigNT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
-  hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, nk);
-  int rc = nt == 1024  ? launch_chain<1024>(b, w, sl, nk, first_step, lds, (long long)timeout_ms * 100000ll, st)
-           : nt == 512 ? launch_chain<512>(b, w, sl, nk, first_step, lds, (long long)timeout_ms * 100000ll, st)
-                       : launch_chain<kSmallNT>(b, w, sl, nk, first_step, lds, (long long)timeout_ms * 100000ll, st);
+  static const bool scene_loop = getenv("R3D_INSERT_SCENE_LOOP") != nullptr;      // experiment: one workgroup per scene, slot after slot
+  hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, nk, scene_loop ? 0 : -1);
+  int rc = R3D_OK;
+  if (!scene_loop) {
+    // Long chains and large range images evaluate most pairs twice (config C5: 89 %): those launches keep the hits of
+    // the first evaluation and replay them (3.7 -> 2.9 ms per 50 slots of 32 scans).  The short chains of config C2
+    // (3 % evaluated twice) run the kernel without that code: it costs them registers, i.e. spills (0.35 against 0.32 ms).
+    const bool hits = nk >= 8 || (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN;
+    const long long tt = (long long)timeout_ms * 100000ll;
+    if (hits)
+      rc = nt == 1024  ? launch_chain<1024, true>(b, w, sl, nk, first_step, lds, tt, st)
+           : nt == 512 ? launch_chain<512, true>(b, w, sl, nk, first_step, lds, tt, st)
+                       : launch_chain<kSmallNT, true>(b, w, sl, nk, first_step, lds, tt, st);
+    else
+      rc = nt == 1024  ? launch_chain<1024, false>(b, w, sl, nk, first_step, lds, tt, st)
+           : nt == 512 ? launch_chain<512, false>(b, w, sl, nk, first_step, lds, tt, st)
+                       : launch_chain<kSmallNT, false>(b, w, sl, nk, first_step, lds, tt, st);
+  }
   if (rc != R3D_OK) return rc;
   hipLaunchKernelGGL(k_insert_big<kBigNT>, dim3(b.B), dim3(kBigNT), kBigLds, st, b, sl, nk, first_step, w,
                      chunks_of(b), kBigLds);

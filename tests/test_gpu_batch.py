@@ -744,3 +744,20 @@ def test_chain_timeout_is_recovered_in_process(P, synth):
         vb, lb, cb, oacc = _oracle_chain(xyzi, label, sl, nd)
         assert a == oacc
         _check_scene(r, vb, lb, cb)
+
+
+def test_window_larger_than_the_lds_images_on_448x2880(P, synth, monkeypatch):
+    """A car a few metres from the sensor on the 448 x 2880 grid: its window of the range image has ~5 000 words, six
+    bit images of that size do not fit a CU's LDS next to the per-point arrays -- the three scratch images then live
+    in the launch's pool.  (Met by config C5 as soon as a batch holds enough scans: scene 74 of the bench's seeds.)"""
+    monkeypatch.setattr(O, "NUMROW", 448)
+    monkeypatch.setattr(O, "NUMCOLUMN", 2880)
+    xyzi, label = synth.make_scene(502, n_beams=256, n_az=3906)
+    near = synth.make_inserts(74, ["car", "pedestrian", "cyclist", "pedestrian", "cyclist"] * 10)[40]
+    assert np.sqrt((near[:, :3] ** 2).sum(1)).min() < 4.0
+    sl = [[near], [synth.make_insert(5021, "pedestrian", rng_range=(6.0, 9.0))]]
+    nd = [20, 20]
+    res, acc = P.augment_batch([(xyzi, label)], [sl], [nd], rows=448, cols=2880)
+    vb, lb, cb, oacc = _oracle_chain(xyzi, label, sl, nd)
+    assert acc[0] == oacc and oacc[0] == 0
+    _check_scene(res[0], vb, lb, cb)
