@@ -100,11 +100,12 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.defer_from = c.take<int32_t>((size_t)b.B);
   w.recs = c.take<int32_t>((size_t)b.B * kMaxChain * kRecInts);
   w.glist = c.take<unsigned char>((size_t)b.B * (kMaxChain + 1) * chunks_of(b) * 24);
-  // per scene 4 MB or 32 bytes per point of its slab (the hits of up to 32 slots' windows on a large range image),
-  // between 256 MB and 8 GB
-  const int64_t per_scene = (int64_t)b.cap * 32 > (4 << 20) ? (int64_t)b.cap * 32 : (4 << 20);
+  // per scene 4 MB or 96 bytes per point of its slab (on a large range image the hits of up to 32 slots' windows, 16
+  // bytes per scene point inside a window, plus the tiles and scratch images that exceed the LDS), between 256 MB
+  // and 24 GB; an exhausted pool costs time, not results (the evaluations fall back to bands / full re-evaluation)
+  const int64_t per_scene = (int64_t)b.cap * 96 > (4 << 20) ? (int64_t)b.cap * 96 : (4 << 20);
   w.pool_bytes = (int64_t)b.B * per_scene;
-  w.pool_bytes = w.pool_bytes < (256ll << 20) ? (256ll << 20) : (w.pool_bytes > (8ll << 30) ? (8ll << 30) : w.pool_bytes);
+  w.pool_bytes = w.pool_bytes < (256ll << 20) ? (256ll << 20) : (w.pool_bytes > (24ll << 30) ? (24ll << 30) : w.pool_bytes);
   w.tile_pool = c.take<unsigned char>((size_t)w.pool_bytes);
   w.pool_head = c.take<unsigned long long>(1);
   w.pairs = c.take<PairRec>((size_t)b.B * kMaxChain);

@@ -52,6 +52,11 @@
 #ifndef R3D_CHAIN_WAVES
 #define R3D_CHAIN_WAVES 4
 #endif
+// listed points a thread of the gather has in flight at a time.  8 costs the chain kernels 32 - 64 bytes of scratch
+// per lane (they sit on their 128-register budget), 4 none
+#ifndef R3D_GATHER_PER
+#define R3D_GATHER_PER 4
+#endif
 
 namespace r3d {
 
@@ -214,12 +219,14 @@ enum { kOk = 0, kNoFit = 1, kNeedSerial = 2, kStale = 3 };
 enum { kPairIdle = 0, kPairSampled = 1, kPairEvaluated = 2, kPairNoFit = 3 };
 // diagnostic counters (BatchWs::dbg): what k_eval did with its pairs, which way k_commit_chain took per slot
 enum { D_EVAL_STORED = 0, D_EVAL_POOL, D_EVAL_SERIAL, D_EVAL_NOFIT, D_CHAIN_STORED, D_CHAIN_REJECTED, D_CHAIN_CONFLICT,
-       D_CHAIN_UNEVAL, D_DEFER_PREP, D_DEFER_BOUNDS, D_DEFER_NOFIT, D_REBASE, D_PREP_NOFIT };
+       D_CHAIN_UNEVAL, D_DEFER_PREP, D_DEFER_BOUNDS, D_DEFER_NOFIT, D_REBASE, D_PREP_NOFIT, D_POOL_FULL };
 
 // A value every lane holds (read from LDS or global memory): into a scalar register.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <int NT, bool HITS>
+// NT threads; HITS: keeps / replays hits; POOL: the scratch images of a window too large for the LDS may live in the pool
+// (the flavours for large range images: every access to those images is then a flat one, which the others avoid)
+template <int NT, bool HITS, bool POOL>
 struct Ins {
   const r3d_batch_t &b;
   const BatchWs &w;
@@ -376,7 +383,7 @@ struct Ins {
     // than the depth tile, which goes to the pool first.)
     const long long after_sort = 4ll * nocc + 2ll * nvalid + 64;                 // the sample phase's sort scratch
     const long long after_scene = 2ll * nvalid + 44ll * dt.W + 4 * 1024;           // visible list, one band of the tile, slack
-    planes_pooled = (int64_t)rec_end + 3ll * ww * 4 + (after_sort > after_scene ? after_sort : after_scene) > lds_cap;
+    planes_pooled = POOL && (int64_t)rec_end + 3ll * ww * 4 + (after_sort > after_scene ? after_sort : after_scene) > lds_cap;
     uint32_t *scr = reinterpret_cast<uint32_t *>(smem + rec_end);
     T.w = scr;
     D.w = scr + ww;
@@ -385,7 +392,7 @@ struct Ins {
   }
   // kOk, or kNoFit when the pool is exhausted.  Called by the whole workgroup after carve_tail().
   __device__ __forceinline__ int place_scratch_images() {
-    if (!planes_pooled) return kOk;
+    if (!POOL || !planes_pooled) return kOk;
     const long long want = (3ll * ww * 4 + 255) & ~255ll;
     __syncthreads();
     if (tid == 0) {
@@ -686,19 +693,21 @@ struct Ins {
         int left = n_base - (c << 6);                       // points of the chunk below the base count
         unsigned long long a = aw[u];
         if (left < 64) a = left > 0 ? a & ((1ull << left) - 1ull) : 0ull;
-        if (c == c_first && (p_first & 63)) a &= ~((1ull << (p_first & 63)) - 1ull);
+        if (HITS && c == c_first && (p_first & 63)) a &= ~((1ull << (p_first & 63)) - 1ull);
         int rmin = (int)(bx[u] & 0xFFFF), rmax = (int)((bx[u] >> 16) & 0xFFFF);
         int jmin = (int)((bx[u] >> 32) & 0xFFFF) >> 5, jmax = (int)((bx[u] >> 48) & 0xFFFF) >> 5;
         bool hit = a && rmin <= win.r_hi && rmax >= win.r_lo && win.touches_words(jmin, jmax);
         if (hit) {
           int slot = atomicAdd(&H[H_NLIST], 1);
           if (slot < list_cap) set_entry(slot, a, (uint32_t)c, (uint32_t)rmin | ((uint32_t)rmax << 16));
-          hitcap += __popcll(a);
+          if (HITS) hitcap += __popcll(a);
         }
       }
     }
-    hitcap = wave_sum_i32(hitcap);
-    if ((tid & 63) == 0 && hitcap) atomicAdd(&H[H_HITCAP], hitcap);
+    if (HITS) {
+      hitcap = wave_sum_i32(hitcap);
+      if ((tid & 63) == 0 && hitcap) atomicAdd(&H[H_HITCAP], hitcap);
+    }
   }
 
   // The living points of the listed chunks whose pixel lies in rows [bt.r0, bt.r1] of the tile are
@@ -707,7 +716,7 @@ struct Ins {
   // loaded only for the points inside the band.  all_rows_bits: also set the scene occupancy bit of
   // every point of the window (banded tiles: the occupancy of the whole window is needed up front).
   __device__ __forceinline__ void gather(bool all_rows_bits, const uint16_t *sub, int nsub) {
-    constexpr int kPer = HITS ? 4 : 8;                      // (the kernels that keep hits sit on their register budget)
+    constexpr int kPer = NT == 1024 ? 8 : R3D_GATHER_PER;    // (one workgroup per CU: nothing else hides the loads)
     const int n_head = uni(b.n_head[s]);
     const double q_min = w.q_ext[2 * s + 0], q_max = w.q_ext[2 * s + 1];
     const int32_t *pixs = b.pix + (int64_t)s * b.cap;
@@ -776,11 +785,11 @@ struct Ins {
           uint32_t holder = 0u;
           if (fabs(z - q_min * r) <= tol && z / r == q_min) {
             H[H_EXT0] = p[h + u];
-            holder |= 0x40000000u;
+            if (HITS) holder |= 0x40000000u;
           }
           if (fabs(z - q_max * r) <= tol && z / r == q_max) {
             H[H_EXT1] = p[h + u];
-            holder |= 0x80000000u;
+            if (HITS) holder |= 0x80000000u;
           }
           if (HITS && g_hits) {
             const unsigned long long key = depth_key(r);
@@ -939,6 +948,7 @@ struct Ins {
         if (tid == 0) {
           unsigned long long o = atomicAdd(w.pool_head, (unsigned long long)want);
           H[H_FILL] = o + want <= (unsigned long long)w.pool_bytes ? (int)(o >> 8) : -2;
+          if (H[H_FILL] == -2) atomicAdd(&w.dbg[D_POOL_FULL], 1);
         }
         __syncthreads();
         const int got = uni(H[H_FILL]);
@@ -968,6 +978,7 @@ struct Ins {
       if (tid == 0) {
         unsigned long long o = atomicAdd(w.pool_head, (unsigned long long)want);
         H[H_FILL] = o + want <= (unsigned long long)w.pool_bytes ? (int)(o >> 8) : -1;
+        if (H[H_FILL] < 0) atomicAdd(&w.dbg[D_POOL_FULL], 1);
       }
       __syncthreads();
       const int got = uni(H[H_FILL]);
@@ -1534,19 +1545,19 @@ __device__ __forceinline__ int conflict_with(const BatchWs &w, int s, int j0, in
   return wave_or_i32(out);
 }
 
-template <int NT, bool HITS>
-__global__ void __launch_bounds__(NT, NT == 1024 ? 1 : R3D_CHAIN_WAVES)
-k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int chunks, int lds_cap,
-               long long timeout_ticks, int B8) {
-  extern __shared__ __align__(16) unsigned char smem[];     // no static __shared__ here: one LDS array
+// One (slot, scene) pair of the chain kernel.  Returns 1 when the pair does not fit this flavour's LDS and nothing
+// has been done for it yet (the caller may try the POOL flavour), else 0.
+template <int NT, bool HITS, bool POOL>
+__device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots &slots, int nk, int first_step, const BatchWs &w,
+                                          int chunks, int lds_cap, long long timeout_ticks, int B8, unsigned char *smem) {
   // B8 > 0: slot-major numbering (slot k of every scene, then slot k + 1; a scene's slots on one residue of the
   // block id mod 8); B8 == 0: scene-major (the slots of scene 0, then those of scene 1, ...)
   const int k = B8 ? (int)blockIdx.x / B8 : (int)blockIdx.x % nk, s = B8 ? (int)blockIdx.x % B8 : (int)blockIdx.x / nk;
-  if (s >= b.B) return;
+  if (s >= b.B) return 0;
   const int tid = threadIdx.x, slot_no = k;
   (void)slot_no;
   int *H = reinterpret_cast<int *>(smem);
-  Ins<NT, HITS> I(b, w, smem, lds_cap, s, chunks, k, k, false);
+  Ins<NT, HITS, POOL> I(b, w, smem, lds_cap, s, chunks, k, k, false);
 
   // wait until `want` slots of the scene are done (or the chain is abandoned); ONE lane polls relaxed,
   // then ONE agent-scope acquire; the scalar cache is dropped as well (counters travel through it)
@@ -1618,10 +1629,10 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
   int p0 = 0;
   if (k > 0) {
     p0 = wait_for(0);
-    if (p0 == kProgDeferred) return;                      // k_insert_big does this slot
+    if (p0 == kProgDeferred) return 0;                      // k_insert_big does this slot
     if (p0 < 0) {
       outputs(0, 0);
-      return;
+      return 0;
     }
   }
   bool waited = p0 >= k;
@@ -1647,10 +1658,10 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
         // of the launch).  New bounds in between: the sample is projected again.
         if (rc == kOk && !waited) {
           const int p1 = wait_for(speculate ? 0 : k);         // not speculating: the sample is ready, now the predecessors
-          if (p1 == kProgDeferred) return;
+          if (p1 == kProgDeferred) return 0;
           if (p1 < 0) {
             outputs(0, 0);
-            return;
+            return 0;
           }
           if (p1 > p0) {
             bool moved = false;
@@ -1700,10 +1711,10 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
         sv_n0 = n_base_used;
       }
       if (rc == kStale) {
-        if (gone == kProgDeferred) return;
+        if (gone == kProgDeferred) return 0;
         if (gone < 0) {
           outputs(0, 0);
-          return;
+          return 0;
         }
         n_base = w.recs[((int64_t)s * kMaxChain + p0 - 1) * kRecInts + REC_NTOTAL];
         waited = p0 >= k;
@@ -1713,10 +1724,10 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
       if (rc == kNoFit) break;
       if (!waited) {
         int seen = wait_for(k);
-        if (seen == kProgDeferred) return;
+        if (seen == kProgDeferred) return 0;
         if (seen < 0) {
           outputs(0, 0);
-          return;
+          return 0;
         }
         waited = true;
         STAMP(13);
@@ -1739,29 +1750,30 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
     }
   } else if (!waited) {
     int seen = wait_for(k);
-    if (seen == kProgDeferred) return;
+    if (seen == kProgDeferred) return 0;
     if (seen < 0) {
       outputs(0, 0);
-      return;
+      return 0;
     }
     waited = true;
   }
   if (on && rc == kNoFit) {
+    if (!POOL && NT == 1024) return 1;                      // once more with the scratch images in the pool
     // the rest of this scene's chain goes to k_insert_big; the predecessors must be done first, so
     // that nobody overwrites the mark
     if (!waited) {
       int seen = wait_for(k);
-      if (seen == kProgDeferred) return;
+      if (seen == kProgDeferred) return 0;
       if (seen < 0) {
         outputs(0, 0);
-        return;
+        return 0;
       }
     }
     if (tid == 0) {
       w.defer_from[s] = k;
       __hip_atomic_store(&w.chain_progress[s], kProgDeferred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    return;
+    return 0;
   }
   // 2. commit, publish
   const int n_now = count_now();
@@ -1789,6 +1801,20 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
         (long long)attempts | ((long long)(rc == kOk ? 1 : 0) << 8) | ((long long)I.ww << 16) | ((long long)I.nlist << 32) |
         ((long long)(I.dt.npx >> 4) << 48);
 #endif
+  return 0;
+}
+
+// Range images of KITTI's size never need the pool for their scratch images; on large ones a window can exceed the
+// LDS (a car a few metres from the sensor on 448 x 2880).  The POOL flavour reaches those images through flat
+// accesses -- 35 % slower on config C5 when every pair takes it -- so a pair runs it only after the LDS flavour
+// has turned it down.
+template <int NT, bool HITS>
+__global__ void __launch_bounds__(NT, NT == 1024 ? 1 : R3D_CHAIN_WAVES)
+k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int chunks, int lds_cap,
+               long long timeout_ticks, int B8) {
+  extern __shared__ __align__(16) unsigned char smem[];     // no static __shared__ here: one LDS array
+  const int again = chain_pair<NT, HITS, false>(b, slots, nk, first_step, w, chunks, lds_cap, timeout_ticks, B8, smem);
+  if (NT == 1024 && uni(again)) chain_pair<NT, HITS, true>(b, slots, nk, first_step, w, chunks, lds_cap, timeout_ticks, B8, smem);
 }
 
 // ====================================================================================================
@@ -1817,7 +1843,7 @@ k_sample_prep(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w
   if (s >= b.B) return;
   const int tid = threadIdx.x;
   int *H = reinterpret_cast<int *>(smem);
-  Ins<NT, false> I(b, w, smem, lds_cap, s, chunks, k, k, false);
+  Ins<NT, false, NT == 1024> I(b, w, smem, lds_cap, s, chunks, k, k, false);
   const int pid = s * kMaxChain + k;
   PairRec *pr = w.pairs + pid;
   const bool on = load_slot(I, b, slots, k, s, first_step);
@@ -1887,7 +1913,7 @@ k_eval(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int c
   if ((int)blockIdx.x >= w.cls_count[cls]) return;
   const int pid = w.cls_list[(int64_t)cls * b.B * kMaxChain + blockIdx.x];
   const int s = pid / kMaxChain, k = pid % kMaxChain;
-  Ins<NT, true> I(b, w, smem, lds_cap, s, chunks, k, k, false);
+  Ins<NT, true, NT == 1024> I(b, w, smem, lds_cap, s, chunks, k, k, false);
   load_slot(I, b, slots, k, s, first_step);
   PairRec *pr = w.pairs + pid;
   int rc = I.load_record(w.tile_pool + pr->rec_off, pr->rec_bytes);
@@ -1914,7 +1940,7 @@ k_commit_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
   int n_now = uni(w.n_total0[s]);
   int defer = nk;
   for (int k = 0; k < nk; ++k) {
-    Ins<NT, true> I(b, w, smem, lds_ins, s, chunks, k, kMaxChain, false);
+    Ins<NT, true, NT == 1024> I(b, w, smem, lds_ins, s, chunks, k, kMaxChain, false);
     const bool on = load_slot(I, b, slots, k, s, first_step);
     const long long t_slot = wall_clock64();
     int path = 0;
@@ -2031,7 +2057,7 @@ k_insert_big(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w,
   const int tid = threadIdx.x;
   const int k0 = w.defer_from[s];
   for (int k = k0; k < nk; ++k) {
-    Ins<NT, false> I(b, w, smem, lds_cap, s, chunks, k, kMaxChain, true);
+    Ins<NT, false, true> I(b, w, smem, lds_cap, s, chunks, k, kMaxChain, true);
     const bool on = load_slot(I, b, slots, k, s, first_step);
     int nv = 0, acc = 0;
     if (on) {
@@ -2256,7 +2282,8 @@ static int launch_slots_legacy(const r3d_batch_t &b, const BatchWs &w, const Cha
     // Long chains and large range images evaluate most pairs twice (config C5: 89 %): those launches keep the hits of
     // the first evaluation and replay them (3.7 -> 2.9 ms per 50 slots of 32 scans).  The short chains of config C2
     // (3 % evaluated twice) run the kernel without that code: it costs them registers, i.e. spills (0.35 against 0.32 ms).
-    const bool hits = nk >= 8 || (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN;
+    static const int hits_env = env_int("R3D_CHAIN_HITS", -1);
+    const bool hits = hits_env >= 0 ? hits_env != 0 : nk >= 8 || (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN;
     const long long tt = (long long)timeout_ms * 100000ll;
     if (hits)
       rc = nt == 1024  ? launch_chain<1024, true>(b, w, sl, nk, first_step, lds, tt, st)
