@@ -1758,7 +1758,7 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
     waited = true;
   }
   if (on && rc == kNoFit) {
-    if (!POOL && NT == 1024) return 1;                      // once more with the scratch images in the pool
+    if (!POOL) return 1;                                    // once more with the scratch images in the pool
     // the rest of this scene's chain goes to k_insert_big; the predecessors must be done first, so
     // that nobody overwrites the mark
     if (!waited) {
@@ -1814,7 +1814,7 @@ k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs 
                long long timeout_ticks, int B8) {
   extern __shared__ __align__(16) unsigned char smem[];     // no static __shared__ here: one LDS array
   const int again = chain_pair<NT, HITS, false>(b, slots, nk, first_step, w, chunks, lds_cap, timeout_ticks, B8, smem);
-  if (NT == 1024 && uni(again)) chain_pair<NT, HITS, true>(b, slots, nk, first_step, w, chunks, lds_cap, timeout_ticks, B8, smem);
+  if (uni(again)) chain_pair<NT, HITS, true>(b, slots, nk, first_step, w, chunks, lds_cap, timeout_ticks, B8, smem);
 }
 
 // ====================================================================================================
