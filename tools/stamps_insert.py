@@ -56,6 +56,12 @@ for n, (a, z) in zip(names, edges):
     c = ((st[:, :, z] - st[:, :, a]) / 100.0)[once]
     print(f"| {n} | {c.mean():.2f} | {np.percentile(c, 50):.2f} | {np.percentile(c, 95):.2f} | {c.max():.2f} | {100 * c.mean() / tot[once].mean():.1f} % |")
 print(f"| total (pairs evaluated once) | {tot[once].mean():.2f} | {np.percentile(tot[once], 50):.2f} | {np.percentile(tot[once], 95):.2f} | {tot[once].max():.2f} | |")
+print("per slot, mean us of the phases from the chunk list on (chain kernel; pairs evaluated once):")
+for k in range(K):
+    sel = once[k]
+    if sel.any():
+        print(f"  slot {k} ({KINDS[k]}): " + ", ".join(
+            f"{n.split(' ')[0]} {((st[k, :, z] - st[k, :, a]) / 100.0)[sel].mean():.1f}" for n, (a, z) in list(zip(names, edges))[6:]))
 t0 = raw[:, :, 0].min()
 print(f"pairs: {once.sum()} evaluated once, {(attempts == 2).sum()} twice (a predecessor changed their pixels), "
       f"{(attempts == 0).sum()} not at all; {(all_lds == 0).sum()} left to k_insert_big")
