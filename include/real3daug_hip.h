@@ -415,6 +415,19 @@ int r3d_host_merge_frames(const float *in_xyzi, const uint32_t *in_label, int64_
                           int32_t B, float *out_xyzi, uint32_t *out_label, int64_t out_cap, int32_t *n_out, float *check,
                           int64_t check_stride, int32_t check_cols, int32_t threads);
 
+/* HOST: the files of B frames straight into / out of the staging slabs, by `threads` native threads (a Python reader per
+ * file serialises on the interpreter lock).  r3d_host_read_frames = what SemanticKITTI.__getitem__ / KITTI.__getitem__ read
+ * (SS tools/datasets.py:51-56: velodyne/{f}.bin float32 rows of 4, labels/{f}.label uint32) into the layout of
+ * r3d_host_pack_frames (labels masked with 0xFFFF, or collapsed with collapse_keep >= 0; label_paths NULL: labels 0), with
+ * n_points [B] = rows of every file.  r3d_host_write_frames = the files save_data stores (SS :80-89, OD :86-93): float32
+ * rows of 4, uint32 labels (label_paths NULL or a NULL entry: none), check rows; each under "<path>.tmp" first, then
+ * renamed, check last; a NULL velodyne path skips the frame.  Errors (R3D_E_ARG) name the file in r3d_last_error(). */
+int r3d_host_read_frames(const char *const *velodyne_paths, const char *const *label_paths, int32_t B, int64_t cap, float *dst_xyzi,
+                         uint32_t *dst_label, int32_t *n_points, int32_t collapse_keep, int32_t threads);
+int r3d_host_write_frames(const char *const *velodyne_paths, const char *const *label_paths, const char *const *check_paths, int32_t B,
+                          const float *xyzi, const uint32_t *label, int64_t cap, const int32_t *n_out, const float *check,
+                          int64_t check_stride, int32_t check_cols, const int32_t *n_check, int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

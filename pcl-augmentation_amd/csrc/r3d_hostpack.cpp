@@ -1,9 +1,16 @@
 // Host side of the file-to-file pipeline: the packer that lays the frames of
 // a batch out in the pinned staging buffer the way r3d_batch_t wants them on the device.  Plain C++
 // (std::thread), no HIP: the copies into HBM are the caller's (hipMemcpyAsync on its copy streams).
+#include <cerrno>
+#include <cstdio>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "r3d_host.hpp"
 
@@ -106,6 +113,144 @@ int r3d_host_merge_frames(const float *in_xyzi, const uint32_t *in_label, int64_
   for (auto &th : pool) th.join();
   for (int t = 0; t < threads; ++t)
     if (bad[t]) return r3d::fail(R3D_E_ARG, "host_merge_frames: a merged cloud exceeds out_cap");
+  return R3D_OK;
+}
+
+// ---- frames straight between files and the staging slabs (the Python file objects serialise on the interpreter lock:
+// sixteen reader threads deliver fewer frames per second than one) --------------------------------------------------------
+namespace {
+
+bool read_all(int fd, void *dst, size_t bytes) {
+  char *p = static_cast<char *>(dst);
+  while (bytes) {
+    ssize_t got = ::read(fd, p, bytes);
+    if (got < 0 && errno == EINTR) continue;
+    if (got <= 0) return false;
+    p += got;
+    bytes -= (size_t)got;
+  }
+  return true;
+}
+
+bool write_all(int fd, const void *src, size_t bytes) {
+  const char *p = static_cast<const char *>(src);
+  while (bytes) {
+    ssize_t put = ::write(fd, p, bytes);
+    if (put < 0 && errno == EINTR) continue;
+    if (put <= 0) return false;
+    p += put;
+    bytes -= (size_t)put;
+  }
+  return true;
+}
+
+// the file whole or absent: path.tmp, then rename (what Real3DAug/tools/datasets.py:_commit does)
+bool commit_file(const char *path, const void *data, size_t bytes) {
+  std::string tmp = std::string(path) + ".tmp";
+  int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) return false;
+  bool ok = write_all(fd, data, bytes);
+  ok = (::close(fd) == 0) && ok;
+  if (ok) ok = ::rename(tmp.c_str(), path) == 0;
+  return ok;
+}
+
+}  // namespace
+
+// velodyne/{f}.bin (float32 rows of 4) and labels/{f}.label (uint32) of B frames, the way the reference's __getitem__
+// reads them (SS tools/datasets.py:51-56), straight into the staging slabs r3d_host_pack_frames fills: dst_xyzi [B][cap][4],
+// dst_label [B][cap] (masked with 0xFFFF or collapsed, see there), n_points [B].  label_paths may be NULL (all labels 0).
+int r3d_host_read_frames(const char *const *velodyne_paths, const char *const *label_paths, int32_t B, int64_t cap, float *dst_xyzi,
+                         uint32_t *dst_label, int32_t *n_points, int32_t collapse_keep, int32_t threads) {
+  if (!velodyne_paths || !dst_xyzi || !dst_label || !n_points || B <= 0 || cap <= 0)
+    return r3d::fail(R3D_E_ARG, "host_read_frames: null pointer or non-positive shape");
+  if (threads < 1) threads = 1;
+  if (threads > B) threads = B;
+  std::vector<std::string> err(threads);
+  auto work = [&](int t) {
+    for (int s = t; s < B; s += threads) {
+      int fd = ::open(velodyne_paths[s], O_RDONLY);
+      struct stat st;
+      if (fd < 0 || ::fstat(fd, &st) != 0) {
+        err[t] = std::string("host_read_frames: cannot open ") + velodyne_paths[s];
+        if (fd >= 0) ::close(fd);
+        return;
+      }
+      const int64_t n = (int64_t)st.st_size / 16;
+      if ((int64_t)st.st_size % 16 != 0 || n > cap) {
+        err[t] = std::string("host_read_frames: not rows of 4 float32, or more points than the capacity: ") + velodyne_paths[s];
+        ::close(fd);
+        return;
+      }
+      bool ok = read_all(fd, dst_xyzi + (int64_t)s * cap * 4, (size_t)n * 16);
+      ::close(fd);
+      uint32_t *dl = dst_label + (int64_t)s * cap;
+      if (ok && label_paths && label_paths[s]) {
+        int fl = ::open(label_paths[s], O_RDONLY);
+        ok = fl >= 0 && ::fstat(fl, &st) == 0 && (int64_t)st.st_size == n * 4 && read_all(fl, dl, (size_t)n * 4);
+        if (fl >= 0) ::close(fl);
+        if (!ok) {
+          err[t] = std::string("host_read_frames: label file missing or not one uint32 per point: ") + label_paths[s];
+          return;
+        }
+        if (collapse_keep < 0)
+          for (int64_t i = 0; i < n; ++i) dl[i] &= 0xFFFFu;
+        else
+          for (int64_t i = 0; i < n; ++i) dl[i] = (dl[i] & 0xFFFFu) == (uint32_t)collapse_keep ? (uint32_t)collapse_keep : 1u;
+      } else if (ok) {
+        std::memset(dl, 0, (size_t)n * 4);
+      }
+      if (!ok) {
+        err[t] = std::string("host_read_frames: short read: ") + velodyne_paths[s];
+        return;
+      }
+      n_points[s] = (int32_t)n;
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+  work(0);
+  for (auto &th : pool) th.join();
+  for (int t = 0; t < threads; ++t)
+    if (!err[t].empty()) return r3d::fail(R3D_E_ARG, err[t].c_str());
+  return R3D_OK;
+}
+
+// The files save_data stores for B frames (SS tools/datasets.py:80-89; OD :86-93): velodyne_paths[s] <- xyzi [s][0..n_out[s])
+// as float32 rows of 4, label_paths[s] (NULL entries / NULL array: not written) <- label, check_paths[s] <- check
+// [s][0..n_check[s])[check_cols].  Every file under a temporary name first, then renamed; check last.
+int r3d_host_write_frames(const char *const *velodyne_paths, const char *const *label_paths, const char *const *check_paths, int32_t B,
+                          const float *xyzi, const uint32_t *label, int64_t cap, const int32_t *n_out, const float *check,
+                          int64_t check_stride, int32_t check_cols, const int32_t *n_check, int32_t threads) {
+  if (!velodyne_paths || !xyzi || !n_out || B <= 0 || cap <= 0) return r3d::fail(R3D_E_ARG, "host_write_frames: null pointer or shape");
+  if (check_paths && (!check || !n_check || check_cols < 1)) return r3d::fail(R3D_E_ARG, "host_write_frames: check rows missing");
+  if (label_paths && !label) return r3d::fail(R3D_E_ARG, "host_write_frames: labels missing");
+  if (threads < 1) threads = 1;
+  if (threads > B) threads = B;
+  std::vector<std::string> err(threads);
+  auto work = [&](int t) {
+    for (int s = t; s < B; s += threads) {
+      if (!velodyne_paths[s]) continue;                                            // (a padded slot of the last batch)
+      const int64_t n = n_out[s];
+      bool ok = n >= 0 && n <= cap && commit_file(velodyne_paths[s], xyzi + (int64_t)s * cap * 4, (size_t)n * 16);
+      if (ok && label_paths && label_paths[s]) ok = commit_file(label_paths[s], label + (int64_t)s * cap, (size_t)n * 4);
+      if (ok && check_paths && check_paths[s]) {
+        const int64_t m = n_check[s];
+        ok = m >= 0 && m <= check_stride &&
+             commit_file(check_paths[s], check + (int64_t)s * check_stride * check_cols, (size_t)m * check_cols * 4);
+      }
+      if (!ok) {
+        err[t] = std::string("host_write_frames: could not write ") + velodyne_paths[s] + " (" + std::strerror(errno) + ")";
+        return;
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+  work(0);
+  for (auto &th : pool) th.join();
+  for (int t = 0; t < threads; ++t)
+    if (!err[t].empty()) return r3d::fail(R3D_E_ARG, err[t].c_str());
   return R3D_OK;
 }
 

@@ -173,13 +173,19 @@ class AugmentPipeline:
         read_q, errors, stop = queue.Queue(maxsize=2), [], threading.Event()
         pool = ThreadPoolExecutor(max_workers=max(1, int(io_threads)))
 
-        def read_one(i):
-            return read_frame(frames[i].velodyne_file, frames[i].label_file)[:2], inserts_for(i)
+        base = os.path.join(self.output_path, self.folder)
+        for sub in ("velodyne", "check") + (("labels",) if self.write_labels else ()):
+            os.makedirs(os.path.join(base, sub), exist_ok=True)
+
+        def look_one(i):
+            # the frame's size from its file, its inserts from the caller: the points themselves are read by native
+            # threads straight into the lane's pinned input (StreamedAugmenter.submit_files)
+            return os.path.getsize(frames[i].velodyne_file) // 16, inserts_for(i)
 
         def reader():
             try:
                 for chunk in chunks:
-                    got = list(pool.map(read_one, chunk))
+                    got = list(pool.map(look_one, chunk))
                     got += [got[-1]] * (B - len(chunk))             # the last batch: repeat its last frame, drop the copies
                     item = (chunk, [g[0] for g in got], [g[1] for g in got])
                     while not stop.is_set():                       # do not block for ever on a consumer that has failed
@@ -202,24 +208,29 @@ class AugmentPipeline:
 
         rt = threading.Thread(target=reader, daemon=True)
         rt.start()
-
-        def write_one(args):
-            i, (xyzi, label, check), acc = args
-            write_frame(self.output_path, self.folder, frames[i].name, xyzi, label, check, self.write_labels,
-                        label_2=label_2_for(i, acc) if label_2_for else None)
-            return sum(1 for a in acc if a >= 0)
+        aug_box = [None]
 
         def consume(tag, results, accepted):
             chunk = tag
-            # straight from the lane's buffers: the lane is not submitted again before these writes are done
-            for n_ins in pool.map(write_one, zip(chunk, results[:len(chunk)], accepted[:len(chunk)])):
-                stats["written"] += 1
-                stats["inserted"] += n_ins
+            aug = aug_box[0]
+            names = [frames[i].name for i in chunk] + [None] * (B - len(chunk))
+            path = lambda sub, ext: [None if n is None else os.path.join(base, sub, f"{n}.{ext}") for n in names]
+            if label_2_for:                                        # object detection: label_2/{f}.txt first (OD tools/datasets.py:81-84)
+                from .Real3DAug.tools.datasets import create_annotation
+                os.makedirs(os.path.join(base, "label_2"), exist_ok=True)
+                for i, acc in zip(chunk, accepted):
+                    src, lines = label_2_for(i, acc)
+                    create_annotation(src, os.path.join(base, "label_2", f"{frames[i].name}.txt"), lines)
+            # straight from the lane's buffers, by native threads: the lane is not submitted again before this returns
+            aug.write_files(aug.current_lane, path("velodyne", "bin"), path("labels", "label") if self.write_labels else None,
+                            path("check", "bin"))
+            stats["written"] += len(chunk)
+            stats["inserted"] += sum(1 for acc in accepted[:len(chunk)] for a in acc if a >= 0)
 
         def shape_of(item):
-            chunk, scenes, ins = item
+            chunk, sizes, ins = item
             K = max(len(x[0]) for x in ins)
-            n_max = max(len(x) for x, _ in scenes)
+            n_max = max(sizes)
             grow = max(sum(len(s) for s in x[0] if s is not None) for x in ins)
             srows = max((sum(len(x[0][k]) for x in ins if k < len(x[0]) and x[0][k] is not None) for k in range(K)), default=0)
             return K, n_max, grow, srows
@@ -238,8 +249,10 @@ class AugmentPipeline:
                 if K > caps[0] or n_max > caps[1] or grow > caps[2] or srows > caps[3]:
                     pending[0] = item
                     return
-                chunk, scenes, ins = item
-                yield scenes, [x[0] for x in ins], [x[1] for x in ins], chunk
+                chunk, sizes, ins = item
+                fr = [frames[i] for i in chunk] + [frames[chunk[-1]]] * (B - len(chunk))
+                yield (("files", [f.velodyne_file for f in fr], [f.label_file for f in fr]),
+                       [x[0] for x in ins], [x[1] for x in ins], chunk)
 
         try:
             aug = None
@@ -251,10 +264,11 @@ class AugmentPipeline:
                 K, n_max, grow, srows = shape_of(pending[0])       # (larger) lanes with 25 % headroom
                 caps = (max(K, caps[0]), max(int(n_max * 1.25) + 64, caps[1]), max(int(grow * 1.25) + 64, caps[2]),
                         max(int(srows * 1.25) + 64, caps[3]))
-                aug = None                                         # free the old lanes first
-                aug = StreamedAugmenter(B, caps[1], caps[2], caps[0], caps[3], lanes=lanes, device=self.device,
-                                        check_cols=self.check_cols, collapse_keep=-1 if self.road_label is None else self.road_label,
-                                        pack_threads=pack_threads, delta=delta)
+                aug = aug_box[0] = None                            # free the old lanes first
+                aug = aug_box[0] = StreamedAugmenter(B, caps[1], caps[2], caps[0], caps[3], lanes=lanes, device=self.device,
+                                                     check_cols=self.check_cols,
+                                                     collapse_keep=-1 if self.road_label is None else self.road_label,
+                                                     pack_threads=pack_threads, delta=delta)
                 aug.run(segment(), consume)
         finally:
             stop.set()

@@ -109,6 +109,37 @@ class StreamedAugmenter:
         _lib.check(self.lib.r3d_host_pack_frames(px, pl, n.ctypes.data, B, bt.cap, ln.in_xyzi.data_ptr(), ln.in_label.data_ptr(),
                                                  self.collapse_keep, self.pack_threads), "r3d_host_pack_frames")
         ln.in_n.numpy()[:] = n
+        return self._enqueue(lane_no, inserts, min_points, tag)
+
+    def submit_files(self, lane_no, velodyne_files, label_files, inserts, min_points, tag=None):
+        """Like ``submit`` with the frames still in their files (velodyne/{f}.bin, labels/{f}.label; label_files
+        may be None): native threads read them straight into the lane's pinned input (``r3d_host_read_frames``)."""
+        ln = self.lanes[lane_no]
+        assert not ln.busy and len(velodyne_files) == self.B
+        B = self.B
+        enc = lambda paths: (C.c_char_p * B)(*[None if p is None else str(p).encode() for p in paths])
+        pv = enc(velodyne_files)
+        pl = enc(label_files) if label_files is not None else None
+        _lib.check(self.lib.r3d_host_read_frames(pv, pl, B, ln.bt.cap, ln.in_xyzi.data_ptr(), ln.in_label.data_ptr(),
+                                                 ln.in_n.data_ptr(), self.collapse_keep, self.pack_threads), "r3d_host_read_frames")
+        return self._enqueue(lane_no, inserts, min_points, tag)
+
+    def write_files(self, lane_no, velodyne_files, label_files, check_files):
+        """The results of the lane (after ``collect``, before its next submit) into files, by native threads
+        (``r3d_host_write_frames``): lists of B paths, None = skip (label_files / check_files may be None altogether)."""
+        ln = self.lanes[lane_no]
+        B = self.B
+        enc = lambda paths: None if paths is None else (C.c_char_p * B)(*[None if p is None else str(p).encode() for p in paths])
+        n_out = ln.h_n_out if self.delta else ln.out_counts[0]
+        cc = max(ln.check_cols, 4)
+        _lib.check(self.lib.r3d_host_write_frames(
+            enc(velodyne_files), enc(label_files), enc(check_files) if ln.check_cols else None, B, ln.out_xyzi.data_ptr(),
+            ln.out_label.data_ptr(), ln.bt.cap, n_out.data_ptr(), ln.out_check.data_ptr(), ln.bt.log_cap, cc,
+            ln.out_counts[1].data_ptr(), self.pack_threads), "r3d_host_write_frames")
+
+    def _enqueue(self, lane_no, inserts, min_points, tag):
+        ln = self.lanes[lane_no]
+        torch, bt, B, K = ln.torch, ln.bt, self.B, self.K
         off = ln.in_off.numpy()
         need = ln.in_need.numpy()
         for k in range(K):
@@ -226,7 +257,9 @@ class StreamedAugmenter:
                     return
                 try:
                     if not errors:
-                        consume(*self.collect(lane))
+                        got = self.collect(lane)
+                        self.current_lane = lane                   # (consume may hand the lane's buffers to write_files)
+                        consume(*got)
                 except Exception as e:                             # surfaces in the submitting thread
                     errors.append(e)
                     self.lanes[lane].busy = False
@@ -246,7 +279,10 @@ class StreamedAugmenter:
                     if errors:
                         break
                     lane = self.free_lane()
-                self.submit(lane, scenes, inserts, min_points, tag)
+                if isinstance(scenes, tuple) and len(scenes) == 3 and scenes[0] == "files":
+                    self.submit_files(lane, scenes[1], scenes[2], inserts, min_points, tag)
+                else:
+                    self.submit(lane, scenes, inserts, min_points, tag)
                 in_flight += 1
                 submitted.put(lane)
         finally:

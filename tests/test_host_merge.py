@@ -56,3 +56,51 @@ def test_merge_rejects_bad_counts(pkg):
     rc = lib.r3d_host_merge_frames(z.ctypes.data, z.ctypes.data, 256, z.ctypes.data, 4, z.ctypes.data, z.ctypes.data, 4,
                                    counts.ctypes.data, 1, z.ctypes.data, z.ctypes.data, 256, z.ctypes.data, None, 4, 5, 1)
     assert rc == pkg._lib.E_ARG if hasattr(pkg._lib, "E_ARG") else rc < 0
+
+
+def test_native_file_readers_and_writers(pkg, tmp_path):
+    """r3d_host_read_frames / r3d_host_write_frames against NumPy's fromfile / tofile: same arrays in, same bytes out,
+    labels masked or collapsed like the packer's, a missing file named in the error."""
+    lib = pkg._lib.load()
+    rng = np.random.default_rng(8)
+    B, cap = 4, 500
+    ns = [500, 0, 37, 256]
+    vel, lab = [], []
+    for s, n in enumerate(ns):
+        x = rng.random((n, 4), dtype=np.float32)
+        l = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        x.tofile(tmp_path / f"{s}.bin")
+        l.tofile(tmp_path / f"{s}.label")
+        vel.append(x)
+        lab.append(l)
+    enc = lambda names: (C.c_char_p * B)(*[None if n is None else str(tmp_path / n).encode() for n in names])
+    for keep in (-1, 40):
+        dx = np.full((B, cap, 4), -1, np.float32)
+        dl = np.full((B, cap), 7, np.uint32)
+        dn = np.zeros(B, np.int32)
+        rc = lib.r3d_host_read_frames(enc([f"{s}.bin" for s in range(B)]), enc([f"{s}.label" for s in range(B)]), B, cap,
+                                      dx.ctypes.data, dl.ctypes.data, dn.ctypes.data, keep, 3)
+        assert rc == 0, lib.r3d_last_error()
+        assert list(dn) == ns
+        for s, n in enumerate(ns):
+            assert np.array_equal(dx[s, :n], vel[s])
+            exp = lab[s] & 0xFFFF if keep < 0 else np.where((lab[s] & 0xFFFF) == keep, keep, 1)
+            assert np.array_equal(dl[s, :n], exp.astype(np.uint32))
+    rc = lib.r3d_host_read_frames(enc(["0.bin", "nope.bin", "2.bin", "3.bin"]), None, B, cap, dx.ctypes.data, dl.ctypes.data,
+                                  dn.ctypes.data, -1, 2)
+    assert rc < 0 and b"nope.bin" in lib.r3d_last_error()
+    rc = lib.r3d_host_read_frames(enc([f"{s}.bin" for s in range(B)]), None, B, 100, dx.ctypes.data, dl.ctypes.data,
+                                  dn.ctypes.data, -1, 2)
+    assert rc < 0                                               # 500 points do not fit a capacity of 100
+    # writing: frame 1 is skipped (NULL path), no label file for frame 2
+    n_out = np.array([400, 5, 37, 0], np.int32)
+    ck = rng.random((B, 16, 5), dtype=np.float32)
+    n_ck = np.array([16, 0, 3, 0], np.int32)
+    rc = lib.r3d_host_write_frames(enc(["o0.bin", None, "o2.bin", "o3.bin"]), enc(["o0.label", None, None, "o3.label"]),
+                                   enc(["c0.bin", None, "c2.bin", "c3.bin"]), B, dx.ctypes.data, dl.ctypes.data, cap,
+                                   n_out.ctypes.data, ck.ctypes.data, 16, 5, n_ck.ctypes.data, 3)
+    assert rc == 0, lib.r3d_last_error()
+    assert (tmp_path / "o0.bin").read_bytes() == dx[0, :400].tobytes() and (tmp_path / "o0.label").read_bytes() == dl[0, :400].tobytes()
+    assert (tmp_path / "c0.bin").read_bytes() == ck[0, :16].tobytes() and (tmp_path / "c2.bin").read_bytes() == ck[2, :3].tobytes()
+    assert (tmp_path / "o3.bin").read_bytes() == b"" and not (tmp_path / "o2.label").exists() and not (tmp_path / "o1.bin").exists()
+    assert not list(tmp_path.glob("*.tmp"))

@@ -58,10 +58,12 @@ def measure(pkg, n_frames=1024, B=256, lanes=3, pack_threads=16, delta=True):
                     " on three lanes -> merged cloud, labels, check rows in host memory; disk excluded"}
 
 
-def measure_disk(pkg, n_frames=512, B=64, io_threads=16):
+def measure_disk(pkg, n_frames=512, B=64, io_threads=16, where=None):
+    """where: directory for the files (default: the system's temporary directory, i.e. the box's local disk;
+    /dev/shm shows what the software does when the file system is memory)."""
     synth = pkg.synth
     kinds = synth.CONFIG_INSERTS["C2"]
-    root = tempfile.mkdtemp(prefix="r3d_e2e_")
+    root = tempfile.mkdtemp(prefix="r3d_e2e_", dir=where)
     try:
         os.makedirs(f"{root}/in/velodyne"), os.makedirs(f"{root}/in/labels")
         frames, ins = [], {}
@@ -72,12 +74,12 @@ def measure_disk(pkg, n_frames=512, B=64, io_threads=16):
             frames.append(pkg.Frame(f"{root}/in/velodyne/{i:06d}.bin", f"{root}/in/labels/{i:06d}.label"))
             ins[i] = (synth.make_inserts(i % 64, kinds), [20] * len(kinds))
         pipe = pkg.AugmentPipeline(f"{root}/out", "run", batch_size=B)
-        pipe.run_streamed(frames[:B], lambda i: ins[i], io_threads=io_threads)   # warm-up
+        pipe.run_streamed(frames[:B], lambda i: ins[i], io_threads=io_threads, pack_threads=io_threads)   # warm-up
         shutil.rmtree(f"{root}/out")
-        st = pipe.run_streamed(frames, lambda i: ins[i], io_threads=io_threads)
+        st = pipe.run_streamed(frames, lambda i: ins[i], io_threads=io_threads, pack_threads=io_threads)
         return {"frames_per_s": round(st["frames_per_s"], 1), "frames": st["written"], "batch": B,
-                "io_threads": io_threads,
-                "what": "the same frames as .bin / .label files on local disk, read, processed and written back (velodyne, labels, check)"}
+                "io_threads": io_threads, "directory": where or tempfile.gettempdir(),
+                "what": "the same frames as .bin / .label files, read, processed and written back (velodyne, labels, check)"}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
@@ -89,3 +91,5 @@ if __name__ == "__main__":
     print("in memory:", measure(pkg, n, bs))
     print("in memory, whole clouds downloaded:", measure(pkg, n, bs, delta=False))
     print("disk     :", measure_disk(pkg, min(n, 512), min(bs, 64)))
+    if os.path.isdir("/dev/shm"):
+        print("tmpfs    :", measure_disk(pkg, min(n, 2048), 256, where="/dev/shm"))

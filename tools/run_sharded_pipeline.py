@@ -92,10 +92,12 @@ def main():
     tot = torch.tensor([st["written"], st["skipped_existing"], st["inserted"]], dtype=torch.int64)
     if world > 1:
         dist.all_reduce(tot)
-    print(json.dumps({"rank": rank, "world_size": world, "frames": len(frames), "mine": len(st["frame_indices"]),
-                      "written": st["written"], "skipped_existing": st["skipped_existing"],
-                      "frames_per_s": round(st.get("frames_per_s", 0.0), 1),
-                      "all_ranks": {"written": int(tot[0]), "skipped_existing": int(tot[1]), "inserted": int(tot[2])}}), flush=True)
+    line = json.dumps({"rank": rank, "world_size": world, "frames": len(frames), "mine": len(st["frame_indices"]),
+                       "written": st["written"], "skipped_existing": st["skipped_existing"],
+                       "frames_per_s": round(st.get("frames_per_s", 0.0), 1),
+                       "all_ranks": {"written": int(tot[0]), "skipped_existing": int(tot[1]), "inserted": int(tot[2])}})
+    sys.stdout.flush()
+    os.write(1, (line + "\n").encode())                      # one write: the ranks share the launcher's pipe
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
