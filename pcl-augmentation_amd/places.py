@@ -143,6 +143,8 @@ class PlaceBatch:
         torch = _lib.require_gpu()
         self.lib = _lib.load()
         self.device, self.cand_cap = device, int(cand_cap)
+        if isinstance(queries, dict):                       # descriptors already packed (PlacedInserter): no per-query work
+            return self._from_arrays(queries, packed)
         self.nq = nq = len(queries)
         if nq == 0:
             raise ValueError("no queries")
@@ -165,6 +167,34 @@ class PlaceBatch:
         if packed:
             cand_off = self.total * self.cand_cap
         self.d_desc = torch.from_numpy(np.frombuffer(descs, dtype=np.uint8).copy()).to(device)
+        self._outputs(cand_off, max(q["scene"].n_boxes for q in queries), max(q["scene"].scene.shape[0] for q in queries),
+                      max(q["scene"].orig.shape[0] for q in queries), max(s.shape[0] for s in self.samples))
+
+    def _from_arrays(self, a, packed):
+        """a: {"desc": structured array of PlaceQuery records (cand_off / cand_stride / cand_cap filled here), "m": sample sizes,
+        "max_boxes", "max_n_scene", "max_n_orig", "keep": tensors the descriptors point into}; packed layout only."""
+        torch = _lib.require_gpu()
+        assert packed
+        desc, m = a["desc"], np.asarray(a["m"], dtype=np.int64)
+        self.nq = len(desc)
+        if self.nq == 0:
+            raise ValueError("no queries")
+        if (m <= 0).any():
+            raise ValueError("empty sample")
+        self.queries, self.samples, self.packed = None, None, True
+        self.sample_sizes = m
+        self.total = int(m.sum()) * 5
+        offs = np.zeros(self.nq, dtype=np.int64)
+        offs[1:] = np.cumsum(m[:-1] * 5)
+        self.offs = [int(x) for x in offs]
+        desc["cand_cap"], desc["cand_off"], desc["cand_stride"] = self.cand_cap, offs, self.total
+        self._keep = a.get("keep")
+        self.d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(self.device)
+        self._outputs(self.total * self.cand_cap, int(a["max_boxes"]), int(a["max_n_scene"]), int(a["max_n_orig"]), int(m.max()))
+
+    def _outputs(self, cand_off, max_boxes, max_n_scene, max_n_orig, max_m):
+        torch = _lib.require_gpu()
+        device, nq = self.device, self.nq
         rot = _lib.PLACE_ROTATIONS
         self.flags = torch.zeros((nq, rot), dtype=torch.uint8, device=device)
         self.n_possible = torch.zeros(nq, dtype=torch.int32, device=device)
@@ -172,15 +202,13 @@ class PlaceBatch:
         self.anno_out = torch.zeros((nq, rot, 7), dtype=torch.float64, device=device)
         self.cand = torch.empty(max(cand_off, 1), dtype=torch.float64, device=device)
         self.status = torch.zeros(nq, dtype=torch.int32, device=device)
-        self.max_boxes = max(q["scene"].n_boxes for q in queries)
+        self.max_boxes = max_boxes
         self.ws_bytes = self.lib.r3d_places_workspace_bytes(nq, self.max_boxes)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
         radii = search_radii_sq()
         self.n_radii = len(radii)
         self.radii_c = (C.c_double * len(radii))(*radii)
-        self.max_n_scene = max(q["scene"].scene.shape[0] for q in queries)
-        self.max_n_orig = max(q["scene"].orig.shape[0] for q in queries)
-        self.max_m = max(s.shape[0] for s in self.samples)
+        self.max_n_scene, self.max_n_orig, self.max_m = max_n_scene, max_n_orig, max_m
         self.first_cand = 0
 
     @_lib.on_own_device

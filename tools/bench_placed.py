@@ -51,6 +51,19 @@ def main():
         batch.finish()
         res = batch.results()
         t3 = time.perf_counter()
+    if os.environ.get("R3D_PROFILE_SLOT"):                     # where the host time of one slot goes
+        import cProfile, pstats
+        batch.load(scenes)
+        batch.begin()
+        ins = pkg.PlacedInserter(batch, [f["rich"] for f in frames], [f["move"] for f in frames], [f["pose"] for f in frames],
+                                 [f["boxes"] for f in frames])
+        pr = cProfile.Profile()
+        pr.enable()
+        for smp, annos, okl, okm in slots:
+            ins.insert_slot(smp, annos, okl, okm, [20] * B)
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
     print(f"B={B} slots={K}: load+begin+setup {1e3*(t1-t0):.1f} ms, {K} placed slots {1e3*(t2-t1):.1f} ms "
           f"({1e3*(t2-t1)/K:.1f} ms per slot), finish+download {1e3*(t3-t2):.1f} ms; {placed} objects placed; "
           f"{B/(t3-t0):.0f} frames/s end to end")
