@@ -195,7 +195,9 @@ class SceneBatch:
         """After ``begin_f64`` and the inserts: per scene (merged N' x 5 float64 rows [x y z intensity label] in
         the reference's order -- surviving frame points, then surviving inserted points --, added M x 5 float64 =
         all_visible_parts).  Coordinates and labels come from ``r3d_batch_export_rows`` (exact float64), the
-        intensity column from the compaction (``finish``)."""
+        intensity column of the MERGED rows from the compaction (``finish``), i.e. rounded to float32 -- exact for every
+        dataset flavour of the reference (their intensities are float32 in the files) and what ``save_data`` stores anyway;
+        the ADDED rows come from the log and keep the float64 value they were given."""
         rows4, n_rows = self.export_rows()
         self.finish(check_cols=0)
         rows4, n_rows = rows4.cpu().numpy(), n_rows.cpu().numpy()
