@@ -238,7 +238,8 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream);
  * evaluated again after a conflicting predecessor / evaluated because k_eval had not; [8..10] scenes handed
  * to k_insert_big: sample too large for k_sample_prep, bounds moved, evaluation too large; [11] rebases;
  * [12] pairs whose sample phase did not fit k_sample_prep; [13] allocations the launch's pool could not serve (depth tiles,
- * hit lists: those evaluations took a slower route). */
+ * hit lists: those evaluations took a slower route); [14] evaluations whose depth tile lived in the pool (window too large for
+ * the workgroup's LDS). */
 int r3d_batch_debug_counters(const r3d_batch_t *b, int32_t *host_out16, int32_t reset, void *stream);
 /* Diagnostic: per (scene, slot) of the last insert launch, two int64 words [B][32][2] to HOST memory: 100 MHz
  * ticks k_commit_chain spent on the slot | the counter index (above) of the way it took << 48; the tick at which

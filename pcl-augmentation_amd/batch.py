@@ -304,7 +304,7 @@ class SceneBatch:
         _lib.check(self.lib.r3d_batch_debug_counters(C.byref(self.desc), out, 1 if reset else 0, _lib.stream_ptr()),
                    "r3d_batch_debug_counters")
         names = ["eval_stored", "eval_pool_full", "eval_far_scene", "eval_nofit", "chain_stored", "chain_rejected",
-                 "chain_conflict", "chain_unevaluated", "defer_prep", "defer_bounds", "defer_nofit", "rebases", "prep_nofit", "pool_exhausted"]
+                 "chain_conflict", "chain_unevaluated", "defer_prep", "defer_bounds", "defer_nofit", "rebases", "prep_nofit", "pool_exhausted", "tiles_pooled"]
         return dict(zip(names, list(out)))
 
     @_lib.on_own_device

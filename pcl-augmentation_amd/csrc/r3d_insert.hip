@@ -219,7 +219,7 @@ enum { kOk = 0, kNoFit = 1, kNeedSerial = 2, kStale = 3 };
 enum { kPairIdle = 0, kPairSampled = 1, kPairEvaluated = 2, kPairNoFit = 3 };
 // diagnostic counters (BatchWs::dbg): what k_eval did with its pairs, which way k_commit_chain took per slot
 enum { D_EVAL_STORED = 0, D_EVAL_POOL, D_EVAL_SERIAL, D_EVAL_NOFIT, D_CHAIN_STORED, D_CHAIN_REJECTED, D_CHAIN_CONFLICT,
-       D_CHAIN_UNEVAL, D_DEFER_PREP, D_DEFER_BOUNDS, D_DEFER_NOFIT, D_REBASE, D_PREP_NOFIT, D_POOL_FULL };
+       D_CHAIN_UNEVAL, D_DEFER_PREP, D_DEFER_BOUNDS, D_DEFER_NOFIT, D_REBASE, D_PREP_NOFIT, D_POOL_FULL, D_TILE_POOLED };
 
 // A value every lane holds (read from LDS or global memory): into a scalar register.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -956,6 +956,7 @@ struct Ins {
         __syncthreads();
       }
       if (pool_off >= 0) {
+        if (tid == 0) atomicAdd(&w.dbg[D_TILE_POOLED], 1);
         g_dtile = reinterpret_cast<unsigned long long *>(w.tile_pool + pool_off);
         g_cand = reinterpret_cast<uint32_t *>(w.tile_pool + pool_off + (((long long)dt.npx * 8 + 255) & ~255ll));
         single = true;
