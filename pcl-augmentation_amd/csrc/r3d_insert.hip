@@ -2276,10 +2276,9 @@ static int launch_slots_legacy(const r3d_batch_t &b, const BatchWs &w, const Cha
   chain_shape(b, nt, lds);
   R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_big<kBigNT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
-  static const bool scene_loop = getenv("R3D_INSERT_SCENE_LOOP") != nullptr;      // experiment: one workgroup per scene, slot after slot
-  hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, nk, scene_loop ? 0 : -1);
+  hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, nk, -1);
   int rc = R3D_OK;
-  if (!scene_loop) {
+  {
     // Long chains and large range images evaluate most pairs twice (config C5: 89 %): those launches keep the hits of
     // the first evaluation and replay them (3.7 -> 2.9 ms per 50 slots of 32 scans).  The short chains of config C2
     // (3 % evaluated twice) run the kernel without that code: it costs them registers, i.e. spills (0.35 against 0.32 ms).
