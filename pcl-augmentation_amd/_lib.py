@@ -30,6 +30,7 @@ K_BOUNDS, K_PREPARE, K_PROJECT, K_ALIVE_WRITE = 1, 2, 3, 5
 NUMROW, NUMCOLUMN = 112, 1440
 MAX_SAMPLE = 8192
 FAR_CAP = 1024
+MAX_CHAIN = 64           # insert slots one launch of the chain kernel takes (kMaxChain in csrc/r3d_batch.hpp); insert_many splits longer lists
 
 
 class R3DError(RuntimeError):

@@ -310,8 +310,8 @@ class SceneBatch:
     @_lib.on_own_device
     def debug_trace(self):
         """Per (scene, slot) of the last insert launch: (ticks of 10 ns k_commit_chain spent, path id, start tick)
-        as int64 arrays [B, 32] each (r3d_batch_debug_trace)."""
-        out = np.zeros((self.B, 32, 2), dtype=np.int64)
+        as int64 arrays [B, MAX_CHAIN] each (r3d_batch_debug_trace)."""
+        out = np.zeros((self.B, _lib.MAX_CHAIN, 2), dtype=np.int64)
         _lib.check(self.lib.r3d_batch_debug_trace(C.byref(self.desc), out.ctypes.data, out.size, _lib.stream_ptr()),
                    "r3d_batch_debug_trace")
         return out[:, :, 0] & ((1 << 48) - 1), out[:, :, 0] >> 48, out[:, :, 1]

@@ -19,7 +19,7 @@ constexpr int kPT = 256;             // threads of the streaming kernels
 constexpr int kPerThread = 8;
 constexpr int kTile = kPT * kPerThread;   // points per block tile
 constexpr int kKeyCap = R3D_MAX_SAMPLE;
-constexpr int kMaxChain = 32;        // insert slots of one k_insert_chain launch
+constexpr int kMaxChain = 64;        // insert slots of one k_insert_chain launch
 constexpr int kRecInts = 16;         // int32 words of a published slot record
 constexpr int kEvalClasses = 4;      // launch shapes of k_eval (LDS need of the pair)
 

@@ -1519,7 +1519,7 @@ __device__ __forceinline__ bool load_slot(INS &I, const r3d_batch_t &b, const Ch
 
 // Did one of the slots [j0, k) of this launch change a pixel the evaluation read (or the bounds, or
 // the far list)?  bit 0: yes; bit 1: the bounds moved (the sample must be projected again).
-// Lane L of every wave looks at slot j0 + L (a launch has at most kMaxChain = 32 slots): one trip to the records
+// Lane L of every wave looks at slot j0 + L (a launch has at most kMaxChain = 64 slots): one trip to the records
 // however many slots there are.  Must be called by whole waves.
 __device__ __forceinline__ int conflict_with(const BatchWs &w, int s, int j0, int k, const int *H, int rows, int cols) {
   static_assert(kMaxChain <= 64, "one lane per slot of the launch");

@@ -21,7 +21,7 @@ for _ in range(3):
     bt.begin(); bt.insert_many_device(pk, [nd] * K); bt.finish()
 torch.cuda.synchronize()
 bt.debug_counters()
-K = min(K, 32)
+K = min(K, 64)
 bt.begin(); bt.insert_many_device(pk[:K], [nd] * K); torch.cuda.synchronize()
 print(bt.debug_counters())
 ticks, path, start = bt.debug_trace()
