@@ -1,0 +1,42 @@
+"""A fixed slice of the randomised parity campaign (tools/fuzz_parity.py) inside the GPU suite: random scenes, grids,
+chains with clustered placements, far points, duplicated points, samples outside the field of view, several candidates
+per slot -- HIP path against the oracle, byte for byte, on the default insert launch, the three-kernel launch and
+without speculation.  The long campaign is the tool; its log of the round is quoted in DESIGN.md par.5."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import real3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.mark.parametrize("seed0", [1000, 1040])
+def test_random_batches_equal_the_oracle(pkg, synth, monkeypatch, seed0):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    F = importlib.import_module("fuzz_parity")
+    scenes = 0
+    for seed in range(seed0, seed0 + 10):
+        rng = np.random.default_rng(seed)
+        rows, cols = F.GRIDS[int(rng.integers(len(F.GRIDS)))]
+        B = int(rng.choice([1, 2, 3, 6, 9]))
+        if rows * cols > 128 * 2048:
+            rows, cols = 128, 2048                            # (the oracle needs seconds per scene on 448 x 2880)
+        cases = [F.make_case(synth, rng, rows, cols) for _ in range(min(B, 3))]
+        debug = int(rng.choice([0, 0, 0, 64, 2]))
+        monkeypatch.setattr(O, "NUMROW", rows)
+        monkeypatch.setattr(O, "NUMCOLUMN", cols)
+        res, acc = pkg.augment_batch([(c[0], c[1]) for c in cases], [c[2] for c in cases], [c[3] for c in cases],
+                                     rows=rows, cols=cols, debug=debug)
+        for i, c in enumerate(cases):
+            vb, lb, cb, oacc = F.oracle_case((rows, cols) + c)
+            assert list(acc[i]) == list(oacc), (seed, i)
+            assert res[i][0].tobytes() == vb and res[i][1].tobytes() == lb and res[i][2].tobytes() == cb, (seed, i)
+            scenes += 1
+    assert scenes >= 10
