@@ -91,6 +91,15 @@ int r3d_geometrical_front_view(double *pcl9, int64_t n, int32_t num_row, int32_t
                                double *train, double *label,
                                void *workspace, size_t workspace_bytes,
                                int32_t *status, void *stream);
+/* The same with the reference's GLOBAL NUMCOLUMN as an argument: the pixel id of col 8 is row*id_columns+col.  The
+ * reference's function multiplies by the module global (insertion.py:23, :116, :127), not by its num_column
+ * argument; a user who works on another grid edits that global -- here it is passed in.  r3d_geometrical_front_view
+ * = this with id_columns = R3D_NUMCOLUMN. */
+int r3d_geometrical_front_view_grid(double *pcl9, int64_t n, int32_t num_row, int32_t num_column, int32_t id_columns,
+                                    double max_el, double min_el, int32_t sample,
+                                    double *train, double *label,
+                                    void *workspace, size_t workspace_bytes,
+                                    int32_t *status, void *stream);
 
 /* a4  class_closing(original_label)                   SS Real3DAug/tools/closing.py:9-23
  * closed [rows][cols] uint8 in {0,255}: grey closing of clip(label,0,1) with rectangle(5,3)
@@ -117,6 +126,12 @@ int r3d_occlusion_merge(const double *scene9, int64_t n, const double *sample9, 
                         int32_t rows, int32_t cols,
                         double *scene_out9, double *visible9, double *covered9, int64_t *counts,
                         void *workspace, size_t workspace_bytes, void *stream);
+/* The same for pixel ids row*id_columns+col (insertion.py:470 divides by the global NUMCOLUMN), cols <= id_columns. */
+int r3d_occlusion_merge_grid(const double *scene9, int64_t n, const double *sample9, int64_t m,
+                             const double *scene_train, const double *sample_train,
+                             int32_t rows, int32_t cols, int32_t id_columns,
+                             double *scene_out9, double *visible9, double *covered9, int64_t *counts,
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* a9  remove_space_for_spherical + the casts of save_data
  *                         SS Real3DAug/tools/datasets.py:72-106, OD tools/datasets.py:76-109

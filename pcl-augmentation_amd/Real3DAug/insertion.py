@@ -14,7 +14,9 @@ from .. import _lib
 from ._dev import back, ptr, to_device
 
 NUMROW = 112          # SS Real3DAug/insertion.py:22
-NUMCOLUMN = 360 * 4   # SS Real3DAug/insertion.py:23
+NUMCOLUMN = 360 * 4   # SS Real3DAug/insertion.py:23.  As in the reference, the pixel ids of column 8 multiply by THIS global
+                      # (:116, :127, :470), read at call time, not by the num_column argument: whoever works on another
+                      # grid edits the two globals (level1.augment_scene does, for the duration of its call)
 
 
 def add_space_for_spherical(point_cloud):
@@ -62,10 +64,10 @@ def geometrical_front_view(point_cloud, num_row, num_column, max_elevation_angle
     ws_bytes = lib.r3d_front_view_workspace_bytes(num_row, num_column)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev.device)
     status = torch.zeros(1, dtype=torch.int32, device=dev.device)
-    _lib.check(lib.r3d_geometrical_front_view(ptr(dev), n, num_row, num_column,
-                                              float(max_elevation_angle), float(min_elevation_angle),
-                                              1 if sample else 0, ptr(train), ptr(label), ptr(ws), ws_bytes,
-                                              ptr(status), _lib.stream_ptr()), "geometrical_front_view")
+    _lib.check(lib.r3d_geometrical_front_view_grid(ptr(dev), n, num_row, num_column, int(NUMCOLUMN),
+                                                   float(max_elevation_angle), float(min_elevation_angle),
+                                                   1 if sample else 0, ptr(train), ptr(label), ptr(ws), ws_bytes,
+                                                   ptr(status), _lib.stream_ptr()), "geometrical_front_view")
     _lib.raise_status(int(status.item()), "geometrical_front_view")
     if was_np:
         if n:
@@ -98,8 +100,8 @@ def occlusion_merge(scene_pcl, sample_pcl, scene_train, sample_train):
     if ws_bytes == 0:
         raise _lib.R3DError("occlusion_merge: workspace query failed: " + lib.r3d_last_error().decode())
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=sc.device)
-    _lib.check(lib.r3d_occlusion_merge(ptr(sc), n, ptr(sm), m, ptr(st), ptr(mt), rows, cols, ptr(out), ptr(vis),
-                                       ptr(cov), ptr(counts), ptr(ws), ws_bytes, _lib.stream_ptr()),
+    _lib.check(lib.r3d_occlusion_merge_grid(ptr(sc), n, ptr(sm), m, ptr(st), ptr(mt), rows, cols, int(NUMCOLUMN), ptr(out),
+                                            ptr(vis), ptr(cov), ptr(counts), ptr(ws), ws_bytes, _lib.stream_ptr()),
                "occlusion_merge")
     n_out, n_vis, n_cov = (int(v) for v in counts.cpu().numpy())
     scene_out, visible, covered = out[:n_out], vis[:n_vis], cov[:n_cov]

@@ -82,11 +82,15 @@ _SIGNATURES = {
     "r3d_front_view_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "r3d_geometrical_front_view": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double,
                                              C.c_int32, _P, _P, _P, C.c_size_t, _P, _P]),
+    "r3d_geometrical_front_view_grid": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                                  C.c_int32, _P, _P, _P, C.c_size_t, _P, _P]),
     "r3d_class_closing": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "r3d_smooth_out": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "r3d_occlusion_merge_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "r3d_occlusion_merge": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int32, C.c_int32,
                                       _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "r3d_occlusion_merge_grid": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int32, C.c_int32, C.c_int32,
+                                           _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "r3d_remove_space_for_spherical": (C.c_int, [_P, C.c_int64, _P, _P, _P, C.c_int32, _P]),
     "r3d_batch_workspace_bytes": (C.c_size_t, [C.POINTER(BatchDesc)]),
     "r3d_batch_create": (C.c_int, [C.POINTER(BatchDesc), _P]),

@@ -16,7 +16,7 @@ std::string &last_error_ref() {
 }
 
 constexpr int kThreads = 256;
-constexpr unsigned kNoKey = 1u << 18;   // sorts after every pixel id (112*1440 < 2^18)
+constexpr unsigned kNoKey = 0xFFFFFFFFu;   // sorts after every pixel id (ids are non-negative 32-bit ints)
 
 // ---------------------------------------------------------------------------------------------
 // a1  add_space_for_spherical                                  SS Real3DAug/insertion.py:54-64
@@ -93,7 +93,7 @@ __global__ void k_fill_u64(unsigned long long *p, int64_t n, unsigned long long 
 }
 
 __global__ void __launch_bounds__(kThreads)
-k_front_view(double *__restrict__ pcl9, int64_t n, int rows, int cols, double max_el, double min_el,
+k_front_view(double *__restrict__ pcl9, int64_t n, int rows, int cols, int id_cols, double max_el, double min_el,
              int sample, unsigned long long *__restrict__ grid, int32_t *status) {
   Binning b = make_binning(max_el, min_el, rows, cols);
   int flags = 0;
@@ -113,7 +113,7 @@ k_front_view(double *__restrict__ pcl9, int64_t n, int rows, int cols, double ma
       } else if (!(ok & 2)) {
         flags |= R3D_S_COL_RANGE;                      // assert :112
       } else {
-        p[8] = (double)(row * R3D_NUMCOLUMN + col);    // :116 / :127 (global constant)
+        p[8] = (double)(row * id_cols + col);          // :116 / :127 (the global NUMCOLUMN, not the argument)
         cell = (long long)row * cols + col;
         key = depth_key(p[3]);
       }
@@ -240,10 +240,10 @@ __global__ void k_vis_mask(const double *__restrict__ scene_train, const double 
   }
 }
 
-__device__ __forceinline__ bool pid_visible(double pid, int rows, int cols, const uint32_t *vis_words) {
+__device__ __forceinline__ bool pid_visible(double pid, int rows, int cols, int id_cols, const uint32_t *vis_words) {
   if (!(pid >= 0.0)) return false;                     // -1: never binned (:107-108)
   int id = (int)pid;
-  int row = id / R3D_NUMCOLUMN, col = id - row * R3D_NUMCOLUMN;      // :470
+  int row = id / id_cols, col = id - row * id_cols;    // :470
   if (row >= rows || col >= cols) return false;
   int p = row * cols + col;
   return (vis_words[p >> 5] >> (p & 31)) & 1u;
@@ -253,7 +253,7 @@ __device__ __forceinline__ bool pid_visible(double pid, int rows, int cols, cons
 constexpr int kTile = 2048;
 
 __global__ void __launch_bounds__(kThreads)
-k_mark(const double *__restrict__ pcl9, int64_t n, int rows, int cols, const uint32_t *__restrict__ vis_words,
+k_mark(const double *__restrict__ pcl9, int64_t n, int rows, int cols, int id_cols, const uint32_t *__restrict__ vis_words,
        unsigned long long *__restrict__ keys, int32_t *__restrict__ tile_keep, int64_t *hit_count) {
   __shared__ int s_cnt[kThreads / 64];
   int64_t t0 = (int64_t)blockIdx.x * kTile;
@@ -262,7 +262,7 @@ k_mark(const double *__restrict__ pcl9, int64_t n, int rows, int cols, const uin
     int64_t i = t0 + k;
     if (i >= n) break;
     double pid = pcl9[i * 9 + 8];
-    bool hit = pid_visible(pid, rows, cols, vis_words);
+    bool hit = pid_visible(pid, rows, cols, id_cols, vis_words);
     // unique 64-bit key (pixel id, row index): the sort order does not lean on stability
     keys[i] = ((unsigned long long)(hit ? (uint32_t)(int)pid : kNoKey) << 32) | (uint32_t)i;
     keep += hit ? 0 : 1;
@@ -372,7 +372,7 @@ struct MergeWs {
 static hipError_t sort_query(size_t &bytes, int64_t n) {
   bytes = 0;
   unsigned long long *k = nullptr;
-  return rocprim::radix_sort_keys(nullptr, bytes, k, k, (size_t)(n < 1 ? 1 : n), 0, 51);
+  return rocprim::radix_sort_keys(nullptr, bytes, k, k, (size_t)(n < 1 ? 1 : n), 0, 64);
 }
 
 static int carve_merge(MergeWs &w, void *ws, int64_t n, int64_t m, int rows, int cols) {
@@ -431,8 +431,16 @@ int r3d_geometrical_front_view(double *pcl9, int64_t n, int32_t num_row, int32_t
                                double max_el, double min_el, int32_t sample, double *train,
                                double *label, void *workspace, size_t workspace_bytes,
                                int32_t *status, void *stream) {
-  if (n < 0 || num_row <= 0 || num_column <= 0 || !train || !label || !status || !workspace ||
-      (n > 0 && !pcl9))
+  return r3d_geometrical_front_view_grid(pcl9, n, num_row, num_column, R3D_NUMCOLUMN, max_el, min_el, sample, train, label,
+                                         workspace, workspace_bytes, status, stream);
+}
+
+int r3d_geometrical_front_view_grid(double *pcl9, int64_t n, int32_t num_row, int32_t num_column, int32_t id_columns,
+                                    double max_el, double min_el, int32_t sample, double *train,
+                                    double *label, void *workspace, size_t workspace_bytes,
+                                    int32_t *status, void *stream) {
+  if (n < 0 || num_row <= 0 || num_column <= 0 || id_columns <= 0 || (int64_t)num_row * id_columns > 0x7FFFFFFFll || !train ||
+      !label || !status || !workspace || (n > 0 && !pcl9))
     return fail(R3D_E_ARG, "front_view: bad argument");
   if (workspace_bytes < r3d_front_view_workspace_bytes(num_row, num_column))
     return fail(R3D_E_WORKSPACE, "front_view: workspace too small");
@@ -443,7 +451,7 @@ int r3d_geometrical_front_view(double *pcl9, int64_t n, int32_t num_row, int32_t
                      npix, R3D_SENT);
   if (n > 0)
     hipLaunchKernelGGL(k_front_view, dim3(blocks_for(n, kThreads, 2048)), dim3(kThreads), 0, st, pcl9,
-                       n, num_row, num_column, max_el, min_el, sample, grid, status);
+                       n, num_row, num_column, id_columns, max_el, min_el, sample, grid, status);
   hipLaunchKernelGGL(k_grid_export, dim3(blocks_for(npix, kThreads, 1024)), dim3(kThreads), 0, st,
                      grid, npix, train, label);
   R3D_LAUNCHED("front_view kernels");
@@ -484,10 +492,23 @@ int r3d_occlusion_merge(const double *scene9, int64_t n, const double *sample9, 
                         const double *scene_train, const double *sample_train, int32_t rows,
                         int32_t cols, double *scene_out9, double *visible9, double *covered9,
                         int64_t *counts, void *workspace, size_t workspace_bytes, void *stream) {
-  if (n < 0 || m < 0 || rows <= 0 || cols <= 0 || cols > R3D_NUMCOLUMN || !scene_train ||
-      !sample_train || !counts || !workspace || (n > 0 && (!scene9 || !scene_out9 || !covered9)) ||
+  return r3d_occlusion_merge_grid(scene9, n, sample9, m, scene_train, sample_train, rows, cols, R3D_NUMCOLUMN, scene_out9,
+                                  visible9, covered9, counts, workspace, workspace_bytes, stream);
+}
+
+int r3d_occlusion_merge_grid(const double *scene9, int64_t n, const double *sample9, int64_t m,
+                             const double *scene_train, const double *sample_train, int32_t rows,
+                             int32_t cols, int32_t id_columns, double *scene_out9, double *visible9, double *covered9,
+                             int64_t *counts, void *workspace, size_t workspace_bytes, void *stream) {
+  if (n < 0 || m < 0 || rows <= 0 || cols <= 0 || cols > id_columns || (int64_t)rows * id_columns > 0x7FFFFFFFll ||
+      !scene_train || !sample_train || !counts || !workspace || (n > 0 && (!scene9 || !scene_out9 || !covered9)) ||
       (m > 0 && (!sample9 || !visible9)))
-    return fail(R3D_E_ARG, "occlusion_merge: bad argument (cols must be <= R3D_NUMCOLUMN)");
+    return fail(R3D_E_ARG, "occlusion_merge: bad argument (cols must be <= the id stride, R3D_NUMCOLUMN unless given)");
+  // the sort keys: (pixel id << 32) | row index; bits of the largest pixel id and of kNoKey (it sorts last)
+  int key_end = 33;
+  while (key_end < 64 && ((int64_t)rows * id_columns) >> (key_end - 32)) ++key_end;
+  ++key_end;                                             // one more: kNoKey's leading ones beat every id
+  if (key_end > 64) key_end = 64;
   MergeWs w;
   int rc = carve_merge(w, workspace, n, m, rows, cols);
   if (rc != R3D_OK) return rc;
@@ -500,22 +521,22 @@ int r3d_occlusion_merge(const double *scene9, int64_t n, const double *sample9, 
   int n_tiles = (int)((n + kTile - 1) / kTile);
   if (n > 0) {
     // counts[2] temporarily accumulates the scene hit count
-    hipLaunchKernelGGL(k_mark, dim3(n_tiles), dim3(kThreads), 0, st, scene9, n, rows, cols,
+    hipLaunchKernelGGL(k_mark, dim3(n_tiles), dim3(kThreads), 0, st, scene9, n, rows, cols, id_columns,
                        w.vis_words, w.skey, w.tiles, counts + 2);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, w.tiles, n_tiles, counts + 0);
     hipLaunchKernelGGL(k_scatter_keep, dim3(n_tiles), dim3(kThreads), 0, st, scene9, n, w.skey, w.tiles,
                        scene_out9);
     size_t sb = w.sort_bytes;
-    R3D_HIP(rocprim::radix_sort_keys(w.sort_tmp, sb, w.skey, w.skey2, (size_t)n, 0, 51, st));
+    R3D_HIP(rocprim::radix_sort_keys(w.sort_tmp, sb, w.skey, w.skey2, (size_t)n, 0, key_end, st));
     hipLaunchKernelGGL(k_gather_rows, dim3(blocks_for(n * 9, kThreads, 2048)), dim3(kThreads), 0, st,
                        scene9, w.skey2, counts + 2, n, covered9);
   }
   if (m > 0) {
     int m_tiles = (int)((m + kTile - 1) / kTile);
-    hipLaunchKernelGGL(k_mark, dim3(m_tiles), dim3(kThreads), 0, st, sample9, m, rows, cols,
+    hipLaunchKernelGGL(k_mark, dim3(m_tiles), dim3(kThreads), 0, st, sample9, m, rows, cols, id_columns,
                        w.vis_words, w.mkey, (int32_t *)nullptr, counts + 1);
     size_t sb = w.sort_bytes;
-    R3D_HIP(rocprim::radix_sort_keys(w.sort_tmp, sb, w.mkey, w.mkey2, (size_t)m, 0, 51, st));
+    R3D_HIP(rocprim::radix_sort_keys(w.sort_tmp, sb, w.mkey, w.mkey2, (size_t)m, 0, key_end, st));
     hipLaunchKernelGGL(k_gather_rows, dim3(blocks_for(m * 9, kThreads, 2048)), dim3(kThreads), 0, st,
                        sample9, w.mkey2, counts + 1, m, visible9);
   }

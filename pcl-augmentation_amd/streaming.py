@@ -226,7 +226,10 @@ class StreamedAugmenter:
         assert ln.busy
         ln.done.synchronize()
         counts = ln.out_counts.numpy()
+        redo = [int(s) for s in np.nonzero(counts[2] & _lib.S_WINDOW_TOO_LARGE)[0]]   # see _redo_level1
         for s in np.nonzero(counts[2])[0]:
+            if int(s) in redo:
+                continue
             ln.busy = False
             _lib.raise_status(int(counts[2][s]), f"scene {s}")
         cc = max(ln.check_cols, 4)
@@ -240,6 +243,13 @@ class StreamedAugmenter:
             n_out = ln.h_n_out.numpy()
         else:
             n_out = counts[0]
+        if redo:
+            try:
+                for s in redo:
+                    self._redo_level1(ln, s, n_out, counts)
+            except Exception:
+                ln.busy = False
+                raise
         ox, ol, ck = ln.out_xyzi.numpy(), ln.out_label.numpy().view(np.uint32), ln.out_check.numpy()
         acc = ln.out_acc.numpy()
         results = [(ox[s, :n_out[s]], ol[s, :n_out[s]], ck[s, :counts[1][s], :ln.check_cols] if ln.check_cols else None)
@@ -247,6 +257,27 @@ class StreamedAugmenter:
         accepted = [[0 if acc[k, s] else -1 for k in range(self.K)] for s in range(self.B)]
         ln.busy = False
         return ln.tag, results, accepted
+
+    def _redo_level1(self, ln, s, n_out, counts):
+        """Frame s of the lane came back with R3D_S_WINDOW_TOO_LARGE (an insert's window exceeds a CU's LDS: an object
+        a few metres from the sensor on a grid several times the reference's): once more, alone, through the Level-1
+        kernels (``level1.augment_scene``), its results into the lane's output slabs."""
+        from . import level1
+        bt, K = ln.bt, self.K
+        n = int(ln.in_n.numpy()[s])
+        off, need = ln.in_off.numpy(), ln.in_need.numpy()
+        cands = [[ln.in_rows[k].numpy()[int(off[k, s]):int(off[k, s + 1])].copy()] for k in range(K)]
+        (x, l, ck), acc = level1.augment_scene(ln.in_xyzi.numpy()[s, :n], ln.in_label.numpy().view(np.uint32)[s, :n], cands,
+                                               [int(need[k, s]) for k in range(K)], bt.rows, bt.cols, self.device, ln.check_cols)
+        ln.out_xyzi.numpy()[s, :len(x)] = x
+        ln.out_label.numpy().view(np.uint32)[s, :len(l)] = l
+        n_out[s] = len(x)
+        if ln.check_cols:
+            ln.out_check.numpy()[s, :len(ck), :ln.check_cols] = ck
+            counts[1][s] = len(ck)
+        for k in range(K):
+            ln.out_acc.numpy()[k, s] = 1 if acc[k] >= 0 else 0
+        self.level1_frames = getattr(self, "level1_frames", 0) + 1
 
     def run(self, batches, consume):
         """batches: iterable of (scenes, inserts, min_points, tag); consume(tag, results, accepted) is

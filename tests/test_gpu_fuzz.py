@@ -40,3 +40,42 @@ def test_random_batches_equal_the_oracle(pkg, synth, monkeypatch, seed0):
             assert res[i][0].tobytes() == vb and res[i][1].tobytes() == lb and res[i][2].tobytes() == cb, (seed, i)
             scenes += 1
     assert scenes >= 10
+
+
+def _near_car_cases(synth):
+    """Seed 5485 of the campaign: two frames on 448 x 2880, one with an object so near that its window exceeds a CU's LDS."""
+    F = importlib.import_module("fuzz_parity")
+    rng = np.random.default_rng(5485)
+    rows, cols = F.GRIDS[int(rng.integers(len(F.GRIDS)))]
+    B = int(rng.choice([1, 2, 3, 6, 9]))
+    assert (rows, cols, B) == (448, 2880, 2)
+    return F, rows, cols, [F.make_case(synth, rng, rows, cols) for _ in range(B)]
+
+
+def test_window_beyond_the_lds_goes_through_the_level1_kernels(pkg, synth, monkeypatch):
+    """R3D_S_WINDOW_TOO_LARGE is not the caller's problem: augment_batch runs such a frame once more through the Level-1
+    kernels (level1.augment_scene), the streamed path does the same in collect -- same bytes as the oracle either way."""
+    F, rows, cols, cases = _near_car_cases(synth)
+    monkeypatch.setattr(O, "NUMROW", rows)
+    monkeypatch.setattr(O, "NUMCOLUMN", cols)
+    res, acc = pkg.augment_batch([(c[0], c[1]) for c in cases], [c[2] for c in cases], [c[3] for c in cases], rows=rows, cols=cols)
+    assert pkg.SceneBatch.last_level1, "the case no longer exceeds the LDS: pick another seed"
+    for i, c in enumerate(cases):
+        vb, lb, cb, oacc = F.oracle_case((rows, cols) + c)
+        assert list(acc[i]) == list(oacc)
+        assert res[i][0].tobytes() == vb and res[i][1].tobytes() == lb and res[i][2].tobytes() == cb
+    # the streamed path: one candidate per slot
+    streaming = importlib.import_module("pcl-augmentation_amd.streaming")
+    firsts = [(c[0], c[1], [[slot[0]] for slot in c[2]], c[3]) for c in cases]
+    K = max(len(c[2]) for c in firsts)
+    n_max = max(len(c[0]) for c in firsts)
+    grow = max(sum(len(slot[0]) for slot in c[2]) for c in firsts)
+    srows = max(sum(len(c[2][k][0]) for c in firsts if k < len(c[2])) for k in range(K))
+    aug = streaming.StreamedAugmenter(len(firsts), n_max, grow, K, srows, lanes=1, rows=rows, cols=cols)
+    aug.submit(0, [(c[0], c[1]) for c in firsts], [[slot[0] for slot in c[2]] for c in firsts], [c[3] for c in firsts])
+    _, results, accepted = aug.collect(0)
+    assert getattr(aug, "level1_frames", 0) >= 1
+    for i, c in enumerate(firsts):
+        vb, lb, cb, oacc = F.oracle_case((rows, cols) + c)
+        assert [a for a in accepted[i][:len(oacc)]] == list(oacc)
+        assert results[i][0].tobytes() == vb and results[i][1].tobytes() == lb and results[i][2].tobytes() == cb
