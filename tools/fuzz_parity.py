@@ -113,6 +113,7 @@ def main():
                     bad.append((seed_, -1, f"oracle raised {oe!r}, the HIP path did not"))
                 else:
                     both_raised += 1                          # e.g. the reference's assert on an empty range image
+                    print(f"seed {seed_}: both raised -- oracle {oe!r:.120}; HIP path {err_!r:.160}", flush=True)
                 continue
             if err_ is not None:
                 bad.append((seed_, -1, f"HIP path raised {err_!r}"))
