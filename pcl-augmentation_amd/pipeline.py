@@ -93,6 +93,24 @@ class AugmentPipeline:
             label = np.where(label == self.road_label, self.road_label, 1).astype(np.uint32)
         return np.ascontiguousarray(xyzi), np.ascontiguousarray(label.astype(np.uint32))
 
+    def _read_batch(self, batch_frames):
+        """The frames of a batch: .bin / .label files by native threads (``r3d_host_read_frames``; NumPy's fromfile
+        holds the interpreter lock, one frame at a time) into one slab, handed out as views."""
+        if self.waymo or any(f.label_file is None for f in batch_frames):
+            return [self._read(f) for f in batch_frames]
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        B = len(batch_frames)
+        cap = max(max(os.path.getsize(f.velodyne_file) // 16 for f in batch_frames), 1)
+        xyzi, label = np.empty((B, cap, 4), dtype=np.float32), np.empty((B, cap), dtype=np.uint32)
+        n = np.zeros(B, dtype=np.int32)
+        enc = lambda paths: (C.c_char_p * B)(*[str(p).encode() for p in paths])
+        _lib.check(lib.r3d_host_read_frames(enc([f.velodyne_file for f in batch_frames]), enc([f.label_file for f in batch_frames]),
+                                            B, cap, xyzi.ctypes.data, label.ctypes.data, n.ctypes.data,
+                                            -1 if self.road_label is None else int(self.road_label), 16), "r3d_host_read_frames")
+        return [(xyzi[s, :n[s]], label[s, :n[s]]) for s in range(B)]
+
     # -- placement search + merge (the whole per-frame body of insertion.py:352-549) -------------------
     def _process_placed(self, scenes, infos, slots):
         """scenes as in _process_hip; infos[s] = (rich_map, map_move, pose 4x4, boxes k x 10);
@@ -301,7 +319,7 @@ class AugmentPipeline:
             try:
                 for chunk in chunks:
                     t0 = time.perf_counter()
-                    scenes = [self._read(frames[i]) for i in chunk]
+                    scenes = self._read_batch([frames[i] for i in chunk])
                     cands = [candidates_for(i) for i in chunk]
                     stats["t_read"] += time.perf_counter() - t0
                     read_q.put((chunk, scenes, cands))
@@ -318,17 +336,24 @@ class AugmentPipeline:
                         return
                     chunk, results, accepted = item
                     t0 = time.perf_counter()
-                    for i, (xyzi, label, check), acc in zip(chunk, results, accepted):
+
+                    def write_one(args):
+                        i, (xyzi, label, check), acc = args
                         if self.waymo:
                             write_frame_waymo(self.output_path, self.folder, frames[i].name, xyzi, label)   # merged5, added5
                         else:
                             write_frame(self.output_path, self.folder, frames[i].name, xyzi, label, check,
                                         self.write_labels, label_2=label_2_for(i, acc) if label_2_for else None)
-                        stats["written"] += 1
+
+                    # the write and rename calls release the interpreter lock: the files of a batch go out side by side
+                    list(write_pool.map(write_one, zip(chunk, results, accepted)))
+                    stats["written"] += len(chunk)
                     stats["t_write"] += time.perf_counter() - t0
             except Exception as e:
                 errors.append(e)
 
+        from concurrent.futures import ThreadPoolExecutor
+        write_pool = ThreadPoolExecutor(max_workers=8)
         threads = [threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)]
         for t in threads:
             t.start()
@@ -355,6 +380,7 @@ class AugmentPipeline:
                 if errors:
                     break
         threads[1].join(timeout=60)
+        write_pool.shutdown(wait=True)
         if errors:
             raise errors[0]
         stats["t_total"] = time.perf_counter() - t_start

@@ -84,6 +84,32 @@ def measure_disk(pkg, n_frames=512, B=64, io_threads=16, where=None):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def measure_run(pkg, n_frames=512, B=64, where=None):
+    """``AugmentPipeline.run`` (the candidate loop: here two placement candidates per insert) with files on both sides."""
+    synth = pkg.synth
+    kinds = synth.CONFIG_INSERTS["C2"]
+    root = tempfile.mkdtemp(prefix="r3d_run_", dir=where)
+    try:
+        os.makedirs(f"{root}/in/velodyne"), os.makedirs(f"{root}/in/labels")
+        frames, ins = [], {}
+        for i in range(n_frames):
+            xyzi, label = synth.make_scene(i % 64)
+            xyzi.tofile(f"{root}/in/velodyne/{i:06d}.bin")
+            label.tofile(f"{root}/in/labels/{i:06d}.label")
+            frames.append(pkg.Frame(f"{root}/in/velodyne/{i:06d}.bin", f"{root}/in/labels/{i:06d}.label"))
+            a, b = synth.make_inserts(i % 64, kinds), synth.make_inserts(i % 64 + 64, kinds)
+            ins[i] = ([[x, y] for x, y in zip(a, b)], [20] * len(kinds))
+        pipe = pkg.AugmentPipeline(f"{root}/out", "run", batch_size=B)
+        pipe.run(frames[:B], lambda i: ins[i])                                                           # warm-up
+        shutil.rmtree(f"{root}/out")
+        st = pipe.run(frames, lambda i: ins[i])
+        return {"frames_per_s": round(st["frames_per_s"], 1), "frames": st["written"], "batch": B,
+                "t_read": round(st["t_read"], 3), "t_process": round(st["t_process"], 3), "t_write": round(st["t_write"], 3),
+                "t_total": round(st["t_total"], 3), "directory": where or tempfile.gettempdir()}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 if __name__ == "__main__":
     pkg = importlib.import_module("pcl-augmentation_amd")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
@@ -93,3 +119,6 @@ if __name__ == "__main__":
     print("disk     :", measure_disk(pkg, min(n, 512), min(bs, 64)))
     if os.path.isdir("/dev/shm"):
         print("tmpfs    :", measure_disk(pkg, min(n, 2048), 256, where="/dev/shm"))
+    print("run, disk:", measure_run(pkg, min(n, 512), min(bs, 64)))
+    if os.path.isdir("/dev/shm"):
+        print("run, tmpfs:", measure_run(pkg, min(n, 512), min(bs, 64), where="/dev/shm"))
