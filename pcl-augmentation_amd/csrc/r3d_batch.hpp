@@ -63,7 +63,7 @@ struct BatchWs {
   PairRec *pairs;               // [B*kMaxChain] the pairs of the running launch
   int32_t *cls_list;            // [kEvalClasses][B*kMaxChain] pair ids (scene * kMaxChain + slot) per launch shape of k_eval
   int32_t *cls_count;           // [kEvalClasses]
-  int32_t *spec;                // [2] pairs of the running launch whose speculative evaluation was committed / had to be redone
+  int32_t *queue_next;          // [16] the running k_insert_chain's work queues: next pair of XCD x's queue in [x] (all pairs: [0])
   int32_t *dbg;                 // [16] diagnostic counters of the insert kernels (r3d_batch_debug_counters)
   long long *trace;             // [B*kMaxChain*2] per slot of the last launch: 100 MHz ticks k_commit_chain spent on it | path << 48
   int64_t pool_bytes;
@@ -111,7 +111,7 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.pairs = c.take<PairRec>((size_t)b.B * kMaxChain);
   w.cls_list = c.take<int32_t>((size_t)kEvalClasses * b.B * kMaxChain);
   w.cls_count = c.take<int32_t>(kEvalClasses);
-  w.spec = c.take<int32_t>(2);
+  w.queue_next = c.take<int32_t>(16);
   w.dbg = c.take<int32_t>(16);
   w.trace = c.take<long long>((size_t)b.B * kMaxChain * 2);
   w.total = c.off;

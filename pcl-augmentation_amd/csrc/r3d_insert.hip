@@ -1550,10 +1550,10 @@ __device__ __forceinline__ int conflict_with(const BatchWs &w, int s, int j0, in
 // has been done for it yet (the caller may try the POOL flavour), else 0.
 template <int NT, bool HITS, bool POOL>
 __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots &slots, int nk, int first_step, const BatchWs &w,
-                                          int chunks, int lds_cap, long long timeout_ticks, int B8, unsigned char *smem) {
+                                          int chunks, int lds_cap, long long timeout_ticks, int B8, unsigned char *smem, int pair_id) {
   // B8 > 0: slot-major numbering (slot k of every scene, then slot k + 1; a scene's slots on one residue of the
-  // block id mod 8); B8 == 0: scene-major (the slots of scene 0, then those of scene 1, ...)
-  const int k = B8 ? (int)blockIdx.x / B8 : (int)blockIdx.x % nk, s = B8 ? (int)blockIdx.x % B8 : (int)blockIdx.x / nk;
+  // pair id mod 8); B8 == 0: scene-major (the slots of scene 0, then those of scene 1, ...)
+  const int k = B8 ? pair_id / B8 : pair_id % nk, s = B8 ? pair_id % B8 : pair_id / nk;
   if (s >= b.B) return 0;
   const int tid = threadIdx.x, slot_no = k;
   (void)slot_no;
@@ -1809,13 +1809,63 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
 // LDS (a car a few metres from the sensor on 448 x 2880).  The POOL flavour reaches those images through flat
 // accesses -- 35 % slower on config C5 when every pair takes it -- so a pair runs it only after the LDS flavour
 // has turned it down.
-template <int NT, bool HITS>
+template <int NT, bool HITS, bool QUEUE>
 __global__ void __launch_bounds__(NT, NT == 1024 ? 1 : R3D_CHAIN_WAVES)
 k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int chunks, int lds_cap,
-               long long timeout_ticks, int B8) {
+               long long timeout_ticks, int B8, int queue_arg) {
   extern __shared__ __align__(16) unsigned char smem[];     // no static __shared__ here: one LDS array
-  const int again = chain_pair<NT, HITS, false>(b, slots, nk, first_step, w, chunks, lds_cap, timeout_ticks, B8, smem);
-  if (uni(again)) chain_pair<NT, HITS, true>(b, slots, nk, first_step, w, chunks, lds_cap, timeout_ticks, B8, smem);
+  // (QUEUE is a template flag: the loop keeps every kernel argument alive across the pairs, which costs the kernel its
+  // spill-free register allocation -- 176 B of scratch per lane; the short chains of config C2 run the plain form)
+  const int queue_mode = QUEUE ? queue_arg : 0;
+  // queue_mode 0: one workgroup per pair, pair = block id.  Otherwise the launch holds only as many workgroups as the
+  // device keeps resident and each takes pairs off a queue until it is empty -- 1: one queue, pairs in id order; 2: a
+  // queue per XCD (workgroups go to the XCDs round robin, a scene's pairs share a residue mod 8: a scene stays with
+  // one XCD's L2), an XCD that runs dry helps the others.  A pair still waits only for pairs with lower ids of its
+  // own queue, which a running workgroup has taken before.  Why: the hardware hands workgroups to the XCDs strictly
+  // round robin, so with one workgroup per pair an XCD whose pairs run long stalls the hand-out to all the others (a
+  // third of the CUs idle on config C5, tools/stamps_insert.py).
+  const int total = (B8 ? B8 : b.B) * nk;
+  int *H = reinterpret_cast<int *>(smem);
+  const int home = queue_mode == 2 ? (int)(blockIdx.x & 7) : 0;
+  int turn = 0;                                              // queues this workgroup has found empty
+  for (;;) {
+    int pair_id = (int)blockIdx.x;
+    if (queue_mode) {
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int id = total;
+        while (turn < (queue_mode == 2 ? 8 : 1)) {
+          const int q = (home + turn) & 7;
+          const int n = atomicAdd(&w.queue_next[q], 1);
+          id = queue_mode == 2 ? n * 8 + q : n;
+          if (id < total) break;
+          id = total;
+          ++turn;
+        }
+        H[H_GO] = id;
+        H[H_GO + 1] = turn;
+      }
+      __syncthreads();
+      pair_id = uni(H[H_GO]);
+      turn = uni(H[H_GO + 1]);
+      if (pair_id >= total) return;
+    }
+#ifdef R3D_STAMPS
+    const int k_ = B8 ? pair_id / B8 : pair_id % nk, s_ = B8 ? pair_id % B8 : pair_id / nk;
+    long long *cell = s_ < b.B ? reinterpret_cast<long long *>(b.out_xyzi + (int64_t)s_ * b.cap * 4) + k_ * 32 : nullptr;
+    if (cell && threadIdx.x == 0) cell[28] = wall_clock64();   // this workgroup takes the pair
+#endif
+    const int again = chain_pair<NT, HITS, false>(b, slots, nk, first_step, w, chunks, lds_cap, timeout_ticks, B8, smem, pair_id);
+#ifdef R3D_STAMPS
+    if (cell && threadIdx.x == 0) cell[29] = uni(again) ? wall_clock64() : 0;   // the LDS flavour turned the pair down here
+#endif
+    if (uni(again)) chain_pair<NT, HITS, true>(b, slots, nk, first_step, w, chunks, lds_cap, timeout_ticks, B8, smem, pair_id);
+#ifdef R3D_STAMPS
+    __syncthreads();
+    if (cell && threadIdx.x == 0) cell[30] = wall_clock64();   // ... and is done with it
+#endif
+    if (!QUEUE || !queue_mode) return;
+  }
 }
 
 // ====================================================================================================
@@ -2092,6 +2142,7 @@ __global__ void k_chain_init(r3d_batch_t b, BatchWs w, int nk, int defer0 = -1) 
   if (s == 0) {
     *w.pool_head = 0ull;
     for (int c = 0; c < kEvalClasses; ++c) w.cls_count[c] = 0;
+    for (int q = 0; q < 16; ++q) w.queue_next[q] = 0;
   }
   w.chain_progress[s] = 0;
   w.n_total0[s] = b.n_total[s];
@@ -2121,19 +2172,43 @@ static void chain_shape(const r3d_batch_t &b, int &nt, int &lds) {
   lds = kb * 1024;
 }
 
+template <int NT, bool HITS, bool QUEUE>
+static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step, int lds,
+                          long long timeout_ticks, int B8, int queue_mode, hipStream_t st) {
+  // per device, every call: the attribute belongs to the current device's copy of the kernel
+  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_chain<NT, HITS, QUEUE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  const int total = (B8 ? B8 : b.B) * nk;
+  int grid = total;
+  if (QUEUE && queue_mode) {
+    int dev = 0, cus = 0, per_cu = 0;
+    R3D_HIP(hipGetDevice(&dev));
+    R3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    R3D_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_insert_chain<NT, HITS, QUEUE>), NT, lds));
+    const int resident = (per_cu < 1 ? 1 : per_cu) * (cus < 8 ? 8 : cus);
+    grid = total < resident ? total : resident;
+  }
+  hipLaunchKernelGGL((k_insert_chain<NT, HITS, QUEUE>), dim3(grid), dim3(NT), lds, st, b, sl, nk, first_step, w, chunks_of(b), lds,
+                     timeout_ticks, B8, queue_mode);
+  R3D_LAUNCHED("k_insert_chain");
+  return R3D_OK;
+}
+
 template <int NT, bool HITS>
 static int launch_chain(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step, int lds,
                         long long timeout_ticks, hipStream_t st) {
   // measured on config C2: scene-major numbering is 10-40 % slower (the big pairs of all scenes no longer start together)
   static const bool scene_major = getenv("R3D_CHAIN_ORDER") && std::string(getenv("R3D_CHAIN_ORDER")) == "scene";
-  const int B8 = scene_major ? 0 : (b.B + 7) & ~7;            // a scene's slots on one residue of the block id mod 8
-  // per device, every call: the attribute belongs to the current device's copy of the kernel
-  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_chain<NT, HITS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL((k_insert_chain<NT, HITS>), dim3((B8 ? B8 : b.B) * nk), dim3(NT), lds, st, b, sl, nk, first_step, w, chunks_of(b), lds,
-                     timeout_ticks, B8);
-  R3D_LAUNCHED("k_insert_chain");
-  return R3D_OK;
+  const int B8 = scene_major ? 0 : (b.B + 7) & ~7;            // a scene's slots on one residue of the pair id mod 8
+  // R3D_CHAIN_QUEUE: 0 one workgroup per pair; 1 resident workgroups that take pairs off one queue; 2 ... off a queue per
+  // XCD.  Default: 2 on large range images (config C5: 6.4 -> 4.8 ms per 128 scans x 50 slots), 0 otherwise (config
+  // C2: 0.33 ms either way without the loop's spills, 0.37 with them).
+  static const int queue_env = env_int("R3D_CHAIN_QUEUE", -1);
+  const bool large = (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN;
+  int queue_mode = queue_env >= 0 ? queue_env : (large ? 2 : 0);
+  if (scene_major && queue_mode == 2) queue_mode = 1;
+  return queue_mode ? launch_chain_q<NT, HITS, true>(b, w, sl, nk, first_step, lds, timeout_ticks, B8, queue_mode, st)
+                    : launch_chain_q<NT, HITS, false>(b, w, sl, nk, first_step, lds, timeout_ticks, B8, 0, st);
 }
 
 // launch shapes of k_eval, smallest first: threads per class, LDS from R3D_EVAL_KB ("24,48,80,160")

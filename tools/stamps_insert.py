@@ -17,8 +17,10 @@ pkg = importlib.import_module("pcl-augmentation_amd")
 synth = pkg.synth
 import os
 if os.environ.get("R3D_STAMPS_CONFIG") == "C5":            # the first launch (32 slots) of config C5's 50 inserts
-    B, KINDS = 32, (["car", "pedestrian", "cyclist", "pedestrian", "cyclist"] * 10)[:32]
-    scenes = [synth.make_scene(s, n_beams=256, n_az=3906) for s in range(B)]
+    B = int(os.environ.get("R3D_STAMPS_SCANS", "32"))        # scans; distinct ones: 8, cycled
+    KINDS = (["car", "pedestrian", "cyclist", "pedestrian", "cyclist"] * 10)[:int(os.environ.get("R3D_STAMPS_SLOTS", "32"))]
+    distinct = [synth.make_scene(s, n_beams=256, n_az=3906) for s in range(min(B, 8))]
+    scenes = [distinct[s % len(distinct)] for s in range(B)]
     shape = dict(rows=448, cols=2880)
 else:
     B, KINDS = 256, ["pedestrian", "cyclist", "car", "pedestrian", "cyclist"]
@@ -83,3 +85,15 @@ if (raw[:, :, 22] > 0).any():
         ((c[:, :, 14] - c[:, :, 25]) / 100)[m].mean()))
 if len(sys.argv) > 1:
     np.savez_compressed(sys.argv[1], raw=raw, names=np.array(names))
+# the workgroup's own span (kernel entry -> exit) against the phases' span, and how long a CU stays empty between two workgroups
+if raw.shape[2] > 30 and raw[:, :, 28].any():
+    ent, ext, retry = raw[:, :, 28].astype(np.float64), raw[:, :, 30].astype(np.float64), raw[:, :, 29]
+    t00 = ent[ent > 0].min()
+    print(f"workgroup entry -> first stamp: mean {((st[:, :, 0] - ent) / 100).mean():.1f} us; last stamp -> exit: {((ext - st[:, :, 15]) / 100).mean():.1f} us; "
+          f"pairs that the LDS flavour turned down (second pass with pooled images): {(retry > 0).sum()}")
+    starts, ends = np.sort(((ent - t00) / 100).ravel()), np.sort(((ext - t00) / 100).ravel())
+    for cap in (192, 224, 256):
+        lag = starts[cap:] - ends[:len(starts) - cap]
+        print(f"  entry of workgroup i minus exit of workgroup i-{cap}: median {np.median(lag):.1f} us, negative for {100 * (lag < 0).mean():.0f} %")
+    span = (ext.max() - t00) / 100
+    print(f"  workgroup-time {((ext - ent) / 100).sum() / 1000:.1f} ms over a span of {span / 1000:.2f} ms = {((ext - ent) / 100).sum() / span:.0f} workgroups on the device on average")
