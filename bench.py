@@ -527,7 +527,7 @@ def main():
             out["e2e"] = e2e.measure(pkg, n_frames=args.e2e or 2048)
         if extra:
             # BASELINE.json's stress configuration in the same line: a child process (its own batches, freed when it ends)
-            cmd = [sys.executable, os.path.abspath(__file__), "--config", "C5", "--scenes", "128", "--distinct", "8", "--steps", "4",
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", "C5", "--scenes", "256", "--distinct", "8", "--steps", "4",
                    "--warmup", "1", "--no-extra-legs", "--parity-scenes", "1", "--cpu-budget", "8"]
             if args.no_cpu_baseline:
                 cmd.append("--no-cpu-baseline")
