@@ -47,6 +47,14 @@ CONFIGS = {
            "kinds": ["pedestrian", "cyclist", "car", "pedestrian", "cyclist"],
            "workload": "C2: batch of 256 synthetic 64-beam 120k-pt scenes, 5 inserts each (2 pedestrians, 2 cyclists, "
                        "1 car), per GPU"},
+    # BASELINE.json configs[2] / [3] as shapes of the hot path (10 resp. 8 inserts per 120k-point frame): not bench lines
+    # of their own (the line is quoted on C2), selectable for measurements of longer chains on the reference's grid
+    "C3": {"scenes": 256, "beams": 64, "az": 1875, "rows": 112, "cols": 1440,
+           "kinds": ["car", "pedestrian", "cyclist", "car", "pedestrian", "cyclist", "car", "pedestrian", "cyclist", "pedestrian"],
+           "workload": "C3 shape: batch of 256 synthetic 64-beam 120k-pt frames, 10 mixed car / pedestrian / cyclist inserts each, per GPU"},
+    "C4": {"scenes": 256, "beams": 64, "az": 1875, "rows": 112, "cols": 1440,
+           "kinds": ["pedestrian", "cyclist", "car", "pedestrian", "cyclist", "car", "pedestrian", "cyclist"],
+           "workload": "C4 shape: batch of 256 synthetic 64-beam 120k-pt frames, 8 inserts each, per GPU"},
     # BASELINE.json configs[4]: the HBM-bound stress run (range image 448 x 2880 as SURVEY.md par.8d proposes)
     "C5": {"scenes": 32, "beams": 256, "az": 3906, "rows": 448, "cols": 2880,
            "kinds": (["car", "pedestrian", "cyclist", "pedestrian", "cyclist"] * 10),
@@ -252,8 +260,8 @@ def main():
     cpu_single = cpu_multi = None
     oracle_bytes = []
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n_check = max(0, min(args.parity_scenes if args.config == "C2" else 1, B))   # a C5 scene takes the oracle ~10 s
-        budget = args.cpu_budget or (20.0 if args.config == "C2" else 30.0)
+        n_check = max(0, min(args.parity_scenes if args.config != "C5" else 1, B))   # a C5 scene takes the oracle ~10 s
+        budget = args.cpu_budget or (20.0 if args.config != "C5" else 30.0)
         cpu_single, cpu_multi, oracle_bytes = cpu_baselines(pkg, cfg, args.config, n_check, budget_s=budget,
                                                             all_cores=budget >= 20.0)
 
@@ -445,7 +453,7 @@ def main():
             "k_alive_write": {"ms": t_write, "launches_per_step": 1, "alg_bytes": 20.0 * n_pts + 20.0 * n_out_pts},
             "k_prepare": {"ms": t_prepare, "launches_per_step": 1, "alg_bytes": 0.0},
         }
-        pmc, pmc_file = {}, f"profiles/{PROFILE_TAG}_pmc.json" if args.config == "C2" else f"profiles/{PROFILE_TAG}_c5_pmc.json"
+        pmc, pmc_file = {}, f"profiles/{PROFILE_TAG}_pmc.json" if args.config != "C5" else f"profiles/{PROFILE_TAG}_c5_pmc.json"
         try:
             pmc = json.load(open(os.path.join(ROOT, pmc_file)))["kernels"]
         except Exception:
@@ -488,7 +496,7 @@ def main():
         floor_bytes = 20.0 * n_pts + 20.0 * n_out_pts
         floor_gbs = floor_bytes * args.steps / elapsed / 1e9
         out = {
-            "metric": "augmented scenes/sec (120k-pt, 64-beam)" if args.config == "C2" else "augmented scenes/sec (1M-pt, 256-beam)",
+            "metric": "augmented scenes/sec (120k-pt, 64-beam)" if args.config != "C5" else "augmented scenes/sec (1M-pt, 256-beam)",
             "value": round(scenes_per_s, 1),
             "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,

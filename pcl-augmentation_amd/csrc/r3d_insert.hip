@@ -2354,11 +2354,14 @@ static int launch_slots_legacy(const r3d_batch_t &b, const BatchWs &w, const Cha
   hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, nk, -1);
   int rc = R3D_OK;
   {
-    // Long chains and large range images evaluate most pairs twice (config C5: 89 %): those launches keep the hits of
-    // the first evaluation and replay them (3.7 -> 2.9 ms per 50 slots of 32 scans).  The short chains of config C2
-    // (3 % evaluated twice) run the kernel without that code: it costs them registers, i.e. spills (0.35 against 0.32 ms).
-    static const int hits_env = env_int("R3D_CHAIN_HITS", -1);
-    const bool hits = hits_env >= 0 ? hits_env != 0 : nk >= 8 || (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN;
+    // Keeping the hits of a pair's first evaluation and replaying them in a later one (R3D_CHAIN_HITS=1) paid while most
+    // pairs of a long chain were evaluated twice (config C5 at 32 scans per batch: 3.7 -> 2.9 ms per 50 slots).  It is
+    // off by default since round 3: with resident workgroups and 128+ scans per batch 4 % of the pairs are evaluated
+    // twice and the replay gains nothing (8.05 against 7.98 ms per 256 scans), and a soak of 10-slot chains on 256
+    // frames showed it non-deterministic once in ~20 000 frame runs (a few hundred points too many in one frame:
+    // tools/soak_chain.py C3) -- cause not found, so nothing that ships takes that path.
+    static const int hits_env = env_int("R3D_CHAIN_HITS", 0);
+    const bool hits = hits_env > 0;
     const long long tt = (long long)timeout_ms * 100000ll;
     if (hits)
       rc = nt == 1024  ? launch_chain<1024, true>(b, w, sl, nk, first_step, lds, tt, st)

@@ -715,9 +715,41 @@ def test_chain_soak_two_batches_in_flight(P, synth):
             assert fingerprint(0, a) == ref and fingerprint(1, b) == ref
 
 
+def test_chain_soak_long_chains_full_batch(P, synth):
+    """256 full-size frames with ten inserts each (the C3 shape), 60 times: every frame's count and bytes as in the first
+    run, and the first frames equal to the oracle.  (The replay of stored hits, once the default for chains of eight
+    slots and more, failed exactly this once in ~20 000 frame runs; it is off by default since.)"""
+    import torch
+    kinds = synth.CONFIG_INSERTS["C3"]
+    B = 256
+    scenes = [synth.make_scene(s) for s in range(B)]
+    inserts = [synth.make_inserts(s, kinds) for s in range(B)]
+    grow = sum(max(len(inserts[s][k]) for s in range(B)) for k in range(len(kinds)))
+    bt = P.SceneBatch(B, 120000 + grow, grow)
+    bt.load(scenes)
+    pk = [bt.pack_samples([inserts[s][k] for s in range(B)]) for k in range(len(kinds))]
+    nd = torch.full((B,), 20, dtype=torch.int32, device=bt.device)
+    ref = None
+    for it in range(60):
+        bt.begin()
+        acc = bt.insert_many_device(pk, [nd] * len(pk))[1].clone()
+        bt.finish(check_cols=5)
+        fp = torch.stack((bt.n_out.to(torch.int64), bt.out_xyzi.view(torch.int32).sum(dim=(1, 2), dtype=torch.int64),
+                          bt.out_label.sum(dim=1, dtype=torch.int64), acc.sum(dim=0, dtype=torch.int64))).cpu().numpy()
+        assert int(bt.status.sum().item()) == 0
+        if ref is None:
+            ref = fp
+            res = bt.results()
+            for s in range(2):
+                vb, lb, cb, oacc = _oracle_chain(scenes[s][0], scenes[s][1], [[i] for i in inserts[s]], [20] * len(kinds))
+                _check_scene(res[s], vb, lb, cb)
+        else:
+            assert np.array_equal(fp, ref), (it, np.argwhere(fp != ref)[:4].tolist())
+
+
 def test_c5_full_size_chain(P, synth, monkeypatch):
     """BASELINE config C5 at full size: one 256-beam 1M-point scan, 50 inserts, range image 448 x 2880,
-    all slots through r3d_batch_insert_many (two launches of the chain kernel: 32 + 18 slots), against
+    all slots through r3d_batch_insert_many (one launch of the chain kernel, resident workgroups on per-XCD queues), against
     the oracle's chain byte for byte."""
     monkeypatch.setattr(O, "NUMROW", 448)
     monkeypatch.setattr(O, "NUMCOLUMN", 2880)

@@ -3,7 +3,7 @@
 same batch again and again, alone and with a second batch in flight on another stream; every
 iteration must give the same survivors, bytes and status.
 
-    python tools/soak_chain.py [iterations]
+    python tools/soak_chain.py [iterations] [C2|C3|C4]          # C3 / C4: ten / eight inserts per frame
 """
 import importlib
 import os
@@ -18,13 +18,20 @@ pkg = importlib.import_module("pcl-augmentation_amd")
 def main():
     n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     synth = pkg.synth
-    B, kinds = 256, synth.CONFIG_INSERTS["C2"]
-    scenes = [synth.make_scene(s) for s in range(B)]
+    which = sys.argv[2] if len(sys.argv) > 2 else "C2"
+    shape = {}
+    if which == "C5":                                          # 64 scans of config C5's size (8 distinct), 20 of its 50 slots
+        B, kinds, shape = 64, (["car", "pedestrian", "cyclist", "pedestrian", "cyclist"] * 4), dict(rows=448, cols=2880)
+        distinct = [synth.make_scene(s, n_beams=256, n_az=3906) for s in range(8)]
+        scenes = [distinct[s % 8] for s in range(B)]
+    else:
+        B, kinds = 256, synth.CONFIG_INSERTS[which]
+        scenes = [synth.make_scene(s) for s in range(B)]
     inserts = [synth.make_inserts(s, kinds) for s in range(B)]
     grow = sum(max(len(inserts[s][k]) for s in range(B)) for k in range(len(kinds)))
     lanes = []
     for _ in range(2):
-        bt = pkg.SceneBatch(B, 120000 + grow, grow)
+        bt = pkg.SceneBatch(B, max(len(x) for x, _ in scenes) + grow, grow, **shape)
         bt.load(scenes)
         pk = [bt.pack_samples([inserts[s][k] for s in range(B)]) for k in range(len(kinds))]
         nd = torch.full((B,), 20, dtype=torch.int32, device=bt.device)
@@ -40,10 +47,9 @@ def main():
 
     def fingerprint(lane, acc):                      # on the default stream, after a device-wide synchronize
         bt = lanes[lane][0]
-        return [int(v.item()) for v in (bt.out_xyzi.view(torch.int32).sum(dtype=torch.int64),
-                                        bt.out_label.view(torch.int32).sum(dtype=torch.int64),
-                                        bt.n_out.sum(dtype=torch.int64), acc.sum(dtype=torch.int64),
-                                        bt.status.sum(dtype=torch.int64))]
+        per_frame = torch.stack((bt.n_out.to(torch.int64), bt.out_xyzi.view(torch.int32).sum(dim=(1, 2), dtype=torch.int64),
+                                 bt.out_label.sum(dim=1, dtype=torch.int64), acc.sum(dim=0, dtype=torch.int64)))
+        return per_frame.cpu().numpy().tolist() + [int(bt.status.sum(dtype=torch.int64).item())]
 
     torch.cuda.synchronize()                          # the uploads ran on the default stream
     acc = step(0)
@@ -56,8 +62,8 @@ def main():
         fa, fb = fingerprint(0, a), fingerprint(1, b)
         if fa != ref or fb != ref:
             bad += 1
-            print("iteration", it, "differs:", fa, fb, ref)
-    print(f"{n_iter} iterations x 2 lanes: {bad} mismatches; fingerprint {ref}")
+            print("iteration", it, "differs in frames", [[s for s in range(B) if f[0][s] != ref[0][s] or f[1][s] != ref[1][s]] for f in (fa, fb)])
+    print(f"{n_iter} iterations x 2 lanes x {B} frames x {len(kinds)} slots: {bad} iterations with a mismatch; status {ref[-1]}")
     sys.exit(1 if bad else 0)
 
 
