@@ -1809,62 +1809,81 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
 // LDS (a car a few metres from the sensor on 448 x 2880).  The POOL flavour reaches those images through flat
 // accesses -- 35 % slower on config C5 when every pair takes it -- so a pair runs it only after the LDS flavour
 // has turned it down.
+// Everything the chain kernel is given, as ONE kernel argument: the QUEUE flavour reads it through the kernarg segment
+// pointer (below), which needs the layout in one piece.
+struct ChainArgs {
+  r3d_batch_t b;
+  ChainSlots slots;
+  BatchWs w;
+  long long timeout_ticks;
+  int nk, first_step, chunks, lds_cap, B8, queue_mode;
+};
+
 template <int NT, bool HITS, bool QUEUE>
 __global__ void __launch_bounds__(NT, NT == 1024 ? 1 : R3D_CHAIN_WAVES)
-k_insert_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int chunks, int lds_cap,
-               long long timeout_ticks, int B8, int queue_arg) {
+k_insert_chain(ChainArgs args) {
   extern __shared__ __align__(16) unsigned char smem[];     // no static __shared__ here: one LDS array
-  // (QUEUE is a template flag: the loop keeps every kernel argument alive across the pairs, which costs the kernel its
-  // spill-free register allocation -- 176 B of scratch per lane; the short chains of config C2 run the plain form)
-  const int queue_mode = QUEUE ? queue_arg : 0;
-  // queue_mode 0: one workgroup per pair, pair = block id.  Otherwise the launch holds only as many workgroups as the
-  // device keeps resident and each takes pairs off a queue until it is empty -- 1: one queue, pairs in id order; 2: a
-  // queue per XCD (workgroups go to the XCDs round robin, a scene's pairs share a residue mod 8: a scene stays with
-  // one XCD's L2), an XCD that runs dry helps the others.  A pair still waits only for pairs with lower ids of its
-  // own queue, which a running workgroup has taken before.  Why: the hardware hands workgroups to the XCDs strictly
-  // round robin, so with one workgroup per pair an XCD whose pairs run long stalls the hand-out to all the others (a
-  // third of the CUs idle on config C5, tools/stamps_insert.py).
-  const int total = (B8 ? B8 : b.B) * nk;
+  // QUEUE false: one workgroup per pair, pair = block id.  QUEUE true: the launch holds only as many workgroups as the
+  // device keeps resident and each takes pairs off a queue until it is empty -- queue_mode 1: one queue, pairs in id
+  // order; 2: a queue per XCD (workgroups go to the XCDs round robin, a scene's pairs share a residue mod 8: a scene
+  // stays with one XCD's L2), an XCD that runs dry helps the others.  A pair still waits only for pairs with lower
+  // ids of its own queue, which a running workgroup has taken before.  Why: the hardware hands workgroups to the XCDs
+  // strictly round robin, so with one workgroup per pair an XCD whose pairs run long stalls the hand-out to all the
+  // others (a third of the CUs idle on config C5, tools/stamps_insert.py).
+  if (!QUEUE) {
+    const int again = chain_pair<NT, HITS, false>(args.b, args.slots, args.nk, args.first_step, args.w, args.chunks, args.lds_cap,
+                                                  args.timeout_ticks, args.B8, smem, (int)blockIdx.x);
+    if (uni(again))
+      chain_pair<NT, HITS, true>(args.b, args.slots, args.nk, args.first_step, args.w, args.chunks, args.lds_cap, args.timeout_ticks,
+                                 args.B8, smem, (int)blockIdx.x);
+    return;
+  }
   int *H = reinterpret_cast<int *>(smem);
+  const int queue_mode = args.queue_mode, total = (args.B8 ? args.B8 : args.b.B) * args.nk;
   const int home = queue_mode == 2 ? (int)(blockIdx.x & 7) : 0;
   int turn = 0;                                              // queues this workgroup has found empty
   for (;;) {
-    int pair_id = (int)blockIdx.x;
-    if (queue_mode) {
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        int id = total;
-        while (turn < (queue_mode == 2 ? 8 : 1)) {
-          const int q = (home + turn) & 7;
-          const int n = atomicAdd(&w.queue_next[q], 1);
-          id = queue_mode == 2 ? n * 8 + q : n;
-          if (id < total) break;
-          id = total;
-          ++turn;
-        }
-        H[H_GO] = id;
-        H[H_GO + 1] = turn;
+    // The arguments through a pointer the compiler cannot see through, taken afresh for every pair: it then loads
+    // them where the pair uses them.  Loaded once in front of the loop they occupy a hundred scalar registers for
+    // the whole pair and the kernel spills (176-256 B of scratch per lane).
+    typedef const __attribute__((address_space(4))) ChainArgs *ArgsPtr;
+    ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap));
+    const ChainArgs &a = *(const ChainArgs *)ap;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int id = total;
+      while (turn < (queue_mode == 2 ? 8 : 1)) {
+        const int q = (home + turn) & 7;
+        const int n = atomicAdd(&a.w.queue_next[q], 1);
+        id = queue_mode == 2 ? n * 8 + q : n;
+        if (id < total) break;
+        id = total;
+        ++turn;
       }
-      __syncthreads();
-      pair_id = uni(H[H_GO]);
-      turn = uni(H[H_GO + 1]);
-      if (pair_id >= total) return;
+      H[H_GO] = id;
+      H[H_GO + 1] = turn;
     }
+    __syncthreads();
+    const int pair_id = uni(H[H_GO]);
+    turn = uni(H[H_GO + 1]);
+    if (pair_id >= total) return;
 #ifdef R3D_STAMPS
-    const int k_ = B8 ? pair_id / B8 : pair_id % nk, s_ = B8 ? pair_id % B8 : pair_id / nk;
-    long long *cell = s_ < b.B ? reinterpret_cast<long long *>(b.out_xyzi + (int64_t)s_ * b.cap * 4) + k_ * 32 : nullptr;
+    const int k_ = a.B8 ? pair_id / a.B8 : pair_id % a.nk, s_ = a.B8 ? pair_id % a.B8 : pair_id / a.nk;
+    long long *cell = s_ < a.b.B ? reinterpret_cast<long long *>(a.b.out_xyzi + (int64_t)s_ * a.b.cap * 4) + k_ * 32 : nullptr;
     if (cell && threadIdx.x == 0) cell[28] = wall_clock64();   // this workgroup takes the pair
 #endif
-    const int again = chain_pair<NT, HITS, false>(b, slots, nk, first_step, w, chunks, lds_cap, timeout_ticks, B8, smem, pair_id);
+    const int again = chain_pair<NT, HITS, false>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8,
+                                                  smem, pair_id);
 #ifdef R3D_STAMPS
     if (cell && threadIdx.x == 0) cell[29] = uni(again) ? wall_clock64() : 0;   // the LDS flavour turned the pair down here
 #endif
-    if (uni(again)) chain_pair<NT, HITS, true>(b, slots, nk, first_step, w, chunks, lds_cap, timeout_ticks, B8, smem, pair_id);
+    if (uni(again))
+      chain_pair<NT, HITS, true>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8, smem, pair_id);
 #ifdef R3D_STAMPS
     __syncthreads();
     if (cell && threadIdx.x == 0) cell[30] = wall_clock64();   // ... and is done with it
 #endif
-    if (!QUEUE || !queue_mode) return;
   }
 }
 
@@ -2188,8 +2207,13 @@ static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlo
     const int resident = (per_cu < 1 ? 1 : per_cu) * (cus < 8 ? 8 : cus);
     grid = total < resident ? total : resident;
   }
-  hipLaunchKernelGGL((k_insert_chain<NT, HITS, QUEUE>), dim3(grid), dim3(NT), lds, st, b, sl, nk, first_step, w, chunks_of(b), lds,
-                     timeout_ticks, B8, queue_mode);
+  ChainArgs args;
+  args.b = b;
+  args.slots = sl;
+  args.w = w;
+  args.timeout_ticks = timeout_ticks;
+  args.nk = nk, args.first_step = first_step, args.chunks = chunks_of(b), args.lds_cap = lds, args.B8 = B8, args.queue_mode = queue_mode;
+  hipLaunchKernelGGL((k_insert_chain<NT, HITS, QUEUE>), dim3(grid), dim3(NT), lds, st, args);
   R3D_LAUNCHED("k_insert_chain");
   return R3D_OK;
 }
