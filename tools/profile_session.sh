@@ -13,8 +13,8 @@ f=$(find /tmp/p_stats3 -name "*kernel_stats.csv" | head -1); (head -1 $f; grep "
 # the three-kernel insert launch (R3D_INSERT_THREE=1), one step at a time
 cd /tmp && R3D_INSERT_THREE=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_three -- python3 $R/bench.py --overlap 1 --steps 5 --warmup 2 $A > /tmp/p5.log 2>&1
 f=$(find /tmp/p_three -name "*kernel_stats.csv" | head -1); (head -1 $f; grep "r3d::" $f) > $R/gpurun_out/prof/r03_kernel_stats_three_kernel_insert.csv
-# config C5, 128 scans
-C="--config C5 --scenes 128 --distinct 8"
+# config C5, 256 scans per batch (what the c5 leg of the default bench line runs)
+C="--config C5 --scenes 256 --distinct 8"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c_stats -- python3 $R/bench.py $C --overlap 1 --steps 2 --warmup 1 $A > /tmp/c1.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/c_fetch -- python3 $R/bench.py $C --overlap 1 --steps 1 --warmup 1 $A > /tmp/c2.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/c_write -- python3 $R/bench.py $C --overlap 1 --steps 1 --warmup 1 $A > /tmp/c3.log 2>&1
