@@ -71,7 +71,7 @@ class SceneBatch:
         d = _lib.BatchDesc()
         # reserved bit 0: evaluate the reference's float64 formula for every point instead of the
         # verified float32 guess (diagnostic; results are identical, tests/test_gpu_batch.py)
-        # `debug`: further diagnostic bits (2 / 4 / 8 / 16: force the insert kernel's other routes, csrc/r3d_insert.hip)
+        # `debug`: further diagnostic bits (2 / 4 / 8 / 16 / 32 / 64 / 128: force the insert kernel's other routes, csrc/r3d_insert.hip)
         import os
         debug = int(debug) | int(os.environ.get("R3D_DEBUG_BITS", "0"))   # (diagnostics: the same bits for every batch of the process)
         d.B, d.rows, d.cols, d.reserved, d.cap, d.log_cap = B, rows, cols, (1 if exact_projection else 0) | int(debug), cap, log_cap

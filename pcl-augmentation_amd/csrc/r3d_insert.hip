@@ -67,6 +67,7 @@ constexpr int kDbgDefer = 8;         // every pair is left to k_insert_big
 constexpr int kDbgDropPublish = 16;  // slot 0 of scene 0 does not publish: its successors time out
 constexpr int kDbgPoolTile = 32;     // every pair's depth tile and candidate list in the global pool
 constexpr int kDbgThree = 64;        // the launch as k_sample_prep / k_eval / k_commit_chain (also: R3D_INSERT_THREE=1)
+constexpr int kDbgKeepHits = 128;    // keep the hits of a first evaluation and replay them in a later one (also: R3D_CHAIN_HITS=1)
 
 struct ChainSlots {
   const double *samples5[kMaxChain];
@@ -1987,7 +1988,7 @@ k_eval(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int c
   load_slot(I, b, slots, k, s, first_step);
   PairRec *pr = w.pairs + pid;
   int rc = I.load_record(w.tile_pool + pr->rec_off, pr->rec_bytes);
-  I.keep_hits = true;
+  I.keep_hits = (b.reserved & kDbgKeepHits) != 0;           // the replay of stored hits is opt-in (see launch_slots_legacy)
   if (rc == kOk) rc = I.scene_phase(w.n_total0[s], false, [] { return false; });
   bool kept = false;
   if (rc == kOk) kept = I.store_results(pr);
@@ -2385,7 +2386,7 @@ static int launch_slots_legacy(const r3d_batch_t &b, const BatchWs &w, const Cha
     // frames showed it non-deterministic once in ~20 000 frame runs (a few hundred points too many in one frame:
     // tools/soak_chain.py C3) -- cause not found, so nothing that ships takes that path.
     static const int hits_env = env_int("R3D_CHAIN_HITS", 0);
-    const bool hits = hits_env > 0;
+    const bool hits = hits_env > 0 || (b.reserved & kDbgKeepHits);
     const long long tt = (long long)timeout_ms * 100000ll;
     if (hits)
       rc = nt == 1024  ? launch_chain<1024, true>(b, w, sl, nk, first_step, lds, tt, st)

@@ -571,11 +571,12 @@ def test_c5_scan_on_the_proposed_448x2880_grid(P, synth, monkeypatch):
     _check_scene(res[0], vb, lb, cb)
 
 
-@pytest.mark.parametrize("debug", [2, 4, 8, 6, 32, 64, 66, 72, 96])
+@pytest.mark.parametrize("debug", [2, 4, 8, 6, 32, 64, 66, 72, 96, 128, 160, 192])
 def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
     """The insert kernel's other routes, forced with the descriptor's diagnostic bits (64 = the launch as three
     kernels without a wait: k_sample_prep, k_eval, k_commit_chain -- alone, with every pair evaluated in the chain,
-    with every pair left to k_insert_big, with pooled tiles): 2 = never
+    with every pair left to k_insert_big, with pooled tiles; 128 = keep and replay the hits of a first evaluation, the
+    opt-in flavour -- alone, with pooled tiles, in the three-kernel launch): 2 = never
     speculate (every slot waits for its predecessor first), 4 = the window's depth tile built and
     evaluated in bands of at most 3 candidate rows, 32 = tile and candidate list in the global pool, 8 = every pair left to k_insert_big (one 1024-thread
     workgroup per scene); all must give the bytes of the oracle chain, through insert_many and slot by slot."""
