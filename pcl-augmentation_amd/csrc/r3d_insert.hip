@@ -267,6 +267,7 @@ struct Ins {
   const uint4 *r_hits;                   // hits to replay, or null
   int r_nhits, r_n0;
   bool keep_hits, hits_done;              // hits_done: the gather that stores them has run to its end
+  bool intile;                            // the gather leaves, in every list entry's kill field, which of its points lie inside the tile
   long long hits_off;
   bool accept;
   FastDiv by_cols, by_W;
@@ -288,6 +289,7 @@ struct Ins {
     r_hits = nullptr;
     r_nhits = r_n0 = 0;
     keep_hits = hits_done = false;
+    intile = false;
     hits_off = -1;
     pool_off = -1;
     by_cols.set(cols);
@@ -748,6 +750,16 @@ struct Ins {
           if (all_rows_bits && (bt.npx == dt.npx ? dl[u] >= 0 : dt.index(r, c) >= 0)) D.set_local(win.lpix_rc(r, c));
         }
       }
+      // one band for the whole window: which points of every listed chunk lie inside the tile (the kill masks are
+      // computed from those alone, and not at all for a chunk that has none)
+      if (intile && !sub) {
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+          const unsigned long long m = __ballot(dl[u] >= 0);
+          const int e = e0 + u * NT;
+          if ((tid & 63) == 0 && e < nitems) set_kill(e >> 6, m);
+        }
+      }
       GSTAMP(2);
       // coordinates: four float32 points in flight at a time
 #pragma unroll
@@ -991,6 +1003,7 @@ struct Ins {
       __syncthreads();
     }
 
+    intile = single && !(HITS && r_hits);                      // (replayed hits are not in the list)
     if (!serial && stale()) return kStale;
     STAMP(7);
     WinImage &vis = T;
@@ -1195,7 +1208,9 @@ struct Ins {
           __syncthreads();
           for (int i = tid; i < nlist; i += NT) {
             uint32_t rr = l_rows(i);
-            if ((int)(rr & 0xFFFF) <= vr1 && (int)(rr >> 16) >= vr0) s_kl[atomicAdd(&H[H_CARRY], 1)] = (uint16_t)i;
+            const bool reach = (int)(rr & 0xFFFF) <= vr1 && (int)(rr >> 16) >= vr0 && (!intile || l_kill(i) != 0ull);
+            if (reach) s_kl[atomicAdd(&H[H_CARRY], 1)] = (uint16_t)i;
+            else if (intile) set_kill(i, 0ull);                // (the field held the in-tile mask)
           }
           __syncthreads();
           nkl = uni(H[H_CARRY]);
@@ -1210,7 +1225,8 @@ struct Ins {
           for (int u = 0; u < kPer; ++u) {
             int e = e0 + u * NT;
             ent[u] = e < nitems ? (s_kl ? (int)s_kl[e >> 6] : (e >> 6)) : 0;
-            on[u] = e < nitems && ((l_alive(ent[u]) >> (e & 63)) & 1ull);
+            // the living points of the chunk -- those inside the tile, when the gather has left their mask
+            on[u] = e < nitems && (((intile ? l_kill(ent[u]) : l_alive(ent[u])) >> (e & 63)) & 1ull);
             p[u] = on[u] ? pixs[(int)(l_chunk(ent[u]) << 6) + (e & 63)] : 0;
           }
 #pragma unroll
@@ -1223,7 +1239,7 @@ struct Ins {
               kill = lp >= 0 && vis.get_local(lp);
             }
             unsigned long long mask = __ballot(kill);
-            if (lane == 0 && e < nitems && mask) set_kill(ent[u], mask);
+            if (lane == 0 && e < nitems && (mask || intile)) set_kill(ent[u], mask);
           }
         }
       }
