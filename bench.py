@@ -532,7 +532,7 @@ def main():
             out["placement_search"] = placement_leg(pkg, torch, args.placement or 64, not args.no_cpu_baseline, CONFIGS["C2"]["kinds"])
         if (args.e2e > 0 or extra) and world == 1:
             e2e = importlib.import_module("tools.e2e_pipeline")
-            out["e2e"] = e2e.measure(pkg, n_frames=args.e2e or 2048)
+            out["e2e"] = e2e.measure(pkg, n_frames=args.e2e or 4096)
         if extra:
             # BASELINE.json's stress configuration in the same line: a child process (its own batches, freed when it ends)
             cmd = [sys.executable, os.path.abspath(__file__), "--config", "C5", "--scenes", "256", "--distinct", "8", "--steps", "4",
