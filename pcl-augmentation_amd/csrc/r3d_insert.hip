@@ -49,6 +49,9 @@
 #include <mutex>
 #include <string>
 
+#ifndef R3D_BIG_WAVES
+#define R3D_BIG_WAVES 1
+#endif
 #ifndef R3D_CHAIN_WAVES
 #define R3D_CHAIN_WAVES 4
 #endif
@@ -1837,7 +1840,7 @@ struct ChainArgs {
 };
 
 template <int NT, bool HITS, bool QUEUE>
-__global__ void __launch_bounds__(NT, NT == 1024 ? 1 : R3D_CHAIN_WAVES)
+__global__ void __launch_bounds__(NT, NT == 1024 ? R3D_BIG_WAVES : R3D_CHAIN_WAVES)
 k_insert_chain(ChainArgs args) {
   extern __shared__ __align__(16) unsigned char smem[];     // no static __shared__ here: one LDS array
   // QUEUE false: one workgroup per pair, pair = block id.  QUEUE true: the launch holds only as many workgroups as the
