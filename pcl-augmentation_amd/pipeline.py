@@ -313,7 +313,16 @@ class AugmentPipeline:
         t_start = time.perf_counter()
         chunks = [todo[i:i + self.batch_size] for i in range(0, len(todo), self.batch_size)]
         read_q, write_q = queue.Queue(maxsize=2), queue.Queue(maxsize=2)
-        errors = []
+        errors, stop = [], threading.Event()
+
+        def put_unless_stopped(q, item):                        # a producer must not block for ever on a consumer that has failed
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.5)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def reader():
             try:
@@ -322,11 +331,12 @@ class AugmentPipeline:
                     scenes = self._read_batch([frames[i] for i in chunk])
                     cands = [candidates_for(i) for i in chunk]
                     stats["t_read"] += time.perf_counter() - t0
-                    read_q.put((chunk, scenes, cands))
+                    if not put_unless_stopped(read_q, (chunk, scenes, cands)):
+                        return
             except Exception as e:                              # surface in the main thread
                 errors.append(e)
             finally:
-                read_q.put(None)
+                put_unless_stopped(read_q, None)
 
         def writer():
             try:
@@ -381,6 +391,7 @@ class AugmentPipeline:
                     break
         threads[1].join(timeout=60)
         write_pool.shutdown(wait=True)
+        stop.set()                                              # (the reader, if it is still waiting to hand over a batch)
         if errors:
             raise errors[0]
         stats["t_total"] = time.perf_counter() - t_start
