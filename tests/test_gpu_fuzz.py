@@ -79,3 +79,51 @@ def test_window_beyond_the_lds_goes_through_the_level1_kernels(pkg, synth, monke
         vb, lb, cb, oacc = F.oracle_case((rows, cols) + c)
         assert [a for a in accepted[i][:len(oacc)]] == list(oacc)
         assert results[i][0].tobytes() == vb and results[i][1].tobytes() == lb and results[i][2].tobytes() == cb
+
+
+def test_random_placement_queries_equal_the_oracle(pkg):
+    """A fixed slice of tools/fuzz_places.py: twelve random placement queries, everything the search returns."""
+    FP = importlib.import_module("fuzz_places")
+    T = importlib.import_module("test_gpu_places")
+    fs = pkg.Real3DAug.tools.find_spot
+    specs = [FP.spec_of(3000 + i) for i in range(12)]
+    queries = []
+    for spec in specs:
+        c = FP.make_case(spec)
+        sa = fs.read_label_line(c["line"])
+        ok_map, ok_labels = fs.placement_surfaces(sa, T.CONFIG)
+        scene = pkg.PlaceScene(c["scene9"], c["original"], [fs._anno10(fs.read_label_line(l)) for l in c["lines"]], c["rich"],
+                               c["move"], c["T"])
+        queries.append({"scene": scene, "sample": c["sample"], "anno": fs._anno10(sa), "ok_labels": ok_labels, "ok_map": ok_map})
+    placements = 0
+    for spec, r in zip(specs, pkg.find_places(queries)):
+        rot, clouds, centres, quats, off, hit = FP.oracle_case(spec)
+        f = r["flags"]
+        assert list(r["rotations"]) == rot, spec
+        assert np.ascontiguousarray(r["clouds"]).tobytes() == clouds, spec
+        assert np.ascontiguousarray(r["anno"][:, :3]).tobytes() == centres and np.ascontiguousarray(r["anno"][:, 3:]).tobytes() == quats, spec
+        assert int(((f & 1) == 0).sum()) == off and int((((f & 3) == 3) & ((f & 16) == 0)).sum()) == hit, spec
+        placements += len(rot)
+    assert placements > 100
+
+
+def test_random_rich_maps_equal_the_oracle(pkg, synth):
+    """A fixed slice of tools/fuzz_rich_map.py: sequences under random poses and single object-detection frames."""
+    FR = importlib.import_module("fuzz_rich_map")
+    M = importlib.import_module("oracle.rich_map_oracle")
+    labels = {1: [40], 2: [48, 72], 3: [44]}
+    for seed in range(9000, 9012):
+        rng = np.random.default_rng(seed)
+        origin = FR.random_pose(rng)
+        frames = []
+        for _ in range(int(rng.integers(1, 6))):
+            xyzi, label = FR.random_frame(synth, rng)
+            T = origin.copy()
+            T[:3, 3] += rng.uniform(-15, 15, 3) * np.array([1, 1, 0.02])
+            frames.append((xyzi, label, T))
+        area, move = pkg.build_rich_map(frames, labels)
+        want, wmove = M.build_rich_map(frames, labels[1], labels[2], labels[3])
+        assert np.array_equal(move, wmove) and area.shape == want.shape and np.array_equal(area, want), seed
+        xyzi, label = FR.random_frame(synth, rng)
+        got, wod = pkg.rich_map.build_od_maps(xyzi, label, 40), M.od_maps(xyzi, label, 40)
+        assert got[2:] == wod[2:] and np.array_equal(got[0], wod[0]) and np.array_equal(got[1], wod[1]), seed
