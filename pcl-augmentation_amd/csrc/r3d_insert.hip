@@ -2220,11 +2220,25 @@ static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlo
   const int total = (B8 ? B8 : b.B) * nk;
   int grid = total;
   if (QUEUE && queue_mode) {
-    int dev = 0, cus = 0, per_cu = 0;
+    // how many workgroups of this shape the device keeps resident: asked once per (device, LDS size) and kernel flavour
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, int> known;
+    int dev = 0;
     R3D_HIP(hipGetDevice(&dev));
-    R3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    R3D_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_insert_chain<NT, HITS, QUEUE>), NT, lds));
-    const int resident = (per_cu < 1 ? 1 : per_cu) * (cus < 8 ? 8 : cus);
+    int resident = 0;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      auto it = known.find({dev, lds});
+      if (it != known.end()) resident = it->second;
+    }
+    if (!resident) {
+      int cus = 0, per_cu = 0;
+      R3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      R3D_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_insert_chain<NT, HITS, QUEUE>), NT, lds));
+      resident = (per_cu < 1 ? 1 : per_cu) * (cus < 8 ? 8 : cus);
+      std::lock_guard<std::mutex> lock(mu);
+      known[{dev, lds}] = resident;
+    }
     grid = total < resident ? total : resident;
   }
   ChainArgs args;
