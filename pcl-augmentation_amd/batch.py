@@ -108,7 +108,10 @@ class SceneBatch:
         assert len(scenes) == self.B
         hx, hl, hn = self.staging_views()
         # the native packer (threads; a Python loop of 256 slab assignments costs 40 ms per batch)
-        xs = [np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 4) for x, _ in scenes]
+        for s, (x, _) in enumerate(scenes):
+            if np.ndim(x) != 2 or np.shape(x)[1] != 4:
+                raise ValueError(f"scene {s}: xyzi must have shape [n, 4], got {np.shape(x)}")
+        xs = [np.ascontiguousarray(x, dtype=np.float32) for x, _ in scenes]
         ls = [np.ascontiguousarray(l).astype(np.uint32, copy=False).reshape(-1) for _, l in scenes]
         for s, (x, l) in enumerate(zip(xs, ls)):
             if len(x) > self.cap:
