@@ -250,3 +250,45 @@ def test_save_data_writes_the_references_bytes(R, tmp_path):
     assert (tmp_path / "od" / "check" / "000000.bin").read_bytes() == g["kitti_1"].tobytes()
     assert (tmp_path / "od" / "label_2" / "000000.txt").read_bytes() == g["kitti_label_2"].tobytes()
     assert not list(tmp_path.rglob("*.tmp"))
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 2048), (448, 2880)])
+def test_another_grid_by_editing_the_two_globals(R, synth, monkeypatch, rows, cols):
+    """The reference's grid is its two module globals (insertion.py:22-23): the pixel id of column 8 multiplies by the
+    global NUMCOLUMN whatever num_column is passed (:116, :127, :470).  The mirror keeps the globals with that meaning
+    (r3d_geometrical_front_view_grid / r3d_occlusion_merge_grid underneath): function by function against the oracle
+    with both edited, on grids wider than the 1440 columns the plain C entry points are fixed at."""
+    ins, clo = R.insertion, R.tools.closing
+    monkeypatch.setattr(O, "NUMROW", rows)
+    monkeypatch.setattr(O, "NUMCOLUMN", cols)
+    monkeypatch.setattr(ins, "NUMROW", rows)
+    monkeypatch.setattr(ins, "NUMCOLUMN", cols)
+    xyzi, label = synth.make_scene(300 + rows, 48, 800, shuffle=True)
+    s5 = synth.scene5_from_packed(xyzi, label)
+    sample5 = synth.make_insert(9, "car", centre_range=6.0, centre_az=1.0)
+    sc, osc = ins.add_space_for_spherical(s5), O.add_space_for_spherical(s5)
+    sc, mx, mn = ins.fill_spherical(sc)
+    osc, omx, omn = O.fill_spherical(osc)
+    assert mx == omx and mn == omn
+    tr, lb, sc = ins.geometrical_front_view(sc, rows, cols, mx, mn)
+    otr, olb, osc = O.geometrical_front_view(osc, rows, cols, omx, omn)
+    assert np.array_equal(sc[:, 8], osc[:, 8]) and sc[:, 8].max() >= 1440 * rows   # ids beyond the fixed stride's range
+    assert np.array_equal(tr, otr) and np.array_equal(lb, olb)
+    tr, lb = clo.smooth_out(tr, lb)
+    otr, olb = O.smooth_out(otr, olb)
+    assert np.array_equal(tr, otr)
+    sm, osm = ins.add_space_for_spherical(sample5), O.add_space_for_spherical(sample5)
+    sm, _, _ = ins.fill_spherical(sm)
+    osm, _, _ = O.fill_spherical(osm)
+    mtr, mlb, sm = ins.geometrical_front_view(sm, rows, cols, mx, mn, sample=True)
+    omtr, omlb, osm = O.geometrical_front_view(osm, rows, cols, omx, omn, sample=True)
+    assert np.array_equal(sm[:, 8], osm[:, 8])
+    mtr, _ = clo.smooth_out(mtr, mlb)
+    omtr, _ = O.smooth_out(omtr, omlb)
+    out, vis, cov = ins.occlusion_merge(sc, sm, tr, mtr)
+    oout, ovis, ocov = O.occlusion_merge(osc, osm, otr, omtr)
+    assert len(vis) > 50 and len(cov) > 0
+    assert out.shape == oout.shape and vis.shape == ovis.shape and cov.shape == ocov.shape, (out.shape, oout.shape, vis.shape, ovis.shape, cov.shape, ocov.shape)
+    for got, want in ((vis, ovis), (cov, ocov), (out, oout)):                 # rows and order exact; the angles to 1e-12 rad
+        assert np.array_equal(got[:, [0, 1, 2, 3, 6, 7, 8]], want[:, [0, 1, 2, 3, 6, 7, 8]])
+        assert np.abs(got[:, 4:6] - want[:, 4:6]).max() <= ANGLE_TOL
