@@ -16,7 +16,8 @@ from ._dev import back, ptr, to_device
 NUMROW = 112          # SS Real3DAug/insertion.py:22
 NUMCOLUMN = 360 * 4   # SS Real3DAug/insertion.py:23.  As in the reference, the pixel ids of column 8 multiply by THIS global
                       # (:116, :127, :470), read at call time, not by the num_column argument: whoever works on another
-                      # grid edits the two globals (level1.augment_scene does, for the duration of its call)
+                      # grid edits the two globals (level1.augment_scene passes its grid to the private helpers
+                      # _front_view / _merge instead, so that concurrent callers never see an edited global)
 
 
 def add_space_for_spherical(point_cloud):
@@ -55,6 +56,11 @@ def geometrical_front_view(point_cloud, num_row, num_column, max_elevation_angle
     """SS Real3DAug/insertion.py:84-129: returns (train, label, point_cloud); column 8 is written
     in place for every binned point; the reference's asserts (:110-112) are raised as
     AssertionError."""
+    return _front_view(point_cloud, num_row, num_column, max_elevation_angle, min_elevation_angle, sample, int(NUMCOLUMN))
+
+
+def _front_view(point_cloud, num_row, num_column, max_elevation_angle, min_elevation_angle, sample, id_columns):
+    """geometrical_front_view with the multiplier of the pixel ids (the reference's global NUMCOLUMN) as an argument."""
     torch = _lib.require_gpu()
     lib = _lib.load()
     dev, was_np = to_device(point_cloud, torch.float64)
@@ -64,7 +70,7 @@ def geometrical_front_view(point_cloud, num_row, num_column, max_elevation_angle
     ws_bytes = lib.r3d_front_view_workspace_bytes(num_row, num_column)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev.device)
     status = torch.zeros(1, dtype=torch.int32, device=dev.device)
-    _lib.check(lib.r3d_geometrical_front_view_grid(ptr(dev), n, num_row, num_column, int(NUMCOLUMN),
+    _lib.check(lib.r3d_geometrical_front_view_grid(ptr(dev), n, num_row, num_column, int(id_columns),
                                                    float(max_elevation_angle), float(min_elevation_angle),
                                                    1 if sample else 0, ptr(train), ptr(label), ptr(ws), ws_bytes,
                                                    ptr(status), _lib.stream_ptr()), "geometrical_front_view")
@@ -84,6 +90,11 @@ def occlusion_merge(scene_pcl, sample_pcl, scene_train, sample_train):
     grouped by pixel (row-major) and then sample order; removed scene rows in the same grouping.
     With no visible pixel the two lists are ``np.array([])`` like the reference's initial values.
     """
+    return _merge(scene_pcl, sample_pcl, scene_train, sample_train, int(NUMCOLUMN))
+
+
+def _merge(scene_pcl, sample_pcl, scene_train, sample_train, id_columns):
+    """occlusion_merge with the multiplier of the pixel ids (the reference's global NUMCOLUMN) as an argument."""
     torch = _lib.require_gpu()
     lib = _lib.load()
     sc, was_np = to_device(scene_pcl, torch.float64)
@@ -100,7 +111,7 @@ def occlusion_merge(scene_pcl, sample_pcl, scene_train, sample_train):
     if ws_bytes == 0:
         raise _lib.R3DError("occlusion_merge: workspace query failed: " + lib.r3d_last_error().decode())
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=sc.device)
-    _lib.check(lib.r3d_occlusion_merge_grid(ptr(sc), n, ptr(sm), m, ptr(st), ptr(mt), rows, cols, int(NUMCOLUMN), ptr(out),
+    _lib.check(lib.r3d_occlusion_merge_grid(ptr(sc), n, ptr(sm), m, ptr(st), ptr(mt), rows, cols, int(id_columns), ptr(out),
                                             ptr(vis), ptr(cov), ptr(counts), ptr(ws), ws_bytes, _lib.stream_ptr()),
                "occlusion_merge")
     n_out, n_vis, n_cov = (int(v) for v in counts.cpu().numpy())

@@ -174,6 +174,7 @@ class SceneBatch:
     @_lib.on_own_device
     def begin(self):
         self.step = 0
+        self._rebegin = self.begin                      # how run_inserts' time-out fallback starts the batch again
         _lib.check(self.lib.r3d_batch_begin(C.byref(self.desc), C.c_void_p(self.n_points.data_ptr()),
                                             _lib.stream_ptr()), "r3d_batch_begin")
 
@@ -196,9 +197,16 @@ class SceneBatch:
             n[s] = len(rows)
             host[s, :len(rows)] = rows[:, :5]
         self._rows5.copy_(self._rows5_pin, non_blocking=True)
-        self.n_points.copy_(torch.from_numpy(n))
         self.n_frame = n.copy()
+        self._begin_rows5()
+
+    @_lib.on_own_device
+    def _begin_rows5(self):
+        """Step 0 from the float64 rows already on the device (``begin_f64``, and again from the time-out fallback of
+        ``run_inserts``: the rows and counts are untouched by the inserts)."""
         self.step = 0
+        self._rebegin = self._begin_rows5
+        self.n_points.copy_(self.torch.from_numpy(self.n_frame))
         _lib.check(self.lib.r3d_batch_begin_f64(C.byref(self.desc), C.c_void_p(self._rows5.data_ptr()),
                                                 C.c_void_p(self.n_points.data_ptr()), _lib.stream_ptr()),
                    "r3d_batch_begin_f64")
@@ -372,7 +380,8 @@ class SceneBatch:
                 # workgroups are dispatched): do the batch again right here, one launch per slot -- the frames are
                 # still in the slabs, step 0 restores everything the inserts changed
                 self.chain_timeouts = getattr(self, "chain_timeouts", 0) + bad
-                self.begin()
+                # (a batch begun with begin_f64 is begun that way again: its frame lives in the float64 rows and the log)
+                getattr(self, "_rebegin", self.begin)()
                 accs = [self.insert_device(p[0], p[1], nd)[1].clone() for p, nd in zip(packed, needs)]
                 acc_h = torch.stack(accs).cpu().numpy()
                 bad = int((self.status & _lib.S_CHAIN_TIMEOUT).sum().item())

@@ -23,12 +23,9 @@ def augment_scene(xyzi, label, candidates, min_points, rows=_lib.NUMROW, cols=_l
     from .Real3DAug import insertion as ins
     from .Real3DAug.tools import closing
     from .Real3DAug.tools.datasets import pack_for_save
-    saved = ins.NUMROW, ins.NUMCOLUMN
-    ins.NUMROW, ins.NUMCOLUMN = int(rows), int(cols)          # the grid is the reference's two globals (insertion.py:22-23)
-    try:
-        return _augment_scene(torch, ins, closing, pack_for_save, xyzi, label, candidates, min_points, rows, cols, device, check_cols)
-    finally:
-        ins.NUMROW, ins.NUMCOLUMN = saved
+    # the grid is the reference's two globals (insertion.py:22-23); they are NOT edited here (another thread may be inside
+    # the Level-1 mirrors): the multiplier of the pixel ids goes to the private helpers as an argument
+    return _augment_scene(torch, ins, closing, pack_for_save, xyzi, label, candidates, min_points, int(rows), int(cols), device, check_cols)
 
 
 def _augment_scene(torch, ins, closing, pack_for_save, xyzi, label, candidates, min_points, rows, cols, device, check_cols):
@@ -41,16 +38,16 @@ def _augment_scene(torch, ins, closing, pack_for_save, xyzi, label, candidates, 
             chosen = -1
             if any(c is not None and len(c) for c in cands):
                 scene, max_el, min_el = ins.fill_spherical(scene)
-                train, lab, scene = ins.geometrical_front_view(scene, rows, cols, max_el, min_el)
+                train, lab, scene = ins._front_view(scene, rows, cols, max_el, min_el, False, cols)
                 train, lab = closing.smooth_out(train, lab)
             for ci, smp in enumerate(cands):
                 if smp is None or not len(smp):
                     continue
                 sm9 = ins.add_space_for_spherical(torch.from_numpy(np.ascontiguousarray(smp, dtype=np.float64)).to(device))
                 sm9, _, _ = ins.fill_spherical(sm9)
-                s_train, s_lab, sm9 = ins.geometrical_front_view(sm9, rows, cols, max_el, min_el, sample=True)
+                s_train, s_lab, sm9 = ins._front_view(sm9, rows, cols, max_el, min_el, True, cols)
                 s_train, s_lab = closing.smooth_out(s_train, s_lab)
-                out, vis, _ = ins.occlusion_merge(scene, sm9, train, s_train)
+                out, vis, _ = ins._merge(scene, sm9, train, s_train, cols)
                 if len(vis) == 0 or len(vis) < need:              # :511-517
                     continue
                 scene = torch.cat((out, vis), dim=0)              # :526

@@ -67,6 +67,9 @@ class _Lane:
                 self.out_check = pin((B, log_cap, max(check_cols, 4)), torch.float32)
             # the batch was built on the device's current stream: this lane's stream starts behind it
             self.stream.wait_stream(torch.cuda.current_stream())
+            # the row counts of the check files as `collect` saw them: the pinned out_counts are overwritten by the
+            # lane's next download, the snapshot belongs to whoever consumes the lane's results
+            self.h_n_log = torch.zeros((B,), dtype=torch.int32)
         self.busy = False
         self.tag = None
 
@@ -135,7 +138,7 @@ class StreamedAugmenter:
         _lib.check(self.lib.r3d_host_write_frames(
             enc(velodyne_files), enc(label_files), enc(check_files) if ln.check_cols else None, B, ln.out_xyzi.data_ptr(),
             ln.out_label.data_ptr(), ln.bt.cap, n_out.data_ptr(), ln.out_check.data_ptr(), ln.bt.log_cap, cc,
-            ln.out_counts[1].data_ptr(), self.pack_threads), "r3d_host_write_frames")
+            ln.h_n_log.data_ptr(), self.pack_threads), "r3d_host_write_frames")
 
     def _enqueue(self, lane_no, inserts, min_points, tag):
         ln = self.lanes[lane_no]
@@ -226,6 +229,8 @@ class StreamedAugmenter:
         assert ln.busy
         ln.done.synchronize()
         counts = ln.out_counts.numpy()
+        n_log = ln.h_n_log.numpy()
+        n_log[:] = counts[1]
         redo = [int(s) for s in np.nonzero(counts[2] & _lib.S_WINDOW_TOO_LARGE)[0]]   # see _redo_level1
         for s in np.nonzero(counts[2])[0]:
             if int(s) in redo:
@@ -246,19 +251,19 @@ class StreamedAugmenter:
         if redo:
             try:
                 for s in redo:
-                    self._redo_level1(ln, s, n_out, counts)
+                    self._redo_level1(ln, s, n_out, n_log)
             except Exception:
                 ln.busy = False
                 raise
         ox, ol, ck = ln.out_xyzi.numpy(), ln.out_label.numpy().view(np.uint32), ln.out_check.numpy()
         acc = ln.out_acc.numpy()
-        results = [(ox[s, :n_out[s]], ol[s, :n_out[s]], ck[s, :counts[1][s], :ln.check_cols] if ln.check_cols else None)
+        results = [(ox[s, :n_out[s]], ol[s, :n_out[s]], ck[s, :n_log[s], :ln.check_cols] if ln.check_cols else None)
                    for s in range(self.B)]
         accepted = [[0 if acc[k, s] else -1 for k in range(self.K)] for s in range(self.B)]
         ln.busy = False
         return ln.tag, results, accepted
 
-    def _redo_level1(self, ln, s, n_out, counts):
+    def _redo_level1(self, ln, s, n_out, n_log):
         """Frame s of the lane came back with R3D_S_WINDOW_TOO_LARGE (an insert's window exceeds a CU's LDS: an object
         a few metres from the sensor on a grid several times the reference's): once more, alone, through the Level-1
         kernels (``level1.augment_scene``), its results into the lane's output slabs."""
@@ -274,7 +279,7 @@ class StreamedAugmenter:
         n_out[s] = len(x)
         if ln.check_cols:
             ln.out_check.numpy()[s, :len(ck), :ln.check_cols] = ck
-            counts[1][s] = len(ck)
+            n_log[s] = len(ck)
         for k in range(K):
             ln.out_acc.numpy()[k, s] = 1 if acc[k] >= 0 else 0
         self.level1_frames = getattr(self, "level1_frames", 0) + 1
@@ -286,7 +291,12 @@ class StreamedAugmenter:
         batch i+1 and its merging / consuming of batch i-1 overlap as well."""
         import queue
         import threading
-        submitted, freed, errors = queue.Queue(), queue.Queue(), []
+        submitted, free, errors = queue.Queue(), queue.Queue(), []
+        # a lane goes back to the submitting thread only when `consume` has returned: its buffers (results, counters,
+        # the pinned input the host merge reads) belong to the drain thread until then.  `collect` clears `busy`
+        # earlier, so lanes are taken from this queue and never from free_lane().
+        for i in range(len(self.lanes)):
+            free.put(i)
 
         def drain():
             while True:
@@ -301,27 +311,21 @@ class StreamedAugmenter:
                 except Exception as e:                             # surfaces in the submitting thread
                     errors.append(e)
                     self.lanes[lane].busy = False
-                freed.put(lane)
+                free.put(lane)
 
         th = threading.Thread(target=drain, daemon=True)
         th.start()
-        in_flight = 0
         try:
             for scenes, inserts, min_points, tag in batches:
                 if errors:
                     break
-                lane = self.free_lane() if in_flight < len(self.lanes) else None
-                if lane is None:
-                    freed.get()
-                    in_flight -= 1
-                    if errors:
-                        break
-                    lane = self.free_lane()
+                lane = free.get()
+                if errors:
+                    break
                 if isinstance(scenes, tuple) and len(scenes) == 3 and scenes[0] == "files":
                     self.submit_files(lane, scenes[1], scenes[2], inserts, min_points, tag)
                 else:
                     self.submit(lane, scenes, inserts, min_points, tag)
-                in_flight += 1
                 submitted.put(lane)
         finally:
             submitted.put(None)

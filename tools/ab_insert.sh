@@ -3,7 +3,7 @@ args=$1; shift
 i=0
 for e in "$@"; do
   i=$((i+1))
-  env $e python bench.py --no-cpu-baseline $args > gpurun_out/r03_ab_$i.log 2>&1
+  env $e python bench.py --no-extra-legs --no-cpu-baseline $args > gpurun_out/r03_ab_$i.log 2>&1
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/r03_ab_$i.log").read().strip().splitlines()[-1])

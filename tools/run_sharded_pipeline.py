@@ -34,7 +34,7 @@ def spawn(args):
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
     env = {**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
     return subprocess.call(cmd, env=env)
 
@@ -46,7 +46,9 @@ def load_plan(plan_dir, name):
         return parts, [int(x) for x in z["min_points"]]
 
 
-def main():
+def main(process=None):
+    """``process``: the per-batch GPU leg of ``run_sharded_files`` (None = the HIP path; the CPU test of the sharding
+    logic, tests/sharded_files_child.py, passes its own stand-in -- this driver knows no other leg)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--velodyne", required=True)
@@ -58,8 +60,6 @@ def main():
     ap.add_argument("--dataset", choices=["semantic", "kitti"], default="semantic")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--lanes", type=int, default=3)
-    ap.add_argument("--cpu-oracle", action="store_true",
-                    help="tests only: the oracle stands in for the GPU leg (no GPU needed; results are the same bytes)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn(args))
@@ -80,11 +80,6 @@ def main():
                     [15] * len(kinds))
         return load_plan(args.plan, names[i])
 
-    process = None
-    if args.cpu_oracle:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from test_pipeline import _oracle_process
-        process = _oracle_process(5 if args.dataset == "semantic" else 4)
     import torch
     n_dev = max(torch.cuda.device_count(), 1)
     st = pkg.run_sharded_files(frames, inserts_for, args.output, args.folder, rank, world, device=f"cuda:{local_rank % n_dev}",
