@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def measure(pkg, n_frames=1024, B=256, lanes=3, pack_threads=16, delta=True):
+def measure(pkg, n_frames=1024, B=256, lanes=3, pack_threads=16, delta=True, device="cuda:0", before_timed=None):
     synth = pkg.synth
     kinds = synth.CONFIG_INSERTS["C2"]
     n_distinct = min(n_frames, B)                     # B distinct frames, cycled: the generator is not what is measured
@@ -34,7 +34,8 @@ def measure(pkg, n_frames=1024, B=256, lanes=3, pack_threads=16, delta=True):
     srows = max(sum(len(ins[k]) for ins in inserts) for k in range(len(kinds))) * (B // n_distinct + 1)
     from importlib import import_module
     streaming = import_module("pcl-augmentation_amd.streaming")
-    aug = streaming.StreamedAugmenter(B, n_max, grow, len(kinds), srows, lanes=lanes, pack_threads=pack_threads, delta=delta)
+    aug = streaming.StreamedAugmenter(B, n_max, grow, len(kinds), srows, lanes=lanes, pack_threads=pack_threads, delta=delta,
+                                      device=device)
     batch = [scenes[s % n_distinct] for s in range(B)], [inserts[s % n_distinct] for s in range(B)]
     n_batches = max(2, n_frames // B)
     got = {"frames": 0, "points": 0}
@@ -46,10 +47,12 @@ def measure(pkg, n_frames=1024, B=256, lanes=3, pack_threads=16, delta=True):
     aug.run([(batch[0], batch[1], need, 0)] * 2, consume)           # warm-up: allocations, kernel load, clocks
     got["frames"] = got["points"] = 0
     aug.bytes_h2d = aug.bytes_d2h = 0
+    if before_timed is not None:
+        before_timed()                                                 # (a barrier: the ranks of one host start together)
     t0 = time.perf_counter()
     aug.run([(batch[0], batch[1], need, i) for i in range(n_batches)], consume)
     dt = time.perf_counter() - t0
-    return {"frames_per_s": round(got["frames"] / dt, 1), "frames": got["frames"], "batch": B, "lanes": lanes,
+    return {"frames_per_s": round(got["frames"] / dt, 1), "frames": got["frames"], "seconds": dt, "batch": B, "lanes": lanes,
             "h2d_GBps": round(aug.bytes_h2d / dt / 1e9, 2), "d2h_GBps": round(aug.bytes_d2h / dt / 1e9, 2),
             "pack_threads": pack_threads, "delta": delta,
             "what": "config C2 frames (120k points, 5 inserts) resident in host memory -> native packer -> pinned staging -> "
