@@ -156,7 +156,7 @@ typedef struct r3d_batch {
   /* the cloud of scene s lives at index s*cap .. s*cap + n_total[s] */
   float *xyzi;           /* [B*cap][4]  x y z intensity as in velodyne .bin files (caller fills [0,n)) */
   uint32_t *label;       /* [B*cap]     semantic label as in .label files, masked with 0xFFFF */
-  int32_t *pix;          /* [B*cap]     row*cols+col under the scene's current bounds */
+  int32_t *pix;          /* [B*cap]     pixel of every point under the scene's current bounds: (row << 16) | column */
   int32_t *n_head;       /* [B] float32-exact points at the front of the cloud */
   int32_t *n_total;      /* [B] n_head + live/dead inserted points */
   int32_t *tail_ref;     /* [B*log_cap] log row of cloud point n_head + t */
@@ -166,7 +166,7 @@ typedef struct r3d_batch {
   int32_t *n_log;        /* [B] */
   /* per-scene range-image state (pixel ids above; liveness, chunk boxes and tile counts live in the workspace) */
   double *bounds;        /* [B][2] max elevation, min elevation */
-  int32_t *far_pix;      /* [B*R3D_FAR_CAP] occupied pixels deeper than 500 m */
+  int32_t *far_pix;      /* [B*R3D_FAR_CAP] occupied pixels deeper than 500 m, (row << 16) | column */
   int32_t *n_far;        /* [B] */
   int32_t *rebase;       /* [B] re-projections forced so far because the elevation bounds may have moved */
   int32_t *status;       /* [B] R3D_S_* bits */
@@ -247,19 +247,12 @@ int r3d_batch_export_rows(const r3d_batch_t *b, double *rows4, int32_t *n_rows, 
 int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream);
 
 /* Diagnostic: the 16 counters the insert kernels keep in the workspace since r3d_batch_create (or the last
- * call with reset != 0), copied to HOST memory; synchronises the stream.  [0..3] pairs k_eval evaluated and
- * stored / could not store (pool exhausted) / left because the scene has pixels beyond 500 m / left because
- * they exceed its LDS; [4..7] slots k_commit_chain committed from the stored evaluation / found rejected /
- * evaluated again after a conflicting predecessor / evaluated because k_eval had not; [8..10] scenes handed
- * to k_insert_big: sample too large for k_sample_prep, bounds moved, evaluation too large; [11] rebases;
- * [12] pairs whose sample phase did not fit k_sample_prep; [13] allocations the launch's pool could not serve (depth tiles,
- * hit lists: those evaluations took a slower route); [14] evaluations whose depth tile lived in the pool (window too large for
- * the workgroup's LDS). */
+ * call with reset != 0), copied to HOST memory; synchronises the stream.  [0] allocations the launch's pool could not
+ * serve (those evaluations took a slower route); [1] evaluations whose depth tile lived in the pool (window too large
+ * for the workgroup's LDS); [2] pairs evaluated more than once (a predecessor changed a pixel they had read); [3] / [4]
+ * evaluations done again for comparison / that differed (descriptor bit 64 of `reserved`: diagnostic, must stay 0);
+ * [5] unused; [6] scenes handed to k_insert_big; [7] rebases inside the chain kernel. */
 int r3d_batch_debug_counters(const r3d_batch_t *b, int32_t *host_out16, int32_t reset, void *stream);
-/* Diagnostic: per (scene, slot) of the last insert launch, two int64 words [B][32][2] to HOST memory: 100 MHz
- * ticks k_commit_chain spent on the slot | the counter index (above) of the way it took << 48; the tick at which
- * it started.  n_words <= B * 64.  Synchronises the stream. */
-int r3d_batch_debug_trace(const r3d_batch_t *b, int64_t *host_out, int64_t n_words, void *stream);
 
 /* =====================================================================================
  * Level 3 -- placement search.

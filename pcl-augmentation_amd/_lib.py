@@ -100,7 +100,6 @@ _SIGNATURES = {
     "r3d_batch_finish": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int32, _P]),
     "r3d_batch_launch_one": (C.c_int, [C.POINTER(BatchDesc), C.c_int32, _P]),
     "r3d_batch_debug_counters": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int32, _P]),
-    "r3d_batch_debug_trace": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int64, _P]),
     "r3d_batch_insert_many": (C.c_int, [C.POINTER(BatchDesc), C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "r3d_batch_export_rows": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P]),
     "r3d_places_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),

@@ -71,7 +71,8 @@ class SceneBatch:
         d = _lib.BatchDesc()
         # reserved bit 0: evaluate the reference's float64 formula for every point instead of the
         # verified float32 guess (diagnostic; results are identical, tests/test_gpu_batch.py)
-        # `debug`: further diagnostic bits (2 / 4 / 8 / 16 / 32 / 64 / 128: force the insert kernel's other routes, csrc/r3d_insert.hip)
+        # `debug`: further diagnostic bits (2 / 4 / 8 / 16 / 32 / 128: force the insert kernel's other routes; 64: verify every
+        # speculative evaluation, csrc/r3d_insert.hip)
         import os
         debug = int(debug) | int(os.environ.get("R3D_DEBUG_BITS", "0"))   # (diagnostics: the same bits for every batch of the process)
         d.B, d.rows, d.cols, d.reserved, d.cap, d.log_cap = B, rows, cols, (1 if exact_projection else 0) | int(debug), cap, log_cap
@@ -324,18 +325,15 @@ class SceneBatch:
         out = (C.c_int32 * 16)()
         _lib.check(self.lib.r3d_batch_debug_counters(C.byref(self.desc), out, 1 if reset else 0, _lib.stream_ptr()),
                    "r3d_batch_debug_counters")
-        names = ["eval_stored", "eval_pool_full", "eval_far_scene", "eval_nofit", "chain_stored", "chain_rejected",
-                 "chain_conflict", "chain_unevaluated", "defer_prep", "defer_bounds", "defer_nofit", "rebases", "prep_nofit", "pool_exhausted", "tiles_pooled"]
+        names = ["pool_exhausted", "tiles_pooled", "evaluated_twice", "verify_runs", "verify_mismatch", "unused5", "deferred_scenes",
+                 "rebases_in_chain"]
         return dict(zip(names, list(out)))
 
-    @_lib.on_own_device
-    def debug_trace(self):
-        """Per (scene, slot) of the last insert launch: (ticks of 10 ns k_commit_chain spent, path id, start tick)
-        as int64 arrays [B, MAX_CHAIN] each (r3d_batch_debug_trace)."""
-        out = np.zeros((self.B, _lib.MAX_CHAIN, 2), dtype=np.int64)
-        _lib.check(self.lib.r3d_batch_debug_trace(C.byref(self.desc), out.ctypes.data, out.size, _lib.stream_ptr()),
-                   "r3d_batch_debug_trace")
-        return out[:, :, 0] & ((1 << 48) - 1), out[:, :, 0] >> 48, out[:, :, 1]
+    def pixel_ids(self):
+        """The pixel id of every point as the reference numbers it (row * cols + col, insertion.py:116): the batch keeps
+        (row << 16) | column."""
+        p = self.pix.cpu().numpy().view(np.uint32)
+        return ((p >> 16).astype(np.int64) * self.cols + (p & 0xFFFF)).astype(np.int32)
 
     # -- results --------------------------------------------------------------------------------
     @_lib.on_own_device

@@ -276,42 +276,7 @@ __global__ void k_col_table(r3d_batch_t b, BatchWs w) {
 // three orders of magnitude above the rounding of the products and of the reference's own float64 evaluation.
 // Cheap float32 angle guesses (about 1e-5 rad, a few per mille of a bin): whatever they get wrong the
 // confirmation rejects, so their accuracy only decides how many points take the slow path, never a result.
-__device__ __forceinline__ float guess_acosf(float q) {
-  if (fabsf(q) > 0.5f) return acosf(q);                       // steep beams: the library routine
-  float q2 = q * q;                                           // asin series, error < 3e-6 for |q| <= 0.5
-  float p = fmaf(q2, 0.02237216f, 0.03038194f);
-  p = fmaf(p, q2, 0.04464286f);
-  p = fmaf(p, q2, 0.075f);
-  p = fmaf(p, q2, 0.16666667f);
-  return 1.57079637f - fmaf(p * q2, q, q);
-}
-__device__ __forceinline__ float guess_atan2f(float y, float x) {
-  float ax = fabsf(x), ay = fabsf(y);
-  float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-  float t = mn * __builtin_amdgcn_rcpf(mx), t2 = t * t;       // atan on [0, 1], odd polynomial, error ~1e-5 (v_rcp_f32: 1 ulp)
-  float p = fmaf(-0.01172120f, t2, 0.05265332f);
-  p = fmaf(p, t2, -0.11643287f);
-  p = fmaf(p, t2, 0.19354346f);
-  p = fmaf(p, t2, -0.33262347f);
-  p = fmaf(p, t2, 0.99997726f);
-  float a = p * t;
-  a = ay > ax ? 1.57079637f - a : a;
-  a = x < 0.f ? 3.14159274f - a : a;
-  return y < 0.f ? -a : a;
-}
-
-// Float64 confirmation of a guessed bin (rg, cg) against the edge tables.
-__device__ __forceinline__ bool confirm_bin(const double *__restrict__ row_cc, const double *__restrict__ col_dir,
-                                            int rg, int cg, double x, double y, double z, double ss) {
-  const double zz = z * fabs(z);
-  const double hi = row_cc[rg == 0 ? 0 : rg + 1], lo = row_cc[rg + 2];
-  const double ax = col_dir[2 * cg], ay = col_dir[2 * cg + 1], bx = col_dir[2 * cg + 2], by = col_dir[2 * cg + 3];
-  const double mr = 4e-12 * ss, mc = 1e-12 * (fabs(x) + fabs(y) + fabs(z));
-  // (non-short-circuit on purpose: six compares and five ANDs instead of five branches)
-  return (int)(fabs(zz) < 0.999998 * ss) &                    // acos is ill-conditioned at the poles
-         (int)(zz < hi * ss - mr) & (int)(zz > lo * ss + mr) & (int)(ax * y - ay * x > mc) &
-         (int)(bx * y - by * x < -mc);
-}
+// (guess_acosf, guess_atan2f, confirm_bin: r3d_batch.hpp -- the insert kernels bin their samples with them too)
 
 // k_project screens in float32 first; the float64 confirmation above runs only for the points the screen
 // cannot decide (a few per mille, those within ~1e-6 of a bin edge).  The screen is a sufficient condition
@@ -394,7 +359,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
           far = ss > R3D_EMPTY_DEPTH * R3D_EMPTY_DEPTH;      // r > 500 (or rounds to it): far list
         }
         if (ok & (int)(!exact)) {
-          int p = row * b.cols + col;
+          int p = (int)pack_pix(row, col);
           box.add(row, col);
           placed = true;
           if (far) {
@@ -421,7 +386,8 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
         if (__ballot(in_order) == ~0ull)
           packed = pack_box(row0, row0, __builtin_amdgcn_readfirstlane(col), __builtin_amdgcn_readlane(col, 63));
         else
-          packed = box.wave_pack();
+          // (a point queued for k_project_slow has made the box the whole image: no arc then)
+          packed = __ballot((i < n) & !placed) ? box.wave_pack() : box.wave_pack_arc(placed ? col : -1, b.cols);
       }
       unsigned long long living = __ballot(i < n);           // every point of the frame is alive at step 0
       int i0 = t0 + k * kPT + (threadIdx.x & ~63);

@@ -10,6 +10,8 @@
 //   tile_alive[t]  living points of the 2048-point tile t: the compaction's offsets without a counting pass
 #pragma once
 
+#include <cstdlib>
+
 #include "r3d_device.hpp"
 #include "r3d_host.hpp"
 
@@ -21,22 +23,7 @@ constexpr int kTile = kPT * kPerThread;   // points per block tile
 constexpr int kKeyCap = R3D_MAX_SAMPLE;
 constexpr int kMaxChain = 64;        // insert slots of one k_insert_chain launch
 constexpr int kRecInts = 16;         // int32 words of a published slot record
-constexpr int kEvalClasses = 4;      // launch shapes of k_eval (LDS need of the pair)
-
-// One (scene, slot) pair of an insert launch: where its sample record and the results of its evaluation live in
-// the launch's pool, and the few numbers the commit chain decides on (r3d_insert.hip).
-struct PairRec {
-  long long rec_off, res_off;        // byte offsets into tile_pool
-  int32_t rec_bytes, state;          // kPair*
-  int32_t sflags;                    // R3D_S_* bits raised by the sample's projection
-  int32_t rmin, rmax, cmin0, cmin1, cmax0, cmax1;   // rows / columns (per image half) of the sample's pixels
-  int32_t nvis, accept, rebase, nkill;              // of the evaluation against the launch-time scene
-  int32_t vrmin, vrmax, vcmin0, vcmin1, vcmax0, vcmax1;   // rows / columns of its visible pixels
-  int32_t nhits;                     // scene points inside the pair's window at launch time ("hits"), -1: not kept
-  long long hits_off;                // {pixel | holder flags, point, depth key} x nhits in tile_pool
-  int32_t n0, pad;                   // the scene's point count the hits were gathered under
-};
-static_assert(sizeof(PairRec) == 112, "PairRec layout");
+constexpr int kEntry = 32;           // bytes of a chunk-list entry of the insert kernels (r3d_insert.hip)
 
 struct BatchWs {
   unsigned long long *qkeys;    // [B][2] ordered keys of min / max of z/r
@@ -56,16 +43,13 @@ struct BatchWs {
   int32_t *n_total0;            // [B] n_total when the running k_insert_chain was launched
   int32_t *defer_from;          // [B] first slot of the launch left to k_insert_big (n_slots: none)
   int32_t *recs;                // [B*kMaxChain*kRecInts] what every finished slot of the launch publishes
-  unsigned char *glist;         // [B*(kMaxChain+1)*chunks*24] chunk lists that exceed a workgroup's LDS: one area per (scene, slot of the
-                                // launch) for k_insert_chain, one per scene for k_insert_big
-  unsigned char *tile_pool;     // [pool_bytes] depth tiles / candidate lists of the pairs whose window exceeds a workgroup's LDS
+  unsigned char *glist;         // [B*chunks*kEntry] k_insert_big's chunk lists, one area per scene (a pair of k_insert_chain whose
+                                // list exceeds its LDS takes room from the pool)
+  unsigned char *tile_pool;     // [pool_bytes] the launch's bump pool: depth tiles / candidate lists / chunk lists / scratch images
+                                // of the pairs whose window exceeds a workgroup's LDS
   unsigned long long *pool_head; // [1] bytes handed out in the running launch
-  PairRec *pairs;               // [B*kMaxChain] the pairs of the running launch
-  int32_t *cls_list;            // [kEvalClasses][B*kMaxChain] pair ids (scene * kMaxChain + slot) per launch shape of k_eval
-  int32_t *cls_count;           // [kEvalClasses]
   int32_t *queue_next;          // [16] the running k_insert_chain's work queues: next pair of XCD x's queue in [x] (all pairs: [0])
   int32_t *dbg;                 // [16] diagnostic counters of the insert kernels (r3d_batch_debug_counters)
-  long long *trace;             // [B*kMaxChain*2] per slot of the last launch: 100 MHz ticks k_commit_chain spent on it | path << 48
   int64_t pool_bytes;
   int64_t cand_stride;          // uint32 entries of `cand` per scene
   size_t total;
@@ -99,21 +83,24 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.n_total0 = c.take<int32_t>((size_t)b.B);
   w.defer_from = c.take<int32_t>((size_t)b.B);
   w.recs = c.take<int32_t>((size_t)b.B * kMaxChain * kRecInts);
-  w.glist = c.take<unsigned char>((size_t)b.B * (kMaxChain + 1) * chunks_of(b) * 24);
-  // per scene 4 MB or 96 bytes per point of its slab (on a large range image the hits of up to 32 slots' windows, 16
-  // bytes per scene point inside a window, plus the tiles and scratch images that exceed the LDS), between 256 MB
-  // and 24 GB; an exhausted pool costs time, not results (the evaluations fall back to bands / full re-evaluation)
-  const int64_t per_scene = (int64_t)b.cap * 96 > (4 << 20) ? (int64_t)b.cap * 96 : (4 << 20);
+  w.glist = c.take<unsigned char>((size_t)b.B * chunks_of(b) * kEntry);
+  // The launch's pool: depth tiles, candidate lists, chunk lists and scratch images of the pairs whose window exceeds a
+  // workgroup's LDS (on the reference's grid a few per cent of the pairs, 10-60 KB each; on a range image several times
+  // that size most cars, up to ~1 MB each).  Per scene 1 MB or 16 bytes per point of its slab, between 64 MB and 4 GB per
+  // batch -- R3D_POOL_MB overrides --; an exhausted pool costs time, not results (tiles in row bands, the pair left to
+  // k_insert_big).  Per-lane footprint: INTEGRATION.md.
+  const int64_t per_scene = (int64_t)b.cap * 16 > (1 << 20) ? (int64_t)b.cap * 16 : (1 << 20);
   w.pool_bytes = (int64_t)b.B * per_scene;
-  w.pool_bytes = w.pool_bytes < (256ll << 20) ? (256ll << 20) : (w.pool_bytes > (24ll << 30) ? (24ll << 30) : w.pool_bytes);
+  w.pool_bytes = w.pool_bytes < (64ll << 20) ? (64ll << 20) : (w.pool_bytes > (4ll << 30) ? (4ll << 30) : w.pool_bytes);
+  static const long long pool_mb = [] {
+    const char *v = getenv("R3D_POOL_MB");
+    return v && atoll(v) > 0 ? atoll(v) : 0ll;
+  }();
+  if (pool_mb) w.pool_bytes = pool_mb << 20;
   w.tile_pool = c.take<unsigned char>((size_t)w.pool_bytes);
   w.pool_head = c.take<unsigned long long>(1);
-  w.pairs = c.take<PairRec>((size_t)b.B * kMaxChain);
-  w.cls_list = c.take<int32_t>((size_t)kEvalClasses * b.B * kMaxChain);
-  w.cls_count = c.take<int32_t>(kEvalClasses);
   w.queue_next = c.take<int32_t>(16);
   w.dbg = c.take<int32_t>(16);
-  w.trace = c.take<long long>((size_t)b.B * kMaxChain * 2);
   w.total = c.off;
   return w;
 }
@@ -141,6 +128,12 @@ __device__ __forceinline__ void load_point(const r3d_batch_t &b, int s, int i, i
   }
 }
 
+// Pixel id of a point as the batched kernels keep it (r3d_batch_t.pix, far_pix): row in the upper, column in the lower
+// 16 bits (rows, cols <= 65535: check_batch) -- no division by the run-time column count wherever a pixel is looked up.
+__device__ __forceinline__ uint32_t pack_pix(int row, int col) { return ((uint32_t)row << 16) | (uint32_t)col; }
+__device__ __forceinline__ int pix_row(uint32_t p) { return (int)(p >> 16); }
+__device__ __forceinline__ int pix_col(uint32_t p) { return (int)(p & 0xFFFFu); }
+
 __device__ __forceinline__ unsigned long long pack_box(int rmin, int rmax, int cmin, int cmax) {
   return (unsigned long long)(rmin & 0xFFFF) | ((unsigned long long)(rmax & 0xFFFF) << 16) |
          ((unsigned long long)(cmin & 0xFFFF) << 32) | ((unsigned long long)(cmax & 0xFFFF) << 48);
@@ -157,11 +150,13 @@ struct BoxAcc {
     clo = (unsigned)col < clo ? (unsigned)col : clo;
     chi = (unsigned)col > chi ? (unsigned)col : chi;
   }
-  __device__ __forceinline__ void add_box(unsigned long long bx) {      // union with a packed box
+  __device__ __forceinline__ void add_box(unsigned long long bx, int cols) {      // union with a packed box
     int rmin = (int)(bx & 0xFFFF), rmax = (int)((bx >> 16) & 0xFFFF);
     if (rmin > rmax) return;                                            // empty
-    add(rmin, (int)((bx >> 32) & 0xFFFF));
-    add(rmax, (int)((bx >> 48) & 0xFFFF));
+    int cmin = (int)((bx >> 32) & 0xFFFF), cmax = (int)((bx >> 48) & 0xFFFF);
+    if (cmin > cmax) cmin = 0, cmax = cols - 1;                         // an arc across the azimuth seam (wave_pack_arc): all columns
+    add(rmin, cmin);
+    add(rmax, cmax);
   }
   __device__ __forceinline__ unsigned long long wave_pack() {          // uniform: the box of the wave's 64 lanes
 #define R3D_STEP(C, M)                                                                       \
@@ -177,7 +172,29 @@ struct BoxAcc {
 #undef R3D_STEP
     return pack_box(wave_last_i32((int)rlo), wave_last_i32((int)rhi), wave_last_i32((int)clo), wave_last_i32((int)chi));   // rmin > rmax: empty box
   }
+  // The same with the columns as the shorter of two arcs of the azimuth circle: [min, max] of the columns themselves, or of
+  // the columns turned by half the image -- which is short when the 64 points sit on either side of the seam (columns
+  // cols-1 | 0), as the chunk does that holds the end of one ring of a scan and the beginning of the next.  A box whose
+  // first column exceeds its last covers [first, cols) and [0, last] (box_touches_cols).  `col`: this lane's column, -1 =
+  // none; the row part comes from the accumulator.
+  __device__ __forceinline__ unsigned long long wave_pack_arc(int col, int cols) {
+    const int half = cols >> 1;
+    int t = col < 0 ? -1 : (col + half >= cols ? col + half - cols : col + half);
+    int tlo = wave_min_i32(t < 0 ? 0x7FFFFFFF : t), thi = wave_max_i32(t);
+    const unsigned long long plain = wave_pack();
+    const int clo_ = (int)((plain >> 32) & 0xFFFF), chi_ = (int)((plain >> 48) & 0xFFFF);
+    if (thi < 0 || thi - tlo >= chi_ - clo_) return plain;
+    int a = tlo - half, z = thi - half;
+    a = a < 0 ? a + cols : a;
+    z = z < 0 ? z + cols : z;
+    return (plain & 0xFFFFFFFFull) | ((unsigned long long)(a & 0xFFFF) << 32) | ((unsigned long long)(z & 0xFFFF) << 48);
+  }
 };
+
+// Does a packed box's column part touch [a, b]?  (first column > last column: the arc across the azimuth seam)
+__device__ __forceinline__ bool box_touches_cols(int cmin, int cmax, int a, int b) {
+  return cmin <= cmax ? (cmin <= b && cmax >= a) : (b >= cmin || a <= cmax);
+}
 
 // The reference formula for one point (insertion.py:74-76, :104-116) as a real function call: inlined,
 // the float64 atan2 / acos of the device library raise the register count of every kernel that
@@ -210,7 +227,7 @@ __device__ __forceinline__ int project_point(const r3d_batch_t &b, int s, const 
   if (!(ok & 1)) flags |= (ok & 4) ? R3D_S_ROW_RANGE : R3D_S_NONFINITE;          // assert :110
   else if (!(ok & 2)) flags |= R3D_S_COL_RANGE;                                   // assert :112
   else {
-    p = row * b.cols + col;
+    p = (int)pack_pix(row, col);
     box.add(row, col);
     if (sp.r > R3D_EMPTY_DEPTH) {           // "first hit overwrites the 500": insertion.py:122-125
       int f = atomicAdd(&b.n_far[s], 1);
@@ -224,6 +241,45 @@ __device__ __forceinline__ int project_point(const r3d_batch_t &b, int s, const 
 __device__ __forceinline__ bool alive_bit(const BatchWs &w, int chunks, int s, int i) {
   return (w.alive[(int64_t)s * chunks + (i >> 6)] >> (i & 63)) & 1ull;
 }
+
+// ---- the verified fast projection's pieces (k_project in r3d_batch.hip explains the margins) -------------------------
+__device__ __forceinline__ float guess_acosf(float q) {
+  if (fabsf(q) > 0.5f) return acosf(q);                       // steep beams: the library routine
+  float q2 = q * q;                                           // asin series, error < 3e-6 for |q| <= 0.5
+  float p = fmaf(q2, 0.02237216f, 0.03038194f);
+  p = fmaf(p, q2, 0.04464286f);
+  p = fmaf(p, q2, 0.075f);
+  p = fmaf(p, q2, 0.16666667f);
+  return 1.57079637f - fmaf(p * q2, q, q);
+}
+__device__ __forceinline__ float guess_atan2f(float y, float x) {
+  float ax = fabsf(x), ay = fabsf(y);
+  float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  float t = mn * __builtin_amdgcn_rcpf(mx), t2 = t * t;       // atan on [0, 1], odd polynomial, error ~1e-5 (v_rcp_f32: 1 ulp)
+  float p = fmaf(-0.01172120f, t2, 0.05265332f);
+  p = fmaf(p, t2, -0.11643287f);
+  p = fmaf(p, t2, 0.19354346f);
+  p = fmaf(p, t2, -0.33262347f);
+  p = fmaf(p, t2, 0.99997726f);
+  float a = p * t;
+  a = ay > ax ? 1.57079637f - a : a;
+  a = x < 0.f ? 3.14159274f - a : a;
+  return y < 0.f ? -a : a;
+}
+
+// Float64 confirmation of a guessed bin (rg, cg) against the edge tables.
+__device__ __forceinline__ bool confirm_bin(const double *__restrict__ row_cc, const double *__restrict__ col_dir,
+                                            int rg, int cg, double x, double y, double z, double ss) {
+  const double zz = z * fabs(z);
+  const double hi = row_cc[rg == 0 ? 0 : rg + 1], lo = row_cc[rg + 2];
+  const double ax = col_dir[2 * cg], ay = col_dir[2 * cg + 1], bx = col_dir[2 * cg + 2], by = col_dir[2 * cg + 3];
+  const double mr = 4e-12 * ss, mc = 1e-12 * (fabs(x) + fabs(y) + fabs(z));
+  // (non-short-circuit on purpose: six compares and five ANDs instead of five branches)
+  return (int)(fabs(zz) < 0.999998 * ss) &                    // acos is ill-conditioned at the poles
+         (int)(zz < hi * ss - mr) & (int)(zz > lo * ss + mr) & (int)(ax * y - ay * x > mc) &
+         (int)(bx * y - by * x < -mc);
+}
+
 
 // ---- rebase: one workgroup re-bases one scene (rare path) ------------------------------------------
 // Triggered when an accepted insert may have moved the elevation bounds.  Does, for that scene only,
@@ -276,6 +332,21 @@ __device__ __forceinline__ void rebase_scene(const r3d_batch_t &b, const BatchWs
     w.q_ext[2 * s + 0] = ordered_key_inv(lmin);
     w.q_ext[2 * s + 1] = ordered_key_inv(lmax);
     b.n_far[s] = 0;
+    s_min[0] = depth_key(max_el);                       // (for the row table below)
+    s_max[0] = depth_key(min_el);
+  }
+  __syncthreads();
+  // the row-edge table of the fast projection under the new bounds (k_prepare's formula): the insert kernels bin their
+  // samples against it
+  {
+    const double max_el = key_depth(s_min[0]), min_el = key_depth(s_max[0]);
+    const double d_el = (max_el - min_el) / (double)b.rows;
+    for (int k = tid; k < b.rows + 2; k += NT) {
+      double edge = min_el + 0.00001 + (double)(k - 1) * d_el;
+      edge = edge < 0.0 ? 0.0 : (edge > kPi ? kPi : edge);
+      const double c = cos(edge);
+      w.row_q[(int64_t)s * (b.rows + 2) + k] = c * fabs(c);
+    }
   }
   phase_sync();
   // (b) re-project the living (insertion.py:74-76, :104-116): pixel ids and chunk boxes

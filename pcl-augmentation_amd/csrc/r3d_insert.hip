@@ -69,8 +69,10 @@ constexpr int kDbgBands = 4;         // the depth tile in bands of at most 3 can
 constexpr int kDbgDefer = 8;         // every pair is left to k_insert_big
 constexpr int kDbgDropPublish = 16;  // slot 0 of scene 0 does not publish: its successors time out
 constexpr int kDbgPoolTile = 32;     // every pair's depth tile and candidate list in the global pool
-constexpr int kDbgThree = 64;        // the launch as k_sample_prep / k_eval / k_commit_chain (also: R3D_INSERT_THREE=1)
-constexpr int kDbgKeepHits = 128;    // keep the hits of a first evaluation and replay them in a later one (also: R3D_CHAIN_HITS=1)
+constexpr int kDbgNoHits = 128;      // the kill masks from the pixel ids in global memory for every chunk (no hits kept in LDS)
+constexpr int kDbgVerify = 64;       // a speculative evaluation that is about to be committed is done again, now after its
+                                     // predecessors, and compared (visible count, accept, visible pixels, kill masks):
+                                     // counters D_VERIFY_RUNS / D_VERIFY_MISMATCH (tests/test_gpu_batch.py soaks on them)
 
 struct ChainSlots {
   const double *samples5[kMaxChain];
@@ -211,26 +213,23 @@ __device__ __forceinline__ double mean_of_keys(const unsigned long long (&v)[15]
 enum {
   H_NVALID = 0, H_NCAND, H_REBASE, H_FLAGS, H_RMIN, H_RMAX, H_CMIN0, H_CMIN1, H_CMAX0, H_CMAX1,
   H_NLIST, H_CARRY, H_EXT0, H_EXT1, H_NOCC, H_NVIS, H_VRMIN, H_VRMAX, H_VCMIN0, H_VCMIN1, H_VCMAX0,
-  H_VCMAX1, H_FARADD, H_FILL, H_HITCAP, H_NHITS,
+  H_VCMAX1, H_FARADD, H_FILL, H_NHIT, H_HITEND,
+  H_SIG = 26,         // two words: the signature's 64-bit sum (diagnostic bit 64)
   H_GO = 30,          // chain logic: broadcast cell (not touched by the phases)
   H_SCAN = 32         // block scan cells [NT/64 + 1]
 };
 constexpr int kHdrBytes = 512;
 
 enum { kOk = 0, kNoFit = 1, kNeedSerial = 2, kStale = 3 };
-// PairRec.state: nothing to do | the sample's record is in the pool | ... and the results of its evaluation
-// against the launch-time scene | the pair does not fit the kernels' LDS (k_insert_big takes the scene from here)
-enum { kPairIdle = 0, kPairSampled = 1, kPairEvaluated = 2, kPairNoFit = 3 };
-// diagnostic counters (BatchWs::dbg): what k_eval did with its pairs, which way k_commit_chain took per slot
-enum { D_EVAL_STORED = 0, D_EVAL_POOL, D_EVAL_SERIAL, D_EVAL_NOFIT, D_CHAIN_STORED, D_CHAIN_REJECTED, D_CHAIN_CONFLICT,
-       D_CHAIN_UNEVAL, D_DEFER_PREP, D_DEFER_BOUNDS, D_DEFER_NOFIT, D_REBASE, D_PREP_NOFIT, D_POOL_FULL, D_TILE_POOLED };
+// diagnostic counters (BatchWs::dbg; r3d_batch_debug_counters)
+enum { D_POOL_FULL = 0, D_TILE_POOLED, D_EVAL_TWICE, D_VERIFY_RUNS, D_VERIFY_MISMATCH, D_HITS_OVERFLOW, D_DEFERRED, D_REBASE };
 
 // A value every lane holds (read from LDS or global memory): into a scalar register.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// NT threads; HITS: keeps / replays hits; POOL: the scratch images of a window too large for the LDS may live in the pool
-// (the flavours for large range images: every access to those images is then a flat one, which the others avoid)
-template <int NT, bool HITS, bool POOL>
+// NT threads; POOL: the scratch images of a window too large for the LDS may live in the pool (the flavour for large
+// range images: every access to those images is then a flat one, which the other avoids)
+template <int NT, bool POOL>
 struct Ins {
   const r3d_batch_t &b;
   const BatchWs &w;
@@ -259,26 +258,25 @@ struct Ins {
   unsigned long long *g_dtile;           // the tile in the global pool (the window does not fit the LDS), or null
   uint32_t *g_cand;
   long long pool_off;                    // this pair's piece of the pool (-1: none yet, -2: the pool was exhausted)
-  unsigned char *s_list, *g_list;        // chunk list: 24-byte entries growing down from the end of the LDS, or of
+  unsigned char *s_list, *g_list;        // chunk list: 32-byte entries growing down from the end of the LDS, or of
   bool glist;                            // the pair's area in global memory when they do not fit there
   DTile bt;                              // the band of the tile currently in LDS
   int list_cap, nlist, nvis, n_base, n_far;
-  // the hits: the living points inside the window as the first evaluation found them.  k_eval stores them (g_hits,
-  // counted in H_NHITS); an evaluation of the same pair after its predecessors (k_commit_chain) replays them -- alive
-  // bit re-read -- instead of listing and gathering the scene again, and gathers only the points appended since.
-  uint4 *g_hits;                         // where this evaluation stores its hits, or null
-  const uint4 *r_hits;                   // hits to replay, or null
-  int r_nhits, r_n0;
-  bool keep_hits, hits_done;              // hits_done: the gather that stores them has run to its end
+  // the hits (gather_flat): {point number, tile pixel << 16 | window pixel} of every living scene point inside the
+  // tile, entry by entry (the entry's `hbase` is where its in-tile points start, in lane order), in LDS behind the tile
+  // as far as the room goes: the coordinates are then fetched for the hits alone, all at once, and the kill masks of
+  // an accepted pair are formed without a second trip to the pixel ids
+  uint2 *s_hit;
+  int hit_cap;
   bool intile;                            // the gather leaves, in every list entry's kill field, which of its points lie inside the tile
-  long long hits_off;
+  bool flat;                              // gather_flat does the gather
   bool accept;
-  FastDiv by_cols, by_W;
+  FastDiv by_W;
 
-  // area: which of the scene's kMaxChain + 1 global list areas this workgroup may use (its slot of the launch;
-  // kMaxChain for k_insert_big, which then uses it for every pair)
+  // k_insert_big passes force_glist: its chunk lists live in the scene's global area (w.glist); a chain pair whose
+  // list exceeds the LDS takes room from the launch's pool
   __device__ __forceinline__ Ins(const r3d_batch_t &b_, const BatchWs &w_, unsigned char *smem_, int lds_cap_, int s_,
-                                 int chunks_, int slot_no_, int area, bool force_glist_)
+                                 int chunks_, int slot_no_, bool force_glist_)
       : b(b_), w(w_), smem(smem_), lds_cap(lds_cap_), s(s_), chunks(chunks_), slot_no(slot_no_), tid(threadIdx.x),
         rows(b_.rows), cols(b_.cols), npix(b_.rows * b_.cols), wpr(b_.cols >> 5), force_glist(force_glist_) {
     H = reinterpret_cast<int *>(smem);
@@ -288,50 +286,67 @@ struct Ins {
     glist = false;
     g_dtile = nullptr;
     g_cand = nullptr;
-    g_hits = nullptr;
-    r_hits = nullptr;
-    r_nhits = r_n0 = 0;
-    keep_hits = hits_done = false;
-    intile = false;
-    hits_off = -1;
+    s_hit = nullptr;
+    hit_cap = 0;
+    intile = flat = false;
     pool_off = -1;
-    by_cols.set(cols);
-    g_list = w.glist + (((int64_t)s * (kMaxChain + 1) + area) + 1) * chunks * 24;     // entries grow down from the area's end
+    g_list = force_glist_ ? w.glist + ((int64_t)s + 1) * chunks * kEntry : nullptr;   // entries grow down from the area's end
   }
 
-  // chunk list entry i: { alive word, kill mask, chunk number, rows of its box (first | last << 16) }
+  // A piece of the launch's pool (bytes: rounded up to 256): its offset, or -1 when the pool is exhausted.  Called by
+  // the whole workgroup (two barriers).
+  __device__ __forceinline__ long long pool_take(long long bytes) {
+    const long long want = (bytes + 255) & ~255ll;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long o = atomicAdd(w.pool_head, (unsigned long long)want);
+      H[H_FILL] = o + want <= (unsigned long long)w.pool_bytes ? (int)(o >> 8) : -1;
+      if (H[H_FILL] < 0) atomicAdd(&w.dbg[D_POOL_FULL], 1);
+    }
+    __syncthreads();
+    const int got = uni(H[H_FILL]);
+    __syncthreads();
+    return got < 0 ? -1ll : (long long)got << 8;
+  }
+
+  // chunk list entry i: { alive word, kill mask, chunk number, rows of its box (first | last << 16), hbase, - }
+  __device__ __forceinline__ unsigned char *entry(int i) const { return (glist ? g_list : s_list) - kEntry * (i + 1); }
   __device__ __forceinline__ unsigned long long l_alive(int i) const {
-    return glist ? *reinterpret_cast<const unsigned long long *>(g_list - 24 * (i + 1))
-                 : *reinterpret_cast<const unsigned long long *>(s_list - 24 * (i + 1));
+    return glist ? *reinterpret_cast<const unsigned long long *>(g_list - kEntry * (i + 1))
+                 : *reinterpret_cast<const unsigned long long *>(s_list - kEntry * (i + 1));
   }
   __device__ __forceinline__ unsigned long long l_kill(int i) const {
-    return glist ? *reinterpret_cast<const unsigned long long *>(g_list - 24 * (i + 1) + 8)
-                 : *reinterpret_cast<const unsigned long long *>(s_list - 24 * (i + 1) + 8);
+    return glist ? *reinterpret_cast<const unsigned long long *>(g_list - kEntry * (i + 1) + 8)
+                 : *reinterpret_cast<const unsigned long long *>(s_list - kEntry * (i + 1) + 8);
   }
   __device__ __forceinline__ void set_kill(int i, unsigned long long m) const {
-    if (glist) *reinterpret_cast<unsigned long long *>(g_list - 24 * (i + 1) + 8) = m;
-    else *reinterpret_cast<unsigned long long *>(s_list - 24 * (i + 1) + 8) = m;
+    if (glist) *reinterpret_cast<unsigned long long *>(g_list - kEntry * (i + 1) + 8) = m;
+    else *reinterpret_cast<unsigned long long *>(s_list - kEntry * (i + 1) + 8) = m;
   }
   __device__ __forceinline__ uint32_t l_chunk(int i) const {
-    return glist ? *reinterpret_cast<const uint32_t *>(g_list - 24 * (i + 1) + 16)
-                 : *reinterpret_cast<const uint32_t *>(s_list - 24 * (i + 1) + 16);
+    return glist ? *reinterpret_cast<const uint32_t *>(g_list - kEntry * (i + 1) + 16)
+                 : *reinterpret_cast<const uint32_t *>(s_list - kEntry * (i + 1) + 16);
   }
   __device__ __forceinline__ uint32_t l_rows(int i) const {
-    return glist ? *reinterpret_cast<const uint32_t *>(g_list - 24 * (i + 1) + 20)
-                 : *reinterpret_cast<const uint32_t *>(s_list - 24 * (i + 1) + 20);
+    return glist ? *reinterpret_cast<const uint32_t *>(g_list - kEntry * (i + 1) + 20)
+                 : *reinterpret_cast<const uint32_t *>(s_list - kEntry * (i + 1) + 20);
+  }
+  __device__ __forceinline__ int l_hbase(int i) const {
+    return glist ? *reinterpret_cast<const int *>(g_list - kEntry * (i + 1) + 24)
+                 : *reinterpret_cast<const int *>(s_list - kEntry * (i + 1) + 24);
+  }
+  __device__ __forceinline__ void set_hbase(int i, int hb) const {
+    if (glist) *reinterpret_cast<int *>(g_list - kEntry * (i + 1) + 24) = hb;
+    else *reinterpret_cast<int *>(s_list - kEntry * (i + 1) + 24) = hb;
   }
   __device__ __forceinline__ void set_entry(int i, unsigned long long a, uint32_t c, uint32_t rr) const {
-    unsigned char *e = (glist ? g_list : s_list) - 24 * (i + 1);
     if (glist) {
-      *reinterpret_cast<unsigned long long *>(g_list - 24 * (i + 1)) = a;
-      *reinterpret_cast<unsigned long long *>(g_list - 24 * (i + 1) + 8) = 0ull;
-      *reinterpret_cast<uint2 *>(g_list - 24 * (i + 1) + 16) = make_uint2(c, rr);
+      *reinterpret_cast<ulonglong2 *>(g_list - kEntry * (i + 1)) = make_ulonglong2(a, 0ull);
+      *reinterpret_cast<uint4 *>(g_list - kEntry * (i + 1) + 16) = make_uint4(c, rr, 0xFFFFFFFFu, 0u);
     } else {
-      *reinterpret_cast<unsigned long long *>(s_list - 24 * (i + 1)) = a;
-      *reinterpret_cast<unsigned long long *>(s_list - 24 * (i + 1) + 8) = 0ull;
-      *reinterpret_cast<uint2 *>(s_list - 24 * (i + 1) + 16) = make_uint2(c, rr);
+      *reinterpret_cast<ulonglong2 *>(s_list - kEntry * (i + 1)) = make_ulonglong2(a, 0ull);
+      *reinterpret_cast<uint4 *>(s_list - kEntry * (i + 1) + 16) = make_uint4(c, rr, 0xFFFFFFFFu, 0u);
     }
-    (void)e;
   }
   __device__ __forceinline__ int rank_of(int lp) const {
     return (int)s_rank[lp >> 5] + __popc(A.w[lp >> 5] & ((1u << (lp & 31)) - 1u));
@@ -339,7 +354,7 @@ struct Ins {
   __device__ __forceinline__ int global_pix(int lp) const {
     int r, j;
     win.row_word(lp >> 5, r, j);
-    return r * cols + (j << 5) + (lp & 31);
+    return pack_pix(r, (j << 5) + (lp & 31));
   }
   // Depth keys without branches (lp: window-local pixel, -1 = outside): the loads of the 15 neighbours of a
   // hole can then be in flight together -- two independent LDS reads, one dependent, instead of 15 chains.
@@ -354,11 +369,9 @@ struct Ins {
   // workgroup has dropped its stale cache lines)
   __device__ __forceinline__ unsigned long long tile_key(int dl) const { return g_dtile ? g_dtile[dl] : s_dtile[dl]; }
 
-  // LDS layout of a pair.  The sample's RECORD -- everything the sample phase leaves behind -- is one contiguous
-  // image [0, rec_end): header | out-of-bounds bits | window pixel per point | sorted order | occupancy, closed,
-  // rank images | first sorted point and min depth per occupied pixel.  k_sample_prep stores that image in the
-  // launch's pool, k_eval and k_commit_chain load it back.  Behind it: the three scratch images, then (from r1)
-  // whatever the scene phase carves.
+  // LDS layout of a pair: header | out-of-bounds bits | window pixel per point | sorted order | occupancy, closed,
+  // rank images | first sorted point and min depth per occupied pixel | the three scratch images | (from r1) whatever
+  // the scene phase carves.
   __device__ __forceinline__ int carve_head() {
     int carve = kHdrBytes;
     s_oob = reinterpret_cast<uint32_t *>(smem + carve);
@@ -399,44 +412,13 @@ struct Ins {
   // kOk, or kNoFit when the pool is exhausted.  Called by the whole workgroup after carve_tail().
   __device__ __forceinline__ int place_scratch_images() {
     if (!POOL || !planes_pooled) return kOk;
-    const long long want = (3ll * ww * 4 + 255) & ~255ll;
-    __syncthreads();
-    if (tid == 0) {
-      unsigned long long o = atomicAdd(w.pool_head, (unsigned long long)want);
-      H[H_FILL] = o + want <= (unsigned long long)w.pool_bytes ? (int)(o >> 8) : -1;
-    }
-    __syncthreads();
-    const int got = uni(H[H_FILL]);
-    __syncthreads();
-    if (got < 0) return kNoFit;
-    uint32_t *scr = reinterpret_cast<uint32_t *>(w.tile_pool + ((long long)got << 8));
+    const long long off = pool_take(3ll * ww * 4);
+    if (off < 0) return kNoFit;
+    uint32_t *scr = reinterpret_cast<uint32_t *>(w.tile_pool + off);
     T.w = scr;
     D.w = scr + ww;
     E.w = scr + 2 * ww;
     return kOk;
-  }
-  __device__ __forceinline__ void store_record(unsigned char *dst) const {       // dst: 16-byte aligned, rec_end bytes
-    const uint4 *from = reinterpret_cast<const uint4 *>(smem);
-    uint4 *to = reinterpret_cast<uint4 *>(dst);
-    for (int i = tid; i < (rec_end >> 4); i += NT) to[i] = from[i];
-  }
-  // kOk, or kNoFit when this kernel's LDS cannot hold the record plus the scratch images
-  __device__ __forceinline__ int load_record(const unsigned char *src, int bytes) {
-    accept = false;
-    nvis = 0;
-    if (bytes + 64 > lds_cap) return kNoFit;
-    __syncthreads();                                         // the previous use of this LDS is over
-    const uint4 *from = reinterpret_cast<const uint4 *>(src);
-    uint4 *to = reinterpret_cast<uint4 *>(smem);
-    for (int i = tid; i < (bytes >> 4); i += NT) to[i] = from[i];
-    __syncthreads();
-    nvalid = uni(H[H_NVALID]);
-    nocc = uni(H[H_NOCC]);
-    ncand = uni(H[H_NCAND]);
-    compute_window();
-    carve_tail(carve_images(carve_head()));
-    if ((int64_t)r1 + 64 > lds_cap) return kNoFit;
-    return place_scratch_images();
   }
 
   // -- the window of a projected sample (H_RMIN .. H_CMAX1, H_NVALID in the header): candidates lie within 2 rows /
@@ -522,15 +504,35 @@ struct Ins {
       const int half = cols >> 1;
       int rmin = 0x7FFFFFFF, rmax = -1, cmin0 = 0x7FFFFFFF, cmax0 = -1, cmin1 = 0x7FFFFFFF, cmax1 = -1;
       int nval = 0, flags = 0;
+      // The bin of a sample point is guessed in float32 and confirmed in float64 on the edges of that bin, as step 0 does
+      // for the scene's points (confirm_bin, r3d_batch.hpp; row table of k_prepare / the last rebase).  A confirmed bin
+      // in rows 1 .. rows-2 also says that the elevation lies strictly inside the scene's bounds; everything else --
+      // unconfirmed, first or last row, outside the image, not finite -- takes the reference formula (spherical_bin).
+      const double *row_cc = w.row_q + (int64_t)s * (rows + 2);
+      const float inv_del = (float)(1.0 / bn.d_el), inv_daz = (float)(1.0 / bn.d_az), elo = (float)(bn.min_el + 0.00001);
       for (int j = tid; j < m; j += NT) {
         uint32_t key = 0xFFFFFFFFu;
         const double *q = rows5 + (int64_t)j * 5;
-        SphBin sb = spherical_bin(bn.max_el, bn.min_el, rows, cols, q[0], q[1], q[2]);
-        int row = sb.row, col = sb.col;
-        if (!(sb.ok & 4)) {
+        const double x = q[0], y = q[1], z = q[2];
+        int row, col, ok;
+        {
+          const float fx = (float)x, fy = (float)y, fz = (float)z;
+          const float ssf = fmaf(fx, fx, fmaf(fy, fy, fz * fz));
+          const float qf = __builtin_amdgcn_fmed3f(fz * __frsqrt_rn(ssf), -1.f, 1.f);
+          row = (int)floorf((guess_acosf(qf) - elo) * inv_del);
+          col = (int)((guess_atan2f(fy, fx) + 3.14159274f) * inv_daz);
+          row = max(1, min(row, rows - 2));
+          col = max(0, min(col, cols - 1));
+          ok = rows > 2 && confirm_bin(row_cc, w.col_dir, row, col, x, y, z, x * x + y * y + z * z) ? 7 : 0;
+        }
+        if (!ok) {
+          SphBin sb = spherical_bin(bn.max_el, bn.min_el, rows, cols, x, y, z);
+          row = sb.row, col = sb.col, ok = sb.ok;
+        }
+        if (!(ok & 4)) {
           flags |= R3D_S_NONFINITE;
-        } else if (sb.ok & 1) {                      // rows outside [0, rows) are skipped (:107-108)
-          if (!(sb.ok & 2)) {
+        } else if (ok & 1) {                         // rows outside [0, rows) are skipped (:107-108)
+          if (!(ok & 2)) {
             flags |= R3D_S_COL_RANGE;                // assert :112
           } else {
             key = ((uint32_t)row << 16) | (uint32_t)col;    // re-keyed by window pixel below
@@ -544,7 +546,7 @@ struct Ins {
               cmin1 = col < cmin1 ? col : cmin1;
               cmax1 = col > cmax1 ? col : cmax1;
             }
-            if (sb.ok & 8) atomicOr(&s_oob[j >> 5], 1u << (j & 31));
+            if (ok & 8) atomicOr(&s_oob[j >> 5], 1u << (j & 31));
           }
         }
         s_lp[j] = key;
@@ -679,13 +681,9 @@ struct Ins {
 
   // The chunks that can hold a point of the window: bounding box touches it, somebody alive (4 chunks
   // per thread in flight).
-  // c_first / p_first: with replayed hits only the chunks from c_first on are listed, and of chunk c_first only the
-  // points from p_first on (the earlier ones are among the hits)
-  __device__ __forceinline__ void build_list(const unsigned long long *boxes, const unsigned long long *alive, int n_chunks,
-                                             int c_first = 0, int p_first = 0) {
+  __device__ __forceinline__ void build_list(const unsigned long long *boxes, const unsigned long long *alive, int n_chunks) {
     constexpr int kU = 4;
-    int hitcap = 0;
-    for (int c0 = c_first + tid; c0 < n_chunks; c0 += kU * NT) {
+    for (int c0 = tid; c0 < n_chunks; c0 += kU * NT) {
       unsigned long long bx[kU], aw[kU];
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
@@ -699,38 +697,39 @@ struct Ins {
         int left = n_base - (c << 6);                       // points of the chunk below the base count
         unsigned long long a = aw[u];
         if (left < 64) a = left > 0 ? a & ((1ull << left) - 1ull) : 0ull;
-        if (HITS && c == c_first && (p_first & 63)) a &= ~((1ull << (p_first & 63)) - 1ull);
         int rmin = (int)(bx[u] & 0xFFFF), rmax = (int)((bx[u] >> 16) & 0xFFFF);
-        int jmin = (int)((bx[u] >> 32) & 0xFFFF) >> 5, jmax = (int)((bx[u] >> 48) & 0xFFFF) >> 5;
-        bool hit = a && rmin <= win.r_hi && rmax >= win.r_lo && win.touches_words(jmin, jmax);
+        // (the exact columns of the tile, not the 32-pixel words around them: nothing outside the tile is ever read --
+        // depth, occupancy and the culled points all lie inside it -- and a chunk of a ring-ordered scan is ~50 columns
+        // wide, so whole words list twice the chunks)
+        int cmin = (int)((bx[u] >> 32) & 0xFFFF), cmax = (int)((bx[u] >> 48) & 0xFFFF);
+        bool hit = a && rmin <= win.r_hi && rmax >= win.r_lo &&
+                   (box_touches_cols(cmin, cmax, dt.c00, dt.c10) || (dt.n_iv > 1 && box_touches_cols(cmin, cmax, dt.c01, dt.c11)));
         if (hit) {
           int slot = atomicAdd(&H[H_NLIST], 1);
           if (slot < list_cap) set_entry(slot, a, (uint32_t)c, (uint32_t)rmin | ((uint32_t)rmax << 16));
-          if (HITS) hitcap += __popcll(a);
         }
       }
     }
-    if (HITS) {
-      hitcap = wave_sum_i32(hitcap);
-      if ((tid & 63) == 0 && hitcap) atomicAdd(&H[H_HITCAP], hitcap);
-    }
   }
 
-  // The living points of the listed chunks whose pixel lies in rows [bt.r0, bt.r1] of the tile are
-  // min-reduced into the band in LDS (insertion.py:118-125).  A wave takes one listed chunk per step
-  // (64 consecutive points: one coalesced load of pixel ids), 8 chunks in flight; coordinates are
-  // loaded only for the points inside the band.  all_rows_bits: also set the scene occupancy bit of
-  // every point of the window (banded tiles: the occupancy of the whole window is needed up front).
+  // The living points of the listed chunks whose pixel lies in rows [bt.r0, bt.r1] of the tile are min-reduced into
+  // the band in LDS (insertion.py:118-125) -- on the SQUARE of the depth, x*x + y*y + z*z in the reference's order:
+  // the square root is monotone, so the minimum of the roots is the root of the minimum, taken once per occupied
+  // pixel when the band is complete (finish_band) instead of once per point.  A wave takes one listed chunk per step
+  // (64 consecutive points: one coalesced load of pixel ids), kPer chunks in flight; coordinates are loaded only for
+  // the points inside the band.  all_rows_bits: also set the scene occupancy bit of every point of the window (banded
+  // and pooled tiles: the occupancy of the whole window is needed up front).
   __device__ __forceinline__ void gather(bool all_rows_bits, const uint16_t *sub, int nsub) {
     constexpr int kPer = NT == 1024 ? 8 : R3D_GATHER_PER;    // (one workgroup per CU: nothing else hides the loads)
     const int n_head = uni(b.n_head[s]);
-    const double q_min = w.q_ext[2 * s + 0], q_max = w.q_ext[2 * s + 1];
-    const int32_t *pixs = b.pix + (int64_t)s * b.cap;
+    const uint32_t *pixs = reinterpret_cast<const uint32_t *>(b.pix) + (int64_t)s * b.cap;
     const float4 *xyzi = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
     const int nitems = (sub ? nsub : nlist) << 6;           // sub: the entries whose rows reach the band
+    const int lane = tid & 63;
     GSTAMP_DECL;
     for (int e0 = tid; e0 < nitems; e0 += kPer * NT) {
-      int idx[kPer], p[kPer], dl[kPer];
+      int idx[kPer], dl[kPer];
+      uint32_t p[kPer];
       GSTAMP(0);
 #pragma unroll
       for (int u = 0; u < kPer; ++u) {
@@ -742,25 +741,25 @@ struct Ins {
         }
       }
 #pragma unroll
-      for (int u = 0; u < kPer; ++u) p[u] = idx[u] >= 0 ? pixs[idx[u]] : 0;
+      for (int u = 0; u < kPer; ++u) p[u] = idx[u] >= 0 ? pixs[idx[u]] : 0u;
       GSTAMP(1);
 #pragma unroll
       for (int u = 0; u < kPer; ++u) {
         dl[u] = -1;
+        int lp = -1;
         if (idx[u] >= 0) {
-          int c, r = by_cols.div(p[u], c);
+          const int r = pix_row(p[u]), c = pix_col(p[u]);
           dl[u] = bt.index(r, c);
-          if (all_rows_bits && (bt.npx == dt.npx ? dl[u] >= 0 : dt.index(r, c) >= 0)) D.set_local(win.lpix_rc(r, c));
+          const bool in_window = bt.npx == dt.npx ? dl[u] >= 0 : dt.index(r, c) >= 0;
+          if (all_rows_bits && in_window) lp = win.lpix_rc(r, c);
+          if (all_rows_bits && in_window) D.set_local(lp);
         }
-      }
-      // one band for the whole window: which points of every listed chunk lie inside the tile (the kill masks are
-      // computed from those alone, and not at all for a chunk that has none)
-      if (intile && !sub) {
-#pragma unroll
-        for (int u = 0; u < kPer; ++u) {
-          const unsigned long long m = __ballot(dl[u] >= 0);
+        // one band for the whole window: which points of every listed chunk lie inside the tile (the kill masks are
+        // computed from those alone, and not at all for a chunk that has none)
+        if (intile && !sub) {
+          const unsigned long long msk = __ballot(dl[u] >= 0);
           const int e = e0 + u * NT;
-          if ((tid & 63) == 0 && e < nitems) set_kill(e >> 6, m);
+          if (lane == 0 && e < nitems) set_kill(e >> 6, msk);
         }
       }
       GSTAMP(2);
@@ -776,42 +775,12 @@ struct Ins {
         GSTAMP(3);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          // where this lane's hit goes: one LDS atomic per wave (every lane of a wave is in this loop: the listed
-          // items come in multiples of 64)
-          int hpos = 0;
-          if (HITS && g_hits) {
-            const unsigned long long hm = __ballot(dl[h + u] >= 0);
-            if (hm) {
-              const int lead = __ffsll((long long)hm) - 1;
-              int base = 0;
-              if ((tid & 63) == lead) base = atomicAdd(&H[H_NHITS], __popcll(hm));
-              hpos = __builtin_amdgcn_readlane(base, lead) + __popcll(hm & ((1ull << (tid & 63)) - 1ull));
-            }
-          }
           if (dl[h + u] < 0) continue;
           double x = (double)f[u].x, y = (double)f[u].y, z = (double)f[u].z;
           if (idx[h + u] >= n_head) load_point(b, s, idx[h + u], n_head, x, y, z);   // an inserted point: float64, from the log
-          double r = sqrt(x * x + y * y + z * z);
-          if (g_dtile) atomicMin(&g_dtile[dl[h + u]], depth_key(r));
-          else atomicMin(&s_dtile[dl[h + u]], depth_key(r));
-          // the points that hold the elevation bounds (max elevation = acos(min z/r)): if the pixel of
-          // one of them turns out visible it is culled and the bounds may move (any holder will do).
-          // z/r is only evaluated for the points that can be one (|z - q r| tiny).
-          double tol = 1e-9 * r;
-          uint32_t holder = 0u;
-          if (fabs(z - q_min * r) <= tol && z / r == q_min) {
-            H[H_EXT0] = p[h + u];
-            if (HITS) holder |= 0x40000000u;
-          }
-          if (fabs(z - q_max * r) <= tol && z / r == q_max) {
-            H[H_EXT1] = p[h + u];
-            if (HITS) holder |= 0x80000000u;
-          }
-          if (HITS && g_hits) {
-            const unsigned long long key = depth_key(r);
-            g_hits[hpos] = make_uint4((uint32_t)p[h + u] | holder, (uint32_t)idx[h + u], (uint32_t)key,
-                                                          (uint32_t)(key >> 32));
-          }
+          const unsigned long long key = depth_key(x * x + y * y + z * z);
+          if (g_dtile) atomicMin(&g_dtile[dl[h + u]], key);
+          else atomicMin(&s_dtile[dl[h + u]], key);
         }
         GSTAMP(4);
       }
@@ -819,36 +788,127 @@ struct Ins {
     GSTAMP_END;
   }
 
-  // The stored hits of this pair that are still alive, into the band (what gather() does for listed chunks).
-  __device__ __forceinline__ void replay_hits(bool all_rows_bits) {
-    const unsigned long long *alive = w.alive + (int64_t)s * chunks;
-    constexpr int kPer = 4;
-    for (int h0 = tid; h0 < r_nhits; h0 += kPer * NT) {
-      uint4 e[kPer];
-      unsigned long long aw[kPer];
+  // The same for one band that holds the whole window (512 threads and fewer: the shapes for range images of the
+  // reference's size), in two flat passes instead of rounds of list -> pixel id -> coordinates: (1) every thread requests
+  // the pixel ids of up to kU listed chunks at once, places them in the tile and leaves the points inside it as HITS in
+  // LDS -- one reservation per wave and round --; (2) the coordinates of the hits, all in flight together.  Two dependent
+  // trips to memory however long the list is.  A wave whose hits do not fit the room fetches its coordinates right away.
+  __device__ __forceinline__ void gather_flat(bool all_rows_bits) {
+    constexpr int kU = 8;
+    const int n_head = uni(b.n_head[s]);
+    const uint32_t *pixs = reinterpret_cast<const uint32_t *>(b.pix) + (int64_t)s * b.cap;
+    const float4 *xyzi = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
+    const int nitems = nlist << 6;
+    const int lane = tid & 63;
+    // tile and window pixel of (row, column) in one go: both number the window's rows from r_lo, the tile its exact
+    // columns, the window the 32-pixel words that hold them
+    const int nrw = win.nrw, njw32 = win.njw << 5, W = dt.W;
+    const int jl0 = win.jl0, nj0 = win.nj0, jl1 = win.jl1, nj1 = win.n_iv > 1 ? win.jh1 - win.jl1 + 1 : 0;
+    const int c00 = dt.c00, w0 = dt.w0, c01 = dt.c01, w1 = dt.n_iv > 1 ? dt.c11 - dt.c01 + 1 : 0;
+    auto place = [&](uint32_t p, int &dl, int &lp) {
+      const int rr = pix_row(p) - win.r_lo, c = pix_col(p), j = c >> 5;
+      const int k0 = j - jl0, k1 = j - jl1;
+      const bool in0 = (unsigned)k0 < (unsigned)nj0, in1 = (unsigned)k1 < (unsigned)nj1;
+      const int t0 = c - c00, t1 = c - c01;
+      const bool ok_r = (unsigned)rr < (unsigned)nrw;
+      const bool tin0 = (unsigned)t0 < (unsigned)w0, tin1 = (unsigned)t1 < (unsigned)w1;   // (w1 = 0: one interval)
+      lp = ok_r && (in0 || in1) ? rr * njw32 + ((in0 ? k0 : nj0 + k1) << 5) + (c & 31) : -1;
+      dl = ok_r && (tin0 || tin1) ? rr * W + (tin0 ? t0 : w0 + t1) : -1;
+    };
+    GSTAMP_DECL;
+    for (int e00 = 0; e00 < nitems; e00 += kU * NT) {
+      int idx[kU];
+      uint32_t p[kU], code[kU];
+      unsigned long long msk[kU];
+      GSTAMP(0);
 #pragma unroll
-      for (int u = 0; u < kPer; ++u) {
-        const int h = h0 + u * NT;
-        e[u] = h < r_nhits ? r_hits[h] : make_uint4(0u, 0u, 0u, 0u);
+      for (int u = 0; u < kU; ++u) {
+        const int e = e00 + u * NT + tid;
+        idx[u] = -1;
+        if (e < nitems && ((l_alive(e >> 6) >> (e & 63)) & 1ull)) idx[u] = (int)(l_chunk(e >> 6) << 6) + (e & 63);
       }
 #pragma unroll
-      for (int u = 0; u < kPer; ++u)
-        aw[u] = h0 + u * NT < r_nhits ? __hip_atomic_load(&alive[e[u].y >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      for (int u = 0; u < kU; ++u) p[u] = idx[u] >= 0 ? pixs[idx[u]] : 0u;
+      GSTAMP(1);
+      int cnt = 0;
 #pragma unroll
-      for (int u = 0; u < kPer; ++u) {
-        if (!((aw[u] >> (e[u].y & 63)) & 1ull)) continue;    // culled by a predecessor (or past the end)
-        const int p = (int)(e[u].x & 0x00FFFFFFu);
-        int c, r = by_cols.div(p, c);
-        const int dl = bt.index(r, c);
-        if (all_rows_bits && (bt.npx == dt.npx ? dl >= 0 : dt.index(r, c) >= 0)) D.set_local(win.lpix_rc(r, c));
-        if (dl < 0) continue;
-        const unsigned long long key = (unsigned long long)e[u].z | ((unsigned long long)e[u].w << 32);
-        if (g_dtile) atomicMin(&g_dtile[dl], key);
-        else atomicMin(&s_dtile[dl], key);
-        if (e[u].x & 0x40000000u) H[H_EXT0] = p;
-        if (e[u].x & 0x80000000u) H[H_EXT1] = p;
+      for (int u = 0; u < kU; ++u) {
+        int dl = -1, lp = -1;
+        if (idx[u] >= 0) place(p[u], dl, lp);
+        if (all_rows_bits && dl >= 0) D.set_local(lp);
+        code[u] = dl >= 0 ? ((uint32_t)dl << 16) | (uint32_t)lp : 0xFFFFFFFFu;
+        msk[u] = __ballot(dl >= 0);
+        cnt += __popcll(msk[u]);
+      }
+      // room for this wave's hits of the round: one LDS atomic
+      int base = -1;
+      if (cnt && hit_cap > 0) {
+        if (lane == 0) {
+          base = atomicAdd(&H[H_NHIT], cnt);
+          if (base + cnt > hit_cap) {
+            atomicMin(&H[H_HITEND], base);                     // the hits end here: every later reservation lies beyond
+            base = -1;
+          }
+        }
+        base = __builtin_amdgcn_readfirstlane(base);
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int e = e00 + u * NT + tid;
+        if (e < nitems) {                                      // (wave-uniform: the listed items come in 64s)
+          if (lane == 0) {
+            set_kill(e >> 6, msk[u]);
+            set_hbase(e >> 6, base);
+          }
+          if (base >= 0) {
+            if (code[u] != 0xFFFFFFFFu)
+              s_hit[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(msk[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)msk[u], 0u))] =
+                  make_uint2((uint32_t)idx[u], code[u]);
+            base += __popcll(msk[u]);
+          }
+        }
+      }
+      GSTAMP(2);
+      if (base < 0 && cnt) {                                   // no room: this wave's coordinates right away
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          if (code[u] == 0xFFFFFFFFu) continue;
+          double x, y, z;
+          load_point(b, s, idx[u], n_head, x, y, z);
+          const unsigned long long key = depth_key(x * x + y * y + z * z);
+          if (g_dtile) atomicMin(&g_dtile[code[u] >> 16], key);
+          else atomicMin(&s_dtile[code[u] >> 16], key);
+        }
       }
     }
+    __syncthreads();
+    GSTAMP(3);
+    const int nh = uni(H[H_NHIT] < H[H_HITEND] ? H[H_NHIT] : H[H_HITEND]);
+    for (int h0 = tid; h0 < nh; h0 += 4 * NT) {
+      uint2 hv[4];
+      float4 f[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int h = h0 + u * NT;
+        hv[u] = h < nh ? s_hit[h] : make_uint2(0xFFFFFFFFu, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f[u] = make_float4(1.f, 0.f, 0.f, 0.f);
+        if (hv[u].x != 0xFFFFFFFFu && (int)hv[u].x < n_head) f[u] = xyzi[hv[u].x];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (hv[u].x == 0xFFFFFFFFu) continue;
+        double x = (double)f[u].x, y = (double)f[u].y, z = (double)f[u].z;
+        if ((int)hv[u].x >= n_head) load_point(b, s, (int)hv[u].x, n_head, x, y, z);   // an inserted point: float64, from the log
+        const unsigned long long key = depth_key(x * x + y * y + z * z);
+        if (g_dtile) atomicMin(&g_dtile[hv[u].y >> 16], key);
+        else atomicMin(&s_dtile[hv[u].y >> 16], key);
+      }
+    }
+    GSTAMP(4);
+    GSTAMP_END;
   }
 
   // 5-row x 3-column closing (closing.py:9-23) of one bit image of the window: src -> tmp -> dst, dilation
@@ -904,24 +964,31 @@ struct Ins {
     accept = false;
     if (nvalid == 0) return kOk;
     if (n_far > 0 && !serial) return kNeedSerial;
-    // carve the scratch region: visible list | band: candidates, depth tile | ... | chunk list (from the end)
+    // carve the scratch region: visible list | band: candidates, depth tile | hits | kill list | chunk list (from the end)
     int carve = r1;
     s_V = reinterpret_cast<uint16_t *>(smem + carve);
     carve = (carve + nvalid * 2 + 7) & ~7;
     const int W = dt.W;
+    const int lds_end = lds_cap & ~15;
     const int min_band = 5 * W * 8 + W * 4;                   // one candidate row: 5 tile rows, W candidates
-    // the chunk list in LDS, behind room for at least one band; in the pair's global area when that
-    // leaves fewer than 64 entries (or when it overflows, below)
-    s_list = smem + (lds_cap & ~7);
-    if ((lds_cap & ~7) - carve - min_band < 0) return kNoFit;
-    list_cap = ((lds_cap & ~7) - carve - min_band) / 24;
+    // the chunk list in LDS, behind room for at least one band; in global memory when that leaves fewer than 64
+    // entries (or when it overflows, below): k_insert_big in the scene's area, a chain pair in a piece of the pool
+    s_list = smem + lds_end;
+    if (lds_end - carve - min_band < 0) return kNoFit;
+    const int n_chunks = (n_base + 63) >> 6;
+    list_cap = (lds_end - carve - min_band) / kEntry;
     glist = force_glist || list_cap < 64;
-    if (glist) list_cap = chunks;
+    if (glist) {
+      if (!force_glist) {
+        const long long off = pool_take((long long)n_chunks * kEntry);
+        if (off < 0) return kNoFit;
+        g_list = w.tile_pool + off + (long long)n_chunks * kEntry;
+      }
+      list_cap = n_chunks;
+    }
 
     if (tid == 0) {
       H[H_NLIST] = 0;
-      H[H_HITCAP] = H[H_NHITS] = 0;
-      H[H_EXT0] = H[H_EXT1] = -1;
       H[H_NVIS] = 0;
       H[H_REBASE] = 0;
       H[H_VRMIN] = H[H_VCMIN0] = H[H_VCMIN1] = 0x7FFFFFFF;
@@ -931,21 +998,29 @@ struct Ins {
 
     STAMP(6);
     // -- 6. the chunks that can hold a point of the window --------------------------------------------
-    const int c_first = HITS && r_hits ? r_n0 >> 6 : 0, p_first = HITS && r_hits ? r_n0 : 0;   // replayed hits cover the points below r_n0
-    build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, (n_base + 63) >> 6, c_first, p_first);
+    build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, n_chunks);
     __syncthreads();
     nlist = uni(H[H_NLIST]);
     if (nlist > list_cap) {                                   // does not fit the LDS: once more, into global memory
+      // (a racing predecessor's append can grow the box of the one partly filled chunk into the window between the
+      // two passes: room for a few more than the first pass counted)
+      if (!force_glist) {
+        const long long off = pool_take((long long)(nlist + 8) * kEntry);
+        if (off < 0) return kNoFit;
+        g_list = w.tile_pool + off + (long long)(nlist + 8) * kEntry;
+      }
       __syncthreads();
-      if (tid == 0) H[H_NLIST] = H[H_HITCAP] = 0;
+      if (tid == 0) H[H_NLIST] = 0;
       glist = true;
-      list_cap = chunks;
+      list_cap = force_glist ? n_chunks : nlist + 8;
       __syncthreads();
-      build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, (n_base + 63) >> 6, c_first, p_first);
+      build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, n_chunks);
       __syncthreads();
-      nlist = uni(H[H_NLIST]);
+      // (alive bits only ever clear: a second pass lists at most the chunks of the first)
+      nlist = uni(H[H_NLIST]) < list_cap ? uni(H[H_NLIST]) : list_cap;
     }
-    const int band_bytes = (lds_cap & ~7) - (glist ? 0 : 24 * nlist) - carve;
+    const int list_start = lds_end - (glist ? 0 : kEntry * nlist);
+    const int band_bytes = list_start - carve;
     s_cand = reinterpret_cast<uint32_t *>(smem + carve);
 
     // rows of the candidates (the closed sample lies within 2 rows of a sample pixel); the tile as ONE
@@ -959,17 +1034,9 @@ struct Ins {
     g_dtile = nullptr;
     g_cand = nullptr;
     if (!single && !(b.reserved & kDbgBands) && pool_off != -2) {
-      const long long want = (((long long)dt.npx * 8 + 255) & ~255ll) + (((long long)ncand * 4 + 255) & ~255ll);
       if (pool_off == -1) {
-        if (tid == 0) {
-          unsigned long long o = atomicAdd(w.pool_head, (unsigned long long)want);
-          H[H_FILL] = o + want <= (unsigned long long)w.pool_bytes ? (int)(o >> 8) : -2;
-          if (H[H_FILL] == -2) atomicAdd(&w.dbg[D_POOL_FULL], 1);
-        }
-        __syncthreads();
-        const int got = uni(H[H_FILL]);
-        pool_off = got < 0 ? -2 : (long long)got << 8;
-        __syncthreads();
+        pool_off = pool_take((((long long)dt.npx * 8 + 255) & ~255ll) + (long long)ncand * 4);
+        if (pool_off < 0) pool_off = -2;
       }
       if (pool_off >= 0) {
         if (tid == 0) atomicAdd(&w.dbg[D_TILE_POOLED], 1);
@@ -984,29 +1051,33 @@ struct Ins {
       if (b.reserved & kDbgBands) per = per > 3 ? 3 : per;
       if (per < 1) return kNoFit;
     }
-
-    // room for the hits of this evaluation (at most the living points of the listed chunks), when they are wanted
-    g_hits = nullptr;
-    hits_off = -1;
-    hits_done = false;
-    if (HITS && keep_hits && single && !r_hits) {
-      const long long want = ((long long)uni(H[H_HITCAP]) * 16 + 255) & ~255ll;
-      __syncthreads();
-      if (tid == 0) {
-        unsigned long long o = atomicAdd(w.pool_head, (unsigned long long)want);
-        H[H_FILL] = o + want <= (unsigned long long)w.pool_bytes ? (int)(o >> 8) : -1;
-        if (H[H_FILL] < 0) atomicAdd(&w.dbg[D_POOL_FULL], 1);
+    // one band: behind it (behind `carve` when the tile is pooled) the numbers of the entries the kill pass looks at
+    // (from the chunk list downwards) and the hits, up to the chunk list
+    intile = single;
+    s_hit = nullptr;
+    hit_cap = 0;
+    uint16_t *s_kl = nullptr;
+    int kl_room = 0;
+    if (single) {
+      const int band_end = g_dtile ? carve : (((carve + ncand * 4 + 7) & ~7) + dt.npx * 8);
+      const int kl_bytes = nlist <= 0xFFFF ? (nlist * 2 + 7) & ~7 : 0;
+      if (band_end + kl_bytes <= list_start && kl_bytes) {
+        s_kl = reinterpret_cast<uint16_t *>(smem + list_start - kl_bytes);
+        kl_room = nlist;
       }
-      __syncthreads();
-      const int got = uni(H[H_FILL]);
-      if (got >= 0) {
-        hits_off = (long long)got << 8;
-        g_hits = reinterpret_cast<uint4 *>(w.tile_pool + hits_off);
+      const int hit_bytes = list_start - (s_kl ? kl_bytes : 0) - band_end;
+      // (tile and window pixel of a hit share a word: fewer than 65 536 of either)
+      if (NT <= 512 && hit_bytes >= 512 && (ww << 5) < 0xFFFF && dt.npx < 0xFFFF && !(b.reserved & kDbgNoHits)) {
+        s_hit = reinterpret_cast<uint2 *>(smem + band_end);
+        hit_cap = hit_bytes >> 3;
       }
-      __syncthreads();
+    }
+    flat = NT <= 512 && single && (ww << 5) < 0xFFFF && dt.npx < 0xFFFF;
+    if (tid == 0) {
+      H[H_NHIT] = 0;
+      H[H_HITEND] = 0x7FFFFFFF;
     }
 
-    intile = single && !(HITS && r_hits);                      // (replayed hits are not in the list)
     if (!serial && stale()) return kStale;
     STAMP(7);
     WinImage &vis = T;
@@ -1055,26 +1126,35 @@ struct Ins {
       if (bits_in_gather)
         for (int e = tid; e < ww; e += NT) D.w[e] = 0u;
       __syncthreads();
-      gather(bits_in_gather, use_sub ? s_sub : nullptr, nsub);
-      hits_done = g_hits != nullptr;
-      if (HITS && r_hits) replay_hits(bits_in_gather);
+      if (flat) gather_flat(bits_in_gather);
+      else gather(bits_in_gather, use_sub ? s_sub : nullptr, nsub);
       if (g_dtile) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the minima were formed in L2: drop this CU's copies
       __syncthreads();
-
-      if (first) {
-        if (!serial && stale()) return kStale;
-        STAMP(8);
-        if (single && !g_dtile) {                              // scene occupancy bits, from the tile's pixels
+      // the band holds minima of the squared depth: the root of every occupied pixel (and, for one band in LDS, the
+      // scene's occupancy bits off the same pass)
+      {
+        const bool bits_here = first && single && !g_dtile;
+        if (bits_here)
           for (int e = tid; e < ww; e += NT) D.w[e] = 0u;
-          __syncthreads();
-          for (int i = tid; i < bt.npx; i += NT) {
-            if (s_dtile[i] == R3D_SENT) continue;
+        if (bits_here) __syncthreads();
+        for (int i = tid; i < bt.npx; i += NT) {
+          const unsigned long long k2 = g_dtile ? g_dtile[i] : s_dtile[i];
+          if (k2 == R3D_SENT) continue;
+          const unsigned long long k1 = depth_key(sqrt(key_depth(k2)));
+          if (g_dtile) g_dtile[i] = k1;
+          else s_dtile[i] = k1;
+          if (bits_here) {
             int k, r = bt.r0 + by_W.div(i, k);
             int c = k < dt.w0 ? dt.c00 + k : dt.c01 + (k - dt.w0);
             D.set_local(win.lpix_rc(r, c));
           }
-          __syncthreads();
         }
+        __syncthreads();
+      }
+
+      if (first) {
+        if (!serial && stale()) return kStale;
+        STAMP(8);
         // -- 8. closing of the scene's occupancy ------------------------------------------------------
         closing(D, T, E);
         for (int e = tid; e < ww; e += NT) T.w[e] = 0u;        // from here on: the visible pixels
@@ -1174,16 +1254,6 @@ struct Ins {
     nvis = uni(H[H_NVIS]);
     accept = nvis > 0 && nvis >= need;
     if (accept) {
-      if (tid == 0) {
-        for (int h = 0; h < 2; ++h) {
-          int q = H[H_EXT0 + h];
-          if (q >= 0) {
-            int r = q / cols;
-            int lp = win.lpix_rc(r, q - r * cols);
-            if (lp >= 0 && vis.get_local(lp)) H[H_REBASE] = 1;     // a point that holds a bound is culled
-          }
-        }
-      }
       // the visible points in sorted order: thread t takes the sorted points [t*L, t*L + L), one block scan
       {
         const int L = (nvalid + NT - 1) / NT;
@@ -1196,17 +1266,21 @@ struct Ins {
           if (vis.get_local((int)s_lp[s_F[k]])) s_V[o++] = (uint16_t)k;
       }
       // every living scene point in a visible pixel dies (:470-473): one mask per listed chunk, so that
-      // the commit is a handful of atomics.  Only the chunks whose rows reach a visible row are looked at:
-      // their entry numbers are compacted into the room the candidates and the tile no longer need.
+      // the commit is a handful of atomics.  Only the chunks whose rows reach a visible row are looked at (and, with
+      // one band, only those with a point inside the tile): their entry numbers are compacted first.  A chunk whose
+      // in-tile points were kept as hits needs no second trip to its pixel ids.
       {
-        constexpr int kPer = 8;
+        constexpr int kPer = 4;
         const int lane = tid & 63;
-        const int32_t *pixs = b.pix + (int64_t)s * b.cap;
+        const uint32_t *pixs = reinterpret_cast<const uint32_t *>(b.pix) + (int64_t)s * b.cap;
         const int vr0 = uni(H[H_VRMIN]), vr1 = uni(H[H_VRMAX]);
-        uint16_t *s_kl = reinterpret_cast<uint16_t *>(smem + carve);
-        const int room = ((lds_cap & ~7) - (glist ? 0 : 24 * nlist) - carve) / 2;
+        if (!single) {                                         // bands: the room the candidates and the tile no longer need
+          kl_room = (list_start - carve) / 2;
+          s_kl = reinterpret_cast<uint16_t *>(smem + carve);
+          if (nlist > kl_room || nlist > 0xFFFF) s_kl = nullptr;
+        }
         int nkl = nlist;
-        if (nlist <= room && nlist <= 0xFFFF) {
+        if (s_kl) {
           if (tid == 0) H[H_CARRY] = 0;
           __syncthreads();
           for (int i = tid; i < nlist; i += NT) {
@@ -1217,32 +1291,55 @@ struct Ins {
           }
           __syncthreads();
           nkl = uni(H[H_CARRY]);
-        } else {
-          s_kl = nullptr;
         }
         const int nitems = nkl << 6;
         for (int e0 = tid; e0 < nitems; e0 += kPer * NT) {
-          int p[kPer], ent[kPer];
-          bool on[kPer];
+          int lpv[kPer], ent[kPer];
+          uint32_t pg[kPer];
+          bool on[kPer], from_hits[kPer];
 #pragma unroll
           for (int u = 0; u < kPer; ++u) {
             int e = e0 + u * NT;
             ent[u] = e < nitems ? (s_kl ? (int)s_kl[e >> 6] : (e >> 6)) : 0;
             // the living points of the chunk -- those inside the tile, when the gather has left their mask
-            on[u] = e < nitems && (((intile ? l_kill(ent[u]) : l_alive(ent[u])) >> (e & 63)) & 1ull);
-            p[u] = on[u] ? pixs[(int)(l_chunk(ent[u]) << 6) + (e & 63)] : 0;
+            const unsigned long long msk = e < nitems ? (intile ? l_kill(ent[u]) : l_alive(ent[u])) : 0ull;
+            on[u] = (msk >> (e & 63)) & 1ull;
+            const int hb = flat && e < nitems ? l_hbase(ent[u]) : -1;
+            from_hits[u] = hb >= 0;
+            lpv[u] = -1;
+            pg[u] = 0u;
+            if (on[u]) {
+              if (from_hits[u]) lpv[u] = (int)(s_hit[hb + __popcll(msk & ((1ull << (e & 63)) - 1ull))].y & 0xFFFFu);
+              else pg[u] = pixs[(int)(l_chunk(ent[u]) << 6) + (e & 63)];
+            }
           }
 #pragma unroll
           for (int u = 0; u < kPer; ++u) {
             int e = e0 + u * NT;
             bool kill = false;
             if (on[u]) {
-              int c, r = by_cols.div(p[u], c);
-              int lp = win.lpix_rc(r, c);
+              const int lp = from_hits[u] ? lpv[u] : win.lpix_rc(pix_row(pg[u]), pix_col(pg[u]));
               kill = lp >= 0 && vis.get_local(lp);
             }
             unsigned long long mask = __ballot(kill);
             if (lane == 0 && e < nitems && (mask || intile)) set_kill(ent[u], mask);
+          }
+        }
+        // A point that holds an elevation bound (z/r bit-equal to the extreme, w.q_ext) sits in the first or the last
+        // row of the image; if it dies the bounds may move and the scene is re-based (insertion.py:373 recomputes them
+        // from the merged cloud for every insert; a rebase that was not needed changes nothing).  Only a pair whose
+        // visible pixels reach one of those rows has to look: at the points it culls.
+        if (vr0 == 0 || vr1 == rows - 1 || bn.d_el < 1e-4) {
+          __syncthreads();
+          const int n_head = uni(b.n_head[s]);
+          const double q_min = w.q_ext[2 * s + 0], q_max = w.q_ext[2 * s + 1];
+          for (int e = tid; e < (nlist << 6); e += NT) {
+            const int i = e >> 6;
+            if (!((l_kill(i) >> (e & 63)) & 1ull)) continue;
+            double x, y, z;
+            load_point(b, s, (int)(l_chunk(i) << 6) + (e & 63), n_head, x, y, z);
+            const double q = z / sqrt(x * x + y * y + z * z);
+            if (q == q_min || q == q_max) H[H_REBASE] = 1;
           }
         }
       }
@@ -1298,7 +1395,7 @@ struct Ins {
           f.w = (float)q3;
           reinterpret_cast<float4 *>(b.xyzi)[(int64_t)s * b.cap + dst] = f;
           b.label[(int64_t)s * b.cap + dst] = (uint32_t)(int64_t)q4;
-          b.pix[(int64_t)s * b.cap + dst] = row * cols + col;
+          b.pix[(int64_t)s * b.cap + dst] = (int32_t)pack_pix(row, col);
           b.tail_ref[(int64_t)s * b.log_cap + (dst - n_head)] = lr;
           double *l = b.log5 + ((int64_t)s * b.log_cap + lr) * 5;
           l[0] = q0;
@@ -1310,7 +1407,7 @@ struct Ins {
           box.add(row, col);
         }
         const bool old_chunk = (ci << 6) < n_total;           // holds earlier points: extend its box
-        if (lane == 0 && old_chunk) box.add_box(w.chunk_box[(int64_t)s * chunks + ci]);
+        if (lane == 0 && old_chunk) box.add_box(w.chunk_box[(int64_t)s * chunks + ci], cols);
         unsigned long long packed = box.wave_pack();
         unsigned long long living = __ballot(valid);
         if (lane == 0) {
@@ -1329,18 +1426,6 @@ struct Ins {
       int c = (int)l_chunk(i);
       atomicAnd(&alive[c], ~mask);
       atomicSub(&tile_alive[(c << 6) / kTile], __popcll(mask));
-    }
-    if (HITS && r_hits) {                                   // ... and among the replayed hits (T: the visible pixels)
-      for (int h = tid; h < r_nhits; h += NT) {
-        const uint4 e = r_hits[h];
-        const int p = (int)(e.x & 0x00FFFFFFu);
-        int c, r = by_cols.div(p, c);
-        const int lp = win.lpix_rc(r, c);
-        if (lp < 0 || !T.get_local(lp)) continue;
-        const unsigned long long bit = 1ull << (e.y & 63);
-        const unsigned long long old = atomicAnd(&alive[e.y >> 6], ~bit);
-        if (old & bit) atomicSub(&tile_alive[(int)e.y / kTile], 1);
-      }
     }
     STAMP(24);
     // -- pixels that now hold a return beyond 500 m join the far list
@@ -1372,94 +1457,26 @@ struct Ins {
     return rebase;
   }
 
-  // What an evaluation leaves for the commit chain (k_eval -> k_commit_chain), in the launch's pool:
-  //   [visible list: nvis x u16 | kill entries {u64 mask, u32 chunk, u32 0} of the chunks that lose points]
-  // and the numbers of `pr`.  False when the pool is exhausted (the chain then evaluates the pair itself).
-  __device__ __forceinline__ bool store_results(PairRec *pr) {
-    int nkill = 0;
-    long long off = -1;
-    if (accept) {
-      __syncthreads();
-      if (tid == 0) H[H_CARRY] = 0;
-      __syncthreads();
-      int c = 0;
-      for (int i = tid; i < nlist; i += NT) c += l_kill(i) ? 1 : 0;
-      c = wave_sum_i32(c);
-      if ((tid & 63) == 0 && c) atomicAdd(&H[H_CARRY], c);
-      __syncthreads();
-      nkill = uni(H[H_CARRY]);
-      const long long vbytes = ((long long)nvis * 2 + 15) & ~15ll;
-      const long long want = (vbytes + (long long)nkill * 16 + 255) & ~255ll;
-      __syncthreads();
-      if (tid == 0) {
-        unsigned long long o = atomicAdd(w.pool_head, (unsigned long long)want);
-        H[H_FILL] = o + want <= (unsigned long long)w.pool_bytes ? (int)(o >> 8) : -1;
-        H[H_CARRY] = 0;
-      }
-      __syncthreads();
-      const int got = uni(H[H_FILL]);
-      if (got < 0) return false;
-      off = (long long)got << 8;
-      uint16_t *gv = reinterpret_cast<uint16_t *>(w.tile_pool + off);
-      for (int o = tid; o < nvis; o += NT) gv[o] = s_V[o];
-      uint4 *ge = reinterpret_cast<uint4 *>(w.tile_pool + off + vbytes);
-      for (int i = tid; i < nlist; i += NT) {
-        const unsigned long long mask = l_kill(i);
-        if (!mask) continue;
-        const int pos = atomicAdd(&H[H_CARRY], 1);
-        ge[pos] = make_uint4((uint32_t)mask, (uint32_t)(mask >> 32), l_chunk(i), 0u);
-      }
-    }
-    if (tid == 0) {
-      pr->res_off = off;
-      pr->nvis = nvis;
-      pr->accept = accept ? 1 : 0;
-      pr->rebase = H[H_REBASE];
-      pr->nkill = nkill;
-      pr->vrmin = H[H_VRMIN];
-      pr->vrmax = H[H_VRMAX];
-      pr->vcmin0 = H[H_VCMIN0];
-      pr->vcmin1 = H[H_VCMIN1];
-      pr->vcmax0 = H[H_VCMAX0];
-      pr->vcmax1 = H[H_VCMAX1];
-      pr->hits_off = hits_off;
-      pr->nhits = g_hits ? H[H_NHITS] : -1;
-      pr->n0 = n_base;
-      pr->state = kPairEvaluated;
-    }
-    return true;
-  }
-  // The reverse, after load_record: the state commit() reads.  kNoFit when this kernel's LDS cannot hold the lists.
-  __device__ __forceinline__ int load_results(const PairRec &pr) {
-    accept = pr.accept != 0;
-    nvis = pr.nvis;
-    nlist = pr.nkill;
-    n_far = 0;
-    glist = false;
-    s_V = reinterpret_cast<uint16_t *>(smem + r1);
-    s_list = smem + (lds_cap & ~7);
-    const long long vbytes = ((long long)nvis * 2 + 15) & ~15ll;
-    if ((long long)r1 + vbytes + 24ll * nlist + 16 > (lds_cap & ~7)) return kNoFit;
-    const uint16_t *gv = reinterpret_cast<const uint16_t *>(w.tile_pool + pr.res_off);
-    for (int o = tid; o < nvis; o += NT) s_V[o] = gv[o];
-    const uint4 *ge = reinterpret_cast<const uint4 *>(w.tile_pool + pr.res_off + vbytes);
-    for (int i = tid; i < nlist; i += NT) {
-      const uint4 e = ge[i];
-      set_entry(i, 0ull, e.z, 0u);
-      set_kill(i, (unsigned long long)e.x | ((unsigned long long)e.y << 32));
-    }
-    if (tid == 0) {
-      H[H_REBASE] = pr.rebase;
-      H[H_FARADD] = 0;
-      H[H_VRMIN] = pr.vrmin;
-      H[H_VRMAX] = pr.vrmax;
-      H[H_VCMIN0] = pr.vcmin0;
-      H[H_VCMIN1] = pr.vcmin1;
-      H[H_VCMAX0] = pr.vcmax0;
-      H[H_VCMAX1] = pr.vcmax1;
-    }
+  // Diagnostic (bit 64): an order-independent digest of what an evaluation decided -- visible count, accept, rebase
+  // flag, the visible pixels, and for an accepted pair which points of which chunk die.  Whole workgroup.
+  __device__ __forceinline__ unsigned long long signature() {
+    if (nvalid == 0) return 0ull;
+    unsigned long long *cell = reinterpret_cast<unsigned long long *>(&H[H_SIG]);
     __syncthreads();
-    return kOk;
+    if (tid == 0) *cell = 0ull;
+    __syncthreads();
+    unsigned long long h = 0ull;
+    for (int e = tid; e < ww; e += NT) h += (unsigned long long)T.w[e] * (0x9E3779B97F4A7C15ull * (unsigned long long)(e + 1));
+    if (accept)
+      for (int i = tid; i < nlist; i += NT) {
+        const unsigned long long mk = l_kill(i);
+        if (mk) h += (mk ^ (mk >> 29)) * (0xC2B2AE3D27D4EB4Full * (unsigned long long)(l_chunk(i) + 1u));
+      }
+    if (h) atomicAdd(cell, h);
+    __syncthreads();
+    const unsigned long long sum = *cell;
+    __syncthreads();
+    return sum + (unsigned long long)nvis * 1000003ull + (accept ? 7ull : 0ull) + (H[H_REBASE] ? 13ull : 0ull);
   }
 
   // The far pixels that are not candidates of this insert: smoothed sample depth 500 there, the scene's
@@ -1476,11 +1493,10 @@ struct Ins {
     int32_t *tile_alive = w.tile_alive + (int64_t)s * tiles;
     __syncthreads();
     for (int f = tid; f < n_far; f += NT) {
-      int p = b.far_pix[(int64_t)s * R3D_FAR_CAP + f];
-      int r = p / cols;
-      int lp = win.lpix_rc(r, p - r * cols);
+      uint32_t p = (uint32_t)b.far_pix[(int64_t)s * R3D_FAR_CAP + f];
+      int lp = win.lpix_rc(pix_row(p), pix_col(p));
       bool is_cand = lp >= 0 && Cs.get_local(lp);
-      fpx[f] = is_cand ? 0xFFFFFFFFu : (uint32_t)p;
+      fpx[f] = is_cand ? 0xFFFFFFFFu : p;
       fmin[f] = R3D_SENT;
     }
     __syncthreads();
@@ -1567,8 +1583,9 @@ __device__ __forceinline__ int conflict_with(const BatchWs &w, int s, int j0, in
 }
 
 // One (slot, scene) pair of the chain kernel.  Returns 1 when the pair does not fit this flavour's LDS and nothing
-// has been done for it yet (the caller may try the POOL flavour), else 0.
-template <int NT, bool HITS, bool POOL>
+// has been done for it yet (the caller then tries the POOL flavour; LAST: there is none, the scene's chain goes to
+// k_insert_big from here), else 0.
+template <int NT, bool POOL, bool LAST>
 __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots &slots, int nk, int first_step, const BatchWs &w,
                                           int chunks, int lds_cap, long long timeout_ticks, int B8, unsigned char *smem, int pair_id) {
   // B8 > 0: slot-major numbering (slot k of every scene, then slot k + 1; a scene's slots on one residue of the
@@ -1578,7 +1595,7 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
   const int tid = threadIdx.x, slot_no = k;
   (void)slot_no;
   int *H = reinterpret_cast<int *>(smem);
-  Ins<NT, HITS, POOL> I(b, w, smem, lds_cap, s, chunks, k, k, false);
+  Ins<NT, POOL> I(b, w, smem, lds_cap, s, chunks, k, false);
 
   // wait until `want` slots of the scene are done (or the chain is abandoned); ONE lane polls relaxed,
   // then ONE agent-scope acquire; the scalar cache is dropped as well (counters travel through it)
@@ -1662,11 +1679,9 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
   int n_base = p0 > 0 ? w.recs[((int64_t)s * kMaxChain + p0 - 1) * kRecInts + REC_NTOTAL]
                       : (k > 0 ? w.n_total0[s] : b.n_total[s]);
   const bool on = load_slot(I, b, slots, k, s, first_step);
-  bool need_sample = true, sample_ok = false;
+  bool need_sample = true, sample_ok = false, speculative = false, verified = false;
+  unsigned long long sig0 = 0ull;
   int rc = kOk, attempts = 0;
-  const uint4 *sv_hits = nullptr;                           // the hits of this pair's first evaluation, for a later one
-  int sv_nhits = 0, sv_n0 = 0;
-  (void)attempts;
   if (on) {
     for (;;) {
       rc = kOk;
@@ -1700,13 +1715,7 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
       // while it speculates, the evaluation looks twice whether a slot that finished meanwhile has already
       // invalidated it: a doomed evaluation of a big pair is given up early and restarted on the fresher state
       int gone = 0, stale_cf = 0;
-      // the first evaluation keeps its hits; a later one of this pair under the same bounds replays them
-      if (need_sample) sv_hits = nullptr;                   // new bounds: other pixel ids
-      I.r_hits = sv_hits;
-      I.r_nhits = sv_nhits;
-      I.r_n0 = sv_n0;
-      I.keep_hits = HITS && sv_hits == nullptr && !waited && speculate;
-      const int n_base_used = n_base;
+      speculative = !waited;
       if (rc == kOk)
         rc = I.scene_phase(n_base, waited, [&]() -> bool {
           const int p1 = wait_for(0);
@@ -1726,11 +1735,6 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
           }
           return false;
         });
-      if (I.hits_done && !sv_hits) {                        // (the count is in LDS until the next evaluation starts)
-        sv_hits = I.g_hits;
-        sv_nhits = uni(H[H_NHITS]);
-        sv_n0 = n_base_used;
-      }
       if (rc == kStale) {
         if (gone == kProgDeferred) return 0;
         if (gone < 0) {
@@ -1767,6 +1771,24 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
           continue;
         }
       }
+      // Diagnostic bit 64: an evaluation that ran ahead of its predecessors and is about to be committed is done again,
+      // now after them, and the two are compared -- the invariant of the speculation (no detected conflict => the same
+      // visible points and the same culled points).  The later one is what is committed.
+      if ((b.reserved & kDbgVerify) && rc == kOk) {
+        if (verified) {
+          const unsigned long long sig1 = I.signature();
+          if (tid == 0 && sig0 != sig1) atomicAdd(&w.dbg[D_VERIFY_MISMATCH], 1);
+        } else if (speculative) {
+          sig0 = I.signature();
+          verified = true;
+          if (tid == 0) atomicAdd(&w.dbg[D_VERIFY_RUNS], 1);
+          n_base = b.n_total[s];
+          need_sample = false;
+          p0 = k;
+          --attempts;
+          continue;
+        }
+      }
       break;
     }
   } else if (!waited) {
@@ -1779,7 +1801,7 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
     waited = true;
   }
   if (on && rc == kNoFit) {
-    if (!POOL) return 1;                                    // once more with the scratch images in the pool
+    if (!LAST) return 1;                                    // once more with the scratch images in the pool
     // the rest of this scene's chain goes to k_insert_big; the predecessors must be done first, so
     // that nobody overwrites the mark
     if (!waited) {
@@ -1792,10 +1814,12 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
     }
     if (tid == 0) {
       w.defer_from[s] = k;
+      atomicAdd(&w.dbg[D_DEFERRED], 1);
       __hip_atomic_store(&w.chain_progress[s], kProgDeferred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return 0;
   }
+  if (on && attempts > 1 && tid == 0) atomicAdd(&w.dbg[D_EVAL_TWICE], 1);
   // 2. commit, publish
   const int n_now = count_now();
   int flags = 0, n_after = waited && !on ? n_now : 0;
@@ -1813,6 +1837,7 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
     phase_sync();
     unsigned long long *s_min = reinterpret_cast<unsigned long long *>(smem + kHdrBytes), *s_max = s_min + NT / 64;
     rebase_scene<NT>(b, w, chunks, s, s_min, s_max);
+    if (tid == 0) atomicAdd(&w.dbg[D_REBASE], 1);
   }
   if (nk > 1) publish(flags, n_after);
   STAMP(15);
@@ -1825,12 +1850,11 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
   return 0;
 }
 
-// Range images of KITTI's size never need the pool for their scratch images; on large ones a window can exceed the
-// LDS (a car a few metres from the sensor on 448 x 2880).  The POOL flavour reaches those images through flat
-// accesses -- 35 % slower on config C5 when every pair takes it -- so a pair runs it only after the LDS flavour
-// has turned it down.
-// Everything the chain kernel is given, as ONE kernel argument: the QUEUE flavour reads it through the kernarg segment
-// pointer (below), which needs the layout in one piece.
+// Everything the chain kernel is given, as ONE kernel argument.  The kernel reads it through the kernarg segment
+// pointer behind an `asm volatile` the compiler cannot see through: the fields are then loaded (scalar loads from the
+// constant cache) where a phase uses them.  Passed the plain way the compiler fetches the ~100 scalar registers of
+// r3d_batch_t / BatchWs in the prologue and keeps them alive across every phase of the pair: hundreds of SGPR spills
+// (v_writelane / v_readlane in the dependent chain of a latency-bound kernel).
 struct ChainArgs {
   r3d_batch_t b;
   ChainSlots slots;
@@ -1839,7 +1863,11 @@ struct ChainArgs {
   int nk, first_step, chunks, lds_cap, B8, queue_mode;
 };
 
-template <int NT, bool HITS, bool QUEUE>
+// Range images of KITTI's size never need the pool for their scratch images; on large ones a window can exceed the
+// LDS (a car a few metres from the sensor on 448 x 2880).  The POOL flavour reaches those images through flat
+// accesses -- 35 % slower on config C5 when every pair takes it -- so a pair runs it only after the LDS flavour
+// has turned it down.
+template <int NT, bool QUEUE>
 __global__ void __launch_bounds__(NT, NT == 1024 ? R3D_BIG_WAVES : R3D_CHAIN_WAVES)
 k_insert_chain(ChainArgs args) {
   extern __shared__ __align__(16) unsigned char smem[];     // no static __shared__ here: one LDS array
@@ -1850,12 +1878,16 @@ k_insert_chain(ChainArgs args) {
   // ids of its own queue, which a running workgroup has taken before.  Why: the hardware hands workgroups to the XCDs
   // strictly round robin, so with one workgroup per pair an XCD whose pairs run long stalls the hand-out to all the
   // others (a third of the CUs idle on config C5, tools/stamps_insert.py).
+  typedef const __attribute__((address_space(4))) ChainArgs *ArgsPtr;
   if (!QUEUE) {
-    const int again = chain_pair<NT, HITS, false>(args.b, args.slots, args.nk, args.first_step, args.w, args.chunks, args.lds_cap,
-                                                  args.timeout_ticks, args.B8, smem, (int)blockIdx.x);
-    if (uni(again))
-      chain_pair<NT, HITS, true>(args.b, args.slots, args.nk, args.first_step, args.w, args.chunks, args.lds_cap, args.timeout_ticks,
-                                 args.B8, smem, (int)blockIdx.x);
+    ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap));
+    const ChainArgs &a = *(const ChainArgs *)ap;
+    // (only the shape for large range images carries the POOL flavour: half the code for the others)
+    const int again = chain_pair<NT, false, NT != 1024>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks,
+                                                        a.B8, smem, (int)blockIdx.x);
+    if (NT == 1024 && uni(again))
+      chain_pair<NT, true, true>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8, smem, (int)blockIdx.x);
     return;
   }
   int *H = reinterpret_cast<int *>(smem);
@@ -1863,10 +1895,7 @@ k_insert_chain(ChainArgs args) {
   const int home = queue_mode == 2 ? (int)(blockIdx.x & 7) : 0;
   int turn = 0;                                              // queues this workgroup has found empty
   for (;;) {
-    // The arguments through a pointer the compiler cannot see through, taken afresh for every pair: it then loads
-    // them where the pair uses them.  Loaded once in front of the loop they occupy a hundred scalar registers for
-    // the whole pair and the kernel spills (176-256 B of scratch per lane).
-    typedef const __attribute__((address_space(4))) ChainArgs *ArgsPtr;
+    // (the pointer is taken afresh for every pair: nothing of the arguments stays in registers across pairs)
     ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ap));
     const ChainArgs &a = *(const ChainArgs *)ap;
@@ -1893,249 +1922,18 @@ k_insert_chain(ChainArgs args) {
     long long *cell = s_ < a.b.B ? reinterpret_cast<long long *>(a.b.out_xyzi + (int64_t)s_ * a.b.cap * 4) + k_ * 32 : nullptr;
     if (cell && threadIdx.x == 0) cell[28] = wall_clock64();   // this workgroup takes the pair
 #endif
-    const int again = chain_pair<NT, HITS, false>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8,
-                                                  smem, pair_id);
+    const int again = chain_pair<NT, false, NT != 1024>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8,
+                                                        smem, pair_id);
 #ifdef R3D_STAMPS
     if (cell && threadIdx.x == 0) cell[29] = uni(again) ? wall_clock64() : 0;   // the LDS flavour turned the pair down here
 #endif
-    if (uni(again))
-      chain_pair<NT, HITS, true>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8, smem, pair_id);
+    if (NT == 1024 && uni(again))
+      chain_pair<NT, true, true>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8, smem, pair_id);
 #ifdef R3D_STAMPS
     __syncthreads();
     if (cell && threadIdx.x == 0) cell[30] = wall_clock64();   // ... and is done with it
 #endif
   }
-}
-
-// ====================================================================================================
-// The insert launch in three kernels without a wait inside any of them:
-//   k_sample_prep   every (slot, scene) pair at once: the sample phase, its record into the launch's pool, the pair
-//                   into the list of the k_eval launch shape whose LDS holds its evaluation
-//   k_eval          every pair at once, against the scene as it stood when the launch began: the scene phase; visible
-//                   list and kill masks into the pool
-//   k_commit_chain  one workgroup per scene walks its slots in order: a pair none of whose accepted predecessors
-//                   touched the pixels it read commits what k_eval found; any other pair is evaluated again right
-//                   there, after its predecessors, and committed.  What no LDS of these kernels holds, and whatever
-//                   follows a rebase, is left to k_insert_big behind them.
-// (The round-2 kernel, k_insert_chain above, did all of this per pair in one workgroup that waited for its scene's
-// previous slot; it stays selectable with R3D_INSERT_LEGACY=1.)
-// ====================================================================================================
-struct EvalShapes {
-  int lds[kEvalClasses];       // LDS bytes of the class's k_eval launch, ascending; 0 = class not used
-};
-
-template <int NT>
-__global__ void __launch_bounds__(NT)
-k_sample_prep(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int chunks, int lds_cap, int B8,
-              EvalShapes shapes) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int k = (int)blockIdx.x / B8, s = (int)blockIdx.x % B8;
-  if (s >= b.B) return;
-  const int tid = threadIdx.x;
-  int *H = reinterpret_cast<int *>(smem);
-  Ins<NT, false, NT == 1024> I(b, w, smem, lds_cap, s, chunks, k, k, false);
-  const int pid = s * kMaxChain + k;
-  PairRec *pr = w.pairs + pid;
-  const bool on = load_slot(I, b, slots, k, s, first_step);
-  if (!on) {
-    if (tid == 0) pr->state = kPairIdle;
-    return;
-  }
-  int rc = (b.reserved & kDbgDefer) ? kNoFit : I.sample_phase();
-  long long off = -1;
-  if (rc == kOk) {
-    const long long want = ((long long)I.rec_end + 255) & ~255ll;
-    __syncthreads();
-    if (tid == 0) {
-      unsigned long long o = atomicAdd(w.pool_head, (unsigned long long)want);
-      H[H_GO] = o + want <= (unsigned long long)w.pool_bytes ? (int)(o >> 8) : -1;
-    }
-    __syncthreads();
-    const int got = uni(H[H_GO]);
-    if (got < 0) rc = kNoFit;
-    else off = (long long)got << 8;
-  }
-  if (rc != kOk) {
-    if (tid == 0) {
-      pr->state = kPairNoFit;
-      atomicAdd(&w.dbg[D_PREP_NOFIT], 1);
-    }
-    return;
-  }
-  I.store_record(w.tile_pool + off);
-  if (tid == 0) {
-    pr->rec_off = off;
-    pr->rec_bytes = I.rec_end;
-    pr->res_off = -1;
-    pr->sflags = H[H_FLAGS];
-    pr->rmin = H[H_RMIN];
-    pr->rmax = H[H_RMAX];
-    pr->cmin0 = H[H_CMIN0];
-    pr->cmin1 = H[H_CMIN1];
-    pr->cmax0 = H[H_CMAX0];
-    pr->cmax1 = H[H_CMAX1];
-    pr->nvis = 0;
-    pr->accept = 0;
-    pr->rebase = 0;
-    pr->nkill = 0;
-    pr->nhits = -1;
-    pr->hits_off = -1;
-    pr->n0 = 0;
-    pr->vrmin = pr->vcmin0 = pr->vcmin1 = 0x7FFFFFFF;
-    pr->vrmax = pr->vcmax0 = pr->vcmax1 = -1;
-    if (I.nvalid == 0) {
-      pr->state = kPairEvaluated;                           // nothing of the sample is inside the image: rejected
-    } else {
-      pr->state = kPairSampled;
-      // LDS of the evaluation: record, scratch images, visible list, candidates, depth tile, ~160 listed chunks
-      const long long need = (long long)I.r1 + 2ll * I.nvalid + 4ll * I.ncand + 8ll * I.dt.npx + 24 * 160 + 64;
-      int c = 0;
-      while (c + 1 < kEvalClasses && shapes.lds[c + 1] > 0 && need > shapes.lds[c]) ++c;
-      if (!(b.reserved & kDbgSerial)) w.cls_list[(int64_t)c * b.B * kMaxChain + atomicAdd(&w.cls_count[c], 1)] = pid;
-    }
-  }
-}
-
-template <int NT>
-__global__ void __launch_bounds__(NT, NT == 1024 ? 1 : R3D_CHAIN_WAVES)
-k_eval(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int chunks, int lds_cap, int cls) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  if ((int)blockIdx.x >= w.cls_count[cls]) return;
-  const int pid = w.cls_list[(int64_t)cls * b.B * kMaxChain + blockIdx.x];
-  const int s = pid / kMaxChain, k = pid % kMaxChain;
-  Ins<NT, true, NT == 1024> I(b, w, smem, lds_cap, s, chunks, k, k, false);
-  load_slot(I, b, slots, k, s, first_step);
-  PairRec *pr = w.pairs + pid;
-  int rc = I.load_record(w.tile_pool + pr->rec_off, pr->rec_bytes);
-  I.keep_hits = (b.reserved & kDbgKeepHits) != 0;           // the replay of stored hits is opt-in (see launch_slots_legacy)
-  if (rc == kOk) rc = I.scene_phase(w.n_total0[s], false, [] { return false; });
-  bool kept = false;
-  if (rc == kOk) kept = I.store_results(pr);
-  if (threadIdx.x == 0) atomicAdd(&w.dbg[kept ? D_EVAL_STORED : (rc == kOk ? D_EVAL_POOL : (rc == kNeedSerial ? D_EVAL_SERIAL : D_EVAL_NOFIT))], 1);
-  // anything else (the scene has pixels beyond 500 m; the evaluation does not fit this LDS): the chain does it
-}
-
-template <int NT>
-__global__ void __launch_bounds__(NT)
-k_commit_chain(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w, int chunks, int lds_cap) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int s = (int)blockIdx.x;
-  const int tid = threadIdx.x;
-  int *H = reinterpret_cast<int *>(smem);
-  // what the slots so far did to the scene: kRec* flags, count afterwards, rows / columns of the visible pixels;
-  // kept in the last KB of this workgroup's LDS (the Ins below sees the rest)
-  int *recs = reinterpret_cast<int *>(smem + lds_cap - kMaxChain * 8 * 4);
-  const int lds_ins = lds_cap - kMaxChain * 8 * 4;
-  const int n_head0 = uni(b.n_head[s]);
-  int n_now = uni(w.n_total0[s]);
-  int defer = nk;
-  for (int k = 0; k < nk; ++k) {
-    Ins<NT, true, NT == 1024> I(b, w, smem, lds_ins, s, chunks, k, kMaxChain, false);
-    const bool on = load_slot(I, b, slots, k, s, first_step);
-    const long long t_slot = wall_clock64();
-    int path = 0;
-    int flags = 0, n_after = n_now, nv = 0, acc = 0;
-    bool rebase = false;
-    if (on) {
-      const PairRec pr = w.pairs[s * kMaxChain + k];
-      const bool have_rec = pr.state == kPairSampled || pr.state == kPairEvaluated;
-      if (!have_rec && (b.reserved & kDbgDefer)) {
-        if (tid == 0) atomicAdd(&w.dbg[D_DEFER_PREP], 1);
-        defer = k;
-        break;
-      }
-      // did an accepted predecessor change a pixel this pair's evaluation read, the bounds or the far list?
-      int cf = pr.state == kPairEvaluated && !(b.reserved & kDbgSerial) ? 0 : 1;
-      if (have_rec) {
-        int out = 0;
-        const int j = tid & 63;
-        if (j < k) {
-          const int *r = recs + j * 8;
-          if (r[REC_FLAGS] & kRecAccepted) {
-            if (r[REC_FLAGS] & kRecRebased) out |= 3;
-            if (r[REC_FLAGS] & kRecFar) out |= 1;
-            if (!(r[REC_RHI] < pr.rmin - 6 || r[REC_RLO] > pr.rmax + 6)) {
-              const int slo[2] = {pr.cmin0, pr.cmin1}, shi[2] = {pr.cmax0, pr.cmax1};
-              for (int h = 0; h < 2; ++h) {
-                if (shi[h] < 0) continue;
-                for (int g = 0; g < 2; ++g) {
-                  const int clo = r[REC_CLO0 + 2 * g], chi = r[REC_CHI0 + 2 * g];
-                  if (chi >= clo && clo <= shi[h] + 3 && chi >= slo[h] - 3) out |= 1;
-                }
-              }
-            }
-          }
-        }
-        cf |= wave_or_i32(out);
-      }
-      cf = uni(cf);
-      if (cf & 2) {                                         // the bounds moved: the sample is projected again
-        if (tid == 0) atomicAdd(&w.dbg[D_DEFER_BOUNDS], 1);
-        defer = k;
-        break;
-      }
-      int rc = kOk;
-      if (!cf && !pr.accept) {                              // rejected, and nothing has changed that
-        nv = pr.nvis;
-        if (tid == 0 && pr.sflags) atomicOr(&b.status[s], pr.sflags);
-        if (tid == 0) atomicAdd(&w.dbg[D_CHAIN_REJECTED], 1);
-      } else {
-        // (a sample too large for k_sample_prep's LDS is projected here)
-        rc = have_rec ? I.load_record(w.tile_pool + pr.rec_off, pr.rec_bytes) : I.sample_phase();
-        bool stored = rc == kOk && !cf;
-        if (stored && I.load_results(pr) != kOk) stored = false;   // lists too long for this LDS: evaluate here
-        if (rc == kOk && !stored) {
-          if (pr.state == kPairEvaluated && pr.nhits >= 0 && !(b.reserved & kDbgSerial)) {   // replay what k_eval gathered
-            I.r_hits = reinterpret_cast<const uint4 *>(w.tile_pool + pr.hits_off);
-            I.r_nhits = pr.nhits;
-            I.r_n0 = pr.n0;
-          }
-          rc = I.scene_phase(n_now, true, [] { return false; });
-        }
-        path = rc != kOk ? D_DEFER_NOFIT : (stored ? D_CHAIN_STORED : (cf ? D_CHAIN_CONFLICT : D_CHAIN_UNEVAL));
-        if (tid == 0) atomicAdd(&w.dbg[path], 1);
-        if (rc != kOk) {
-          defer = k;
-          break;
-        }
-        rebase = I.commit(flags, n_after, n_now, n_head0);
-        nv = I.nvis;
-        acc = I.accept ? 1 : 0;
-      }
-    } else {
-      // nothing to insert here
-    }
-    if (tid == 0) {
-      slots.n_visible[k][s] = nv;
-      slots.accepted[k][s] = acc;
-      int *r = recs + k * 8;
-      r[REC_FLAGS] = flags;
-      r[REC_NTOTAL] = n_after;
-      r[REC_RLO] = acc ? H[H_VRMIN] : 0x7FFFFFFF;
-      r[REC_RHI] = acc ? H[H_VRMAX] : -1;
-      r[REC_CLO0] = acc ? H[H_VCMIN0] : 0x7FFFFFFF;
-      r[REC_CHI0] = acc ? H[H_VCMAX0] : -1;
-      r[REC_CLO1] = acc ? H[H_VCMIN1] : 0x7FFFFFFF;
-      r[REC_CHI1] = acc ? H[H_VCMAX1] : -1;
-    }
-    n_now = n_after;
-    // The next slot of this workgroup reads what this one wrote: a barrier is all it takes (one CU, one L1; alive bits
-    // and counters are atomics).  An agent-scope fence here writes the whole L2 back -- 50 us per slot while the
-    // L2 is still full of what k_eval stored.
-    __syncthreads();
-    if (tid == 0) {
-      w.trace[((int64_t)s * kMaxChain + k) * 2] = (wall_clock64() - t_slot) | ((long long)path << 48);
-      w.trace[((int64_t)s * kMaxChain + k) * 2 + 1] = t_slot;
-    }
-    if (rebase) {
-      unsigned long long *s_min = reinterpret_cast<unsigned long long *>(smem + kHdrBytes), *s_max = s_min + NT / 64;
-      rebase_scene<NT>(b, w, chunks, s, s_min, s_max);
-      if (tid == 0) atomicAdd(&w.dbg[D_REBASE], 1);
-      defer = k + 1;                                        // the later samples are projected under the new bounds
-      break;
-    }
-  }
-  if (tid == 0 && defer < nk) w.defer_from[s] = defer;
 }
 
 // The pairs the chain kernel could not hold in its LDS, scene by scene, slot after slot.
@@ -2147,7 +1945,7 @@ k_insert_big(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w,
   const int tid = threadIdx.x;
   const int k0 = w.defer_from[s];
   for (int k = k0; k < nk; ++k) {
-    Ins<NT, false, true> I(b, w, smem, lds_cap, s, chunks, k, kMaxChain, true);
+    Ins<NT, true> I(b, w, smem, lds_cap, s, chunks, k, true);
     const bool on = load_slot(I, b, slots, k, s, first_step);
     int nv = 0, acc = 0;
     if (on) {
@@ -2175,17 +1973,16 @@ k_insert_big(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w,
   }
 }
 
-__global__ void k_chain_init(r3d_batch_t b, BatchWs w, int nk, int defer0 = -1) {
+__global__ void k_chain_init(r3d_batch_t b, BatchWs w, int nk) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= b.B) return;
   if (s == 0) {
     *w.pool_head = 0ull;
-    for (int c = 0; c < kEvalClasses; ++c) w.cls_count[c] = 0;
     for (int q = 0; q < 16; ++q) w.queue_next[q] = 0;
   }
   w.chain_progress[s] = 0;
   w.n_total0[s] = b.n_total[s];
-  w.defer_from[s] = defer0 >= 0 ? defer0 : nk;
+  w.defer_from[s] = nk;
 }
 
 constexpr int kSmallNT = 256;
@@ -2211,11 +2008,11 @@ static void chain_shape(const r3d_batch_t &b, int &nt, int &lds) {
   lds = kb * 1024;
 }
 
-template <int NT, bool HITS, bool QUEUE>
+template <int NT, bool QUEUE>
 static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step, int lds,
                           long long timeout_ticks, int B8, int queue_mode, hipStream_t st) {
   // per device, every call: the attribute belongs to the current device's copy of the kernel
-  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_chain<NT, HITS, QUEUE>),
+  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_chain<NT, QUEUE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   const int total = (B8 ? B8 : b.B) * nk;
   int grid = total;
@@ -2234,7 +2031,7 @@ static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlo
     if (!resident) {
       int cus = 0, per_cu = 0;
       R3D_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      R3D_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_insert_chain<NT, HITS, QUEUE>), NT, lds));
+      R3D_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_insert_chain<NT, QUEUE>), NT, lds));
       resident = (per_cu < 1 ? 1 : per_cu) * (cus < 8 ? 8 : cus);
       std::lock_guard<std::mutex> lock(mu);
       known[{dev, lds}] = resident;
@@ -2247,189 +2044,40 @@ static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlo
   args.w = w;
   args.timeout_ticks = timeout_ticks;
   args.nk = nk, args.first_step = first_step, args.chunks = chunks_of(b), args.lds_cap = lds, args.B8 = B8, args.queue_mode = queue_mode;
-  hipLaunchKernelGGL((k_insert_chain<NT, HITS, QUEUE>), dim3(grid), dim3(NT), lds, st, args);
+  hipLaunchKernelGGL((k_insert_chain<NT, QUEUE>), dim3(grid), dim3(NT), lds, st, args);
   R3D_LAUNCHED("k_insert_chain");
   return R3D_OK;
 }
 
-template <int NT, bool HITS>
+template <int NT>
 static int launch_chain(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step, int lds,
                         long long timeout_ticks, hipStream_t st) {
   // measured on config C2: scene-major numbering is 10-40 % slower (the big pairs of all scenes no longer start together)
   static const bool scene_major = getenv("R3D_CHAIN_ORDER") && std::string(getenv("R3D_CHAIN_ORDER")) == "scene";
   const int B8 = scene_major ? 0 : (b.B + 7) & ~7;            // a scene's slots on one residue of the pair id mod 8
   // R3D_CHAIN_QUEUE: 0 one workgroup per pair; 1 resident workgroups that take pairs off one queue; 2 ... off a queue per
-  // XCD.  Default: 2 on large range images (config C5: 6.4 -> 4.8 ms per 128 scans x 50 slots), 0 otherwise (config
-  // C2: 0.33 ms either way without the loop's spills, 0.37 with them).
+  // XCD.  Default: 2 on large range images (config C5: 6.4 -> 4.8 ms per 128 scans x 50 slots), 0 otherwise.
   static const int queue_env = env_int("R3D_CHAIN_QUEUE", -1);
   const bool large = (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN;
   int queue_mode = queue_env >= 0 ? queue_env : (large ? 2 : 0);
   if (scene_major && queue_mode == 2) queue_mode = 1;
-  return queue_mode ? launch_chain_q<NT, HITS, true>(b, w, sl, nk, first_step, lds, timeout_ticks, B8, queue_mode, st)
-                    : launch_chain_q<NT, HITS, false>(b, w, sl, nk, first_step, lds, timeout_ticks, B8, 0, st);
+  return queue_mode ? launch_chain_q<NT, true>(b, w, sl, nk, first_step, lds, timeout_ticks, B8, queue_mode, st)
+                    : launch_chain_q<NT, false>(b, w, sl, nk, first_step, lds, timeout_ticks, B8, 0, st);
 }
 
-// launch shapes of k_eval, smallest first: threads per class, LDS from R3D_EVAL_KB ("24,48,80,160")
-constexpr int kEvalNT[kEvalClasses] = {256, 256, 512, 1024};
-
-// The launch shapes of k_eval run side by side: shape 0 on the caller's stream, the others on helper streams of the
-// device (created on first use, kept for the life of the process) that fork from the caller's stream behind
-// k_sample_prep and join it before k_commit_chain.  Events are made per call, so calls from several host threads
-// and streams do not share any.
-struct Helpers {
-  hipStream_t st[kEvalClasses - 1];
-  bool ok = false;
-};
-static Helpers *device_helpers() {
-  static std::mutex mu;
-  static std::map<int, Helpers> per_device;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  Helpers &h = per_device[dev];
-  if (!h.ok) {
-    for (int i = 0; i < kEvalClasses - 1; ++i)
-      if (hipStreamCreateWithFlags(&h.st[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
-    h.ok = true;
-  }
-  return &h;
-}
-
-template <int NT>
-static int launch_eval(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step, int lds, int cls,
-                       hipStream_t st) {
-  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(k_eval<NT>, dim3(b.B * nk), dim3(NT), lds, st, b, sl, nk, first_step, w, chunks_of(b), lds, cls);
-  R3D_LAUNCHED("k_eval");
-  return R3D_OK;
-}
-
-template <int NTP, int NTC>
-static int launch_three(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step, int lds_prep,
-                        int lds_chain, const EvalShapes &sh, hipStream_t st) {
-  const int B8 = (b.B + 7) & ~7;
-  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sample_prep<NTP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              lds_prep));
-  hipLaunchKernelGGL(k_sample_prep<NTP>, dim3(B8 * nk), dim3(NTP), lds_prep, st, b, sl, nk, first_step, w, chunks_of(b), lds_prep,
-                     B8, sh);
-  R3D_LAUNCHED("k_sample_prep");
-  static const bool side_by_side = !getenv("R3D_EVAL_ONE_STREAM");
-  int n_shapes = 0;
-  for (int c = 0; c < kEvalClasses; ++c) n_shapes += sh.lds[c] > 0;
-  Helpers *hp = side_by_side && n_shapes > 1 ? device_helpers() : nullptr;
-  hipEvent_t fork = nullptr, join[kEvalClasses] = {nullptr, nullptr, nullptr, nullptr};
-  if (hp) {
-    R3D_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-    R3D_HIP(hipEventRecord(fork, st));
-  }
-  int first = -1;
-  for (int c = kEvalClasses - 1; c >= 0; --c) {             // the big shapes first: they take longest
-    if (sh.lds[c] <= 0) continue;
-    if (first < 0) first = c;
-    hipStream_t on = st;
-    if (hp && c != 0) {
-      on = hp->st[c - 1];
-      R3D_HIP(hipStreamWaitEvent(on, fork, 0));
-    }
-    int rc = kEvalNT[c] == 256   ? launch_eval<256>(b, w, sl, nk, first_step, sh.lds[c], c, on)
-             : kEvalNT[c] == 512 ? launch_eval<512>(b, w, sl, nk, first_step, sh.lds[c], c, on)
-                                 : launch_eval<1024>(b, w, sl, nk, first_step, sh.lds[c], c, on);
-    if (rc != R3D_OK) return rc;
-    if (on != st) {
-      R3D_HIP(hipEventCreateWithFlags(&join[c], hipEventDisableTiming));
-      R3D_HIP(hipEventRecord(join[c], on));
-    }
-  }
-  for (int c = 0; c < kEvalClasses; ++c)
-    if (join[c]) {
-      R3D_HIP(hipStreamWaitEvent(st, join[c], 0));
-      R3D_HIP(hipEventDestroy(join[c]));                    // released once it has completed
-    }
-  if (fork) R3D_HIP(hipEventDestroy(fork));
-  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_commit_chain<NTC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              lds_chain));
-  hipLaunchKernelGGL(k_commit_chain<NTC>, dim3(b.B), dim3(NTC), lds_chain, st, b, sl, nk, first_step, w, chunks_of(b), lds_chain);
-  R3D_LAUNCHED("k_commit_chain");
-  return R3D_OK;
-}
-
-static int launch_slots_legacy(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step,
-                               hipStream_t st);
-
+// One launch of the chain kernel for the slots of `sl`, k_insert_big behind it for what it left (idle otherwise).
 static int launch_slots(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step,
                         hipStream_t st) {
-  static const bool three = getenv("R3D_INSERT_THREE") != nullptr;
-  if (!(three || (b.reserved & kDbgThree)) || (b.reserved & kDbgDropPublish)) return launch_slots_legacy(b, w, sl, nk, first_step, st);
-  static int kb[kEvalClasses] = {0, 0, 0, 0};
-  static const bool parsed = [] {
-    const char *v = getenv("R3D_EVAL_KB");
-    const int dflt[kEvalClasses] = {24, 48, 80, 160};
-    for (int c = 0; c < kEvalClasses; ++c) kb[c] = dflt[c];
-    if (v && *v) {
-      int c = 0;
-      for (const char *q = v; c < kEvalClasses; ++c) {
-        kb[c] = atoi(q);
-        q = strchr(q, ',');
-        if (!q) {
-          for (++c; c < kEvalClasses; ++c) kb[c] = 0;
-          break;
-        }
-        ++q;
-      }
-    }
-    return true;
-  }();
-  (void)parsed;
-  static const int prep_kb = env_int("R3D_PREP_KB", 40);
-  const bool large = (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN;
-  EvalShapes sh{};
-  for (int c = 0; c < kEvalClasses; ++c) sh.lds[c] = large ? (c == kEvalClasses - 1 ? kBigLds : 0) : kb[c] * 1024;
-  if (large) {                                              // one shape: the whole CU per pair (see chain_shape)
-    sh.lds[0] = kBigLds;
-    for (int c = 1; c < kEvalClasses; ++c) sh.lds[c] = 0;
-  }
-  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_big<kBigNT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
-  hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, nk);
-  static const int chain_nt = env_int("R3D_CHAIN_NT", 1024);
-  int rc = large ? launch_three<1024, 1024>(b, w, sl, nk, first_step, kBigLds, kBigLds, sh, st)
-           : chain_nt == 1024 ? launch_three<256, 1024>(b, w, sl, nk, first_step, prep_kb * 1024, kBigLds, sh, st)
-                              : launch_three<256, 512>(b, w, sl, nk, first_step, prep_kb * 1024, 80 * 1024, sh, st);
-  if (rc != R3D_OK) return rc;
-  hipLaunchKernelGGL(k_insert_big<kBigNT>, dim3(b.B), dim3(kBigNT), kBigLds, st, b, sl, nk, first_step, w,
-                     chunks_of(b), kBigLds);
-  R3D_LAUNCHED("k_insert_big");
-  return R3D_OK;
-}
-
-static int launch_slots_legacy(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step,
-                               hipStream_t st) {
   static const int timeout_ms = env_int("R3D_CHAIN_TIMEOUT_MS", 2000);
   int nt, lds;
   chain_shape(b, nt, lds);
   R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_big<kBigNT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
-  hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, nk, -1);
-  int rc = R3D_OK;
-  {
-    // Keeping the hits of a pair's first evaluation and replaying them in a later one (R3D_CHAIN_HITS=1) paid while most
-    // pairs of a long chain were evaluated twice (config C5 at 32 scans per batch: 3.7 -> 2.9 ms per 50 slots).  It is
-    // off by default since round 3: with resident workgroups and 128+ scans per batch 4 % of the pairs are evaluated
-    // twice and the replay gains nothing (8.05 against 7.98 ms per 256 scans), and a soak of 10-slot chains on 256
-    // frames showed it non-deterministic once in ~20 000 frame runs (a few hundred points too many in one frame:
-    // tools/soak_chain.py C3) -- cause not found, so nothing that ships takes that path.
-    static const int hits_env = env_int("R3D_CHAIN_HITS", 0);
-    const bool hits = hits_env > 0 || (b.reserved & kDbgKeepHits);
-    const long long tt = (long long)timeout_ms * 100000ll;
-    if (hits)
-      rc = nt == 1024  ? launch_chain<1024, true>(b, w, sl, nk, first_step, lds, tt, st)
-           : nt == 512 ? launch_chain<512, true>(b, w, sl, nk, first_step, lds, tt, st)
-                       : launch_chain<kSmallNT, true>(b, w, sl, nk, first_step, lds, tt, st);
-    else
-      rc = nt == 1024  ? launch_chain<1024, false>(b, w, sl, nk, first_step, lds, tt, st)
-           : nt == 512 ? launch_chain<512, false>(b, w, sl, nk, first_step, lds, tt, st)
-                       : launch_chain<kSmallNT, false>(b, w, sl, nk, first_step, lds, tt, st);
-  }
+  hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, nk);
+  const long long tt = (long long)timeout_ms * 100000ll;
+  int rc = nt == 1024  ? launch_chain<1024>(b, w, sl, nk, first_step, lds, tt, st)
+           : nt == 512 ? launch_chain<512>(b, w, sl, nk, first_step, lds, tt, st)
+                       : launch_chain<kSmallNT>(b, w, sl, nk, first_step, lds, tt, st);
   if (rc != R3D_OK) return rc;
   hipLaunchKernelGGL(k_insert_big<kBigNT>, dim3(b.B), dim3(kBigNT), kBigLds, st, b, sl, nk, first_step, w,
                      chunks_of(b), kBigLds);
@@ -2489,16 +2137,6 @@ int r3d_batch_insert_many(const r3d_batch_t *b, int32_t n_slots, const double *c
     rc = launch_slots(*b, w, sl, nk, (int)(first_step + k0), (hipStream_t)stream);
     if (rc != R3D_OK) return rc;
   }
-  return R3D_OK;
-}
-
-int r3d_batch_debug_trace(const r3d_batch_t *b, int64_t *host_out, int64_t n_words, void *stream) {
-  int rc = check_batch(b);
-  if (rc != R3D_OK) return rc;
-  BatchWs w = carve_batch(*b, b->workspace);
-  if (!host_out || n_words < 0 || n_words > (int64_t)b->B * kMaxChain * 2) return fail(R3D_E_ARG, "batch_debug_trace: size");
-  R3D_HIP(hipMemcpyAsync(host_out, w.trace, n_words * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
-  R3D_HIP(hipStreamSynchronize((hipStream_t)stream));
   return R3D_OK;
 }
 

@@ -112,7 +112,7 @@ def test_begin_matches_golden_pixels_and_bounds(P, synth):
     b = P.SceneBatch(1, len(xyzi) + 512, 512)
     b.load([(xyzi, label)])
     b.begin()
-    assert np.array_equal(b.pix[0, :len(xyzi)].cpu().numpy(), g["scene_pix"])
+    assert np.array_equal(b.pixel_ids()[0, :len(xyzi)], g["scene_pix"])
     assert np.abs(b.bounds[0].cpu().numpy() - g["bounds"]).max() <= 1e-12
     nv, acc = b.insert([g["sample5"]], [20])
     assert nv[0] == len(g["visible_idx"]) and acc[0] == 1
@@ -274,7 +274,7 @@ def test_fast_projection_equals_reference_formula(P, synth):
         b = P.SceneBatch(len(scenes), cap, 64, exact_projection=exact)
         b.load(scenes)
         b.begin()
-        pix.append((b.pix.cpu().numpy(), b.status.cpu().numpy(), b.bounds.cpu().numpy(),
+        pix.append((b.pixel_ids(), b.status.cpu().numpy(), b.bounds.cpu().numpy(),
                     b.n_far.cpu().numpy()))
     for a, c in zip(pix[0], pix[1]):
         assert np.array_equal(a, c)
@@ -571,15 +571,14 @@ def test_c5_scan_on_the_proposed_448x2880_grid(P, synth, monkeypatch):
     _check_scene(res[0], vb, lb, cb)
 
 
-@pytest.mark.parametrize("debug", [2, 4, 8, 6, 32, 64, 66, 72, 96, 128, 160, 192])
+@pytest.mark.parametrize("debug", [2, 4, 8, 6, 32, 64, 96, 128, 160, 132])
 def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
-    """The insert kernel's other routes, forced with the descriptor's diagnostic bits (64 = the launch as three
-    kernels without a wait: k_sample_prep, k_eval, k_commit_chain -- alone, with every pair evaluated in the chain,
-    with every pair left to k_insert_big, with pooled tiles; 128 = keep and replay the hits of a first evaluation, the
-    opt-in flavour -- alone, with pooled tiles, in the three-kernel launch): 2 = never
-    speculate (every slot waits for its predecessor first), 4 = the window's depth tile built and
-    evaluated in bands of at most 3 candidate rows, 32 = tile and candidate list in the global pool, 8 = every pair left to k_insert_big (one 1024-thread
-    workgroup per scene); all must give the bytes of the oracle chain, through insert_many and slot by slot."""
+    """The insert kernel's other routes, forced with the descriptor's diagnostic bits: 2 = never speculate (every slot
+    waits for its predecessor first), 4 = the window's depth tile built and evaluated in bands of at most 3 candidate
+    rows, 32 = tile and candidate list in the global pool, 8 = every pair left to k_insert_big (one 1024-thread workgroup
+    per scene), 128 = the kill masks from the pixel ids in global memory (no hits kept in LDS), 64 = every speculative
+    evaluation done again after its predecessors and compared (alone and with pooled tiles); all must give the bytes of
+    the oracle chain, through insert_many and slot by slot, and the comparison of bit 64 must never differ."""
     import torch
     cases = [_random_case(synth, 11), _random_case(synth, 12, 32, 900, shuffle=True), _random_case(synth, 13, 64, 500)]
     xyzi, label = synth.make_scene(14, 48, 700)
@@ -599,6 +598,8 @@ def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
             acc = np.stack([batch.insert_device(p[0], p[1], nd)[1].cpu().numpy().copy() for p, nd in zip(packed, needs)])
         batch.finish()
         res = batch.results()
+        cnt = batch.debug_counters()
+        assert cnt["verify_mismatch"] == 0 and ((debug & 64) == 0 or not many or cnt["verify_runs"] > 0), cnt
         for i, c in enumerate(cases):
             vb, lb, cb, oacc = _oracle_chain(*c)
             assert [0 if acc[k, i] else -1 for k in range(K)] == oacc
@@ -652,7 +653,7 @@ def test_chain_timeout_is_reported(P, synth):
 def test_bench_scenes_against_the_oracle(P, synth, debug):
     """Short form of tests/crosscheck_bench.py: 12 scenes of the bench workload (config C2, the seeds the
     bench times) through one batch, byte for byte against the oracle; 4 more with blobs in front of the
-    extreme-elevation points so that the chain re-bases in the middle.  debug = 64: the launch as three kernels."""
+    extreme-elevation points so that the chain re-bases in the middle.  debug = 64: every speculative evaluation verified."""
     from conftest import blob_in_front_of_extreme
     kinds = synth.CONFIG_INSERTS["C2"]
     seeds = list(range(12)) + [100, 101, 102, 103]

@@ -142,6 +142,6 @@ def test_begin_f64_is_within_three_times_of_begin(pkg, synth):
     s9 = O.add_space_for_spherical(rows[0])
     s9, mx, mn = O.fill_spherical(s9)
     _, _, s9 = O.geometrical_front_view(s9, O.NUMROW, O.NUMCOLUMN, mx, mn)
-    assert np.array_equal(b64.pix[0, :len(rows[0])].cpu().numpy(), s9[:, 8].astype(np.int32))
+    assert np.array_equal(b64.pixel_ids()[0, :len(rows[0])], s9[:, 8].astype(np.int32))
     print(f"begin_f64 {t64:.3f} ms, begin {t32:.3f} ms, ratio {t64 / t32:.2f}")
     assert t64 < 3.0 * t32 + 0.05
