@@ -97,3 +97,12 @@ if raw.shape[2] > 30 and raw[:, :, 28].any():
         print(f"  entry of workgroup i minus exit of workgroup i-{cap}: median {np.median(lag):.1f} us, negative for {100 * (lag < 0).mean():.0f} %")
     span = (ext.max() - t00) / 100
     print(f"  workgroup-time {((ext - ent) / 100).sum() / 1000:.1f} ms over a span of {span / 1000:.2f} ms = {((ext - ent) / 100).sum() / span:.0f} workgroups on the device on average")
+# the chain that ends last: per slot when it started, how long each phase took, when it published
+last = np.unravel_index(np.argmax(raw[:, :, 15]), raw[:, :, 15].shape)[1]
+print(f"the scene whose chain ends last (scene {last}):")
+for k in range(K):
+    r = st[k, last]
+    ph = ", ".join(f"{n.split(' ')[0]} {(r[z] - r[a]) / 100.0:.1f}" for n, (a, z) in zip(names, edges))
+    print(f"  slot {k} ({KINDS[k]}): start {(r[0] - t0) / 100.0:.1f} end {(r[15] - t0) / 100.0:.1f} attempts {attempts[k, last]} words {ww[k, last]} chunks {nlist[k, last]} tile px {(info[k, last] >> 48) << 4} | {ph}")
+ends = (raw[K - 1, :, 15] - t0) / 100.0
+print("end of the scenes' chains, us after launch: p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(ends, [50, 90, 99, 100])))
