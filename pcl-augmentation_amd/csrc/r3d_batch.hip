@@ -127,30 +127,18 @@ k_bounds_sample(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchW
   }
 }
 
-// Besides the extremes, k_bounds does the half of the projection that does not depend on them (round 4): the COLUMN
-// of every point -- float32 guess, float32 screen against the column's two edges (k_project's comment has the error
-// budget) -- and leaves per point the float32 z/r (w.qf, 4 bytes) and the column with three flags (w.colinfo, 2 bytes).
-// k_project then reads those 6 bytes instead of the 16-byte point and only decides the row; it fetches the point itself
-// for the few per mille the screens leave open.  This kernel streams the cloud anyway and had idle vector ALUs
-// (HBM-bound at 76 % of peak with 33 VALU instructions per point where k_project, VALU-bound, spent 143).
-constexpr uint32_t kColOk = 1u << 13, kSsNormal = 1u << 14, kSsBig = 1u << 15;   // colinfo flags; columns < 8192 (check_batch)
-
 __global__ void __launch_bounds__(kPT)
 k_bounds(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
   __shared__ unsigned long long s_min[kPT / 64], s_max[kPT / 64];
-  extern __shared__ __align__(16) float s_tabf[];          // [(cols+1)*2] column edges
-  float2 *s_col = reinterpret_cast<float2 *>(s_tabf);
-  for (int e = threadIdx.x; e < b.cols + 1; e += kPT) s_col[e] = reinterpret_cast<const float2 *>(w.col_dirf)[e];
-  __syncthreads();
   int cnt = *count;
-  const float inv_daz = (float)((double)b.cols / kTwoPi);
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
     int n = b.n_total[s], n_head = b.n_head[s];
-    if ((int)blockIdx.x * kTile >= n) continue;
+    int t0 = blockIdx.x * kTile;
+    if (t0 >= n) continue;
     unsigned long long lmin = ~0ull, lmax = 0ull;
     int bad = 0;
-    // what the sample found: every other value is only more extreme
+    // what the sample (or the tiles that finished before this one) found: every later value is only more extreme
     const unsigned long long k_lo = __hip_atomic_load(&w.qkeys[2 * s + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long k_hi = __hip_atomic_load(&w.qkeys[2 * s + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float lo_t = __builtin_inff(), hi_t = -__builtin_inff();    // no sample: nothing is excluded
@@ -158,40 +146,24 @@ k_bounds(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
       lo_t = (float)(ordered_key_inv(k_lo) + 2.5e-6);            // 2e-6 and the rounding of the conversion
       hi_t = (float)(ordered_key_inv(k_hi) - 2.5e-6);
     }
+    // the thread's 8 float32 points are requested together (inserted float64 points, which only exist when a
+    // re-based scene comes through here, are fetched from the log by exact_q)
     const float4 *src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
-    float *qf_out = w.qf + (int64_t)s * b.cap;
-    uint16_t *ci_out = w.colinfo + (int64_t)s * b.cap;
-    for (int t0 = blockIdx.x * kTile; t0 < n; t0 += gridDim.x * kTile) {
-      // the thread's 8 float32 points are requested together (inserted float64 points, which only exist when a
-      // re-based scene comes through here, are fetched from the log by exact_q)
-      float4 pt[kPerThread];
+    float4 pt[kPerThread];
 #pragma unroll
-      for (int k = 0; k < kPerThread; ++k) {
-        int i = t0 + k * kPT + threadIdx.x;
-        // x y z only, non-temporal: nothing else of the cloud is wanted here (0.078 ms against 0.086 ms alone)
-        const float *f = reinterpret_cast<const float *>(src + (i < n ? i : n - 1));
-        pt[k] = make_float4(__builtin_nontemporal_load(f), __builtin_nontemporal_load(f + 1), __builtin_nontemporal_load(f + 2), 0.f);
-      }
+    for (int k = 0; k < kPerThread; ++k) {
+      int i = t0 + k * kPT + threadIdx.x;
+      // x y z only, non-temporal: nothing else of the cloud is wanted here (0.078 ms against 0.086 ms alone)
+      const float *f = reinterpret_cast<const float *>(src + (i < n ? i : n - 1));
+      pt[k] = make_float4(__builtin_nontemporal_load(f), __builtin_nontemporal_load(f + 1), __builtin_nontemporal_load(f + 2), 0.f);
+    }
 #pragma unroll
-      for (int k = 0; k < kPerThread; ++k) {
-        int i = t0 + k * kPT + threadIdx.x;
-        float ssf = fmaf(pt[k].x, pt[k].x, fmaf(pt[k].y, pt[k].y, pt[k].z * pt[k].z));
-        float qf = pt[k].z * __frsqrt_rn(ssf);
-        const bool normal = (ssf > 1e-30f) & (ssf < 1e30f);
-        const bool inside = normal & (qf > lo_t) & (qf < hi_t) & (i < n_head);
-        if (i < n && !inside) exact_q(b, s, i, n_head, pt[k], lmin, lmax, bad);
-        // the column: guess, then the float32 screen on its two edges
-        int col = (int)((guess_atan2f(pt[k].y, pt[k].x) + 3.14159274f) * inv_daz);
-        col = max(0, min(col, b.cols - 1));
-        const float2 ea = s_col[col], eb = s_col[col + 1];
-        const float mcf = 1e-6f * (fabsf(pt[k].x) + fabsf(pt[k].y));
-        const bool col_ok = (fmaf(ea.x, pt[k].y, -(ea.y * pt[k].x)) > mcf) & (fmaf(eb.x, pt[k].y, -(eb.y * pt[k].x)) < -mcf) &
-                            (i < n_head);          // (a float64 point: the float32 screen says nothing about it)
-        if (i < n) {
-          qf_out[i] = qf;
-          ci_out[i] = (uint16_t)((uint32_t)col | (col_ok ? kColOk : 0u) | (normal ? kSsNormal : 0u) | (ssf > 249000.f ? kSsBig : 0u));
-        }
-      }
+    for (int k = 0; k < kPerThread; ++k) {
+      int i = t0 + k * kPT + threadIdx.x;
+      float ssf = fmaf(pt[k].x, pt[k].x, fmaf(pt[k].y, pt[k].y, pt[k].z * pt[k].z));
+      float qf = pt[k].z * __frsqrt_rn(ssf);
+      const bool inside = (ssf > 1e-30f) & (ssf < 1e30f) & (qf > lo_t) & (qf < hi_t) & (i < n_head);
+      if (i < n && !inside) exact_q(b, s, i, n_head, pt[k], lmin, lmax, bad);
     }
     lmin = wave_min_u64(lmin);
     lmax = wave_max_u64(lmax);
@@ -319,8 +291,9 @@ __global__ void k_col_table(r3d_batch_t b, BatchWs w) {
 //   ss must be a normal float32 far from overflow / flush-to-zero (1e-30 < ss < 1e30).
 __global__ void __launch_bounds__(kPT)
 k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int chunks) {
-  extern __shared__ __align__(16) float s_tabf[];          // [(rows+2)*2] row limits
-  float2 *s_row = reinterpret_cast<float2 *>(s_tabf);
+  extern __shared__ __align__(16) float s_tabf[];          // [(cols+1)*2] column edges, [(rows+2)*2] row limits
+  float2 *s_col = reinterpret_cast<float2 *>(s_tabf), *s_row = s_col + (b.cols + 1);
+  for (int e = threadIdx.x; e < b.cols + 1; e += kPT) s_col[e] = reinterpret_cast<const float2 *>(w.col_dirf)[e];
   int cnt = *count;
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
@@ -331,55 +304,56 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
     __syncthreads();
     Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
     const bool exact = b.reserved & 1;                       // diagnostic: reference formula only
-    const float inv_del = (float)(1.0 / bn.d_el);
+    const float inv_del = (float)(1.0 / bn.d_el), inv_daz = (float)(1.0 / bn.d_az);
     const float elo = (float)(bn.min_el + 0.00001);
     const double *row_cc = w.row_q + (int64_t)s * (b.rows + 2);
     uint32_t *queue = w.cand + (int64_t)s * w.cand_stride;  // insert scratch, free during step 0
     int flags = 0;
-    // 8 points per thread and tile: what k_bounds left of them (z/r in float32, column + flags: 6 bytes); unconfirmed
-    // points are queued for k_project_slow.  A block walks several tiles so that the table is staged once.  The records
-    // are requested two rounds ahead of their use (indices clamped to the scene: no branch around a load).
+    // 8 points per thread and tile; unconfirmed points are queued for k_project_slow.  A block walks
+    // several tiles so that the tables are staged once.  Points are requested two rounds ahead of their use
+    // (indices clamped to the scene: no branch around a load).
     const float4 *__restrict__ src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
-    const float *__restrict__ qfs = w.qf + (int64_t)s * b.cap;
-    const uint16_t *__restrict__ cis = w.colinfo + (int64_t)s * b.cap;
-    const unsigned int last = (unsigned int)(n > 0 ? n - 1 : 0);
-    struct Rec {
-      float qf;
-      uint32_t ci;
-    };
+    const unsigned int last = (unsigned int)(n > 0 ? n - 1 : 0);   // (the slab holds the float32 rounding of float64 points)
     auto fetch = [&](int i) {
       unsigned int j = (unsigned int)i < last ? (unsigned int)i : last;
-      Rec r;
-      r.qf = qfs[j];
-      r.ci = cis[j];
-      return r;
+      return src[j];
     };
     for (int t0 = blockIdx.x * kTile; t0 < n; t0 += gridDim.x * kTile) {
-    Rec rc = fetch(t0 + threadIdx.x), rc1 = fetch(t0 + kPT + threadIdx.x);
+    float4 pt = fetch(t0 + threadIdx.x), pt1 = fetch(t0 + kPT + threadIdx.x);
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
       int i = t0 + k * kPT + threadIdx.x;
-      Rec rc2 = rc1;
-      if (k + 2 < kPerThread) rc2 = fetch(t0 + (k + 2) * kPT + threadIdx.x);
+      float4 pt2 = pt1;
+      if (k + 2 < kPerThread) pt2 = fetch(t0 + (k + 2) * kPT + threadIdx.x);
       BoxAcc box;
       int row = 0, col = 0;
       bool placed = false;
       if (i < n) {
-        // row guess (about 1e-5 rad off at worst, a few per mille of a bin) and its float32 screen
-        const float qf = __builtin_amdgcn_fmed3f(rc.qf, -1.f, 1.f);
+        // (inserted float64 points, which only exist when a re-based scene is projected by this kernel,
+        // take the queue)
+        // bin guess (about 1e-5 rad off at worst, a few per mille of a bin)
+        float ssf = fmaf(pt.x, pt.x, fmaf(pt.y, pt.y, pt.z * pt.z));
+        float qf = pt.z * __frsqrt_rn(ssf);
+        qf = __builtin_amdgcn_fmed3f(qf, -1.f, 1.f);
         row = (int)floorf((guess_acosf(qf) - elo) * inv_del);
+        col = (int)((guess_atan2f(pt.y, pt.x) + 3.14159274f) * inv_daz);
         row = max(0, min(row, bn.rows - 1));
-        col = (int)(rc.ci & 0x1FFFu);
-        int ok = (int)((rc.ci & (kColOk | kSsNormal)) == (kColOk | kSsNormal)) & (int)(fabsf(qf) < 0.9999f) &
-                 (int)(qf < s_row[row == 0 ? 0 : row + 1].x) & (int)(qf > s_row[row + 2].y);
+        col = max(0, min(col, bn.cols - 1));
+        // float32 screen
+        float2 ea = s_col[col], eb = s_col[col + 1];
+        float mcf = 1e-6f * (fabsf(pt.x) + fabsf(pt.y));
+        int ok = (int)(ssf > 1e-30f) & (int)(ssf < 1e30f) & (int)(fabsf(qf) < 0.9999f) &
+                 (int)(qf < s_row[row == 0 ? 0 : row + 1].x) & (int)(qf > s_row[row + 2].y) &
+                 (int)(fmaf(ea.x, pt.y, -(ea.y * pt.x)) > mcf) & (int)(fmaf(eb.x, pt.y, -(eb.y * pt.x)) < -mcf);
         bool far = false;
         // A point with genuine float64 coordinates (r3d_batch_begin_f64; an inserted point of a re-projected scene):
-        // the float32 slab gave the guesses, the float64 confirmation decides on the exact coordinates from the log
-        // (k_bounds never sets its column flag).
-        if (!ok | (int)((rc.ci & kSsBig) != 0u)) {           // undecided in float32, or r near / above 500
-          const float4 pt = src[i];
+        // the float32 slab gave the guess, the float64 confirmation decides on the exact coordinates from the log
+        // (the float32 screen is a statement about float32-exact inputs).
+        const bool is64 = i >= n_head;
+        if (is64) ok = 0;
+        if (!ok | (ssf > 249000.f)) {                        // undecided in float32, or r near / above 500
           double x = (double)pt.x, y = (double)pt.y, z = (double)pt.z;
-          if (i >= n_head) load_point(b, s, i, n_head, x, y, z);
+          if (is64) load_point(b, s, i, n_head, x, y, z);
           double ss = x * x + y * y + z * z;
           if (!ok) ok = confirm_bin(row_cc, w.col_dir, row, col, x, y, z, ss);
           far = ss > R3D_EMPTY_DEPTH * R3D_EMPTY_DEPTH;      // r > 500 (or rounds to it): far list
@@ -400,8 +374,8 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
           box.add(b.rows - 1, b.cols - 1);                   // the whole image
         }
       }
-      rc = rc1;
-      rc1 = rc2;
+      pt = pt1;
+      pt1 = pt2;
       // the chunk's box.  A scan in ring order gives 64 points of one row whose columns rise with the lane:
       // then the box is lane 0's and lane 63's pixel (checked, not assumed); anything else takes the reduction.
       unsigned long long packed;
@@ -602,8 +576,8 @@ int check_batch(const r3d_batch_t *b) {
     return fail(R3D_E_ARG, "batch: null array");
   if (b->cols % 32 != 0)
     return fail(R3D_E_ARG, "batch: cols must be a multiple of 32 (row-aligned bit images)");
-  if (((size_t)(b->cols + 1) + b->rows + 2) * 2 * sizeof(float) > 64 * 1024 || b->cols >= 8192)
-    return fail(R3D_E_ARG, "batch: range image too large for the projection kernels' LDS edge tables (and 13-bit column records)");
+  if (((size_t)(b->cols + 1) + b->rows + 2) * 2 * sizeof(float) > 64 * 1024)
+    return fail(R3D_E_ARG, "batch: range image too large for the projection kernel's LDS edge tables");
   if ((int64_t)b->rows * b->cols >= (1 << 24))
     return fail(R3D_E_ARG, "batch: range image of 2^24 pixels or more");
   if (b->workspace_bytes < carve_batch(*b, nullptr).total)
@@ -618,15 +592,16 @@ static int project_blocks(const r3d_batch_t &b) {
   return per < 1 ? 1 : per;
 }
 
-static size_t project_lds_bytes(const r3d_batch_t &b) { return ((size_t)b.rows + 2) * 2 * sizeof(float); }   // k_project: row limits
-static size_t bounds_lds_bytes(const r3d_batch_t &b) { return ((size_t)b.cols + 1) * 2 * sizeof(float); }    // k_bounds: column edges
+static size_t project_lds_bytes(const r3d_batch_t &b) {
+  return ((size_t)(b.cols + 1) + b.rows + 2) * 2 * sizeof(float);
+}
 
 // bounds -> tables -> project for the scenes of (list, count); rows = block rows of the launches.
 static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_t *list,
                             const int32_t *count, int rows, hipStream_t st, int slow_blocks = 4) {
   int tiles = tiles_of(b);
   hipLaunchKernelGGL(k_bounds_sample, dim3((tiles + kPT / 64 - 1) / (kPT / 64), rows), dim3(kPT), 0, st, b, list, count, w);
-  hipLaunchKernelGGL(k_bounds, dim3(project_blocks(b), rows), dim3(kPT), bounds_lds_bytes(b), st, b, list, count, w);
+  hipLaunchKernelGGL(k_bounds, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_prepare, dim3(1, rows), dim3(kPT), 0, st, b, list, count, w, tiles);
   hipLaunchKernelGGL(k_project, dim3(project_blocks(b), rows), dim3(kPT), project_lds_bytes(b), st, b, list,
                      count, w, chunks_of(b));
@@ -701,7 +676,7 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream) {
   int tiles = tiles_of(*b);
   switch (which) {
     case R3D_K_BOUNDS:
-      hipLaunchKernelGGL(k_bounds, dim3(project_blocks(*b), b->B), dim3(kPT), bounds_lds_bytes(*b), st, *b, w.all_list, w.all_count, w);
+      hipLaunchKernelGGL(k_bounds, dim3(tiles, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w);
       break;
     case R3D_K_PREPARE:
       hipLaunchKernelGGL(k_prepare, dim3(1, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w, tiles);

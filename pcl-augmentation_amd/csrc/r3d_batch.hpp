@@ -37,8 +37,6 @@ struct BatchWs {
   double *col_dir;              // [(cols+1)*2] unit vector of every column edge
   float *row_qf;                // [B*(rows+2)*2] float32 limits of z/r either side of every row edge (k_project's screen)
   float *col_dirf;              // [(cols+1)*2] col_dir in float32
-  float *qf;                    // [B*cap] z/r of every point in float32 (k_bounds -> k_project)
-  uint16_t *colinfo;            // [B*cap] column guess of every point | screen / range flags (k_bounds -> k_project)
   double *q_ext;                // [B*2] min and max of z/r (the points that hold the elevation bounds)
   int32_t *n_slow;              // [B] points queued for k_project_slow
   int32_t *chain_progress;      // [B] slots of the scene completed by the running k_insert_chain (< 0: see r3d_insert.hip)
@@ -79,8 +77,6 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.col_dir = c.take<double>((size_t)(b.cols + 1) * 2);
   w.row_qf = c.take<float>((size_t)b.B * (b.rows + 2) * 2);
   w.col_dirf = c.take<float>((size_t)(b.cols + 1) * 2);
-  w.qf = c.take<float>((size_t)b.B * b.cap);
-  w.colinfo = c.take<uint16_t>((size_t)b.B * b.cap);
   w.q_ext = c.take<double>((size_t)b.B * 2);
   w.n_slow = c.take<int32_t>((size_t)b.B);
   w.chain_progress = c.take<int32_t>((size_t)b.B);
