@@ -226,6 +226,8 @@ def main():
     ap.add_argument("--e2e", type=int, default=0, metavar="FRAMES",
                     help="also time the file-to-file pipeline (SURVEY.md par.8 f-2) on FRAMES frames: host frames in, "
                          "pinned double-buffered transfers overlapped with the kernels, host files' bytes out")
+    ap.add_argument("--e2e-files", type=int, default=0, metavar="FRAMES",
+                    help="also time the file-to-file pipelines of configs C3 / C4 (files on tmpfs) on FRAMES frames each")
     ap.add_argument("--distinct", type=int, default=0, metavar="N",
                     help="generate only N distinct scenes and cycle them through the batch (the inserts stay per scene); "
                          "default: every scene of the batch is its own")
@@ -581,6 +583,16 @@ def main():
         if (args.e2e > 0 or extra) and world == 1:
             e2e = importlib.import_module("tools.e2e_pipeline")
             out["e2e"] = e2e.measure(pkg, n_frames=args.e2e or 4096)
+        if extra or args.e2e_files:
+            # file to file, the shapes of configs C3 (object detection, label_2) and C4 (SemanticKITTI sweep), files on tmpfs
+            e2e = importlib.import_module("tools.e2e_pipeline")
+            out["e2e_files"] = {}
+            for shape in ("C3", "C4"):
+                try:
+                    out["e2e_files"][shape] = e2e.measure_files(pkg, shape, n_frames=args.e2e_files or 4096,
+                                                                check=0 if args.no_cpu_baseline else 2)
+                except Exception as e:                             # the headline must not depend on this leg
+                    out["e2e_files"][shape] = {"error": repr(e)[:300]}
         if extra:
             # BASELINE.json's stress configuration in the same line: a child process (its own batches, freed when it ends)
             cmd = [sys.executable, os.path.abspath(__file__), "--config", "C5", "--scenes", "256", "--distinct", "8", "--steps", "4",

@@ -424,6 +424,31 @@ k_project_slow(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs
   }
 }
 
+// ... and the boxes of their chunks.  k_project gave a chunk with an unconfirmed point the whole image as box (the point's
+// pixel was not known yet); on a grid several times finer than the reference's a per cent or two of the points go that
+// way, i.e. a few per cent of the CHUNKS -- some 600 of a 1M-point scan on 448 x 2880, every one of them in every
+// insert's chunk list.  One wave per queued point (duplicates of a chunk write the same box): the chunk's 64 final
+// pixels, their box with the columns as the shorter arc.
+__global__ void __launch_bounds__(kPT)
+k_fix_boxes(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int chunks) {
+  int cnt = *count;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    int s = list[li];
+    const int n_slow = w.n_slow[s], n = b.n_total[s];
+    if (b.status[s] & (R3D_S_ROW_RANGE | R3D_S_COL_RANGE | R3D_S_NONFINITE)) continue;   // (a point without a pixel: the boxes stay whole)
+    const uint32_t *queue = w.cand + (int64_t)s * w.cand_stride;
+    for (int e = blockIdx.x * (kPT / 64) + wave; e < n_slow; e += gridDim.x * (kPT / 64)) {
+      const int c = (int)(queue[e] >> 6), i = (c << 6) + lane;
+      BoxAcc box;
+      const uint32_t p = i < n ? (uint32_t)b.pix[(int64_t)s * b.cap + i] : 0u;
+      if (i < n) box.add(pix_row(p), pix_col(p));
+      const unsigned long long packed = box.wave_pack_arc(i < n ? pix_col(p) : -1, b.cols);
+      if (lane == 0) w.chunk_box[(int64_t)s * chunks + c] = packed;
+    }
+  }
+}
+
 // Survivors in original order (insertion.py:472-473 applied once for all steps), float4 + label
 // straight into the output arrays.  A wave owns 8 consecutive chunks (512 points) of its block's tile and
 // needs nobody else: its output offset is the sum of the living counts of the scene's preceding tiles
@@ -606,6 +631,7 @@ static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_
   hipLaunchKernelGGL(k_project, dim3(project_blocks(b), rows), dim3(kPT), project_lds_bytes(b), st, b, list,
                      count, w, chunks_of(b));
   hipLaunchKernelGGL(k_project_slow, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w);
+  hipLaunchKernelGGL(k_fix_boxes, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w, chunks_of(b));
   R3D_LAUNCHED("reproject kernels");
   return R3D_OK;
 }

@@ -283,11 +283,15 @@ class AugmentPipeline:
                 caps = (max(K, caps[0]), max(int(n_max * 1.25) + 64, caps[1]), max(int(grow * 1.25) + 64, caps[2]),
                         max(int(srows * 1.25) + 64, caps[3]))
                 aug = aug_box[0] = None                            # free the old lanes first
+                t_setup = time.perf_counter()
                 aug = aug_box[0] = StreamedAugmenter(B, caps[1], caps[2], caps[0], caps[3], lanes=lanes, device=self.device,
                                                      check_cols=self.check_cols,
                                                      collapse_keep=-1 if self.road_label is None else self.road_label,
                                                      pack_threads=pack_threads, delta=delta)
+                stats["t_setup"] = stats.get("t_setup", 0.0) + time.perf_counter() - t_setup   # lanes: device + pinned memory
                 aug.run(segment(), consume)
+                for k, v in aug.times.items():
+                    stats["t_" + k] = stats.get("t_" + k, 0.0) + v
         finally:
             stop.set()
             rt.join(timeout=30)

@@ -89,6 +89,9 @@ class StreamedAugmenter:
                             self.delta) for _ in range(lanes)]
         self.device = device
         self.bytes_h2d = self.bytes_d2h = 0
+        # seconds spent per stage, summed over the batches (submitting thread: read / pack, enqueue; drain thread: wait for
+        # the device, host merge, the caller's consume)
+        self.times = {"read_or_pack": 0.0, "enqueue": 0.0, "wait_device": 0.0, "merge": 0.0, "consume": 0.0, "wait_free_lane": 0.0}
 
     def free_lane(self):
         for i, ln in enumerate(self.lanes):
@@ -109,9 +112,12 @@ class StreamedAugmenter:
         n = np.array([len(x) for x in xs], dtype=np.int32)
         px = (C.c_void_p * B)(*[x.ctypes.data for x in xs])
         pl = (C.c_void_p * B)(*[l.ctypes.data for l in ls])
+        import time
+        t0 = time.perf_counter()
         _lib.check(self.lib.r3d_host_pack_frames(px, pl, n.ctypes.data, B, bt.cap, ln.in_xyzi.data_ptr(), ln.in_label.data_ptr(),
                                                  self.collapse_keep, self.pack_threads), "r3d_host_pack_frames")
         ln.in_n.numpy()[:] = n
+        self.times["read_or_pack"] += time.perf_counter() - t0
         return self._enqueue(lane_no, inserts, min_points, tag)
 
     def submit_files(self, lane_no, velodyne_files, label_files, inserts, min_points, tag=None):
@@ -123,8 +129,11 @@ class StreamedAugmenter:
         enc = lambda paths: (C.c_char_p * B)(*[None if p is None else str(p).encode() for p in paths])
         pv = enc(velodyne_files)
         pl = enc(label_files) if label_files is not None else None
+        import time
+        t0 = time.perf_counter()
         _lib.check(self.lib.r3d_host_read_frames(pv, pl, B, ln.bt.cap, ln.in_xyzi.data_ptr(), ln.in_label.data_ptr(),
                                                  ln.in_n.data_ptr(), self.collapse_keep, self.pack_threads), "r3d_host_read_frames")
+        self.times["read_or_pack"] += time.perf_counter() - t0
         return self._enqueue(lane_no, inserts, min_points, tag)
 
     def write_files(self, lane_no, velodyne_files, label_files, check_files):
@@ -141,6 +150,8 @@ class StreamedAugmenter:
             ln.h_n_log.data_ptr(), self.pack_threads), "r3d_host_write_frames")
 
     def _enqueue(self, lane_no, inserts, min_points, tag):
+        import time
+        t_enq = time.perf_counter()
         ln = self.lanes[lane_no]
         torch, bt, B, K = ln.torch, ln.bt, self.B, self.K
         off = ln.in_off.numpy()
@@ -219,15 +230,20 @@ class StreamedAugmenter:
             ln.out_counts[3].copy_(bt.rebase, non_blocking=True)
             ln.done.record(ln.stream)
         ln.busy, ln.tag = True, tag
+        self.times["enqueue"] += time.perf_counter() - t_enq
         return lane_no
 
     def collect(self, lane_no):
         """Wait for the lane; (tag, results, accepted): results[s] = (xyzi [n,4] float32, label [n] uint32,
         check [m,cols] float32) as VIEWS of the lane's buffers (valid until the lane's next submit),
         accepted[s][k] = 0 (accepted) or -1."""
+        import time
         ln = self.lanes[lane_no]
         assert ln.busy
+        t0 = time.perf_counter()
         ln.done.synchronize()
+        t1 = time.perf_counter()
+        self.times["wait_device"] += t1 - t0
         counts = ln.out_counts.numpy()
         n_log = ln.h_n_log.numpy()
         n_log[:] = counts[1]
@@ -246,6 +262,7 @@ class StreamedAugmenter:
                 ln.out_label.data_ptr(), bt.cap, ln.h_n_out.data_ptr(), ln.out_check.data_ptr() if ln.check_cols else None,
                 bt.log_cap, cc, self.pack_threads), "r3d_host_merge_frames")
             n_out = ln.h_n_out.numpy()
+            self.times["merge"] += time.perf_counter() - t1
         else:
             n_out = counts[0]
         if redo:
@@ -291,6 +308,7 @@ class StreamedAugmenter:
         batch i+1 and its merging / consuming of batch i-1 overlap as well."""
         import queue
         import threading
+        import time
         submitted, free, errors = queue.Queue(), queue.Queue(), []
         # a lane goes back to the submitting thread only when `consume` has returned: its buffers (results, counters,
         # the pinned input the host merge reads) belong to the drain thread until then.  `collect` clears `busy`
@@ -307,7 +325,9 @@ class StreamedAugmenter:
                     if not errors:
                         got = self.collect(lane)
                         self.current_lane = lane                   # (consume may hand the lane's buffers to write_files)
+                        t0 = time.perf_counter()
                         consume(*got)
+                        self.times["consume"] += time.perf_counter() - t0
                 except Exception as e:                             # surfaces in the submitting thread
                     errors.append(e)
                     self.lanes[lane].busy = False
@@ -319,7 +339,9 @@ class StreamedAugmenter:
             for scenes, inserts, min_points, tag in batches:
                 if errors:
                     break
+                t0 = time.perf_counter()
                 lane = free.get()
+                self.times["wait_free_lane"] += time.perf_counter() - t0
                 if errors:
                     break
                 if isinstance(scenes, tuple) and len(scenes) == 3 and scenes[0] == "files":

@@ -18,6 +18,8 @@ def _stub_augmenter(n_lanes):
     aug = object.__new__(streaming.StreamedAugmenter)
     aug.lanes = [_StubLane() for _ in range(n_lanes)]
     aug.consuming = set()
+    import collections
+    aug.times = collections.defaultdict(float)
     aug.lock = threading.Lock()
     aug.violations = []
     aug.order = []

@@ -113,6 +113,91 @@ def measure_run(pkg, n_frames=512, B=64, where=None):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def measure_files(pkg, shape="C3", n_frames=4096, B=256, where=None, check=2, io_threads=16):
+    """File to file, the shapes of BASELINE.json's configs C3 and C4, with the files on tmpfs (what the software does when
+    the file system is memory; the box's disk is measure_disk's business):
+
+    C3: the object-detection flavour -- velodyne/*.bin + pseudo-label files in, labels collapsed to {Road, 1} (OD
+        insertion.py:353-355), 10 mixed inserts per frame, velodyne/ + check/ (4 columns) + label_2/{f}.txt with the lines of
+        the inserted objects out (OD tools/datasets.py:76-95) -- through AugmentPipeline.run_streamed(label_2_for=...);
+    C4: SemanticKITTI, 8 inserts per frame, velodyne/ + labels/ + check/ out, through run_sharded_files (this rank's
+        share of the sweep; one rank here).
+
+    64 distinct frames, hard-linked to n_frames names (the generator and 2.4 MB of tmpfs per frame are not what is
+    measured).  `check` frames of the timed run are compared byte for byte with the oracle."""
+    synth = pkg.synth
+    kinds = synth.CONFIG_INSERTS[shape]
+    od = shape == "C3"
+    where = where or ("/dev/shm" if os.path.isdir("/dev/shm") else None)
+    root = tempfile.mkdtemp(prefix="r3d_files_", dir=where)
+    n_distinct = 64
+    try:
+        os.makedirs(f"{root}/src"), os.makedirs(f"{root}/in/velodyne"), os.makedirs(f"{root}/in/labels"), os.makedirs(f"{root}/in/label_2")
+        for d in range(n_distinct):
+            xyzi, label = synth.make_scene(d)
+            xyzi.tofile(f"{root}/src/{d}.bin")
+            label.tofile(f"{root}/src/{d}.label")
+        with open(f"{root}/src/label_2.txt", "w") as fh:
+            fh.write("Car 0.00 0 -1.57 599.41 156.40 629.75 189.25 2.85 2.63 12.34 0.47 1.49 69.44 -1.56\n")
+        frames = []
+        for i in range(n_frames):
+            os.link(f"{root}/src/{i % n_distinct}.bin", f"{root}/in/velodyne/{i:06d}.bin")
+            os.link(f"{root}/src/{i % n_distinct}.label", f"{root}/in/labels/{i:06d}.label")
+            os.link(f"{root}/src/label_2.txt", f"{root}/in/label_2/{i:06d}.txt")
+            frames.append(pkg.Frame(f"{root}/in/velodyne/{i:06d}.bin", f"{root}/in/labels/{i:06d}.label"))
+        ins = [(synth.make_inserts(d, kinds), [20] * len(kinds)) for d in range(n_distinct)]
+        # the annotation lines of a frame's inserted objects (OD insertion.py:227-265), made once per distinct frame: the
+        # caller's business, like the placement itself
+        from importlib import import_module
+        mirror = import_module("pcl-augmentation_amd.Real3DAug.insertion")
+        names = {"car": "Car", "pedestrian": "Pedestrian", "cyclist": "Cyclist"}
+        lines = [[mirror.create_annotation_line("Car 0.00 0 -1.57 599.41 156.40 629.75 189.25 1.50 1.80 4.20 0.47 1.49 69.44 -1.56",
+                                                {"class": names[k], "center": {"x": float(x[:, 0].mean()), "y": float(x[:, 1].mean()),
+                                                                               "z": float(x[:, 2].mean())}}, 17 * j)
+                  for j, (k, x) in enumerate(zip(kinds, ins[d][0]))] for d in range(n_distinct)]
+
+        def label_2_for(i, acc):
+            return f"{root}/in/label_2/{i:06d}.txt", [ln for ln, a in zip(lines[i % n_distinct], acc) if a >= 0]
+
+        def run(fr, out):
+            if od:
+                pipe = pkg.AugmentPipeline(out, "run", dataset="kitti", batch_size=B)
+                return pipe.run_streamed(fr, lambda i: ins[i % n_distinct], label_2_for=label_2_for, io_threads=io_threads,
+                                         pack_threads=io_threads)
+            return pkg.run_sharded_files(fr, lambda i: ins[i % n_distinct], out, "run", rank=0, world_size=1, device="cuda:0",
+                                         dataset="semantic", batch_size=B)
+
+        run(frames[:B], f"{root}/warm")                                                                   # warm-up
+        shutil.rmtree(f"{root}/warm")
+        st = run(frames, f"{root}/out")
+        # a sample of the written files against the oracle (labels collapsed for the object-detection flavour)
+        from oracle import real3d_oracle as O
+        same = 0
+        for i in range(min(check, n_frames)):
+            xyzi, label = synth.make_scene(i % n_distinct)
+            if od:
+                label = np.where(label == 40, 40, 1).astype(np.uint32)
+            merged, allvis, _ = O.augment_scene(synth.scene5_from_packed(xyzi, label), [[x] for x in ins[i % n_distinct][0]], ins[i % n_distinct][1])
+            got_v = open(f"{root}/out/run/velodyne/{i:06d}.bin", "rb").read()
+            got_c = open(f"{root}/out/run/check/{i:06d}.bin", "rb").read()
+            if od:
+                vb, cb = O.save_bytes_kitti(merged, allvis)
+                ok = got_v == vb and got_c == cb and open(f"{root}/out/run/label_2/{i:06d}.txt").read().count("\n") == 1 + len(kinds)
+            else:
+                vb, lb, cb = O.save_bytes_semantic(merged, allvis)
+                ok = got_v == vb and got_c == cb and open(f"{root}/out/run/labels/{i:06d}.label", "rb").read() == lb
+            same += 1 if ok else 0
+        steady = st["t_total"] - st.get("t_setup", 0.0)
+        return {"frames_per_s": round(st["frames_per_s"], 1), "frames": st["written"], "batch": B, "inserts_per_frame": len(kinds),
+                "frames_per_s_without_lane_setup": round(st["written"] / steady, 1) if steady > 0 else None,
+                "flavour": "object detection: velodyne + check (4 columns) + label_2" if od else "SemanticKITTI: velodyne + labels + check",
+                "through": "AugmentPipeline.run_streamed(label_2_for=...)" if od else "run_sharded_files (rank 0 of 1)",
+                "directory": where or tempfile.gettempdir(), "files_equal_to_oracle": f"{same} of {min(check, n_frames)} checked",
+                "seconds": {k[2:]: round(v, 3) for k, v in st.items() if k.startswith("t_")}}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 if __name__ == "__main__":
     pkg = importlib.import_module("pcl-augmentation_amd")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
@@ -125,3 +210,5 @@ if __name__ == "__main__":
     print("run, disk:", measure_run(pkg, min(n, 512), min(bs, 64)))
     if os.path.isdir("/dev/shm"):
         print("run, tmpfs:", measure_run(pkg, min(n, 512), min(bs, 64), where="/dev/shm"))
+    print("files C3:", measure_files(pkg, "C3", n, bs))
+    print("files C4:", measure_files(pkg, "C4", n, bs))
