@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define R3D_VERSION 0x00020001
+#define R3D_VERSION 0x00020002   /* 2.2: r3d_batch_t.pix / far_pix hold (row << 16) | column; r3d_batch_debug_trace is gone; r3d_build_info */
 
 #define R3D_NUMROW 112        /* insertion.py:22 */
 #define R3D_NUMCOLUMN 1440    /* insertion.py:23; the pixel id always multiplies by THIS (:116,:127) */
@@ -65,6 +65,8 @@ extern "C" {
 
 int r3d_version(void);
 const char *r3d_last_error(void);   /* host string, thread-local, valid until the next failing call */
+/* "sources <sha256 of the library's sources as csrc/Makefile hashed them>": which sources this binary was built from */
+const char *r3d_build_info(void);
 
 /* ============================================================================================
  * Level 1 -- one cloud at a time, the reference's functions one for one (float64 N x 9 layout).

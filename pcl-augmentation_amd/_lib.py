@@ -77,6 +77,7 @@ _P = C.c_void_p
 _SIGNATURES = {
     "r3d_version": (C.c_int, []),
     "r3d_last_error": (C.c_char_p, []),
+    "r3d_build_info": (C.c_char_p, []),
     "r3d_add_space_for_spherical": (C.c_int, [_P, C.c_int64, _P, _P]),
     "r3d_fill_spherical": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "r3d_front_view_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),

@@ -400,6 +400,11 @@ using namespace r3d;
 extern "C" {
 
 int r3d_version(void) { return R3D_VERSION; }
+
+#ifndef R3D_SRC_HASH
+#define R3D_SRC_HASH "unknown"
+#endif
+const char *r3d_build_info(void) { return "sources " R3D_SRC_HASH; }
 const char *r3d_last_error(void) { return last_error_ref().c_str(); }
 
 int r3d_add_space_for_spherical(const double *pcl5, int64_t n, double *pcl9, void *stream) {

@@ -64,6 +64,13 @@ def main():
             bad += 1
             print("iteration", it, "differs in frames", [[s for s in range(B) if f[0][s] != ref[0][s] or f[1][s] != ref[1][s]] for f in (fa, fb)])
     print(f"{n_iter} iterations x 2 lanes x {B} frames x {len(kinds)} slots: {bad} iterations with a mismatch; status {ref[-1]}")
+    # R3D_DEBUG_BITS=64: every speculative evaluation that was about to be committed was done again after its
+    # predecessors and compared (csrc/r3d_insert.hip, kDbgVerify)
+    for lane, (bt, _, _, _) in enumerate(lanes):
+        cnt = bt.debug_counters()
+        print(f"lane {lane}: {cnt}")
+        if cnt["verify_mismatch"]:
+            bad += 1
     sys.exit(1 if bad else 0)
 
 
