@@ -327,7 +327,10 @@ class SceneBatch:
                    "r3d_batch_debug_counters")
         names = ["pool_exhausted", "tiles_pooled", "evaluated_twice", "verify_runs", "verify_mismatch", "unused5", "deferred_scenes",
                  "rebases_in_chain"]
-        return dict(zip(names, list(out)))
+        d = dict(zip(names, list(out)))
+        if any(out[8:]):                 # a diagnostic build (-DR3D_CHECK) counted index checks that failed: [8 + code]
+            d["check_failures"] = list(out[8:])
+        return d
 
     def pixel_ids(self):
         """The pixel id of every point as the reference numbers it (row * cols + col, insertion.py:116): the batch keeps

@@ -507,6 +507,11 @@ k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
       }
     } else {
       // (named scalars, not arrays: the compiler keeps arrays of float4 filled under a branch in scratch)
+#ifdef R3D_CHECK
+#define R3D_CHECK_O(o) if (o >= (unsigned int)b.cap) { atomicAdd(&w.dbg[15], 1); o = 0u; }
+#else
+#define R3D_CHECK_O(o)
+#endif
 #define R3D_LOAD(K)                                                                                     \
   unsigned int i##K = ibase + K * 64;                                                                      \
   i##K = i##K < (unsigned int)n ? i##K : (unsigned int)n - 1u; /* dead points are few: every lane loads */ \
@@ -524,6 +529,7 @@ k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
 #define R3D_STORE(K)                                                                                    \
   if ((((unsigned long long)mhi[K] << 32 | mlo[K]) >> lane) & 1ull) {                                   \
     unsigned int o = (unsigned int)run + __builtin_amdgcn_mbcnt_hi(mhi[K], __builtin_amdgcn_mbcnt_lo(mlo[K], 0u)); \
+    R3D_CHECK_O(o)                                                                                        \
     if (NONTEMP) {                                                                                      \
       float *f = reinterpret_cast<float *>(dst + o);                                                    \
       __builtin_nontemporal_store(p##K.x, f);                                                           \

@@ -224,6 +224,14 @@ enum { kOk = 0, kNoFit = 1, kNeedSerial = 2, kStale = 3 };
 // diagnostic counters (BatchWs::dbg; r3d_batch_debug_counters)
 enum { D_POOL_FULL = 0, D_TILE_POOLED, D_EVAL_TWICE, D_VERIFY_RUNS, D_VERIFY_MISMATCH, D_HITS_OVERFLOW, D_DEFERRED, D_REBASE };
 
+// Diagnostic builds (-DR3D_CHECK): the index of every access the gather / kill / commit code derives from data is
+// checked against its array; a violation is counted in BatchWs::dbg[8 + code] and the access skipped.
+#ifdef R3D_CHECK
+#define CHK(cond, code) ((cond) ? true : (atomicAdd(&w.dbg[8 + (code)], 1), false))
+#else
+#define CHK(cond, code) true
+#endif
+
 // A value every lane holds (read from LDS or global memory): into a scalar register.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -828,7 +836,7 @@ struct Ins {
         if (e < nitems && ((l_alive(e >> 6) >> (e & 63)) & 1ull)) idx[u] = (int)(l_chunk(e >> 6) << 6) + (e & 63);
       }
 #pragma unroll
-      for (int u = 0; u < kU; ++u) p[u] = idx[u] >= 0 ? pixs[idx[u]] : 0u;
+      for (int u = 0; u < kU; ++u) p[u] = idx[u] >= 0 && CHK(idx[u] < n_base && idx[u] < b.cap, 0) ? pixs[idx[u]] : 0u;
       GSTAMP(1);
       int cnt = 0;
 #pragma unroll
@@ -836,6 +844,7 @@ struct Ins {
         int dl = -1, lp = -1;
         if (idx[u] >= 0) place(p[u], dl, lp);
         if (all_rows_bits && dl >= 0) D.set_local(lp);
+        if (dl >= 0 && !CHK(dl < dt.npx && lp >= 0 && lp < (ww << 5), 1)) dl = -1;
         code[u] = dl >= 0 ? ((uint32_t)dl << 16) | (uint32_t)lp : 0xFFFFFFFFu;
         msk[u] = __ballot(dl >= 0);
         cnt += __popcll(msk[u]);
@@ -861,9 +870,10 @@ struct Ins {
             set_hbase(e >> 6, base);
           }
           if (base >= 0) {
-            if (code[u] != 0xFFFFFFFFu)
-              s_hit[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(msk[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)msk[u], 0u))] =
-                  make_uint2((uint32_t)idx[u], code[u]);
+            if (code[u] != 0xFFFFFFFFu) {
+              const int at = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(msk[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)msk[u], 0u));
+              if (CHK(at >= 0 && at < hit_cap, 2)) s_hit[at] = make_uint2((uint32_t)idx[u], code[u]);
+            }
             base += __popcll(msk[u]);
           }
         }
@@ -895,6 +905,7 @@ struct Ins {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         f[u] = make_float4(1.f, 0.f, 0.f, 0.f);
+        if (hv[u].x != 0xFFFFFFFFu && !CHK((int)hv[u].x < n_base && (int)(hv[u].y >> 16) < dt.npx, 3)) hv[u].x = 0xFFFFFFFFu;
         if (hv[u].x != 0xFFFFFFFFu && (int)hv[u].x < n_head) f[u] = xyzi[hv[u].x];
       }
 #pragma unroll
@@ -1309,8 +1320,11 @@ struct Ins {
             lpv[u] = -1;
             pg[u] = 0u;
             if (on[u]) {
-              if (from_hits[u]) lpv[u] = (int)(s_hit[hb + __popcll(msk & ((1ull << (e & 63)) - 1ull))].y & 0xFFFFu);
-              else pg[u] = pixs[(int)(l_chunk(ent[u]) << 6) + (e & 63)];
+              if (from_hits[u]) {
+                const int at = hb + __popcll(msk & ((1ull << (e & 63)) - 1ull));
+                lpv[u] = CHK(at < hit_cap, 4) ? (int)(s_hit[at].y & 0xFFFFu) : -1;
+              } else if (CHK((int)l_chunk(ent[u]) < chunks, 5))
+                pg[u] = pixs[(int)(l_chunk(ent[u]) << 6) + (e & 63)];
             }
           }
 #pragma unroll
@@ -1424,7 +1438,15 @@ struct Ins {
       unsigned long long mask = l_kill(i);
       if (!mask) continue;
       int c = (int)l_chunk(i);
+      if (!CHK(c < chunks, 5)) continue;
+#ifdef R3D_CHECK
+      {
+        const unsigned long long was = atomicAnd(&alive[c], ~mask);
+        CHK((was & mask) == mask, 6);                        // every culled point was alive
+      }
+#else
       atomicAnd(&alive[c], ~mask);
+#endif
       atomicSub(&tile_alive[(c << 6) / kTile], __popcll(mask));
     }
     STAMP(24);
