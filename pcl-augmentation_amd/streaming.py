@@ -252,7 +252,7 @@ class StreamedAugmenter:
             if int(s) in redo:
                 continue
             ln.busy = False
-            _lib.raise_status(int(counts[2][s]), f"scene {s}")
+            _lib.raise_status(int(counts[2][s]), f"scene {s} of the batch (status {int(counts[2][s])}, {int(counts[3][s])} rebases, {int(counts[1][s])} inserted points)")
         cc = max(ln.check_cols, 4)
         if self.delta:
             bt = ln.bt
