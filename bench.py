@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MIN_POINTS = 20
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 CONFIGS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on

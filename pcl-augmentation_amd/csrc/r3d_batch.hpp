@@ -179,10 +179,11 @@ struct BoxAcc {
   // none; the row part comes from the accumulator.
   __device__ __forceinline__ unsigned long long wave_pack_arc(int col, int cols) {
     const int half = cols >> 1;
-    int t = col < 0 ? -1 : (col + half >= cols ? col + half - cols : col + half);
-    int tlo = wave_min_i32(t < 0 ? 0x7FFFFFFF : t), thi = wave_max_i32(t);
     const unsigned long long plain = wave_pack();
     const int clo_ = (int)((plain >> 32) & 0xFFFF), chi_ = (int)((plain >> 48) & 0xFFFF);
+    if (chi_ - clo_ < half) return plain;                    // (an arc across the seam can only be shorter than half the circle)
+    int t = col < 0 ? -1 : (col + half >= cols ? col + half - cols : col + half);
+    int tlo = wave_min_i32(t < 0 ? 0x7FFFFFFF : t), thi = wave_max_i32(t);
     if (thi < 0 || thi - tlo >= chi_ - clo_) return plain;
     int a = tlo - half, z = thi - half;
     a = a < 0 ? a + cols : a;

@@ -60,6 +60,9 @@
 #ifndef R3D_GATHER_PER
 #define R3D_GATHER_PER 4
 #endif
+#ifndef R3D_GATHER_PER_BIG
+#define R3D_GATHER_PER_BIG 8
+#endif
 
 namespace r3d {
 
@@ -728,7 +731,7 @@ struct Ins {
   // the points inside the band.  all_rows_bits: also set the scene occupancy bit of every point of the window (banded
   // and pooled tiles: the occupancy of the whole window is needed up front).
   __device__ __forceinline__ void gather(bool all_rows_bits, const uint16_t *sub, int nsub) {
-    constexpr int kPer = NT == 1024 ? 8 : R3D_GATHER_PER;    // (one workgroup per CU: nothing else hides the loads)
+    constexpr int kPer = NT == 1024 ? R3D_GATHER_PER_BIG : R3D_GATHER_PER;    // (one workgroup per CU: nothing else hides the loads)
     const int n_head = uni(b.n_head[s]);
     const uint32_t *pixs = reinterpret_cast<const uint32_t *>(b.pix) + (int64_t)s * b.cap;
     const float4 *xyzi = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;

@@ -1,22 +1,19 @@
-# One profiling session on the GPU box (round 3): kernel trace + the two PMC passes for config C2 (one step at a time and
-# three in flight), for config C5 (128 scans) and for the three-kernel insert launch; summaries under gpurun_out/prof/.
+# One profiling session on the GPU box (round 4): kernel trace + the two PMC passes for config C2 (one step at a time and
+# three in flight) and for config C5 (256 scans); summaries under gpurun_out/prof/ and profiles/.
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-A="--no-cpu-baseline --no-extra-legs"
+A="--no-cpu-baseline --no-extra-legs --repeats 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python3 $R/bench.py --overlap 1 --steps 5 --warmup 2 $A > /tmp/p1.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -- python3 $R/bench.py --overlap 1 --steps 2 --warmup 1 $A > /tmp/p2.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -- python3 $R/bench.py --overlap 1 --steps 2 --warmup 1 $A > /tmp/p3.log 2>&1
-cd $R && python3 tools/make_profiles.py /tmp/p_stats /tmp/p_fetch /tmp/p_write r03 && mkdir -p gpurun_out/prof && cp profiles/r03_* gpurun_out/prof/
+cd $R && python3 tools/make_profiles.py /tmp/p_stats /tmp/p_fetch /tmp/p_write r04 && mkdir -p gpurun_out/prof && cp profiles/r04_* gpurun_out/prof/
 cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats3 -- python3 $R/bench.py --steps 6 --warmup 3 $A > /tmp/p4.log 2>&1
-f=$(find /tmp/p_stats3 -name "*kernel_stats.csv" | head -1); (head -1 $f; grep "r3d::" $f) > $R/gpurun_out/prof/r03_kernel_stats_three_in_flight.csv
-# the three-kernel insert launch (R3D_INSERT_THREE=1), one step at a time
-cd /tmp && R3D_INSERT_THREE=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_three -- python3 $R/bench.py --overlap 1 --steps 5 --warmup 2 $A > /tmp/p5.log 2>&1
-f=$(find /tmp/p_three -name "*kernel_stats.csv" | head -1); (head -1 $f; grep "r3d::" $f) > $R/gpurun_out/prof/r03_kernel_stats_three_kernel_insert.csv
+f=$(find /tmp/p_stats3 -name "*kernel_stats.csv" | head -1); (head -1 $f; grep "r3d::" $f) > $R/gpurun_out/prof/r04_kernel_stats_three_in_flight.csv
 # config C5, 256 scans per batch (what the c5 leg of the default bench line runs)
 C="--config C5 --scenes 256 --distinct 8"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c_stats -- python3 $R/bench.py $C --overlap 1 --steps 2 --warmup 1 $A > /tmp/c1.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/c_fetch -- python3 $R/bench.py $C --overlap 1 --steps 1 --warmup 1 $A > /tmp/c2.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/c_write -- python3 $R/bench.py $C --overlap 1 --steps 1 --warmup 1 $A > /tmp/c3.log 2>&1
-cd $R && python3 tools/make_profiles.py /tmp/c_stats /tmp/c_fetch /tmp/c_write r03_c5 && cp profiles/r03_c5_* gpurun_out/prof/
+cd $R && python3 tools/make_profiles.py /tmp/c_stats /tmp/c_fetch /tmp/c_write r04_c5 && cp profiles/r04_c5_* gpurun_out/prof/
 ls -la gpurun_out/prof
