@@ -226,6 +226,8 @@ def main():
     ap.add_argument("--e2e", type=int, default=0, metavar="FRAMES",
                     help="also time the file-to-file pipeline (SURVEY.md par.8 f-2) on FRAMES frames: host frames in, "
                          "pinned double-buffered transfers overlapped with the kernels, host files' bytes out")
+    ap.add_argument("--placed", type=int, default=0, metavar="FRAMES",
+                    help="also time placement search + merge per insert slot (PlacedInserter) on a batch of FRAMES frames")
     ap.add_argument("--e2e-files", type=int, default=0, metavar="FRAMES",
                     help="also time the file-to-file pipelines of configs C3 / C4 (files on tmpfs) on FRAMES frames each")
     ap.add_argument("--distinct", type=int, default=0, metavar="N",
@@ -583,6 +585,13 @@ def main():
         if (args.e2e > 0 or extra) and world == 1:
             e2e = importlib.import_module("tools.e2e_pipeline")
             out["e2e"] = e2e.measure(pkg, n_frames=args.e2e or 4096)
+        if extra or args.placed:
+            # the placement search in the loop (SURVEY.md par.8 f-1 + the hot path): search -> candidates -> merge per insert slot
+            try:
+                out["placed"] = importlib.import_module("tools.bench_placed").measure(pkg, B=args.placed or 256, K=len(CONFIGS["C2"]["kinds"]),
+                                                                                   reps=4, lanes=3)
+            except Exception as e:
+                out["placed"] = {"error": repr(e)[:300]}
         if extra or args.e2e_files:
             # file to file, the shapes of configs C3 (object detection, label_2) and C4 (SemanticKITTI sweep), files on tmpfs
             e2e = importlib.import_module("tools.e2e_pipeline")

@@ -134,6 +134,7 @@ class SceneBatch:
         self.xyzi.copy_(pin["xyzi"], non_blocking=True)
         self.label.copy_(pin["label"], non_blocking=True)
         self.n_points.copy_(pin["n"], non_blocking=True)
+        self._loaded_from_staging = True
 
     def staging_views(self):
         """NumPy views of the pinned input slabs: xyzi [B,cap,4] float32, label [B,cap] uint32,
@@ -170,6 +171,7 @@ class SceneBatch:
         self.xyzi.copy_(xyzi)
         self.label.copy_(label)
         self.n_points.copy_(n_points)
+        self._loaded_from_staging = False
 
     # -- the three phases -----------------------------------------------------------------------
     @_lib.on_own_device

@@ -62,12 +62,20 @@ class AugmentPipeline:
         self.waymo = dataset == "waymo"
         self.process = process or (self._process_waymo if self.waymo else self._process_hip)
         self._batches = {}
+        self._lane_batches = threading.local()       # run(lanes > 1): every worker thread keeps its own device batches
 
     # -- the GPU leg ------------------------------------------------------------------------------
+    def _cache(self):
+        """The device batches this thread re-uses (one set per worker thread of ``run``)."""
+        c = getattr(self._lane_batches, "cache", None)
+        if c is None:
+            c = self._lane_batches.cache = {} if threading.current_thread() is not threading.main_thread() else self._batches
+        return c
+
     def _process_hip(self, scenes, candidates, min_points):
         from .batch import augment_batch
         return augment_batch(scenes, candidates, min_points, device=self.device, check_cols=self.check_cols,
-                             reuse=self._batches)
+                             reuse=self._cache())
 
     def _process_waymo(self, scenes5, candidates, min_points):
         """Float64 frames (N x 5 rows) through ``SceneBatch.begin_f64``; results = (merged N' x 5, added M x 5, None)."""
@@ -75,10 +83,11 @@ class AugmentPipeline:
         B = len(scenes5)
         grow = max(sum(max((len(x) for x in slot), default=0) for slot in c) for c in candidates)
         n_max = max(len(x) for x in scenes5)
-        batch = self._batches.get(("waymo", B))
+        cache = self._cache()
+        batch = cache.get(("waymo", B))
         if batch is None or batch.cap < n_max + grow or batch.log_cap < n_max + grow:
             batch = SceneBatch(B, int((n_max + grow) * 1.05) + 64, int((n_max + grow) * 1.05) + 64, device=self.device)
-            self._batches[("waymo", B)] = batch
+            cache[("waymo", B)] = batch
         batch.begin_f64(scenes5)
         accepted = batch.run_inserts(candidates, min_points)
         batch.raise_on_status()
@@ -121,10 +130,11 @@ class AugmentPipeline:
         k_max = max(len(sl) for sl in slots)
         grow = sum(max((len(sl[k]["sample"]) if k < len(sl) else 0) for sl in slots) for k in range(k_max))
         cap = max(len(x) for x, _ in scenes) + grow
-        batch = self._batches.get(("placed", B))
+        cache = self._cache()
+        batch = cache.get(("placed", B))
         if batch is None or batch.cap < cap or batch.log_cap < max(grow, 1):
             batch = SceneBatch(B, int(cap * 1.05) + 64, max(grow, 1) * 2, device=self.device)
-            self._batches[("placed", B)] = batch
+            cache[("placed", B)] = batch
         batch.load(scenes)
         batch.begin()
         ins = PlacedInserter(batch, [i[0] for i in infos], [i[1] for i in infos], [i[2] for i in infos], [i[3] for i in infos])
@@ -140,21 +150,18 @@ class AugmentPipeline:
         batch.finish(self.check_cols)
         return batch.results(), chosen
 
-    def run_placed(self, frames, scene_info_for, slots_for):
+    def run_placed(self, frames, scene_info_for, slots_for, lanes=1):
         """Frames with the placement search in the loop: scene_info_for(i) -> (rich_map, map_move,
         pose, boxes) of frame i, slots_for(i) -> the samples to insert (see _process_placed).  Writes
         what ``run`` writes plus ``added_objects/{f}.txt`` with one line per inserted object,
         '<name> with rotation: <r>' (insertion.py:513)."""
-        infos, frame_ids = {}, []           # filled by the reader thread, consumed in the same order by the GPU leg
+        infos = {}                          # filled by the reader thread, taken by the GPU leg of the frame's batch
 
         def candidates_and_id(i):
             infos[i] = scene_info_for(i)
-            frame_ids.append(i)
-            return slots_for(i), None
+            return slots_for(i), i          # (the frame's index travels where `run` carries min_points)
 
-        def process_placed(scenes, cands, _):
-            ids = frame_ids[:len(scenes)]
-            del frame_ids[:len(scenes)]
+        def process_placed(scenes, cands, ids):
             results, chosen = self._process_placed(scenes, [infos.pop(i) for i in ids], cands)
             os.makedirs(os.path.join(self.output_path, self.folder, "added_objects"), exist_ok=True)
             for i, sl, ch in zip(ids, cands, chosen):
@@ -167,7 +174,7 @@ class AugmentPipeline:
         saved = self.process
         self.process = process_placed
         try:
-            return self.run(frames, candidates_and_id)
+            return self.run(frames, candidates_and_id, lanes=lanes)
         finally:
             self.process = saved
 
@@ -302,8 +309,10 @@ class AugmentPipeline:
         stats["frames_per_s"] = stats["written"] / stats["t_total"] if stats["t_total"] > 0 else 0.0
         return stats
 
-    def run(self, frames, candidates_for, label_2_for=None):
-        """Process every frame; returns a dict of counters and timings.
+    def run(self, frames, candidates_for, label_2_for=None, lanes=1):
+        """Process every frame; returns a dict of counters and timings.  ``lanes`` > 1: that many batches are on the GPU
+        at a time, each on a worker thread with its own HIP stream and device batch (the upload and host work of one
+        batch overlap the kernels of another); results are written in frame order all the same.
 
         candidates_for(i) -> (slots, min_points): slots[k] = ordered list of M x 5 float64
         candidates of insert k of frame i, min_points[k] its acceptance threshold.
@@ -371,14 +380,24 @@ class AugmentPipeline:
         threads = [threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)]
         for t in threads:
             t.start()
-        while True:
-            item = read_q.get()
-            if item is None or errors:
-                break
+        def process_one(item):
             chunk, scenes, cands = item
             t0 = time.perf_counter()
-            results, accepted = self.process(scenes, [c[0] for c in cands], [c[1] for c in cands])
-            stats["t_process"] += time.perf_counter() - t0
+            if lanes > 1:
+                import torch
+                st = getattr(self._lane_batches, "stream", None)
+                if st is None:
+                    st = self._lane_batches.stream = torch.cuda.Stream(device=self.device)
+                with torch.cuda.stream(st):
+                    results, accepted = self.process(scenes, [c[0] for c in cands], [c[1] for c in cands])
+                    st.synchronize()
+            else:
+                results, accepted = self.process(scenes, [c[0] for c in cands], [c[1] for c in cands])
+            return chunk, results, accepted, time.perf_counter() - t0
+
+        def hand_over(done):
+            chunk, results, accepted, secs = done
+            stats["t_process"] += secs
             stats["inserted"] += sum(1 for a in accepted for x in a if x >= 0)
             while not errors:                                   # do not block on a dead writer
                 try:
@@ -386,6 +405,27 @@ class AugmentPipeline:
                     break
                 except queue.Full:
                     pass
+
+        workers = ThreadPoolExecutor(max_workers=int(lanes)) if lanes > 1 else None
+        pending = []                                            # futures in submission order
+        try:
+            while True:
+                item = read_q.get()
+                if item is None or errors:
+                    break
+                if workers is None:
+                    hand_over(process_one(item))
+                    continue
+                pending.append(workers.submit(process_one, item))
+                while pending and (len(pending) >= lanes or pending[0].done()):
+                    hand_over(pending.pop(0).result())
+            while pending and not errors:
+                hand_over(pending.pop(0).result())
+        except Exception as e:
+            errors.append(e)
+        finally:
+            if workers is not None:
+                workers.shutdown(wait=True)
         while threads[1].is_alive():
             try:
                 write_q.put(None, timeout=0.5)

@@ -26,12 +26,19 @@ class PlacedInserter:
         self.batch, self.torch = batch, torch
         B = batch.B
         assert len(rich_maps) == len(map_moves) == len(poses) == len(scene_boxes) == B
-        self.maps = [upload_map(m, batch.device) for m in rich_maps]
+        # (maps of one shape -- the usual case, one map geometry per dataset -- go up as one slab)
+        if all(isinstance(m, np.ndarray) and m.dtype == np.uint8 and m.shape == rich_maps[0].shape and m.ndim == 2 for m in rich_maps):
+            slab = torch.from_numpy(np.ascontiguousarray(np.stack(rich_maps))).to(batch.device, non_blocking=True)
+            self.maps = [slab[s] for s in range(B)]
+        else:
+            self.maps = [upload_map(m, batch.device) for m in rich_maps]
         self.moves = [(float(np.asarray(m).reshape(-1)[0]), float(np.asarray(m).reshape(-1)[1])) for m in map_moves]
         self.poses = [np.asarray(p, dtype=np.float64)[:2, :4].reshape(8).copy() for p in poses]
         self.boxes = [np.asarray(b, dtype=np.float64).reshape(-1, 10) for b in scene_boxes]
         # original_pcl (insertion.py:360): the clouds as loaded, as packed float64 rows
-        n0 = batch.n_points.cpu().numpy()
+        # (the counts `load` wrote into the pinned staging, when the batch was loaded that way: no wait for the device)
+        pin = getattr(batch, "_pin", None)
+        n0 = pin["n"].numpy() if pin is not None and getattr(batch, "_loaded_from_staging", False) else batch.n_points.cpu().numpy()
         self.n_orig = [int(v) for v in n0]
         self.orig_rows = torch.cat([batch.xyzi[:, :, :3].to(torch.float64),
                                     (batch.label.to(torch.int64) & 0xFFFF).to(torch.float64)[:, :, None]], dim=2).contiguous()

@@ -350,9 +350,11 @@ def test_large_samples_many_boxes_and_far_circles(P, synth, m, n_boxes, dist):
     assert 0 < len(r["rotations"]) < 360
 
 
-def test_file_to_file_with_placement(P, synth, tmp_path):
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_file_to_file_with_placement(P, synth, tmp_path, lanes):
     """AugmentPipeline.run_placed: frames from disk, placement search + merge on the device, written
-    velodyne / labels / check files and added_objects lines against the two oracles."""
+    velodyne / labels / check files and added_objects lines against the two oracles; lanes = 2: two batches on the
+    GPU at a time, each on its own thread, stream and device batch."""
     import os
     fs = P.Real3DAug.tools.find_spot
     root = tmp_path / "data"
@@ -387,7 +389,7 @@ def test_file_to_file_with_placement(P, synth, tmp_path):
         return out
 
     pipe = P.AugmentPipeline(str(tmp_path / "out"), "placed", dataset="semantic", batch_size=2)
-    stats = pipe.run_placed(frames, scene_info_for, slots_for)
+    stats = pipe.run_placed(frames, scene_info_for, slots_for, lanes=lanes)
     assert stats["written"] == 3
     for i, (c, slots) in enumerate(cases):
         scene = c["scene9"].copy()
