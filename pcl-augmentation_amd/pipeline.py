@@ -450,7 +450,8 @@ def run_sharded_files(frames, inserts_for, output_path, folder, rank=None, world
     is written by exactly one rank (the reference shards by letting N copies of the script race for claim files,
     SS insertion.py:339-350; resume is by the existence of a frame's outputs, as there).
 
-    inserts_for(i) -> (samples, min_points) of frame i: one placement per insert (``run_streamed``).  ``process``
+    inserts_for(i) -> (samples, min_points) of frame i: one placement per insert (``run_streamed``; the Waymo flavour,
+    whose clouds are float64, goes through ``run(lanes=...)``: the same overlap of consecutive batches, whole clouds back).  ``process``
     (tests only): a CPU stand-in for the GPU leg with ``AugmentPipeline.run``'s signature; it gets one candidate per
     insert.  Returns this rank's counters; `frames` holds the rank's own frame indices."""
     if rank is None or world_size is None:
@@ -462,6 +463,15 @@ def run_sharded_files(frames, inserts_for, output_path, folder, rank=None, world
     pipe = AugmentPipeline(output_path, folder, dataset=dataset, batch_size=batch_size,
                            device=device or f"cuda:{rank}", resume=resume, process=process)
     local = [frames[i] for i in mine]
+    if dataset == "waymo" and process is None:
+        # float64 frames (lidar/{f}.npy, SS tools/datasets.py:239-270): `lanes` batches in flight, each on its own thread,
+        # stream and device batch (begin_f64 / results_f64); the float32 delta path below does not carry float64 clouds
+        def cands64(j):
+            smp, need = inserts_for(mine[j])
+            return [[x] for x in smp], need
+        st = pipe.run(local, cands64, lanes=lanes)
+        st.update(rank=rank, world_size=world_size, frame_indices=mine)
+        return st
     if process is not None:
         def cands(j):
             smp, need = inserts_for(mine[j])

@@ -108,6 +108,24 @@ def test_waymo_pipeline_on_gpu(pkg, synth, tmp_path):
 
 
 @pytest.mark.gpu
+def test_waymo_frames_with_batches_in_flight_and_sharded(pkg, synth, tmp_path):
+    """The float64 flavour with several batches on the GPU at a time (``run(lanes=2)``: a worker thread, a HIP stream and a
+    device batch per lane) and through the sharded file driver (``run_sharded_files(dataset="waymo")``, this rank's share):
+    the three .npy files of every frame equal what the reference's ``Waymo.save_data`` would have written."""
+    files = _dataset(synth, tmp_path / "in", 7)
+    fr = [pkg.Frame(f, None, f"{i:06d}") for i, f in enumerate(files)]
+    pipe = pkg.AugmentPipeline(str(tmp_path / "out"), "lanes", dataset="waymo", batch_size=2)
+    st = pipe.run(fr, lambda i: _inserts(synth, i), lanes=2)
+    assert st["written"] == 7 and st["inserted"] > 0
+    _check(pkg, synth, files, tmp_path / "out", "lanes")
+    one_each = lambda i: ([c[0] for c in _inserts(synth, i)[0]], _inserts(synth, i)[1])      # one placement per insert
+    st = pkg.run_sharded_files(fr, one_each, str(tmp_path / "out"), "sharded", rank=0, world_size=1, device="cuda:0",
+                               dataset="waymo", batch_size=3, lanes=2)
+    assert st["written"] == 7
+    _check(pkg, synth, files, tmp_path / "out", "sharded")
+
+
+@pytest.mark.gpu
 def test_begin_f64_is_within_three_times_of_begin(pkg, synth):
     """The float64 flavour's step 0 (guess from the float32 rounding, float64 confirmation on the exact coordinates)
     against the float32 one on the same 64 frames of 120k points."""
