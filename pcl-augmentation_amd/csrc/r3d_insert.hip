@@ -281,6 +281,7 @@ struct Ins {
   int hit_cap;
   bool intile;                            // the gather leaves, in every list entry's kill field, which of its points lie inside the tile
   bool flat;                              // gather_flat does the gather
+  bool lazy_root;                         // the pooled tile keeps squared depths (tile_key)
   bool accept;
   FastDiv by_W;
 
@@ -299,7 +300,7 @@ struct Ins {
     g_cand = nullptr;
     s_hit = nullptr;
     hit_cap = 0;
-    intile = flat = false;
+    intile = flat = lazy_root = false;
     pool_off = -1;
     g_list = force_glist_ ? w.glist + ((int64_t)s + 1) * chunks * kEntry : nullptr;   // entries grow down from the area's end
   }
@@ -378,7 +379,18 @@ struct Ins {
   }
   // dl: pixel of the band in LDS / the pool (plain loads: after the gather the pooled tile is read-only, and the
   // workgroup has dropped its stale cache lines)
-  __device__ __forceinline__ unsigned long long tile_key(int dl) const { return g_dtile ? g_dtile[dl] : s_dtile[dl]; }
+  // A pooled tile with many more pixels than the evaluation has candidates (`lazy_root`: a car a few metres from the sensor
+  // on 448 x 2880, 100 000 pixels for a few thousand candidates) keeps the minima of the SQUARED depth the gather formed: the
+  // root is taken per read instead of in a pass over the whole tile (a read-modify-write trip through L2 per pixel: config C5
+  // 342 -> 311 us for such a pair).  Any other tile is converted in place (scene_phase) -- on the reference's grid the pooled
+  // tiles are a few times their candidates and the evaluation reads most pixels several times (72 against 50 us with the
+  // root per read).
+  __device__ __forceinline__ unsigned long long tile_key(int dl) const {
+    if (!g_dtile) return s_dtile[dl];
+    const unsigned long long k2 = g_dtile[dl];
+    if (NT != 1024) return k2;                              // (only the shape for large range images meets such tiles)
+    return !lazy_root || k2 == R3D_SENT ? k2 : depth_key(sqrt(key_depth(k2)));
+  }
 
   // LDS layout of a pair: header | out-of-bounds bits | window pixel per point | sorted order | occupancy, closed,
   // rank images | first sorted point and min depth per occupied pixel | the three scratch images | (from r1) whatever
@@ -1059,6 +1071,7 @@ struct Ins {
         single = true;
       }
     }
+    lazy_root = NT == 1024 && g_dtile != nullptr && dt.npx > 8 * ncand;
     int per = cr1 - cr0 + 1;
     if (!single) {
       per = (band_bytes - 4 * W * 8 - 8) / (12 * W);
@@ -1140,13 +1153,15 @@ struct Ins {
       if (bits_in_gather)
         for (int e = tid; e < ww; e += NT) D.w[e] = 0u;
       __syncthreads();
+      if (first) STAMP(26);                                    // (candidates listed, tile and occupancy bits cleared)
       if (flat) gather_flat(bits_in_gather);
       else gather(bits_in_gather, use_sub ? s_sub : nullptr, nsub);
+      if (first) STAMP(27);                                    // (gathered)
       if (g_dtile) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the minima were formed in L2: drop this CU's copies
       __syncthreads();
-      // the band holds minima of the squared depth: the root of every occupied pixel (and, for one band in LDS, the
+      // a band in LDS holds minima of the squared depth: the root of every occupied pixel (and, for one band, the
       // scene's occupancy bits off the same pass)
-      {
+      if (!lazy_root) {                                        // (else: the root per read, tile_key)
         const bool bits_here = first && single && !g_dtile;
         if (bits_here)
           for (int e = tid; e < ww; e += NT) D.w[e] = 0u;
@@ -1279,12 +1294,13 @@ struct Ins {
         for (int k = k_lo; k < k_hi; ++k)
           if (vis.get_local((int)s_lp[s_F[k]])) s_V[o++] = (uint16_t)k;
       }
+      STAMP(31);                                               // (visible list made)
       // every living scene point in a visible pixel dies (:470-473): one mask per listed chunk, so that
       // the commit is a handful of atomics.  Only the chunks whose rows reach a visible row are looked at (and, with
       // one band, only those with a point inside the tile): their entry numbers are compacted first.  A chunk whose
       // in-tile points were kept as hits needs no second trip to its pixel ids.
       {
-        constexpr int kPer = 4;
+        constexpr int kPer = NT == 1024 ? 8 : 4;             // (the 1024-thread shape keeps no hits: its pixel ids come from memory)
         const int lane = tid & 63;
         const uint32_t *pixs = reinterpret_cast<const uint32_t *>(b.pix) + (int64_t)s * b.cap;
         const int vr0 = uni(H[H_VRMIN]), vr1 = uni(H[H_VRMAX]);

@@ -85,6 +85,19 @@ if (raw[:, :, 22] > 0).any():
         ((c[:, :, 14] - c[:, :, 25]) / 100)[m].mean()))
 if len(sys.argv) > 1:
     np.savez_compressed(sys.argv[1], raw=raw, names=np.array(names))
+# inside the two longest phases, by size of the depth tile (pooled tiles: the windows that exceed the LDS)
+if (raw[:, :, 26] > 0).any():
+    npx = (info >> 48) << 4
+    cls = [(0, 4000, "tile < 4k px"), (4000, 9000, "4k - 9k"), (9000, 10**9, ">= 9k px")] if shape == {} else \
+          [(0, 15000, "tile < 15k px"), (15000, 40000, "15k - 40k"), (40000, 10**9, ">= 40k px")]
+    for lo, hi, lab in cls:
+        sel = once & (npx >= lo) & (npx < hi) & (raw[:, :, 26] > 0)
+        if not sel.any():
+            continue
+        f = lambda a, z: ((st[:, :, z] - st[:, :, a]) / 100.0)[sel].mean()
+        print(f"{lab}: {sel.sum()} pairs, total {tot[sel].mean():.1f} us ({100 * tot[sel].sum() / tot[once].sum():.0f} % of all pair time) | "
+              f"list candidates + clear {f(7, 26):.1f}, gather {f(26, 27):.1f}, roots + bits {f(27, 8):.1f}, evaluate {f(9, 10):.1f}, "
+              f"visible list {f(10, 31):.1f}, kill masks {f(31, 11):.1f}")
 # the workgroup's own span (kernel entry -> exit) against the phases' span, and how long a CU stays empty between two workgroups
 if raw.shape[2] > 30 and raw[:, :, 28].any():
     ent, ext, retry = raw[:, :, 28].astype(np.float64), raw[:, :, 30].astype(np.float64), raw[:, :, 29]
