@@ -702,6 +702,20 @@ struct Ins {
     return kOk;
   }
 
+  // Tile pixel (one band = the whole window) and window pixel of a packed pixel id in one go: both number the window's
+  // rows from r_lo, the tile its exact columns, the window the 32-pixel words that hold them.  -1: outside.
+  __device__ __forceinline__ void place_rc(uint32_t p, int &dl, int &lp) const {
+    const int nj1 = win.n_iv > 1 ? win.jh1 - win.jl1 + 1 : 0, w1 = dt.n_iv > 1 ? dt.c11 - dt.c01 + 1 : 0;
+    const int rr = pix_row(p) - win.r_lo, c = pix_col(p), j = c >> 5;
+    const int k0 = j - win.jl0, k1 = j - win.jl1;
+    const bool in0 = (unsigned)k0 < (unsigned)win.nj0, in1 = (unsigned)k1 < (unsigned)nj1;
+    const int t0 = c - dt.c00, t1 = c - dt.c01;
+    const bool ok_r = (unsigned)rr < (unsigned)win.nrw;
+    const bool tin0 = (unsigned)t0 < (unsigned)dt.w0, tin1 = (unsigned)t1 < (unsigned)w1;   // (w1 = 0: one interval)
+    lp = ok_r && (in0 || in1) ? rr * (win.njw << 5) + ((in0 ? k0 : win.nj0 + k1) << 5) + (c & 31) : -1;
+    dl = ok_r && (tin0 || tin1) ? rr * dt.W + (tin0 ? t0 : dt.w0 + t1) : -1;
+  }
+
   // The chunks that can hold a point of the window: bounding box touches it, somebody alive (4 chunks
   // per thread in flight).
   __device__ __forceinline__ void build_list(const unsigned long long *boxes, const unsigned long long *alive, int n_chunks) {
@@ -771,11 +785,14 @@ struct Ins {
         dl[u] = -1;
         int lp = -1;
         if (idx[u] >= 0) {
-          const int r = pix_row(p[u]), c = pix_col(p[u]);
-          dl[u] = bt.index(r, c);
-          const bool in_window = bt.npx == dt.npx ? dl[u] >= 0 : dt.index(r, c) >= 0;
-          if (all_rows_bits && in_window) lp = win.lpix_rc(r, c);
-          if (all_rows_bits && in_window) D.set_local(lp);
+          if (bt.npx == dt.npx) {                            // one band: the whole window
+            place_rc(p[u], dl[u], lp);
+            if (all_rows_bits && dl[u] >= 0) D.set_local(lp);
+          } else {
+            const int r = pix_row(p[u]), c = pix_col(p[u]);
+            dl[u] = bt.index(r, c);
+            if (all_rows_bits && dt.index(r, c) >= 0) D.set_local(win.lpix_rc(r, c));
+          }
         }
         // one band for the whole window: which points of every listed chunk lie inside the tile (the kill masks are
         // computed from those alone, and not at all for a chunk that has none)
@@ -823,21 +840,6 @@ struct Ins {
     const float4 *xyzi = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
     const int nitems = nlist << 6;
     const int lane = tid & 63;
-    // tile and window pixel of (row, column) in one go: both number the window's rows from r_lo, the tile its exact
-    // columns, the window the 32-pixel words that hold them
-    const int nrw = win.nrw, njw32 = win.njw << 5, W = dt.W;
-    const int jl0 = win.jl0, nj0 = win.nj0, jl1 = win.jl1, nj1 = win.n_iv > 1 ? win.jh1 - win.jl1 + 1 : 0;
-    const int c00 = dt.c00, w0 = dt.w0, c01 = dt.c01, w1 = dt.n_iv > 1 ? dt.c11 - dt.c01 + 1 : 0;
-    auto place = [&](uint32_t p, int &dl, int &lp) {
-      const int rr = pix_row(p) - win.r_lo, c = pix_col(p), j = c >> 5;
-      const int k0 = j - jl0, k1 = j - jl1;
-      const bool in0 = (unsigned)k0 < (unsigned)nj0, in1 = (unsigned)k1 < (unsigned)nj1;
-      const int t0 = c - c00, t1 = c - c01;
-      const bool ok_r = (unsigned)rr < (unsigned)nrw;
-      const bool tin0 = (unsigned)t0 < (unsigned)w0, tin1 = (unsigned)t1 < (unsigned)w1;   // (w1 = 0: one interval)
-      lp = ok_r && (in0 || in1) ? rr * njw32 + ((in0 ? k0 : nj0 + k1) << 5) + (c & 31) : -1;
-      dl = ok_r && (tin0 || tin1) ? rr * W + (tin0 ? t0 : w0 + t1) : -1;
-    };
     GSTAMP_DECL;
     for (int e00 = 0; e00 < nitems; e00 += kU * NT) {
       int idx[kU];
@@ -857,7 +859,7 @@ struct Ins {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         int dl = -1, lp = -1;
-        if (idx[u] >= 0) place(p[u], dl, lp);
+        if (idx[u] >= 0) place_rc(p[u], dl, lp);
         if (all_rows_bits && dl >= 0) D.set_local(lp);
         if (dl >= 0 && !CHK(dl < dt.npx && lp >= 0 && lp < (ww << 5), 1)) dl = -1;
         code[u] = dl >= 0 ? ((uint32_t)dl << 16) | (uint32_t)lp : 0xFFFFFFFFu;
@@ -1351,7 +1353,8 @@ struct Ins {
             int e = e0 + u * NT;
             bool kill = false;
             if (on[u]) {
-              const int lp = from_hits[u] ? lpv[u] : win.lpix_rc(pix_row(pg[u]), pix_col(pg[u]));
+              int lp = lpv[u], dl_unused;
+              if (!from_hits[u]) place_rc(pg[u], dl_unused, lp);
               kill = lp >= 0 && vis.get_local(lp);
             }
             unsigned long long mask = __ballot(kill);
