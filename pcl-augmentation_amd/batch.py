@@ -327,7 +327,7 @@ class SceneBatch:
         out = (C.c_int32 * 16)()
         _lib.check(self.lib.r3d_batch_debug_counters(C.byref(self.desc), out, 1 if reset else 0, _lib.stream_ptr()),
                    "r3d_batch_debug_counters")
-        names = ["pool_exhausted", "tiles_pooled", "evaluated_twice", "verify_runs", "verify_mismatch", "unused5", "deferred_scenes",
+        names = ["pool_exhausted", "tiles_pooled", "evaluated_twice", "verify_runs", "verify_mismatch", "hits_overflow", "deferred_scenes",
                  "rebases_in_chain"]
         d = dict(zip(names, list(out)))
         if any(out[8:]):                 # a diagnostic build (-DR3D_CHECK) counted index checks that failed: [8 + code]

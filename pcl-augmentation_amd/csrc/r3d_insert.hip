@@ -873,6 +873,7 @@ struct Ins {
           base = atomicAdd(&H[H_NHIT], cnt);
           if (base + cnt > hit_cap) {
             atomicMin(&H[H_HITEND], base);                     // the hits end here: every later reservation lies beyond
+            atomicAdd(&w.dbg[D_HITS_OVERFLOW], 1);
             base = -1;
           }
         }
