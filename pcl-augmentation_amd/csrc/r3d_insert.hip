@@ -253,7 +253,7 @@ struct Ins {
   const double *rows5;
   int m, need, step;
   // sample phase results
-  Binning bn;
+  bool tiny_el;                           // the scene's elevation span is so small that a bound's holder may sit in any row
   Window win;
   DTile dt;
   int nvalid, ww, nocc, ncand, r1, rec_end;
@@ -517,7 +517,8 @@ struct Ins {
                          ? -1
                          : 0;
     __syncthreads();
-    bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], rows, cols);
+    const Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], rows, cols);
+    tiny_el = bn.d_el < 1e-4;
 
     STAMP(0);
     // -- 1. project the sample with the scene's bounds, sample=True (insertion.py:455-459) ---------
@@ -1366,7 +1367,7 @@ struct Ins {
         // row of the image; if it dies the bounds may move and the scene is re-based (insertion.py:373 recomputes them
         // from the merged cloud for every insert; a rebase that was not needed changes nothing).  Only a pair whose
         // visible pixels reach one of those rows has to look: at the points it culls.
-        if (vr0 == 0 || vr1 == rows - 1 || bn.d_el < 1e-4) {
+        if (vr0 == 0 || vr1 == rows - 1 || tiny_el) {
           __syncthreads();
           const int n_head = uni(b.n_head[s]);
           const double q_min = w.q_ext[2 * s + 0], q_max = w.q_ext[2 * s + 1];
