@@ -254,7 +254,8 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream);
  * for the workgroup's LDS); [2] pairs evaluated more than once (a predecessor changed a pixel they had read); [3] / [4]
  * evaluations done again for comparison / that differed (descriptor bit 64 of `reserved`: diagnostic, must stay 0);
  * [5] wave-rounds of the gather whose hits did not fit the workgroup's LDS (their coordinates were fetched right away);
- * [6] scenes handed to k_insert_big; [7] rebases inside the chain kernel. */
+ * [6] scenes handed to k_insert_big; [7] rebases inside the chain kernel; [8..11] rebases by reason: a visible sample point
+ * outside the elevation bounds / a culled point held a bound / the same found by the far-pixel pass / none of these (must stay 0). */
 int r3d_batch_debug_counters(const r3d_batch_t *b, int32_t *host_out16, int32_t reset, void *stream);
 
 /* =====================================================================================

@@ -328,10 +328,11 @@ class SceneBatch:
         _lib.check(self.lib.r3d_batch_debug_counters(C.byref(self.desc), out, 1 if reset else 0, _lib.stream_ptr()),
                    "r3d_batch_debug_counters")
         names = ["pool_exhausted", "tiles_pooled", "evaluated_twice", "verify_runs", "verify_mismatch", "hits_overflow", "deferred_scenes",
-                 "rebases_in_chain"]
+                 "rebases_in_chain", "rebase_for_sample_point_outside_bounds", "rebase_for_culled_holder", "rebase_from_far_pass",
+                 "rebase_without_reason"]
         d = dict(zip(names, list(out)))
-        if any(out[8:]):                 # a diagnostic build (-DR3D_CHECK) counted index checks that failed: [8 + code]
-            d["check_failures"] = list(out[8:])
+        if any(out[12:]):                # a diagnostic build (-DR3D_CHECK) counted index checks that failed: [12 + (code & 3)]
+            d["check_failures"] = list(out[12:])
         return d
 
     def pixel_ids(self):

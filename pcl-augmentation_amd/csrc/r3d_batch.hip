@@ -508,7 +508,7 @@ k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
     } else {
       // (named scalars, not arrays: the compiler keeps arrays of float4 filled under a branch in scratch)
 #ifdef R3D_CHECK
-#define R3D_CHECK_O(o) if (o >= (unsigned int)b.cap) { atomicAdd(&w.dbg[15], 1); o = 0u; }
+#define R3D_CHECK_O(o) if (o >= (unsigned int)b.cap) { atomicAdd(&w.dbg[15], 1); o = 0u; }   /* (code 3 of the insert kernels shares the cell) */
 #else
 #define R3D_CHECK_O(o)
 #endif

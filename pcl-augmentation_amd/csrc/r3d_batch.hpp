@@ -297,6 +297,9 @@ template <int NT>
 __device__ __forceinline__ void rebase_scene(const r3d_batch_t &b, const BatchWs &w, int chunks, const int s,
                                              unsigned long long *s_min, unsigned long long *s_max) {
   const int tid = threadIdx.x;
+  // (the caller has fenced; the scalar cache is dropped as well: the counts below may travel through it, and this
+  // workgroup read the older ones before its commit)
+  asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
   const int n = b.n_total[s], n_head = b.n_head[s];
   int32_t *pix = b.pix + (int64_t)s * b.cap;
   // (a) bounds (insertion.py:78-79) via the extreme z/r of the living
@@ -350,8 +353,9 @@ __device__ __forceinline__ void rebase_scene(const r3d_batch_t &b, const BatchWs
     }
   }
   phase_sync();
-  // (b) re-project the living (insertion.py:74-76, :104-116): pixel ids and chunk boxes
-  Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
+  // (b) re-project the living (insertion.py:74-76, :104-116): pixel ids and chunk boxes -- under the bounds this
+  // workgroup has just computed (from LDS: not through a cache that may still hold the old ones)
+  Binning bn = make_binning(key_depth(s_min[0]), key_depth(s_max[0]), b.rows, b.cols);
   int flags = 0;
   for (int i0 = 0; i0 < n; i0 += NT) {
     int i = i0 + tid;

@@ -225,12 +225,13 @@ constexpr int kHdrBytes = 512;
 
 enum { kOk = 0, kNoFit = 1, kNeedSerial = 2, kStale = 3 };
 // diagnostic counters (BatchWs::dbg; r3d_batch_debug_counters)
-enum { D_POOL_FULL = 0, D_TILE_POOLED, D_EVAL_TWICE, D_VERIFY_RUNS, D_VERIFY_MISMATCH, D_HITS_OVERFLOW, D_DEFERRED, D_REBASE };
+enum { D_POOL_FULL = 0, D_TILE_POOLED, D_EVAL_TWICE, D_VERIFY_RUNS, D_VERIFY_MISMATCH, D_HITS_OVERFLOW, D_DEFERRED, D_REBASE,
+       D_REBASE_OOB, D_REBASE_HOLDER, D_REBASE_FAR, D_REBASE_OTHER };     // (a diagnostic build, -DR3D_CHECK, counts its failed checks from [12] on)
 
 // Diagnostic builds (-DR3D_CHECK): the index of every access the gather / kill / commit code derives from data is
 // checked against its array; a violation is counted in BatchWs::dbg[8 + code] and the access skipped.
 #ifdef R3D_CHECK
-#define CHK(cond, code) ((cond) ? true : (atomicAdd(&w.dbg[8 + (code)], 1), false))
+#define CHK(cond, code) ((cond) ? true : (atomicAdd(&w.dbg[12 + ((code) & 3)], 1), false))
 #else
 #define CHK(cond, code) true
 #endif
@@ -1260,7 +1261,7 @@ struct Ins {
               v_n += p1 - p0;
               for (int p = p0; p < p1; ++p) {
                 int j = s_F[p];
-                if ((s_oob[j >> 5] >> (j & 31)) & 1u) H[H_REBASE] = 1;   // bounds move: new extreme elevation
+                if ((s_oob[j >> 5] >> (j & 31)) & 1u) atomicOr(&H[H_REBASE], 1);   // bounds move: new extreme elevation
               }
             }
           }
@@ -1377,7 +1378,7 @@ struct Ins {
             double x, y, z;
             load_point(b, s, (int)(l_chunk(i) << 6) + (e & 63), n_head, x, y, z);
             const double q = z / sqrt(x * x + y * y + z * z);
-            if (q == q_min || q == q_max) H[H_REBASE] = 1;
+            if (q == q_min || q == q_max) atomicOr(&H[H_REBASE], 2);
           }
         }
       }
@@ -1417,6 +1418,7 @@ struct Ins {
         int dst = (ci << 6) + lane, o = dst - n_total;
         bool valid = o >= 0 && o < nvis;
         BoxAcc box;
+        if (valid && !CHK(dst < b.cap && n_log + o < b.log_cap && dst >= n_head && (int)s_V[o] < nvalid && (int)s_F[s_V[o]] < m, 7)) valid = false;
         if (valid) {
           int j = s_F[s_V[o]];
           int lp = (int)s_lp[j];
@@ -1498,7 +1500,15 @@ struct Ins {
     if (tid == 0) {
       b.n_total[s] = n_total + nvis;
       b.n_log[s] = n_log + nvis;
-      if (rebase) b.rebase[s] += 1;                           // single writer per scene
+      if (rebase) {
+        b.rebase[s] += 1;                                     // single writer per scene
+        // why: a visible sample point outside the bounds | a culled point held a bound | ... found by the far pass
+        const int why = H[H_REBASE];
+        if (why & 1) atomicAdd(&w.dbg[D_REBASE_OOB], 1);
+        if (why & 2) atomicAdd(&w.dbg[D_REBASE_HOLDER], 1);
+        if (why & 4) atomicAdd(&w.dbg[D_REBASE_FAR], 1);
+        if (!(why & 7)) atomicAdd(&w.dbg[D_REBASE_OTHER], 1);
+      }
     }
     return rebase;
   }
@@ -1566,7 +1576,7 @@ struct Ins {
             else if (key_depth(__hip_atomic_load(&fmin[hit], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > R3D_EMPTY_DEPTH) {
               kill = true;
               double q = z / r;
-              if (q == q_min || q == q_max) H[H_REBASE] = 1;
+              if (q == q_min || q == q_max) atomicOr(&H[H_REBASE], 4);
             }
           }
         }

@@ -28,6 +28,10 @@ from . import _lib
 from .batch import SceneBatch
 
 
+import os as _os
+_SUM_COUNTERS = {} if _os.environ.get("R3D_SUM_COUNTERS") else None      # diagnostics (tools/soak_files.py)
+
+
 class _Lane:
     def __init__(self, B, cap, log_cap, K, sample_rows, rows, cols, device, check_cols, delta):
         torch = _lib.require_gpu()
@@ -245,6 +249,10 @@ class StreamedAugmenter:
         t1 = time.perf_counter()
         self.times["wait_device"] += t1 - t0
         counts = ln.out_counts.numpy()
+        if _SUM_COUNTERS is not None:                                # R3D_SUM_COUNTERS=1: the insert kernels' diagnostic counters, summed
+            for k, v in ln.bt.debug_counters(reset=True).items():
+                _SUM_COUNTERS[k] = (_SUM_COUNTERS.get(k, 0) + v) if not isinstance(v, list) else [a + b for a, b in zip(_SUM_COUNTERS.get(k, [0] * len(v)), v)]
+            _SUM_COUNTERS["rebases"] = _SUM_COUNTERS.get("rebases", 0) + int(counts[3].sum())
         n_log = ln.h_n_log.numpy()
         n_log[:] = counts[1]
         redo = [int(s) for s in np.nonzero(counts[2] & _lib.S_WINDOW_TOO_LARGE)[0]]   # see _redo_level1
@@ -252,7 +260,12 @@ class StreamedAugmenter:
             if int(s) in redo:
                 continue
             ln.busy = False
-            _lib.raise_status(int(counts[2][s]), f"scene {s} of the batch (status {int(counts[2][s])}, {int(counts[3][s])} rebases, {int(counts[1][s])} inserted points)")
+            try:
+                why = ln.bt.debug_counters(reset=False)
+            except Exception as e:                                  # (the device is gone: keep the status)
+                why = repr(e)[:80]
+            _lib.raise_status(int(counts[2][s]), f"scene {s} of the batch (status {int(counts[2][s])}, {int(counts[3][s])} rebases, "
+                                                 f"{int(counts[1][s])} inserted points; counters {why})")
         cc = max(ln.check_cols, 4)
         if self.delta:
             bt = ln.bt
@@ -353,4 +366,13 @@ class StreamedAugmenter:
             submitted.put(None)
             th.join()
         if errors:
+            # lanes that were submitted but never collected still have work on the device: wait for it before the caller
+            # lets go of their buffers (kernels writing into memory the allocator has handed to somebody else end in a
+            # memory fault, as a soak showed after a frame had been flagged)
+            for ln in self.lanes:
+                try:
+                    ln.stream.synchronize()
+                except Exception:
+                    pass
+                ln.busy = False
             raise errors[0]
