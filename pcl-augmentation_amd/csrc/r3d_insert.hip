@@ -1947,21 +1947,27 @@ k_insert_chain(ChainArgs args) {
     return;
   }
   int *H = reinterpret_cast<int *>(smem);
-  const int queue_mode = args.queue_mode, total = (args.B8 ? args.B8 : args.b.B) * args.nk;
-  const int home = queue_mode == 2 ? (int)(blockIdx.x & 7) : 0;
+  // queue_mode 3 (R3D_CHAIN_QUEUE=3, not a default): the queues hold SCENES; a workgroup runs the whole chain of the
+  // scene it takes, slot after slot -- every wait finds its predecessor done, nothing is evaluated twice, the scene stays
+  // with one CU.  Config C5 (256 scans on 256 CUs): the mean pair 94 us instead of 105, but the launch 6.4 ms instead of
+  // 5.9 (the slowest scan's 50 slots in a row); with three steps in flight 9.3 ms per step instead of 9.55.
+  const int queue_mode = args.queue_mode;
+  const bool owner = queue_mode == 3;
+  const int total = (args.B8 ? args.B8 : args.b.B) * (owner ? 1 : args.nk);
+  const int home = queue_mode >= 2 ? (int)(blockIdx.x & 7) : 0;
   int turn = 0;                                              // queues this workgroup has found empty
   for (;;) {
     // (the pointer is taken afresh for every pair: nothing of the arguments stays in registers across pairs)
     ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ap));
-    const ChainArgs &a = *(const ChainArgs *)ap;
     __syncthreads();
     if (threadIdx.x == 0) {
+      const ChainArgs &a = *(const ChainArgs *)ap;
       int id = total;
-      while (turn < (queue_mode == 2 ? 8 : 1)) {
+      while (turn < (queue_mode >= 2 ? 8 : 1)) {
         const int q = (home + turn) & 7;
         const int n = atomicAdd(&a.w.queue_next[q], 1);
-        id = queue_mode == 2 ? n * 8 + q : n;
+        id = queue_mode >= 2 ? n * 8 + q : n;
         if (id < total) break;
         id = total;
         ++turn;
@@ -1970,25 +1976,34 @@ k_insert_chain(ChainArgs args) {
       H[H_GO + 1] = turn;
     }
     __syncthreads();
-    const int pair_id = uni(H[H_GO]);
+    const int taken = uni(H[H_GO]);
     turn = uni(H[H_GO + 1]);
-    if (pair_id >= total) return;
+    if (taken >= total) return;
+    for (int ko = 0; ko < (owner ? args.nk : 1); ++ko) {
+      if (ko) {
+        __syncthreads();                                       // (the next slot's set-up writes the header the last one may still read)
+        ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ap));
+      }
+      const ChainArgs &a = *(const ChainArgs *)ap;
+      const int pair_id = owner ? ko * a.B8 + taken : taken;
 #ifdef R3D_STAMPS
-    const int k_ = a.B8 ? pair_id / a.B8 : pair_id % a.nk, s_ = a.B8 ? pair_id % a.B8 : pair_id / a.nk;
-    long long *cell = s_ < a.b.B ? reinterpret_cast<long long *>(a.b.out_xyzi + (int64_t)s_ * a.b.cap * 4) + k_ * 32 : nullptr;
-    if (cell && threadIdx.x == 0) cell[28] = wall_clock64();   // this workgroup takes the pair
+      const int k_ = a.B8 ? pair_id / a.B8 : pair_id % a.nk, s_ = a.B8 ? pair_id % a.B8 : pair_id / a.nk;
+      long long *cell = s_ < a.b.B ? reinterpret_cast<long long *>(a.b.out_xyzi + (int64_t)s_ * a.b.cap * 4) + k_ * 32 : nullptr;
+      if (cell && threadIdx.x == 0) cell[28] = wall_clock64();   // this workgroup takes the pair
 #endif
-    const int again = chain_pair<NT, false, NT != 1024>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8,
-                                                        smem, pair_id);
+      const int again = chain_pair<NT, false, NT != 1024>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks,
+                                                          a.B8, smem, pair_id);
 #ifdef R3D_STAMPS
-    if (cell && threadIdx.x == 0) cell[29] = uni(again) ? wall_clock64() : 0;   // the LDS flavour turned the pair down here
+      if (cell && threadIdx.x == 0) cell[29] = uni(again) ? wall_clock64() : 0;   // the LDS flavour turned the pair down here
 #endif
-    if (NT == 1024 && uni(again))
-      chain_pair<NT, true, true>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8, smem, pair_id);
+      if (NT == 1024 && uni(again))
+        chain_pair<NT, true, true>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8, smem, pair_id);
 #ifdef R3D_STAMPS
-    __syncthreads();
-    if (cell && threadIdx.x == 0) cell[30] = wall_clock64();   // ... and is done with it
+      __syncthreads();
+      if (cell && threadIdx.x == 0) cell[30] = wall_clock64();   // ... and is done with it
 #endif
+    }
   }
 }
 
@@ -2070,7 +2085,7 @@ static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlo
   // per device, every call: the attribute belongs to the current device's copy of the kernel
   R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_chain<NT, QUEUE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  const int total = (B8 ? B8 : b.B) * nk;
+  const int total = (B8 ? B8 : b.B) * (queue_mode == 3 ? 1 : nk);
   int grid = total;
   if (QUEUE && queue_mode) {
     // how many workgroups of this shape the device keeps resident: asked once per (device, LDS size) and kernel flavour
@@ -2112,11 +2127,12 @@ static int launch_chain(const r3d_batch_t &b, const BatchWs &w, const ChainSlots
   static const bool scene_major = getenv("R3D_CHAIN_ORDER") && std::string(getenv("R3D_CHAIN_ORDER")) == "scene";
   const int B8 = scene_major ? 0 : (b.B + 7) & ~7;            // a scene's slots on one residue of the pair id mod 8
   // R3D_CHAIN_QUEUE: 0 one workgroup per pair; 1 resident workgroups that take pairs off one queue; 2 ... off a queue per
-  // XCD.  Default: 2 on large range images (config C5: 6.4 -> 4.8 ms per 128 scans x 50 slots), 0 otherwise.
+  // XCD; 3 ... whole scenes off a queue per XCD (see k_insert_chain).  Default: 2 on large range images (config C5:
+  // 6.4 -> 4.8 ms per 128 scans x 50 slots), 0 otherwise.
   static const int queue_env = env_int("R3D_CHAIN_QUEUE", -1);
   const bool large = (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN;
   int queue_mode = queue_env >= 0 ? queue_env : (large ? 2 : 0);
-  if (scene_major && queue_mode == 2) queue_mode = 1;
+  if (scene_major && queue_mode >= 2) queue_mode = 1;
   return queue_mode ? launch_chain_q<NT, true>(b, w, sl, nk, first_step, lds, timeout_ticks, B8, queue_mode, st)
                     : launch_chain_q<NT, false>(b, w, sl, nk, first_step, lds, timeout_ticks, B8, 0, st);
 }
