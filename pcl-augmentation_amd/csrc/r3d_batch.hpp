@@ -42,6 +42,7 @@ struct BatchWs {
   int32_t *chain_progress;      // [B] slots of the scene completed by the running k_insert_chain (< 0: see r3d_insert.hip)
   int32_t *n_total0;            // [B] n_total when the running k_insert_chain was launched
   int32_t *defer_from;          // [B] first slot of the launch left to k_insert_big (n_slots: none)
+  int32_t *claim_next;          // [B] next slot of the scene a workgroup of k_insert_chain may claim (queue modes 3 / 4)
   int32_t *recs;                // [B*kMaxChain*kRecInts] what every finished slot of the launch publishes
   unsigned char *glist;         // [B*chunks*kEntry] k_insert_big's chunk lists, one area per scene (a pair of k_insert_chain whose
                                 // list exceeds its LDS takes room from the pool)
@@ -82,6 +83,7 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.chain_progress = c.take<int32_t>((size_t)b.B);
   w.n_total0 = c.take<int32_t>((size_t)b.B);
   w.defer_from = c.take<int32_t>((size_t)b.B);
+  w.claim_next = c.take<int32_t>((size_t)b.B);
   w.recs = c.take<int32_t>((size_t)b.B * kMaxChain * kRecInts);
   w.glist = c.take<unsigned char>((size_t)b.B * chunks_of(b) * kEntry);
   // The launch's pool: depth tiles, candidate lists, chunk lists and scratch images of the pairs whose window exceeds a

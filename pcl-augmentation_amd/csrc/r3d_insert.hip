@@ -218,7 +218,7 @@ enum {
   H_NLIST, H_CARRY, H_EXT0, H_EXT1, H_NOCC, H_NVIS, H_VRMIN, H_VRMAX, H_VCMIN0, H_VCMIN1, H_VCMAX0,
   H_VCMAX1, H_FARADD, H_FILL, H_NHIT, H_HITEND,
   H_SIG = 26,         // two words: the signature's 64-bit sum (diagnostic bit 64)
-  H_GO = 30,          // chain logic: broadcast cell (not touched by the phases)
+  H_GO = 30,          // chain logic: broadcast cells [H_GO - 2, H_GO + 1] (not touched by the phases)
   H_SCAN = 32         // block scan cells [NT/64 + 1]
 };
 constexpr int kHdrBytes = 512;
@@ -1916,7 +1916,7 @@ struct ChainArgs {
   ChainSlots slots;
   BatchWs w;
   long long timeout_ticks;
-  int nk, first_step, chunks, lds_cap, B8, queue_mode;
+  int nk, first_step, chunks, lds_cap, B8, queue_mode, lead;
 };
 
 // Range images of KITTI's size never need the pool for their scratch images; on large ones a window can exceed the
@@ -1947,63 +1947,125 @@ k_insert_chain(ChainArgs args) {
     return;
   }
   int *H = reinterpret_cast<int *>(smem);
-  // queue_mode 3 (R3D_CHAIN_QUEUE=3, not a default): the queues hold SCENES; a workgroup runs the whole chain of the
-  // scene it takes, slot after slot -- every wait finds its predecessor done, nothing is evaluated twice, the scene stays
-  // with one CU.  Config C5 (256 scans on 256 CUs): the mean pair 94 us instead of 105, but the launch 6.4 ms instead of
-  // 5.9 (the slowest scan's 50 slots in a row); with three steps in flight 9.3 ms per step instead of 9.55.
+  // queue_mode 3 / 4: the queues hold SCENES, and a scene hands out its slots one at a time (BatchWs::claim_next).  A
+  // workgroup takes a scene and claims slot after slot of it: every wait finds its predecessor done, nothing is evaluated
+  // twice, the scene stays with one CU.  Mode 4: a workgroup that finds the queues empty joins the scene with the most
+  // unclaimed slots and claims from it too (its pairs then run ahead of the owner's, like any pair of mode 2).  A pair
+  // still waits only for pairs claimed before it, by workgroups that are running.
   const int queue_mode = args.queue_mode;
-  const bool owner = queue_mode == 3;
+  const bool owner = queue_mode >= 3, help = queue_mode == 4;
   const int total = (args.B8 ? args.B8 : args.b.B) * (owner ? 1 : args.nk);
   const int home = queue_mode >= 2 ? (int)(blockIdx.x & 7) : 0;
   int turn = 0;                                              // queues this workgroup has found empty
+  int own = -1;                                              // modes 3 / 4: the scene this workgroup is claiming from
   for (;;) {
     // (the pointer is taken afresh for every pair: nothing of the arguments stays in registers across pairs)
     ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ap));
+    const ChainArgs &a = *(const ChainArgs *)ap;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const ChainArgs &a = *(const ChainArgs *)ap;
-      int id = total;
-      while (turn < (queue_mode >= 2 ? 8 : 1)) {
-        const int q = (home + turn) & 7;
-        const int n = atomicAdd(&a.w.queue_next[q], 1);
-        id = queue_mode >= 2 ? n * 8 + q : n;
-        if (id < total) break;
-        id = total;
-        ++turn;
+    if (threadIdx.x < 64) {                                    // wave 0 decides (lane 0 claims, the wave scans)
+      const int lane = (int)threadIdx.x;
+      int id = total, kk = 0;
+      auto claim = [&](int32_t *cell) -> int {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(cell, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+      };
+      if (!owner) {
+        while (turn < (queue_mode == 2 ? 8 : 1)) {
+          const int q = (home + turn) & 7;
+          const int n = claim(&a.w.queue_next[q]);
+          id = queue_mode == 2 ? n * 8 + q : n;
+          if (id < total) break;
+          id = total;
+          ++turn;
+        }
+      } else {
+        const int nk = a.nk, B = a.b.B;
+        // mode 4: the scene with the most unclaimed slots, looked up before every claim -- a workgroup whose own scene is
+        // more than `lead` slots ahead of it (or has none left) claims from that one instead
+        int behind = -1, behind_left = 0;
+        if (help) {
+          int key = -1;
+          for (int sc = lane; sc < B; sc += 64) {
+            const int left = nk - __hip_atomic_load(&a.w.claim_next[sc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int cand = left > 0 ? (left << 20) | sc : -1;
+            key = cand > key ? cand : key;
+          }
+          key = wave_max_i32(key);
+          if (key >= 0) behind = key & 0xFFFFF, behind_left = key >> 20;
+        }
+        if (own >= 0) {                                        // the next slot of the scene in hand
+          int left_own = 0;
+          if (help && behind >= 0 && behind != own)
+            left_own = nk - __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.w.claim_next[own], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          if (help && behind >= 0 && behind != own && left_own > 0 && behind_left > left_own + a.lead) {
+            const int k = claim(&a.w.claim_next[behind]);      // (own stays: the workgroup comes back to it)
+            if (k < nk) id = behind, kk = k;
+          }
+          if (id == total) {
+            const int k = claim(&a.w.claim_next[own]);
+            if (k < nk) id = own, kk = k;
+            else own = -1;
+          }
+        }
+        while (id == total && turn < 8) {                      // a scene nobody has started
+          const int q = (home + turn) & 7;
+          const int sc = claim(&a.w.queue_next[q]) * 8 + q;
+          if (sc >= total) {
+            ++turn;
+            continue;
+          }
+          if (sc >= B) continue;                               // (the batch rounded up to eight)
+          const int k = claim(&a.w.claim_next[sc]);
+          if (k < nk) own = id = sc, kk = k;
+        }
+        for (int tries = 0; help && id == total && tries < 64; ++tries) {   // nothing of its own: join the scene furthest behind
+          if (tries) {
+            int key = -1;
+            for (int sc = lane; sc < B; sc += 64) {
+              const int left = nk - __hip_atomic_load(&a.w.claim_next[sc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const int cand = left > 0 ? (left << 20) | sc : -1;
+              key = cand > key ? cand : key;
+            }
+            key = wave_max_i32(key);
+            behind = key >= 0 ? key & 0xFFFFF : -1;
+          }
+          if (behind < 0) break;                               // every slot of every scene is claimed
+          const int k = claim(&a.w.claim_next[behind]);
+          if (k < nk) own = id = behind, kk = k;
+        }
       }
-      H[H_GO] = id;
-      H[H_GO + 1] = turn;
+      if (lane == 0) {
+        H[H_GO] = id;
+        H[H_GO + 1] = turn;
+        H[H_GO - 2] = kk;
+        H[H_GO - 1] = own;
+      }
     }
     __syncthreads();
     const int taken = uni(H[H_GO]);
     turn = uni(H[H_GO + 1]);
+    own = uni(H[H_GO - 1]);
     if (taken >= total) return;
-    for (int ko = 0; ko < (owner ? args.nk : 1); ++ko) {
-      if (ko) {
-        __syncthreads();                                       // (the next slot's set-up writes the header the last one may still read)
-        ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(ap));
-      }
-      const ChainArgs &a = *(const ChainArgs *)ap;
-      const int pair_id = owner ? ko * a.B8 + taken : taken;
+    const int pair_id = owner ? uni(H[H_GO - 2]) * a.B8 + taken : taken;
 #ifdef R3D_STAMPS
-      const int k_ = a.B8 ? pair_id / a.B8 : pair_id % a.nk, s_ = a.B8 ? pair_id % a.B8 : pair_id / a.nk;
-      long long *cell = s_ < a.b.B ? reinterpret_cast<long long *>(a.b.out_xyzi + (int64_t)s_ * a.b.cap * 4) + k_ * 32 : nullptr;
-      if (cell && threadIdx.x == 0) cell[28] = wall_clock64();   // this workgroup takes the pair
+    const int k_ = a.B8 ? pair_id / a.B8 : pair_id % a.nk, s_ = a.B8 ? pair_id % a.B8 : pair_id / a.nk;
+    long long *cell = s_ < a.b.B ? reinterpret_cast<long long *>(a.b.out_xyzi + (int64_t)s_ * a.b.cap * 4) + k_ * 32 : nullptr;
+    if (cell && threadIdx.x == 0) cell[28] = wall_clock64();   // this workgroup takes the pair
 #endif
-      const int again = chain_pair<NT, false, NT != 1024>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks,
-                                                          a.B8, smem, pair_id);
+    const int again = chain_pair<NT, false, NT != 1024>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8,
+                                                        smem, pair_id);
 #ifdef R3D_STAMPS
-      if (cell && threadIdx.x == 0) cell[29] = uni(again) ? wall_clock64() : 0;   // the LDS flavour turned the pair down here
+    if (cell && threadIdx.x == 0) cell[29] = uni(again) ? wall_clock64() : 0;   // the LDS flavour turned the pair down here
 #endif
-      if (NT == 1024 && uni(again))
-        chain_pair<NT, true, true>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8, smem, pair_id);
+    if (NT == 1024 && uni(again))
+      chain_pair<NT, true, true>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8, smem, pair_id);
 #ifdef R3D_STAMPS
-      __syncthreads();
-      if (cell && threadIdx.x == 0) cell[30] = wall_clock64();   // ... and is done with it
+    __syncthreads();
+    if (cell && threadIdx.x == 0) cell[30] = wall_clock64();   // ... and is done with it
 #endif
-    }
   }
 }
 
@@ -2052,6 +2114,7 @@ __global__ void k_chain_init(r3d_batch_t b, BatchWs w, int nk) {
     for (int q = 0; q < 16; ++q) w.queue_next[q] = 0;
   }
   w.chain_progress[s] = 0;
+  w.claim_next[s] = 0;
   w.n_total0[s] = b.n_total[s];
   w.defer_from[s] = nk;
 }
@@ -2085,7 +2148,7 @@ static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlo
   // per device, every call: the attribute belongs to the current device's copy of the kernel
   R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_chain<NT, QUEUE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  const int total = (B8 ? B8 : b.B) * (queue_mode == 3 ? 1 : nk);
+  const int total = (B8 ? B8 : b.B) * nk;                     // (modes 3 / 4: as many workgroups as pairs at most, too)
   int grid = total;
   if (QUEUE && queue_mode) {
     // how many workgroups of this shape the device keeps resident: asked once per (device, LDS size) and kernel flavour
@@ -2115,6 +2178,8 @@ static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlo
   args.w = w;
   args.timeout_ticks = timeout_ticks;
   args.nk = nk, args.first_step = first_step, args.chunks = chunks_of(b), args.lds_cap = lds, args.B8 = B8, args.queue_mode = queue_mode;
+  static const int lead_env = env_int("R3D_CHAIN_LEAD", 4);
+  args.lead = lead_env;
   hipLaunchKernelGGL((k_insert_chain<NT, QUEUE>), dim3(grid), dim3(NT), lds, st, args);
   R3D_LAUNCHED("k_insert_chain");
   return R3D_OK;
@@ -2127,12 +2192,12 @@ static int launch_chain(const r3d_batch_t &b, const BatchWs &w, const ChainSlots
   static const bool scene_major = getenv("R3D_CHAIN_ORDER") && std::string(getenv("R3D_CHAIN_ORDER")) == "scene";
   const int B8 = scene_major ? 0 : (b.B + 7) & ~7;            // a scene's slots on one residue of the pair id mod 8
   // R3D_CHAIN_QUEUE: 0 one workgroup per pair; 1 resident workgroups that take pairs off one queue; 2 ... off a queue per
-  // XCD; 3 ... whole scenes off a queue per XCD (see k_insert_chain).  Default: 2 on large range images (config C5:
-  // 6.4 -> 4.8 ms per 128 scans x 50 slots), 0 otherwise.
+  // XCD; 3 ... scenes off a queue per XCD, slot after slot; 4 as 3, and idle workgroups join the scenes that are behind
+  // (see k_insert_chain).  Default: 2 on large range images (config C5: 6.4 -> 4.8 ms per 128 scans x 50 slots), 0 otherwise.
   static const int queue_env = env_int("R3D_CHAIN_QUEUE", -1);
   const bool large = (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN;
   int queue_mode = queue_env >= 0 ? queue_env : (large ? 2 : 0);
-  if (scene_major && queue_mode >= 2) queue_mode = 1;
+  if ((scene_major || B8 >= (1 << 20)) && queue_mode >= 2) queue_mode = 1;
   return queue_mode ? launch_chain_q<NT, true>(b, w, sl, nk, first_step, lds, timeout_ticks, B8, queue_mode, st)
                     : launch_chain_q<NT, false>(b, w, sl, nk, first_step, lds, timeout_ticks, B8, 0, st);
 }
