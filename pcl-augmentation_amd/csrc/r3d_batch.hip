@@ -449,6 +449,33 @@ k_fix_boxes(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w,
   }
 }
 
+// The super-boxes of a freshly projected scene: one wave per 64 chunks, a chunk per lane.
+__global__ void __launch_bounds__(kPT)
+k_super_rows(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int chunks) {
+  int cnt = *count;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_sup = (chunks + 63) >> 6;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    const int s = list[li];
+    const int n_chunks = (b.n_total[s] + 63) >> 6;
+    for (int sp = blockIdx.x * (kPT / 64) + wave; sp < n_sup; sp += gridDim.x * (kPT / 64)) {
+      const int c = (sp << 6) + lane;
+      int r0 = 0x7FFFFFFF, r1 = -1;
+      if (c < n_chunks) {
+        const unsigned long long bx = w.chunk_box[(int64_t)s * chunks + c];
+        const int a = (int)(bx & 0xFFFF), z = (int)((bx >> 16) & 0xFFFF);
+        if (a <= z) r0 = a, r1 = z;                            // (an empty box: rows 0xFFFF .. 0)
+      }
+      r0 = wave_min_i32(r0);
+      r1 = wave_max_i32(r1);
+      if (lane == 0) {
+        w.super_rows[((int64_t)s * n_sup + sp) * 2 + 0] = r0;
+        w.super_rows[((int64_t)s * n_sup + sp) * 2 + 1] = r1;
+      }
+    }
+  }
+}
+
 // Survivors in original order (insertion.py:472-473 applied once for all steps), float4 + label
 // straight into the output arrays.  A wave owns 8 consecutive chunks (512 points) of its block's tile and
 // needs nobody else: its output offset is the sum of the living counts of the scene's preceding tiles
@@ -638,6 +665,9 @@ static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_
                      count, w, chunks_of(b));
   hipLaunchKernelGGL(k_project_slow, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_fix_boxes, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w, chunks_of(b));
+  if (supers_on(b, chunks_of(b)))
+    hipLaunchKernelGGL(k_super_rows, dim3((supers_of(b) + kPT / 64 - 1) / (kPT / 64), rows), dim3(kPT), 0, st, b, list, count, w,
+                       chunks_of(b));
   R3D_LAUNCHED("reproject kernels");
   return R3D_OK;
 }

@@ -43,6 +43,8 @@ struct BatchWs {
   int32_t *n_total0;            // [B] n_total when the running k_insert_chain was launched
   int32_t *defer_from;          // [B] first slot of the launch left to k_insert_big (n_slots: none)
   int32_t *claim_next;          // [B] next slot of the scene a workgroup of k_insert_chain may claim (queue modes 3 / 4)
+  int32_t *super_rows;          // [B*supers*2] first / last row over the boxes of 64 consecutive chunks (clouds of kSuperMinChunks
+                                // chunks and more: the chunk list looks at a chunk's box only when its super-box reaches the window)
   int32_t *recs;                // [B*kMaxChain*kRecInts] what every finished slot of the launch publishes
   unsigned char *glist;         // [B*chunks*kEntry] k_insert_big's chunk lists, one area per scene (a pair of k_insert_chain whose
                                 // list exceeds its LDS takes room from the pool)
@@ -58,6 +60,19 @@ struct BatchWs {
 
 inline int tiles_of(const r3d_batch_t &b) { return (int)((b.cap + kTile - 1) / kTile); }
 inline int chunks_of(const r3d_batch_t &b) { return (int)((b.cap + 63) / 64); }
+// Super-boxes: the rows of 64 consecutive chunks (4096 points: a ring or two of a scan in ring order, every column).  Kept
+// for clouds of kSuperMinChunks chunks and more (and under diagnostic bit 256): written by k_super_rows after every
+// projection of the scene and by rebase_scene, widened by the commit of an insert for the chunks it appends to.
+#ifndef R3D_SUPER_MIN_CHUNKS
+#define R3D_SUPER_MIN_CHUNKS 4096
+#endif
+constexpr int kSuperMinChunks = R3D_SUPER_MIN_CHUNKS;
+constexpr int kDbgSuper = 256;
+inline int supers_of(const r3d_batch_t &b) { return (chunks_of(b) + 63) / 64; }
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline bool supers_on(const r3d_batch_t &b, int chunks) { return chunks >= kSuperMinChunks || (b.reserved & kDbgSuper); }
 
 inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   BatchWs w;
@@ -84,6 +99,7 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.n_total0 = c.take<int32_t>((size_t)b.B);
   w.defer_from = c.take<int32_t>((size_t)b.B);
   w.claim_next = c.take<int32_t>((size_t)b.B);
+  w.super_rows = c.take<int32_t>((size_t)b.B * supers_of(b) * 2);
   w.recs = c.take<int32_t>((size_t)b.B * kMaxChain * kRecInts);
   w.glist = c.take<unsigned char>((size_t)b.B * chunks_of(b) * kEntry);
   // The launch's pool: depth tiles, candidate lists, chunk lists and scratch images of the pairs whose window exceeds a
@@ -373,6 +389,24 @@ __device__ __forceinline__ void rebase_scene(const r3d_batch_t &b, const BatchWs
   }
   if (flags) atomicOr(&b.status[s], flags);
   phase_sync();
+  // ... and the super-boxes over them (a chunk without a living point has left an empty box: rows 0xFFFF .. 0)
+  if (supers_on(b, chunks)) {
+    const int n_sup = (chunks + 63) >> 6, n_chunks = (n + 63) >> 6;
+    for (int sp = tid; sp < n_sup; sp += NT) {
+      int r0 = 0x7FFFFFFF, r1 = -1;
+      for (int c = sp << 6; c < ((sp + 1) << 6) && c < n_chunks; ++c) {
+        const unsigned long long bx = w.chunk_box[(int64_t)s * chunks + c];
+        const int a = (int)(bx & 0xFFFF), z = (int)((bx >> 16) & 0xFFFF);
+        if (a <= z) {
+          r0 = a < r0 ? a : r0;
+          r1 = z > r1 ? z : r1;
+        }
+      }
+      w.super_rows[((int64_t)s * n_sup + sp) * 2 + 0] = r0;
+      w.super_rows[((int64_t)s * n_sup + sp) * 2 + 1] = r1;
+    }
+    phase_sync();
+  }
 }
 #endif  // __HIPCC__
 

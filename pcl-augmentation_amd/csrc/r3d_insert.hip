@@ -719,20 +719,26 @@ struct Ins {
   }
 
   // The chunks that can hold a point of the window: bounding box touches it, somebody alive (4 chunks
-  // per thread in flight).
-  __device__ __forceinline__ void build_list(const unsigned long long *boxes, const unsigned long long *alive, int n_chunks) {
+  // per thread in flight).  With super-boxes (sup != nullptr: `nsup` of them reach the window's rows, their numbers in
+  // `sup`) only the chunks of those are looked at.
+  __device__ __forceinline__ void build_list(const unsigned long long *boxes, const unsigned long long *alive, int n_chunks,
+                                             const uint16_t *sup = nullptr, int nsup = 0) {
     constexpr int kU = 4;
-    for (int c0 = tid; c0 < n_chunks; c0 += kU * NT) {
+    const int n_items = sup ? nsup << 6 : n_chunks;
+    for (int c0 = tid; c0 < n_items; c0 += kU * NT) {
       unsigned long long bx[kU], aw[kU];
+      int cc[kU];
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         int c = c0 + u * NT;
+        if (sup) c = c < n_items ? ((int)sup[c >> 6] << 6) + (c & 63) : n_chunks;
+        cc[u] = c;
         bx[u] = c < n_chunks ? boxes[c] : 0xFFFFull;          // empty box
         aw[u] = c < n_chunks ? __hip_atomic_load(&alive[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
       }
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        int c = c0 + u * NT;
+        int c = cc[u];
         int left = n_base - (c << 6);                       // points of the chunk below the base count
         unsigned long long a = aw[u];
         if (left < 64) a = left > 0 ? a & ((1ull << left) - 1ull) : 0ull;
@@ -748,6 +754,16 @@ struct Ins {
           if (slot < list_cap) set_entry(slot, a, (uint32_t)c, (uint32_t)rmin | ((uint32_t)rmax << 16));
         }
       }
+    }
+  }
+
+  // The super-boxes (64 chunks each) whose rows reach the window's: their numbers into `sup`, the count through H_CARRY.
+  __device__ __forceinline__ void list_supers(uint16_t *sup, int n_chunks) {
+    const int n_sup_all = (chunks + 63) >> 6, n_sup = (n_chunks + 63) >> 6;
+    const int2 *rows2 = reinterpret_cast<const int2 *>(w.super_rows) + (int64_t)s * n_sup_all;
+    for (int sp = tid; sp < n_sup; sp += NT) {
+      const int2 r = rows2[sp];
+      if (r.x <= win.r_hi && r.y >= win.r_lo) sup[atomicAdd(&H[H_CARRY], 1)] = (uint16_t)sp;
     }
   }
 
@@ -1020,6 +1036,7 @@ struct Ins {
 
     if (tid == 0) {
       H[H_NLIST] = 0;
+      H[H_CARRY] = 0;
       H[H_NVIS] = 0;
       H[H_REBASE] = 0;
       H[H_VRMIN] = H[H_VCMIN0] = H[H_VCMIN1] = 0x7FFFFFFF;
@@ -1029,7 +1046,21 @@ struct Ins {
 
     STAMP(6);
     // -- 6. the chunks that can hold a point of the window --------------------------------------------
-    build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, n_chunks);
+    // large clouds: first the super-boxes that reach the window's rows (their numbers in the room a band is given
+    // later, in front of the list), then the boxes of their chunks only
+    uint16_t *s_sup = nullptr;
+    int nsup = 0;
+    {
+      const int n_sup = (n_chunks + 63) >> 6;
+      const int room = glist ? lds_end - carve : min_band;
+      if (supers_on(b, chunks) && n_sup <= 0xFFFF && n_sup * 2 <= room) {
+        s_sup = reinterpret_cast<uint16_t *>(smem + carve);
+        list_supers(s_sup, n_chunks);
+        __syncthreads();
+        nsup = uni(H[H_CARRY]);
+      }
+    }
+    build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, n_chunks, s_sup, nsup);
     __syncthreads();
     nlist = uni(H[H_NLIST]);
     if (nlist > list_cap) {                                   // does not fit the LDS: once more, into global memory
@@ -1045,7 +1076,7 @@ struct Ins {
       glist = true;
       list_cap = force_glist ? n_chunks : nlist + 8;
       __syncthreads();
-      build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, n_chunks);
+      build_list(w.chunk_box + (int64_t)s * chunks, w.alive + (int64_t)s * chunks, n_chunks, s_sup, nsup);
       __syncthreads();
       // (alive bits only ever clear: a second pass lists at most the chunks of the first)
       nlist = uni(H[H_NLIST]) < list_cap ? uni(H[H_NLIST]) : list_cap;
@@ -1452,6 +1483,11 @@ struct Ins {
         unsigned long long living = __ballot(valid);
         if (lane == 0) {
           w.chunk_box[(int64_t)s * chunks + ci] = packed;
+          if (supers_on(b, chunks) && (int)(packed & 0xFFFF) <= (int)((packed >> 16) & 0xFFFF)) {
+            int32_t *sr = w.super_rows + ((int64_t)s * ((chunks + 63) >> 6) + (ci >> 6)) * 2;
+            atomicMin(&sr[0], (int)(packed & 0xFFFF));
+            atomicMax(&sr[1], (int)((packed >> 16) & 0xFFFF));
+          }
           if (old_chunk) atomicOr(&alive[ci], living);
           else alive[ci] = living;
           atomicAdd(&tile_alive[(ci << 6) / kTile], __popcll(living));

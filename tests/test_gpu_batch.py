@@ -571,13 +571,14 @@ def test_c5_scan_on_the_proposed_448x2880_grid(P, synth, monkeypatch):
     _check_scene(res[0], vb, lb, cb)
 
 
-@pytest.mark.parametrize("debug", [2, 4, 8, 6, 32, 64, 96, 128, 160, 132])
+@pytest.mark.parametrize("debug", [2, 4, 8, 6, 32, 64, 96, 128, 160, 132, 256, 260, 288, 264])
 def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
     """The insert kernel's other routes, forced with the descriptor's diagnostic bits: 2 = never speculate (every slot
     waits for its predecessor first), 4 = the window's depth tile built and evaluated in bands of at most 3 candidate
     rows, 32 = tile and candidate list in the global pool, 8 = every pair left to k_insert_big (one 1024-thread workgroup
     per scene), 128 = the kill masks from the pixel ids in global memory (no hits kept in LDS), 64 = every speculative
-    evaluation done again after its predecessors and compared (alone and with pooled tiles); all must give the bytes of
+    evaluation done again after its predecessors and compared (alone and with pooled tiles), 256 = the chunk list through
+    super-boxes as on clouds of 260 000 points and more (alone, with bands, pooled tiles, k_insert_big); all must give the bytes of
     the oracle chain, through insert_many and slot by slot, and the comparison of bit 64 must never differ."""
     import torch
     cases = [_random_case(synth, 11), _random_case(synth, 12, 32, 900, shuffle=True), _random_case(synth, 13, 64, 500)]
