@@ -647,7 +647,13 @@ __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_quer
 // Points per thread with which the sample chain takes a sample of m points.
 __host__ __device__ inline int chain_class(int m) {
   int need = (m + kCB - 1) / kCB;
-  return need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16;
+  return need <= 4 ? 4 : need <= 8 ? 8 : 16;
+}
+// threads of the sample chain's workgroup that take part: whole waves, PPT points per lane
+template <int PPT>
+__device__ __forceinline__ int act_threads(int m) {
+  int t = (((m + PPT - 1) / PPT) + 63) & ~63;
+  return t < 64 ? 64 : (t > kCB ? kCB : t);
 }
 
 // ---- k_place_sample_chain: the loop of find_spot.py:228-269 on the sample's points ---------------
@@ -687,12 +693,17 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
   int bad_input = 0;
   float rho2 = 0.f, ext2 = 0.f;                     // largest distance^2 from the sensor / from the box centre
   const double ax = qq.anno[0], ay = qq.anno[1];
+  // The 360 steps are a chain (a step's height correction moves every point for the later ones), and every step has the
+  // workgroup agree once or twice: its cost is the barrier among the waves, not the arithmetic.  So only as many waves
+  // stay as the sample needs at PPT points per lane -- one wave for a pedestrian of 250 points: no barrier left at all --
+  // and the others leave once the tables are staged (a barrier waits for the surviving waves only).
+  const int T = act_threads<PPT>(m);
 #pragma unroll
   for (int u = 0; u < PPT; ++u) {
-    int i = tid + u * kCB;
+    int i = tid + u * T;
     x[u] = y[u] = z[u] = 0.0;
-    valid[u] = i < m;
-    if (i < m) {
+    valid[u] = i < m && tid < T;
+    if (valid[u]) {
       x[u] = in_global(qq.sample)[(size_t)i * 5 + 0];
       y[u] = in_global(qq.sample)[(size_t)i * 5 + 1];
       z[u] = in_global(qq.sample)[(size_t)i * 5 + 2];
@@ -779,6 +790,7 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
     s_allowed[wi] = bits;
   }
   __syncthreads();
+  if (tid >= T) return;
   double anno_z = qq.anno[2];
   int n_out = 0;
   for (int r = 0; r < kRot; ++r) {
@@ -862,7 +874,7 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
         double *out = cand_q + (size_t)j * cand_stride;
 #pragma unroll
         for (int u = 0; u < PPT; ++u) {
-          int i = tid + u * kCB;
+          int i = tid + u * T;
           if (!valid[u]) continue;
           out[(size_t)i * 5 + 0] = x[u];
           out[(size_t)i * 5 + 1] = y[u];
@@ -877,8 +889,8 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
   }
   __syncthreads();
   // the annotation of a possible placement: centre (cx, cy, road level of that step), orientation
-  for (int r = tid; r < kRot; r += kCB) flags[(size_t)q * kRot + r] = s_flags[r];
-  for (int j = tid; j < n_out; j += kCB) {
+  for (int r = tid; r < kRot; r += T) flags[(size_t)q * kRot + r] = s_flags[r];
+  for (int j = tid; j < n_out; j += T) {
     int r = s_rot[j];
     size_t o = (size_t)q * kRot + r, oo = (size_t)q * kRot + j;
     rot_out[oo] = r + 1;
@@ -898,8 +910,6 @@ __global__ __launch_bounds__(kCB) void k_place_sample_chain(const r3d_place_quer
                                                            int32_t *status) {
   __shared__ ChainLds lds;
   switch (chain_class(Q[blockIdx.x].m)) {
-    case 1: sample_chain<1>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
-    case 2: sample_chain<2>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
     case 4: sample_chain<4>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
     default: break;
   }
