@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define R3D_VERSION 0x00020002   /* 2.2: r3d_batch_t.pix / far_pix hold (row << 16) | column; r3d_batch_debug_trace is gone; r3d_build_info */
+#define R3D_VERSION 0x00020003   /* 2.3: min_points < 0 (the state a rejected candidate leaves), r3d_batch_adopt_rejected; 2.2: r3d_batch_t.pix / far_pix
+                                  * hold (row << 16) | column; r3d_batch_debug_trace is gone; r3d_build_info */
 
 #define R3D_NUMROW 112        /* insertion.py:22 */
 #define R3D_NUMCOLUMN 1440    /* insertion.py:23; the pixel id always multiplies by THIS (:116,:127) */
@@ -207,7 +208,16 @@ int r3d_batch_begin_f64(const r3d_batch_t *b, const double *rows5, const int32_t
  * Scenes with active[s] == 0 (nullable = all active) or an empty sample are skipped.
  * n_visible[s] = len(visible_sample); accepted[s] = 1 iff n_visible >= max(1, min_points[s])
  * (:511-517), in which case the scene is updated exactly as :526 would.  `step` is 1-based and
- * must increase by one per call of an insert slot that may accept. */
+ * must increase by one per call of an insert slot that may accept.
+ *
+ * min_points[s] < 0: the state the reference's driver is left with after a REJECTED candidate -- the scene without the
+ * points the candidate covers, and without the candidate (insertion.py:468-471 run, :526 not; the copy stays bound to
+ * scene_pcl until the next candidate restores the backup, :453, so the next sample's placement search :433 sees it, and
+ * when no further candidate comes the next fill_spherical :373 or save_data does).  n_visible[s] as always, accepted[s] =
+ * 0; the scene itself is NOT changed: the copy is kept beside it (alive bits only), r3d_batch_export_rows returns it
+ * instead of the scene until the scene's next evaluated candidate, and r3d_batch_adopt_rejected makes it the scene.  A
+ * driver that wants the reference's behaviour replays a sample's last candidate this way once it has been rejected
+ * with n_visible > 0 (INTEGRATION.md par. 6). */
 int r3d_batch_insert(const r3d_batch_t *b, const double *samples5, const int64_t *sample_off,
                      const int32_t *min_points, const int32_t *active, int32_t step,
                      int32_t *n_visible, int32_t *accepted, void *stream);
@@ -237,6 +247,11 @@ int r3d_batch_insert_many(const r3d_batch_t *b, int32_t n_slots, const double *c
  * surviving original points in their order, then the surviving inserted points with their float64
  * coordinates -- and n_rows int32 [B].  Does not change the batch; may be called between inserts. */
 int r3d_batch_export_rows(const r3d_batch_t *b, double *rows4, int32_t *n_rows, void *stream);
+
+/* The copy a rejected candidate has left (min_points < 0 above) becomes the scene, for the scenes that hold one and
+ * have active[s] != 0 (nullable = all): its bounds and pixels are computed afresh as the next pass of the reference's
+ * while-loop would (insertion.py:373-375); b->rebase[s] counts it.  Scenes without such a copy are left alone. */
+int r3d_batch_adopt_rejected(const r3d_batch_t *b, const int32_t *active, void *stream);
 
 /* One streaming kernel of the batched path on its own, all scenes, for timing it in isolation
  * with HIP events (bench.py) and for rocprofv3: the state must be the one r3d_batch_begin

@@ -103,6 +103,7 @@ _SIGNATURES = {
     "r3d_batch_debug_counters": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int32, _P]),
     "r3d_batch_insert_many": (C.c_int, [C.POINTER(BatchDesc), C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "r3d_batch_export_rows": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P]),
+    "r3d_batch_adopt_rejected": (C.c_int, [C.POINTER(BatchDesc), _P, _P]),
     "r3d_places_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "r3d_cut_boxes_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "r3d_cut_boxes": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int64,

@@ -286,6 +286,10 @@ class SceneBatch:
 
     @_lib.on_own_device
     def insert(self, samples, min_points, active=None, new_slot=True):
+        """One candidate per scene (insertion.py:453-526): (n_visible, accepted) as arrays.  ``min_points[s] < 0`` replays a
+        candidate that HAS been rejected the way the reference's driver is left with it -- the scene without the points the
+        candidate covers, without the candidate (:468-471, not :526): the scene is not changed, ``export_rows`` returns that
+        copy until the scene's next candidate, ``adopt_rejected`` makes it the scene."""
         torch = self.torch
         s5, off = self.pack_samples(samples)
         mp = torch.from_numpy(np.asarray(min_points, dtype=np.int32)).to(self.device)
@@ -306,6 +310,19 @@ class SceneBatch:
                                                   C.c_void_p(self.n_rows.data_ptr()), _lib.stream_ptr()),
                    "r3d_batch_export_rows")
         return self.rows4, self.n_rows
+
+    @_lib.on_own_device
+    def adopt_rejected(self, active=None):
+        """The copy a rejected candidate has left (``insert`` with ``min_points < 0``) becomes the scene, where there is one
+        (and ``active[s]``): what the reference's driver goes on with when no further candidate restores the backup
+        (insertion.py:453, then :373 or save_data)."""
+        torch = self.torch
+        act = None
+        if active is not None:
+            act = active if hasattr(active, "data_ptr") else torch.from_numpy(np.asarray(active, dtype=np.int32)).to(self.device)
+        _lib.check(self.lib.r3d_batch_adopt_rejected(C.byref(self.desc), C.c_void_p(act.data_ptr() if act is not None else 0),
+                                                     _lib.stream_ptr()), "r3d_batch_adopt_rejected")
+        self._keep_adopt = act
 
     @_lib.on_own_device
     def finish(self, check_cols=5):

@@ -36,6 +36,7 @@ __global__ void k_begin_init(r3d_batch_t b, const int32_t *n_points, BatchWs w, 
   b.status[s] = st;
   b.n_out[s] = 0;
   w.all_list[s] = s;
+  w.shadow_valid[s] = 0;
   w.qkeys[2 * s + 0] = ~0ull;   // running min of z/r
   w.qkeys[2 * s + 1] = 0ull;    // running max of z/r
 }
@@ -497,15 +498,19 @@ k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
     const int n = b.n_total[s];
     const int t0 = blockIdx.x * kTile;
     if (t0 >= n) continue;
+    // (r3d_batch_export_rows shows the copy a rejected candidate has left, while there is one: BatchWs::shadow_valid)
+    const bool shadow = ROWS4 && w.shadow_valid[s] != 0;
+    const int32_t *tile_alive = (shadow ? w.tile_shadow : w.tile_alive) + (int64_t)s * tiles;
+    const unsigned long long *alive = (shadow ? w.alive_shadow : w.alive) + (int64_t)s * chunks;
     int pre = 0;
-    for (int t = lane; t < (int)blockIdx.x; t += 64) pre += w.tile_alive[(int64_t)s * tiles + t];
+    for (int t = lane; t < (int)blockIdx.x; t += 64) pre += tile_alive[t];
     const int first = wave * kWaveChunks;                    // my first chunk within the tile
     unsigned long long m = 0ull;                             // lane c: alive word of chunk c of the tile
-    if (lane < first + kWaveChunks && t0 + lane * 64 < n) m = w.alive[(int64_t)s * chunks + (t0 >> 6) + lane];
+    if (lane < first + kWaveChunks && t0 + lane * 64 < n) m = alive[(t0 >> 6) + lane];
     if (lane < first) pre += __popcll(m);
     int run = wave_sum_i32(pre);
     if (threadIdx.x == 0 && t0 + kTile >= n)                 // the scene's last tile publishes the total
-      (ROWS4 ? n_rows : b.n_out)[s] = run + w.tile_alive[(int64_t)s * tiles + blockIdx.x];
+      (ROWS4 ? n_rows : b.n_out)[s] = run + tile_alive[blockIdx.x];
     const int n_head = b.n_head[s];
     const float4 *__restrict__ src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
     float4 *__restrict__ dst = reinterpret_cast<float4 *>(b.out_xyzi) + (int64_t)s * b.cap;
@@ -575,6 +580,27 @@ k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
 #undef R3D_LOAD
 #undef R3D_STORE
     }
+  }
+}
+
+// r3d_batch_adopt_rejected: the copy a rejected candidate has left becomes the scene (the reference's driver goes on
+// with it when no further candidate restores the backup: SS insertion.py:453, :468-471, then :373 / save_data).  One
+// workgroup per scene: alive bits and tile counts from the shadow, then the bounds and every living point's pixel
+// afresh, as the next fill_spherical / geometrical_front_view would (a rebase that was not needed changes nothing).
+constexpr int kAdoptNT = 1024;
+__global__ void __launch_bounds__(kAdoptNT)
+k_adopt_shadow(r3d_batch_t b, BatchWs w, const int32_t *active, int chunks) {
+  __shared__ unsigned long long s_min[kAdoptNT / 64], s_max[kAdoptNT / 64];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  if (!w.shadow_valid[s] || (active && !active[s])) return;
+  const int tiles = (int)((b.cap + kTile - 1) / kTile), n_chunks = (b.n_total[s] + 63) >> 6;
+  for (int c = tid; c < n_chunks; c += kAdoptNT) w.alive[(int64_t)s * chunks + c] = w.alive_shadow[(int64_t)s * chunks + c];
+  for (int t = tid; t < tiles; t += kAdoptNT) w.tile_alive[(int64_t)s * tiles + t] = w.tile_shadow[(int64_t)s * tiles + t];
+  phase_sync();
+  rebase_scene<kAdoptNT>(b, w, chunks, s, s_min, s_max);
+  if (tid == 0) {
+    w.shadow_valid[s] = 0;
+    b.rebase[s] += 1;
   }
 }
 
@@ -753,6 +779,15 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream) {
       return fail(R3D_E_ARG, "batch_launch_one: unknown kernel id");
   }
   R3D_LAUNCHED("batch_launch_one");
+  return R3D_OK;
+}
+
+int r3d_batch_adopt_rejected(const r3d_batch_t *b, const int32_t *active, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  BatchWs w = carve_batch(*b, b->workspace);
+  hipLaunchKernelGGL(k_adopt_shadow, dim3(b->B), dim3(kAdoptNT), 0, (hipStream_t)stream, *b, w, active, chunks_of(*b));
+  R3D_LAUNCHED("k_adopt_shadow");
   return R3D_OK;
 }
 

@@ -43,6 +43,9 @@ struct BatchWs {
   int32_t *n_total0;            // [B] n_total when the running k_insert_chain was launched
   int32_t *defer_from;          // [B] first slot of the launch left to k_insert_big (n_slots: none)
   int32_t *claim_next;          // [B] next slot of the scene a workgroup of k_insert_chain may claim (queue modes 3 / 4)
+  unsigned long long *alive_shadow; // [B*chunks] the alive bits of the culled copy a REJECTED candidate leaves (min_points < 0)
+  int32_t *tile_shadow;         // [B*tiles] ... and its living points per tile
+  int32_t *shadow_valid;        // [B] 1: r3d_batch_export_rows shows that copy; r3d_batch_adopt_rejected makes it the scene
   int32_t *super_rows;          // [B*supers*2] first / last row over the boxes of 64 consecutive chunks (clouds of kSuperMinChunks
                                 // chunks and more: the chunk list looks at a chunk's box only when its super-box reaches the window)
   int32_t *recs;                // [B*kMaxChain*kRecInts] what every finished slot of the launch publishes
@@ -100,6 +103,9 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.defer_from = c.take<int32_t>((size_t)b.B);
   w.claim_next = c.take<int32_t>((size_t)b.B);
   w.super_rows = c.take<int32_t>((size_t)b.B * supers_of(b) * 2);
+  w.alive_shadow = c.take<unsigned long long>((size_t)b.B * chunks_of(b));
+  w.tile_shadow = c.take<int32_t>((size_t)b.B * tiles);
+  w.shadow_valid = c.take<int32_t>((size_t)b.B);
   w.recs = c.take<int32_t>((size_t)b.B * kMaxChain * kRecInts);
   w.glist = c.take<unsigned char>((size_t)b.B * chunks_of(b) * kEntry);
   // The launch's pool: depth tiles, candidate lists, chunk lists and scratch images of the pairs whose window exceeds a

@@ -284,6 +284,7 @@ struct Ins {
   bool flat;                              // gather_flat does the gather
   bool lazy_root;                         // the pooled tile keeps squared depths (tile_key)
   bool accept;
+  bool cull_only;             // min_points < 0: the state a REJECTED candidate leaves (see commit)
   FastDiv by_W;
 
   // k_insert_big passes force_glist: its chunk lists live in the scene's global area (w.glist); a chain pair whose
@@ -1292,7 +1293,7 @@ struct Ins {
               v_n += p1 - p0;
               for (int p = p0; p < p1; ++p) {
                 int j = s_F[p];
-                if ((s_oob[j >> 5] >> (j & 31)) & 1u) atomicOr(&H[H_REBASE], 1);   // bounds move: new extreme elevation
+                if (!cull_only && ((s_oob[j >> 5] >> (j & 31)) & 1u)) atomicOr(&H[H_REBASE], 1);   // bounds move: new extreme elevation
               }
             }
           }
@@ -1317,7 +1318,7 @@ struct Ins {
     STAMP(10);
     // -- 10. accept test (insertion.py:511-517); the visible points in order; who dies -----------------
     nvis = uni(H[H_NVIS]);
-    accept = nvis > 0 && nvis >= need;
+    accept = nvis > 0 && (cull_only || nvis >= need);          // (cull_only: the covered scene points are wanted, see commit)
     if (accept) {
       // the visible points in sorted order: thread t takes the sorted points [t*L, t*L + L), one block scan
       {
@@ -1433,14 +1434,42 @@ struct Ins {
     const int tiles = (int)((b.cap + kTile - 1) / kTile);
     n_total_after = n_total;
     flags_out = 0;
-    if (accept && ((int64_t)n_total + nvis > b.cap || (int64_t)n_log + nvis > b.log_cap)) {
+    if (accept && !cull_only && ((int64_t)n_total + nvis > b.cap || (int64_t)n_log + nvis > b.log_cap)) {
       accept = false;
       if (tid == 0) atomicOr(&b.status[s], R3D_S_CAPACITY);
     }
     if (tid == 0 && H[H_FLAGS]) atomicOr(&b.status[s], H[H_FLAGS]);
-    if (!accept) return false;
     unsigned long long *alive = w.alive + (int64_t)s * chunks;
     int32_t *tile_alive = w.tile_alive + (int64_t)s * tiles;
+    // min_points < 0: what the reference's driver is left with after a REJECTED candidate -- the scene without the points
+    // the candidate covers and without the candidate (insertion.py:468-471 without :526; the copy stays bound to scene_pcl
+    // until the next candidate restores the backup, :453).  It goes into a SHADOW of the alive bits: the scene itself is
+    // untouched, r3d_batch_export_rows shows the copy, r3d_batch_adopt_rejected makes it the scene.
+    if (cull_only) {
+      unsigned long long *sh = w.alive_shadow + (int64_t)s * chunks;
+      int32_t *ts = w.tile_shadow + (int64_t)s * tiles;
+      const int n_chunks = (n_total + 63) >> 6;
+      for (int c = tid; c < n_chunks; c += NT) sh[c] = alive[c];
+      for (int t = tid; t < tiles; t += NT) ts[t] = tile_alive[t];
+      phase_sync();
+      if (accept) {
+        for (int i = tid; i < nlist; i += NT) {
+          const unsigned long long mask = l_kill(i);
+          if (!mask) continue;
+          const int c = (int)l_chunk(i);
+          if (!CHK(c < chunks, 5)) continue;
+          atomicAnd(&sh[c], ~mask);
+          atomicSub(&ts[(c << 6) / kTile], __popcll(mask));
+        }
+        if (n_far > 0) far_pass(n_total, sh, ts);
+      }
+      __syncthreads();
+      if (tid == 0) w.shadow_valid[s] = accept ? 1 : 0;
+      accept = false;
+      return false;
+    }
+    if (tid == 0) w.shadow_valid[s] = 0;                      // an evaluated candidate starts from the backup (:453)
+    if (!accept) return false;
     STAMP(22);
     // -- the visible points, in (pixel, index) order, behind the cloud; one 64-point chunk per wave step
     {
@@ -1573,7 +1602,7 @@ struct Ins {
 
   // The far pixels that are not candidates of this insert: smoothed sample depth 500 there, the scene's
   // depth is the raw minimum (the pixel is occupied): visible iff that minimum exceeds 500.
-  __device__ __forceinline__ void far_pass(int n_total) {
+  __device__ __forceinline__ void far_pass(int n_total, unsigned long long *kill_alive = nullptr, int32_t *kill_tiles = nullptr) {
     const int lane = tid & 63;
     const int n_head = b.n_head[s];
     const int tiles = (int)((b.cap + kTile - 1) / kTile);
@@ -1583,6 +1612,7 @@ struct Ins {
     const int32_t *pixs = b.pix + (int64_t)s * b.cap;
     unsigned long long *alive = w.alive + (int64_t)s * chunks;
     int32_t *tile_alive = w.tile_alive + (int64_t)s * tiles;
+    if (!kill_alive) kill_alive = alive, kill_tiles = tile_alive;   // (else: the shadow of a rejected candidate)
     __syncthreads();
     for (int f = tid; f < n_far; f += NT) {
       uint32_t p = (uint32_t)b.far_pix[(int64_t)s * R3D_FAR_CAP + f];
@@ -1619,8 +1649,8 @@ struct Ins {
         if (pass == 1) {
           unsigned long long mask = __ballot(kill);
           if (lane == 0 && mask) {
-            atomicAnd(&alive[(i0 + tid) >> 6], ~mask);
-            atomicSub(&tile_alive[(i0 + tid) / kTile], __popcll(mask));
+            atomicAnd(&kill_alive[(i0 + tid) >> 6], ~mask);
+            atomicSub(&kill_tiles[(i0 + tid) / kTile], __popcll(mask));
           }
         }
       }
@@ -1640,6 +1670,7 @@ __device__ __forceinline__ bool load_slot(INS &I, const r3d_batch_t &b, const Ch
   I.rows5 = slots.samples5[k] + off * 5;
   I.m = uni((int)m64);
   I.need = uni(slots.min_points[k][s]);
+  I.cull_only = I.need < 0;
   I.step = first_step + k;
   if (act && m64 > kKeyCap && threadIdx.x == 0) atomicOr(&b.status[s], R3D_S_SAMPLE_TOO_LARGE);
   return act && m64 > 0 && m64 <= kKeyCap;

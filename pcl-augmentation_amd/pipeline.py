@@ -47,10 +47,13 @@ def _outputs_exist(output_path, folder, name, write_labels, waymo=False):
 
 class AugmentPipeline:
     def __init__(self, output_path, folder, dataset="semantic", batch_size=64, device="cuda:0",
-                 collapse_labels_to_road=None, resume=True, process=None):
+                 collapse_labels_to_road=None, resume=True, process=None, reference_rejected_state=False):
         """dataset: "semantic" (SemanticKITTI: labels written, 5-column check file) or "kitti"
         (object detection: labels collapsed to {Road, 1} before use, OD insertion.py:353-355,
-        no label file, 4-column check file)."""
+        no label file, 4-column check file).
+        reference_rejected_state (``run_placed``): go on as the reference's driver does after a sample whose candidates were
+        all rejected -- with the scene the last of them has culled (``PlacedInserter``; a slot dict may carry
+        ``last_try: False`` when another sample for the same object follows)."""
         assert dataset in ("semantic", "kitti", "waymo")
         # "waymo": frames are lidar/{f}.npy (+ labels_v3_2/, SS tools/datasets.py:239-270), clouds are float64 after the
         # LiDAR offset is subtracted and go through r3d_batch_begin_f64; outputs are the three .npy files of :287-301
@@ -61,6 +64,7 @@ class AugmentPipeline:
         self.road_label = 40 if collapse_labels_to_road is None and dataset == "kitti" else collapse_labels_to_road
         self.waymo = dataset == "waymo"
         self.process = process or (self._process_waymo if self.waymo else self._process_hip)
+        self.reference_rejected_state = bool(reference_rejected_state)
         self._batches = {}
         self._lane_batches = threading.local()       # run(lanes > 1): every worker thread keeps its own device batches
 
@@ -137,13 +141,15 @@ class AugmentPipeline:
             cache[("placed", B)] = batch
         batch.load(scenes)
         batch.begin()
-        ins = PlacedInserter(batch, [i[0] for i in infos], [i[1] for i in infos], [i[2] for i in infos], [i[3] for i in infos])
+        ins = PlacedInserter(batch, [i[0] for i in infos], [i[1] for i in infos], [i[2] for i in infos], [i[3] for i in infos],
+                             reference_rejected_state=getattr(self, "reference_rejected_state", False))
         chosen = [[] for _ in range(B)]
         for k in range(k_max):
             have = [sl[k] if k < len(sl) else None for sl in slots]
             rot, _ = ins.insert_slot([h["sample"] if h else None for h in have], [h["anno"] if h else None for h in have],
                                      [h["ok_labels"] if h else None for h in have], [h["ok_map"] if h else None for h in have],
-                                     [h["min_points"] if h else 0 for h in have])
+                                     [h["min_points"] if h else 0 for h in have],
+                                     last_try=[bool(h.get("last_try", True)) if h else True for h in have])
             for s in range(B):
                 if have[s]:
                     chosen[s].append(rot[s])

@@ -18,12 +18,19 @@ from .places import PlaceBatch, chunk_ranges, scene_view, upload_map
 
 
 class PlacedInserter:
-    def __init__(self, batch, rich_maps, map_moves, poses, scene_boxes):
+    def __init__(self, batch, rich_maps, map_moves, poses, scene_boxes, reference_rejected_state=False):
         """batch: a SceneBatch after ``begin``.  Per scene: rich map (2D integer codes), its
         ``move`` (first two entries used), the 4 x 4 pose and the annotated boxes (k x 10:
-        centre, quaternion xyzw, length, width, height)."""
+        centre, quaternion xyzw, length, width, height).
+
+        reference_rejected_state: do what the reference's driver does when every candidate of a sample is rejected -- it
+        goes on with the scene WITHOUT the points the last rejected candidate covers (insertion.py:468-471 ran, the next
+        candidate's restore :453 did not): the next sample's placement search sees that copy, and when the sample was the
+        object's last try (``insert_slot(..., last_try=...)``) the copy becomes the scene.  Default: a rejected candidate
+        changes nothing (INTEGRATION.md par. 6)."""
         torch = _lib.require_gpu()
         self.batch, self.torch = batch, torch
+        self.reference_rejected_state = bool(reference_rejected_state)
         B = batch.B
         assert len(rich_maps) == len(map_moves) == len(poses) == len(scene_boxes) == B
         # (maps of one shape -- the usual case, one map geometry per dataset -- go up as one slab)
@@ -58,12 +65,24 @@ class PlacedInserter:
         self.pose_arr = np.array(self.poses, dtype=np.float64)
         self.n_orig_arr = np.array(self.n_orig, dtype=np.int64)
 
-    def insert_slot(self, samples, annos, ok_labels, ok_maps, min_points, chunk=8, flavours=None):
+    def insert_slot(self, samples, annos, ok_labels, ok_maps, min_points, chunk=8, flavours=None, last_try=True):
         """samples[s]: M x 5 float64 or None; annos[s]: the sample's box (10 floats) after
         read_label_line; ok_labels[s] / ok_maps[s]: placement labels / map codes of its class;
         flavours[s] (optional): dict with ``flavour`` / ``collide_label`` / ``collide_dz`` for the
         object-detection rules (``find_spot_od.place_query`` builds them).
+        last_try (bool, or one per scene; only with ``reference_rejected_state``): this sample is the last one tried for
+        its object -- the reference's while-loop then starts over from the scene as the sample has left it (:373).
         Returns (rotation[s] = accepted rotation number or -1, n_possible[s])."""
+        out = self._insert_slot(samples, annos, ok_labels, ok_maps, min_points, chunk, flavours)
+        if self.reference_rejected_state:
+            lt = np.asarray(last_try, dtype=bool)
+            act = np.broadcast_to(lt, (self.batch.B,)).astype(np.int32) if lt.ndim == 0 or lt.shape == (self.batch.B,) else None
+            assert act is not None, "last_try: a bool or one per scene"
+            if act.any():
+                self.batch.adopt_rejected(None if act.all() else act)
+        return out
+
+    def _insert_slot(self, samples, annos, ok_labels, ok_maps, min_points, chunk, flavours):
         torch, batch = self.torch, self.batch
         B = batch.B
         rows, n_rows = batch.export_rows()
@@ -166,11 +185,16 @@ class PlacedInserter:
             n_possible[who_t] = pb.n_possible
             for j in range(chunk):
                 active = still_open * (n_possible > first + j).to(torch.int32)
-                _, acc = batch.insert_device(pb.cand[j * pb.total:], sample_off, need, active, new_slot=new_slot)
+                nv, acc = batch.insert_device(pb.cand[j * pb.total:], sample_off, need, active, new_slot=new_slot)
                 new_slot = False
                 got = acc * active
                 accepted_at = torch.where(got > 0, torch.full_like(accepted_at, first + j), accepted_at)
                 still_open = still_open * (1 - got)
+                if self.reference_rejected_state:
+                    # the sample's LAST candidate, rejected with a visible part: the driver keeps the scene it has culled
+                    # (the candidate is replayed into the batch's shadow; nothing of the scene changes)
+                    last_rejected = active * still_open * (n_possible == first + j + 1).to(torch.int32) * (nv > 0).to(torch.int32)
+                    batch.insert_device(pb.cand[j * pb.total:], sample_off, torch.full_like(need, -1), last_rejected, new_slot=False)
             more = bool(((n_possible > first + chunk).to(torch.int32) * still_open).any().item())   # one sync per chunk
             if not more:
                 break

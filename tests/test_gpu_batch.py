@@ -571,6 +571,44 @@ def test_c5_scan_on_the_proposed_448x2880_grid(P, synth, monkeypatch):
     _check_scene(res[0], vb, lb, cb)
 
 
+@pytest.mark.parametrize("name", ["step_s2k.npz", "step_s8k.npz", "step_s20k.npz"])
+def test_rejected_candidate_state_equals_the_reference(P, name):
+    """``min_points < 0``: what the reference's driver holds after a REJECTED candidate -- `scene_out` of the step fixtures,
+    the scene without the covered points and without the candidate (insertion.py:468-471), captured from the reference's
+    own statements.  The scene itself stays as it was (the next candidate starts from the backup, :453): the same candidate
+    accepted afterwards gives the fixture's merged cloud; ``adopt_rejected`` makes the copy the scene."""
+    g = load_golden(name)
+    xyzi, label, smp = g["in_xyzi"].astype(np.float32), g["in_label"].astype(np.uint32), g["sample5"]
+    out9, vis9 = g["scene_out"], g["visible_sample"]
+    assert 0 < len(vis9) and len(out9) < len(xyzi)
+    for adopt in (False, True):
+        batch = P.SceneBatch(1, len(xyzi) + len(smp) + 64, len(smp) + 64)
+        batch.load([(xyzi, label)])
+        batch.begin()
+        nv, acc = batch.insert([smp], [-1])
+        assert nv[0] == len(vis9) and acc[0] == 0
+        rows, n_rows = batch.export_rows()
+        r = rows[0, :int(n_rows[0])].cpu().numpy()
+        assert np.array_equal(r[:, :3], out9[:, :3]) and np.array_equal(r[:, 3], out9[:, 7])
+        if adopt:
+            batch.adopt_rejected()
+            merged9, added9 = out9, out9[:0]
+        else:                                                    # the same candidate once more, now acceptable
+            nv, acc = batch.insert([smp], [1])
+            assert nv[0] == len(vis9) and acc[0] == 1
+            merged9, added9 = np.append(out9, vis9, axis=0), vis9
+        rows, n_rows = batch.export_rows()
+        r = rows[0, :int(n_rows[0])].cpu().numpy()
+        assert np.array_equal(r[:, :3], merged9[:, :3]) and np.array_equal(r[:, 3], merged9[:, 7])
+        batch.finish()
+        v, l, c = batch.results()[0]
+        assert np.array_equal(v, merged9[:, [0, 1, 2, 6]].astype(np.float32)) and np.array_equal(l, merged9[:, 7].astype(np.uint32))
+        assert len(c) == len(added9)
+        if adopt:                                                # ... and its bounds are those of the culled cloud (:373)
+            b9, max_el, min_el = O.fill_spherical(O.add_space_for_spherical(np.c_[merged9[:, [0, 1, 2, 6]], merged9[:, 7]]))
+            assert np.allclose(batch.bounds.cpu().numpy()[0], [max_el, min_el], rtol=0, atol=1e-12)
+
+
 @pytest.mark.parametrize("debug", [2, 4, 8, 6, 32, 64, 96, 128, 160, 132, 256, 260, 288, 264])
 def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
     """The insert kernel's other routes, forced with the descriptor's diagnostic bits: 2 = never speculate (every slot

@@ -248,6 +248,84 @@ def test_placed_insertion_chain_equals_oracle(P, synth):
         assert res[s][0].tobytes() == vb and res[s][1].tobytes() == lb and res[s][2].tobytes() == cb
 
 
+def test_placed_chain_with_the_reference_rejected_candidate_state(P, synth):
+    """The reference's driver after a sample whose candidates were all rejected: scene_pcl stays bound to the copy the LAST
+    rejected candidate has culled (insertion.py:468-471 ran, :526 did not) until the next candidate restores the backup
+    (:453).  So the next sample's placement search (:433) sees that copy, and when the sample was the object's last try the
+    while-loop starts over from it (:373) or the frame is saved with it.  ``PlacedInserter(reference_rejected_state=True)``
+    against the two oracles sequenced that way; slots 2, 4 and 6 can never be accepted, slot 2 is not its object's last try."""
+    fs = P.Real3DAug.tools.find_spot
+    classes = [31, 30, 18, 31, 30, 31, 18]
+    needs = [25, 10, 10 ** 6, 25, 10 ** 6, 25, 10 ** 6]
+    last_try = [True, True, False, True, True, True, True]
+    cases = [_random_query(synth, 50 + s, classes[0], 2, n_az=400) for s in range(3)]
+    for c in cases:
+        c["scene9"] = c["scene9"][:len(c["original"])]
+    slots = []
+    for k, cls in enumerate(classes):
+        per_scene = []
+        for s in range(3):
+            q = _random_query(synth, 500 + 10 * k + s, cls, 0, beams=4, n_az=16)
+            per_scene.append((q["sample"][:150], q["line"]))
+        slots.append(per_scene)
+    want, leaks_seen, leaks_adopted, leaks_saved = [], 0, 0, 0
+    for s, c in enumerate(cases):
+        scene = c["scene9"].copy()
+        annos = [F.read_label_line(l) for l in c["lines"]]
+        all_visible, rots = np.zeros((0, 9)), []
+        leak, new_iteration = None, True
+        for k in range(len(classes)):
+            if leak is not None and new_iteration:             # the while-loop starts over from what the driver holds (:373)
+                scene, leak = leak, None
+                leaks_adopted += 1
+            scene, s_train, _, max_el, min_el = O.scene_field_of_view(scene)
+            smp, line = slots[k][s]
+            view = scene if leak is None else leak
+            leaks_seen += leak is not None
+            pcl, anno, rot, _, _ = F.find_possible_places(view, annos, smp, line, c["rich"].astype(np.float64), c["move"],
+                                                          c["original"], c["T"], PLACEMENT, PLACEMENT_LABELS)
+            chosen = -1
+            for ci, cand in enumerate(pcl):
+                out, visible, _ = O.evaluate_candidate(scene, s_train, max_el, min_el, cand)   # from the backup (:453)
+                leak = None
+                if len(visible) == 0 or len(visible) < needs[k]:
+                    if len(visible):
+                        leak = out
+                    continue
+                scene = np.append(out, visible, axis=0)
+                all_visible = np.append(all_visible, visible, axis=0)
+                annos.append(anno[ci])
+                chosen = rot[ci]
+                break
+            rots.append(chosen)
+            new_iteration = last_try[k]
+        if leak is not None:                                   # the frame is saved as the driver holds it
+            scene = leak
+            leaks_saved += 1
+        want.append((O.save_bytes_semantic(scene, all_visible), rots))
+    assert leaks_seen > 0 and leaks_adopted > 0 and leaks_saved > 0    # every route is taken
+    n = max(len(c["original"]) for c in cases)
+    batch = P.SceneBatch(3, n + 150 * len(classes) + 64, 150 * len(classes) + 64)
+    batch.load([(c["original"][:, :4].astype(np.float32), c["original"][:, 4].astype(np.uint32)) for c in cases])
+    batch.begin()
+    ins = P.PlacedInserter(batch, [c["rich"] for c in cases], [c["move"] for c in cases], [c["T"] for c in cases],
+                           [[fs._anno10(fs.read_label_line(l)) for l in c["lines"]] for c in cases], reference_rejected_state=True)
+    got_rots = [[] for _ in cases]
+    for k in range(len(classes)):
+        annos = [fs.read_label_line(slots[k][s][1]) for s in range(3)]
+        surf = [fs.placement_surfaces(a, CONFIG) for a in annos]
+        rot, _ = ins.insert_slot([slots[k][s][0] for s in range(3)], [fs._anno10(a) for a in annos],
+                                 [x[1] for x in surf], [x[0] for x in surf], [needs[k]] * 3, chunk=8, last_try=last_try[k])
+        for s in range(3):
+            got_rots[s].append(rot[s])
+    batch.finish()
+    res = batch.results()
+    for s in range(3):
+        assert got_rots[s] == want[s][1]
+        vb, lb, cb = want[s][0]
+        assert res[s][0].tobytes() == vb and res[s][1].tobytes() == lb and res[s][2].tobytes() == cb
+
+
 @pytest.mark.parametrize("name", ["places_od_car.npz", "places_od_pedestrian.npz"])
 def test_object_detection_flavour_equals_reference(P, name):
     """OD tools/find_spot.py:227-304: per-point rotation, map test without pose, Road-only height
