@@ -206,6 +206,57 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def extra_legs(pkg, torch, args, all_of_them):
+    """The objects beside the headline that run on this GPU: placement_search, e2e, placed, e2e_files (config C5 has its own
+    child process).  `all_of_them`: the default line; else only the ones asked for by flag."""
+    out = {}
+    if args.placement > 0 or all_of_them:
+        out["placement_search"] = placement_leg(pkg, torch, args.placement or 64, not args.no_cpu_baseline, CONFIGS["C2"]["kinds"])
+    if args.e2e > 0 or all_of_them:
+        e2e = importlib.import_module("tools.e2e_pipeline")
+        out["e2e"] = e2e.measure(pkg, n_frames=args.e2e or 4096)
+    if all_of_them or args.placed:
+        # the placement search in the loop (SURVEY.md par.8 f-1 + the hot path): search -> candidates -> merge per insert slot
+        try:
+            out["placed"] = importlib.import_module("tools.bench_placed").measure(pkg, B=args.placed or 256, K=len(CONFIGS["C2"]["kinds"]),
+                                                                               reps=4, lanes=3)
+        except Exception as e:
+            out["placed"] = {"error": repr(e)[:300]}
+    if all_of_them or args.e2e_files:
+        # file to file, the shapes of configs C3 (object detection, label_2) and C4 (SemanticKITTI sweep), files on tmpfs
+        e2e = importlib.import_module("tools.e2e_pipeline")
+        out["e2e_files"] = {}
+        for shape in ("C3", "C4"):
+            try:
+                out["e2e_files"][shape] = e2e.measure_files(pkg, shape, n_frames=args.e2e_files or 4096,
+                                                            check=0 if args.no_cpu_baseline else 2)
+            except Exception as e:                             # the headline must not depend on this leg
+                out["e2e_files"][shape] = {"error": repr(e)[:300]}
+    return out
+
+
+def extra_legs_in_child(args, all_of_them):
+    """The same in a child process, so that nothing these legs do -- a frame flagged by the device, a fault of the runtime --
+    can take the headline with it: the child's JSON line is merged, or its failure recorded."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--legs-child", "--placement", str(args.placement), "--e2e", str(args.e2e),
+           "--placed", str(args.placed), "--e2e-files", str(args.e2e_files)]
+    if all_of_them:
+        cmd.append("--legs-all")
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    wanted = [k for k, on in (("placement_search", args.placement > 0), ("e2e", args.e2e > 0), ("placed", args.placed > 0),
+                              ("e2e_files", args.e2e_files > 0)) if on or all_of_them]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        why = f"the legs' process ended with code {r.returncode}: " + " | ".join((r.stderr or "").strip().splitlines()[-3:])[-400:]
+    except Exception as e:
+        why = repr(e)[:300]
+    return {k: {"error": why} for k in wanted}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,9 +293,18 @@ def main():
                     help="the timed region of K steps is run this many times; `value` is the first, `repeats` in the line "
                          "holds min / median / max of all of them")
     ap.add_argument("--cpu-worker", type=int, nargs=2, metavar=("LO", "HI"), help=argparse.SUPPRESS)
+    ap.add_argument("--legs-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--legs-all", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
         return cpu_worker(args)
+    if args.legs_child:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        pkg = importlib.import_module("pcl-augmentation_amd")
+        import torch
+        torch.cuda.set_device(0)
+        print(json.dumps(extra_legs(pkg, torch, args, args.legs_all)), flush=True)
+        return 0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -580,28 +640,8 @@ def main():
             out["cpu_baseline_all_cores"] = cpu_multi
         extra = world == 1 and args.config == "C2" and not args.no_extra_legs
         t_extra = time.perf_counter()
-        if (args.placement > 0 or extra) and world == 1:
-            out["placement_search"] = placement_leg(pkg, torch, args.placement or 64, not args.no_cpu_baseline, CONFIGS["C2"]["kinds"])
-        if (args.e2e > 0 or extra) and world == 1:
-            e2e = importlib.import_module("tools.e2e_pipeline")
-            out["e2e"] = e2e.measure(pkg, n_frames=args.e2e or 4096)
-        if extra or args.placed:
-            # the placement search in the loop (SURVEY.md par.8 f-1 + the hot path): search -> candidates -> merge per insert slot
-            try:
-                out["placed"] = importlib.import_module("tools.bench_placed").measure(pkg, B=args.placed or 256, K=len(CONFIGS["C2"]["kinds"]),
-                                                                                   reps=4, lanes=3)
-            except Exception as e:
-                out["placed"] = {"error": repr(e)[:300]}
-        if extra or args.e2e_files:
-            # file to file, the shapes of configs C3 (object detection, label_2) and C4 (SemanticKITTI sweep), files on tmpfs
-            e2e = importlib.import_module("tools.e2e_pipeline")
-            out["e2e_files"] = {}
-            for shape in ("C3", "C4"):
-                try:
-                    out["e2e_files"][shape] = e2e.measure_files(pkg, shape, n_frames=args.e2e_files or 4096,
-                                                                check=0 if args.no_cpu_baseline else 2)
-                except Exception as e:                             # the headline must not depend on this leg
-                    out["e2e_files"][shape] = {"error": repr(e)[:300]}
+        if world == 1 and (extra or args.placement > 0 or args.e2e > 0 or args.placed or args.e2e_files):
+            out.update(extra_legs_in_child(args, extra))
         if extra:
             # BASELINE.json's stress configuration in the same line: a child process (its own batches, freed when it ends)
             cmd = [sys.executable, os.path.abspath(__file__), "--config", "C5", "--scenes", "256", "--distinct", "8", "--steps", "4",

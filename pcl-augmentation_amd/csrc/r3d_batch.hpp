@@ -144,7 +144,20 @@ __device__ __forceinline__ void load_point(const r3d_batch_t &b, int s, int i, i
     y = (double)p.y;
     z = (double)p.z;
   } else {
+#ifdef R3D_CHECK
+    // (diagnostic build: a tail index or log row out of range is flagged in the scene's status, bit 30, and not followed)
+    if (i - n_head >= b.log_cap) {
+      atomicOr(&b.status[s], 1 << 30);
+      i = n_head;
+    }
+#endif
     int lr = b.tail_ref[(int64_t)s * b.log_cap + (i - n_head)];
+#ifdef R3D_CHECK
+    if ((unsigned)lr >= (unsigned)b.log_cap) {
+      atomicOr(&b.status[s], 1 << 30);
+      lr = 0;
+    }
+#endif
     const double *q = b.log5 + ((int64_t)s * b.log_cap + lr) * 5;
     x = q[0];
     y = q[1];

@@ -1007,6 +1007,9 @@ struct Ins {
   template <class Stale>
   __device__ __forceinline__ int scene_phase(int n_base_, bool serial, Stale &&stale) {
     n_base = uni(n_base_);
+#ifdef R3D_CHECK
+    if (!CHK(n_base >= 0 && n_base <= b.cap && n_base >= uni(b.n_head[s]), 0)) n_base = uni(b.n_head[s]);
+#endif
     n_far = uni(b.n_far[s] < R3D_FAR_CAP ? b.n_far[s] : R3D_FAR_CAP);
     nvis = 0;
     accept = false;

@@ -22,6 +22,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -76,6 +78,14 @@ class _Lane:
             self.h_n_log = torch.zeros((B,), dtype=torch.int32)
         self.busy = False
         self.tag = None
+        if os.environ.get("R3D_DUMP_BUFFERS"):                   # diagnostic: where every buffer of the lane lives
+            import sys
+            for owner, obj in (("lane", self), ("batch", self.bt)):
+                for name, v in sorted(vars(obj).items()):
+                    for j, t in enumerate(v if isinstance(v, (list, tuple)) else [v]):
+                        if hasattr(t, "data_ptr") and hasattr(t, "numel") and t.numel():
+                            a, nb = t.data_ptr(), t.numel() * t.element_size()
+                            print(f"BUF {owner}.{name}[{j}] {a:#x} .. {a + nb:#x} ({nb} B, {'device' if t.is_cuda else 'host'})", file=sys.stderr, flush=True)
 
 
 class StreamedAugmenter:
