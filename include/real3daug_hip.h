@@ -270,7 +270,9 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream);
  * evaluations done again for comparison / that differed (descriptor bit 64 of `reserved`: diagnostic, must stay 0);
  * [5] wave-rounds of the gather whose hits did not fit the workgroup's LDS (their coordinates were fetched right away);
  * [6] scenes handed to k_insert_big; [7] rebases inside the chain kernel; [8..11] rebases by reason: a visible sample point
- * outside the elevation bounds / a culled point held a bound / the same found by the far-pixel pass / none of these (must stay 0). */
+ * outside the elevation bounds / a culled point held a bound / the same found by the far-pixel pass / none of these (must stay 0);
+ * [12..15] index checks a diagnostic build (-DR3D_CHECK) saw fail.  reset: bit 0 clears the counters after the copy; bit 1:
+ * host_out16 holds 32 values, [16..31] are the notes such a build keeps about the first failed check. */
 int r3d_batch_debug_counters(const r3d_batch_t *b, int32_t *host_out16, int32_t reset, void *stream);
 
 /* =====================================================================================

@@ -341,15 +341,16 @@ class SceneBatch:
     @_lib.on_own_device
     def debug_counters(self, reset=True):
         """The insert kernels' diagnostic counters (r3d_batch_debug_counters) as a dict."""
-        out = (C.c_int32 * 16)()
-        _lib.check(self.lib.r3d_batch_debug_counters(C.byref(self.desc), out, 1 if reset else 0, _lib.stream_ptr()),
+        out = (C.c_int32 * 32)()
+        _lib.check(self.lib.r3d_batch_debug_counters(C.byref(self.desc), out, (1 if reset else 0) | 2, _lib.stream_ptr()),
                    "r3d_batch_debug_counters")
         names = ["pool_exhausted", "tiles_pooled", "evaluated_twice", "verify_runs", "verify_mismatch", "hits_overflow", "deferred_scenes",
                  "rebases_in_chain", "rebase_for_sample_point_outside_bounds", "rebase_for_culled_holder", "rebase_from_far_pass",
                  "rebase_without_reason"]
         d = dict(zip(names, list(out)))
-        if any(out[12:]):                # a diagnostic build (-DR3D_CHECK) counted index checks that failed: [12 + (code & 3)]
-            d["check_failures"] = list(out[12:])
+        if any(out[12:16]):              # a diagnostic build (-DR3D_CHECK) counted index checks that failed: [12 + (code & 3)]
+            d["check_failures"] = list(out[12:16])
+            d["check_notes"] = list(out[16:32])               # ... and what it noted about the first one (csrc/r3d_insert.hip)
         return d
 
     def pixel_ids(self):

@@ -729,7 +729,7 @@ int r3d_batch_create(const r3d_batch_t *b, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   BatchWs w = carve_batch(*b, b->workspace);
   hipLaunchKernelGGL(k_col_table, dim3((b->cols + 1 + 255) / 256), dim3(256), 0, st, *b, w);
-  R3D_HIP(hipMemsetAsync(w.dbg, 0, 16 * sizeof(int32_t), st));
+  R3D_HIP(hipMemsetAsync(w.dbg, 0, 32 * sizeof(int32_t), st));
   R3D_LAUNCHED("k_col_table");
   return R3D_OK;
 }

@@ -55,7 +55,8 @@ struct BatchWs {
                                 // of the pairs whose window exceeds a workgroup's LDS
   unsigned long long *pool_head; // [1] bytes handed out in the running launch
   int32_t *queue_next;          // [16] the running k_insert_chain's work queues: next pair of XCD x's queue in [x] (all pairs: [0])
-  int32_t *dbg;                 // [16] diagnostic counters of the insert kernels (r3d_batch_debug_counters)
+  int32_t *dbg;                 // [32] diagnostic counters of the insert kernels (r3d_batch_debug_counters: the first 16;
+                                // [16..31]: what a diagnostic build notes about the first failed check, `reset` bit 1 asks for them)
   int64_t pool_bytes;
   int64_t cand_stride;          // uint32 entries of `cand` per scene
   size_t total;
@@ -124,7 +125,7 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.tile_pool = c.take<unsigned char>((size_t)w.pool_bytes);
   w.pool_head = c.take<unsigned long long>(1);
   w.queue_next = c.take<int32_t>(16);
-  w.dbg = c.take<int32_t>(16);
+  w.dbg = c.take<int32_t>(32);
   w.total = c.off;
   return w;
 }

@@ -446,6 +446,55 @@ struct Ins {
     return kOk;
   }
 
+#ifdef R3D_CHECK
+  // Diagnostic build: a checksum of the sample's record in LDS (s_oob .. s_sdepth, everything the sample phase leaves for
+  // the scene phase and the commit) -- taken at the end of the sample phase (keep = true), compared at the stations of
+  // the scene phase: which phase overwrites the record?  Whole workgroup; cell H_SIG + 1 holds the sum, H_SIG the work.
+  __device__ __forceinline__ void record_check(int station, bool keep = false) {
+    __syncthreads();
+    if (tid == 0) H[H_SIG] = 0;
+    __syncthreads();
+    unsigned sum = 0u;
+    const uint32_t *wds = reinterpret_cast<const uint32_t *>(smem);
+    for (int i = kHdrBytes / 4 + tid; i < rec_end / 4; i += NT) sum += wds[i] * (uint32_t)(2 * i + 1);
+    sum = (unsigned)wave_sum_i32((int)sum);
+    if ((tid & 63) == 0) atomicAdd(reinterpret_cast<unsigned *>(&H[H_SIG]), sum);
+    __syncthreads();
+    // ... and do the waves agree on what every one of them keeps in scalar registers (the layout of the record, the window)?
+    {
+      unsigned hsh = (unsigned)nvalid * 2654435761u;
+      hsh = (hsh ^ (unsigned)ww) * 2246822519u;
+      hsh = (hsh ^ (unsigned)rec_end) * 3266489917u;
+      hsh = (hsh ^ (unsigned)r1) * 668265263u;
+      hsh = (hsh ^ (unsigned)m) * 374761393u;
+      hsh = (hsh ^ (unsigned)(reinterpret_cast<unsigned char *>(A.w) - smem)) * 2654435761u;
+      hsh = (hsh ^ (unsigned)(reinterpret_cast<unsigned char *>(s_F) - smem)) * 2246822519u;
+      hsh = (hsh ^ (unsigned)(reinterpret_cast<unsigned char *>(s_start) - smem)) * 3266489917u;
+      hsh = (hsh ^ (unsigned)dt.npx) * 668265263u;
+      hsh = (hsh ^ (unsigned)win.njw) * 374761393u;
+      hsh = (hsh ^ (unsigned)nocc) * 2654435761u;
+      if ((tid & 63) == 0) scan[tid >> 6] = (int)hsh;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int differ = -1;
+      for (int v = 1; v < NT / 64; ++v)
+        if (scan[v] != scan[0]) differ = v;
+      const bool sum_bad = !keep && H[H_SIG + 1] != H[H_SIG];
+      if (keep) H[H_SIG + 1] = H[H_SIG];
+      if ((sum_bad || differ >= 0) && atomicAdd(&w.dbg[12], 1) < 4) {
+        const int slot = 16 + 4 * (atomicAdd(&w.dbg[13], 1) & 3);
+        w.dbg[slot] = station | (differ >= 0 ? 0x100 * (differ + 1) : 0) | (sum_bad ? 0x10000 : 0);
+        w.dbg[slot + 1] = s, w.dbg[slot + 2] = step, w.dbg[slot + 3] = rec_end;
+      }
+    }
+    __syncthreads();
+  }
+#define RECORD_CHECK(st) record_check(st)
+#else
+#define RECORD_CHECK(st)
+#endif
+
   // -- the window of a projected sample (H_RMIN .. H_CMAX1, H_NVALID in the header): candidates lie within 2 rows /
   // 1 column of a sample pixel, their hole means look 2 / 1 further, their closing 4 / 2 further.  Sets win, dt, ww.
   __device__ __forceinline__ void compute_window() {
@@ -630,6 +679,11 @@ struct Ins {
       __syncthreads();
     }
     nocc = uni(H[H_CARRY]);
+    // EVERY wave has read the carry before thread 0 reuses the cell further down: without this barrier a wave that the CU
+    // schedules late (other workgroups, other kernels in flight) finds the cell already zeroed, lays the record out for
+    // nocc = 0 and writes over what the others have built -- once per several million pairs, and only under load: wrong
+    // visible lists, lost chunks, a spurious rebase, now and then an access far outside (rounds 2-4)
+    __syncthreads();
     if (tid == 0) H[H_NOCC] = nocc;
 
     // per occupied pixel: first sorted point, min depth; scratch: counters, unordered placement
@@ -702,6 +756,9 @@ struct Ins {
     __syncthreads();
     ncand = uni(H[H_NCAND]);
     STAMP(5);
+#ifdef R3D_CHECK
+    record_check(0, true);
+#endif
     return kOk;
   }
 
@@ -1014,6 +1071,7 @@ struct Ins {
     nvis = 0;
     accept = false;
     if (nvalid == 0) return kOk;
+    RECORD_CHECK(1);                                           // on entry
     if (n_far > 0 && !serial) return kNeedSerial;
     // carve the scratch region: visible list | band: candidates, depth tile | hits | kill list | chunk list (from the end)
     int carve = r1;
@@ -1085,6 +1143,7 @@ struct Ins {
       // (alive bits only ever clear: a second pass lists at most the chunks of the first)
       nlist = uni(H[H_NLIST]) < list_cap ? uni(H[H_NLIST]) : list_cap;
     }
+    RECORD_CHECK(2);                                           // chunk list built
     const int list_start = lds_end - (glist ? 0 : kEntry * nlist);
     const int band_bytes = list_start - carve;
     s_cand = reinterpret_cast<uint32_t *>(smem + carve);
@@ -1197,6 +1256,7 @@ struct Ins {
       if (flat) gather_flat(bits_in_gather);
       else gather(bits_in_gather, use_sub ? s_sub : nullptr, nsub);
       if (first) STAMP(27);                                    // (gathered)
+      RECORD_CHECK(3);
       if (g_dtile) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the minima were formed in L2: drop this CU's copies
       __syncthreads();
       // a band in LDS holds minima of the squared depth: the root of every occupied pixel (and, for one band, the
@@ -1225,10 +1285,12 @@ struct Ins {
         if (!serial && stale()) return kStale;
         STAMP(8);
         // -- 8. closing of the scene's occupancy ------------------------------------------------------
+        RECORD_CHECK(4);                                       // tile roots and scene bits
         closing(D, T, E);
         for (int e = tid; e < ww; e += NT) T.w[e] = 0u;        // from here on: the visible pixels
         __syncthreads();
         STAMP(9);
+        RECORD_CHECK(5);                                       // scene closed
       }
 
       // -- 9. visibility on the candidates: smoothed sample depth < smoothed scene depth (:461-467) ----
@@ -1319,6 +1381,7 @@ struct Ins {
     }
 
     STAMP(10);
+    RECORD_CHECK(6);                                           // evaluated
     // -- 10. accept test (insertion.py:511-517); the visible points in order; who dies -----------------
     nvis = uni(H[H_NVIS]);
     accept = nvis > 0 && (cull_only || nvis >= need);          // (cull_only: the covered scene points are wanted, see commit)
@@ -1331,6 +1394,9 @@ struct Ins {
         for (int k = k_lo; k < k_hi; ++k) cnt += vis.get_local((int)s_lp[s_F[k]]) ? 1 : 0;
         int tot;
         int o = block_escan_i32(cnt, scan, tot);
+#ifdef R3D_CHECK
+        if (tid == 0 && tot != nvis) atomicAdd(&w.dbg[15], 1);        // the visible list is not as long as the count says
+#endif
         for (int k = k_lo; k < k_hi; ++k)
           if (vis.get_local((int)s_lp[s_F[k]])) s_V[o++] = (uint16_t)k;
       }
@@ -1420,6 +1486,7 @@ struct Ins {
       __syncthreads();
     }
     STAMP(11);
+    RECORD_CHECK(7);                                           // visible list and kill masks
     return kOk;
   }
 
@@ -1481,7 +1548,18 @@ struct Ins {
         int dst = (ci << 6) + lane, o = dst - n_total;
         bool valid = o >= 0 && o < nvis;
         BoxAcc box;
-        if (valid && !CHK(dst < b.cap && n_log + o < b.log_cap && dst >= n_head && (int)s_V[o] < nvalid && (int)s_F[s_V[o]] < m, 7)) valid = false;
+#ifdef R3D_CHECK
+        if (valid) {                                          // which of the three: room | the visible list | the sorted order
+          const bool c_room = dst < b.cap && n_log + o < b.log_cap && dst >= n_head;
+          const bool c_v = (int)s_V[o] < nvalid;
+          const bool c_f = c_v && (int)s_F[s_V[o]] < m;
+          if (!c_room) atomicAdd(&w.dbg[14], 1);
+          if (!c_v || !c_f) {
+            atomicAdd(&w.dbg[14], 1);
+          }
+          if (!c_room || !c_v || !c_f) valid = false;
+        }
+#endif
         if (valid) {
           int j = s_F[s_V[o]];
           int lp = (int)s_lp[j];
@@ -2352,8 +2430,9 @@ int r3d_batch_debug_counters(const r3d_batch_t *b, int32_t *host_out16, int32_t 
   if (rc != R3D_OK) return rc;
   if (!host_out16) return fail(R3D_E_ARG, "batch_debug_counters: null output");
   BatchWs w = carve_batch(*b, b->workspace);
-  R3D_HIP(hipMemcpyAsync(host_out16, w.dbg, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
-  if (reset) R3D_HIP(hipMemsetAsync(w.dbg, 0, 16 * sizeof(int32_t), (hipStream_t)stream));
+  const size_t n = (reset & 2) ? 32 : 16;                      // (bit 1: the caller's array holds 32, the notes of a diagnostic build too)
+  R3D_HIP(hipMemcpyAsync(host_out16, w.dbg, n * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  if (reset & 1) R3D_HIP(hipMemsetAsync(w.dbg, 0, 32 * sizeof(int32_t), (hipStream_t)stream));
   R3D_HIP(hipStreamSynchronize((hipStream_t)stream));
   return R3D_OK;
 }

@@ -4,6 +4,9 @@ same batch again and again, alone and with a second batch in flight on another s
 iteration must give the same survivors, bytes and status.
 
     python tools/soak_chain.py [iterations] [C2|C3|C4]          # C3 / C4: ten / eight inserts per frame
+
+SOAK_LANES (default 2) batches in flight; SOAK_DEPTH (default 1) rounds enqueued on every lane between two device-wide
+synchronisations (the results of the last round are the ones compared).
 """
 import importlib
 import os
@@ -30,7 +33,8 @@ def main():
     inserts = [synth.make_inserts(s, kinds) for s in range(B)]
     grow = sum(max(len(inserts[s][k]) for s in range(B)) for k in range(len(kinds)))
     lanes = []
-    for _ in range(2):
+    n_lanes, depth = int(os.environ.get("SOAK_LANES", "2")), int(os.environ.get("SOAK_DEPTH", "1"))
+    for _ in range(n_lanes):
         bt = pkg.SceneBatch(B, max(len(x) for x, _ in scenes) + grow, grow, **shape)
         bt.load(scenes)
         pk = [bt.pack_samples([inserts[s][k] for s in range(B)]) for k in range(len(kinds))]
@@ -57,13 +61,30 @@ def main():
     ref = fingerprint(0, acc)
     bad = 0
     for it in range(n_iter):
-        a, b = step(0), step(1)                       # two batches in flight
+        for _ in range(depth):
+            accs = [step(lane) for lane in range(n_lanes)]    # the batches in flight
         torch.cuda.synchronize()
-        fa, fb = fingerprint(0, a), fingerprint(1, b)
-        if fa != ref or fb != ref:
+        fps = [fingerprint(lane, accs[lane]) for lane in range(n_lanes)]
+        if os.environ.get("SOAK_WATCH"):                   # a diagnostic build's failed checks, as soon as they show
+            for lane in range(n_lanes):
+                cnt = lanes[lane][0].debug_counters(reset=False)
+                if "check_failures" in cnt or cnt["rebases_in_chain"]:
+                    print("iteration", it, "lane", lane, {k: v for k, v in cnt.items() if k.startswith(("check", "rebase"))}, flush=True)
+                    lanes[lane][0].debug_counters(reset=True)
+        if any(f != ref for f in fps):
             bad += 1
-            print("iteration", it, "differs in frames", [[s for s in range(B) if f[0][s] != ref[0][s] or f[1][s] != ref[1][s]] for f in (fa, fb)])
-    print(f"{n_iter} iterations x 2 lanes x {B} frames x {len(kinds)} slots: {bad} iterations with a mismatch; status {ref[-1]}")
+            print("iteration", it, "differs in frames", [[s for s in range(B) if f[0][s] != ref[0][s] or f[1][s] != ref[1][s]] for f in fps],
+                  "status sums", [f[-1] for f in fps], flush=True)
+            for lane, f in enumerate(fps):                     # what exactly differs, per frame
+                bt = lanes[lane][0]
+                for s in range(B):
+                    if any(f[j][s] != ref[j][s] for j in range(4)):
+                        a = accs[lane][:, s].cpu().numpy().tolist()
+                        print(f"  lane {lane} frame {s}: n_out {f[0][s]} (want {ref[0][s]}), xyzi sum {f[1][s]} ({ref[1][s]}), labels {f[2][s]} ({ref[2][s]}), "
+                              f"accepted {a} (sum want {ref[3][s]}), status {int(bt.status[s])}, rebases {int(bt.rebase[s])}, n_total {int(bt.n_total[s])}, "
+                              f"n_log {int(bt.n_log[s])}, bounds {bt.bounds[s].cpu().numpy().tolist()}", flush=True)
+                print(f"  lane {lane} counters {bt.debug_counters(reset=False)}", flush=True)
+    print(f"{n_iter} iterations x {depth} rounds x {n_lanes} lanes x {B} frames x {len(kinds)} slots: {bad} iterations with a mismatch; status {ref[-1]}")
     # R3D_DEBUG_BITS=64: every speculative evaluation that was about to be committed was done again after its
     # predecessors and compared (csrc/r3d_insert.hip, kDbgVerify)
     for lane, (bt, _, _, _) in enumerate(lanes):
