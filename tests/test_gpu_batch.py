@@ -2,6 +2,9 @@
 bytes are identical to the reference's K-insert chain (goldens) and to the oracle on fresh
 seeded inputs, including the rebase paths, multi-candidate slots, ragged batches and full-size
 (120k-point) property checks."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -686,6 +689,21 @@ def test_chain_timeout_is_reported(P, synth):
     assert acc.cpu().numpy()[:, 1].tolist() == [1, 1, 1] and acc.cpu().numpy()[1:, 0].tolist() == [0, 0]
     with pytest.raises(ValueError, match="waiting"):
         batch.raise_on_status()
+
+
+def test_resident_soak_three_batches_in_flight():
+    """The harness that exposed the race of the sample phase (a wave reading the occupied-pixel count after thread 0 had
+    reused the cell): three full batches of config C4's shape in flight, four rounds enqueued on every
+    lane between two synchronisations, every frame's survivors, bytes and status compared with the first run.  200
+    iterations = 614 thousand frames here (the race showed once per 0.3 - 1.5 million; `tools/soak_chain.py 4000 C4` is
+    the long form: 12 million)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SOAK_LANES="3", SOAK_DEPTH="4")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_chain.py"), "200", "C4"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    assert "0 iterations with a mismatch; status 0" in p.stdout
 
 
 @pytest.mark.parametrize("debug", [0, 64])
