@@ -6,7 +6,7 @@
 // after the other and scans the whole scene several times per step.  Here the work is regrouped
 // by what it depends on:
 //
-//   k_place_chain        per query, sequential: the box centre and orientation of every step depend
+//   k_place_centres / k_place_orient  per query, sequential: the box centre and orientation of every step depend
 //                        only on the sample's annotation (scipy Rotation round trips + BLAS products,
 //                        restated with explicit fma() in the order the BLAS kernels use).
 //   k_place_road_min     per original point: a point can only matter for the steps whose box centre
@@ -24,7 +24,11 @@
 //
 // Everything that decides an outcome is float64 in the reference's operation order (the library is
 // built with -ffp-contract=off; the fused operations below are the ones the BLAS performs).
+#include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "r3d_device.hpp"
 #include "r3d_host.hpp"
@@ -171,18 +175,40 @@ __device__ __forceinline__ bool inside_box(const double *R, const double *up, co
   return in;
 }
 
-// ---- k_place_chain: find_spot.py:52-70 applied 360 times to the annotation -----------------------
-__global__ void k_place_chain(const r3d_place_query_t *Q, int nq, PlaceWs w, int32_t *status) {
+// ---- k_place_centres / k_place_orient: find_spot.py:52-70 applied 360 times to the annotation -----
+// Two chains that do not depend on each other: the box centre (three fused multiply-adds per step: 5 us for the 360
+// steps) is what the point passes need -- which points can be near which step --, the orientation (matrix, product,
+// back to a quaternion, normalised: 0.8 us per step, 0.30 ms of pure latency per call) only what the planes of the
+// step's box and the candidates' annotations need.  The orientation runs on a stream of its own beside the point passes.
+__global__ void k_place_centres(const r3d_place_query_t *Q, int nq, PlaceWs w, int32_t *status) {
   int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
   const r3d_place_query_t &qq = Q[q];
   double c0 = qq.anno[0], c1 = qq.anno[1], c2 = qq.anno[2];
-  Quat a{qq.anno[3], qq.anno[4], qq.anno[5], qq.anno[6]};
   bool finite = true;
   for (int i = 0; i < 10; ++i) finite = finite && isfinite(qq.anno[i]);
   for (int i = 0; i < 8; ++i) finite = finite && isfinite(qq.pose[i]);
   status[q] = finite ? 0 : R3D_PS_NONFINITE;
   w.gather_sq[q] = 0ull;
+  const double Z[9] = {kCos1, -kSin1, 0.0, kSin1, kCos1, 0.0, 0.0, 0.0, 1.0};
+  for (int r = 0; r < kRot; ++r) {
+    double n0 = fma(Z[2], c2, fma(Z[0], c0, Z[1] * c1));        // np.dot(z_rot_matrix, position), :66-70
+    double n1 = fma(Z[5], c2, fma(Z[3], c0, Z[4] * c1));
+    double n2 = fma(Z[8], c2, fma(Z[6], c0, Z[7] * c1));
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    size_t o = (size_t)q * kRot + r;
+    w.cx[o] = c0;
+    w.cy[o] = c1;
+  }
+}
+
+__global__ void k_place_orient(const r3d_place_query_t *Q, int nq, PlaceWs w) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const r3d_place_query_t &qq = Q[q];
+  Quat a{qq.anno[3], qq.anno[4], qq.anno[5], qq.anno[6]};
   const double Z[9] = {kCos1, -kSin1, 0.0, kSin1, kCos1, 0.0, 0.0, 0.0, 1.0};
   Quat n = quat_normalize(a);                                   // R.from_quat(annotation[1]), :53
   for (int r = 0; r < kRot; ++r) {
@@ -194,15 +220,7 @@ __global__ void k_place_chain(const r3d_place_query_t *Q, int nq, PlaceWs w, int
       for (int j = 0; j < 3; ++j)                               // np.dot(rot_matrix, z_rot_matrix), :61
         F[i * 3 + j] = fma(Rm[i * 3 + 2], Z[6 + j], fma(Rm[i * 3 + 1], Z[3 + j], Rm[i * 3 + 0] * Z[j]));
     a = matrix_to_quat(F);                                      // :63-65
-    double n0 = fma(Z[2], c2, fma(Z[0], c0, Z[1] * c1));        // np.dot(z_rot_matrix, position), :66-70
-    double n1 = fma(Z[5], c2, fma(Z[3], c0, Z[4] * c1));
-    double n2 = fma(Z[8], c2, fma(Z[6], c0, Z[7] * c1));
-    c0 = n0;
-    c1 = n1;
-    c2 = n2;
     size_t o = (size_t)q * kRot + r;
-    w.cx[o] = c0;
-    w.cy[o] = c1;
     w.quat[o * 4 + 0] = a.x;
     w.quat[o * 4 + 1] = a.y;
     w.quat[o * 4 + 2] = a.z;
@@ -929,6 +947,37 @@ __global__ __launch_bounds__(kCB) void k_place_sample_chain_large(const r3d_plac
 
 }  // namespace
 
+// A stream of its own per (device, caller's stream) for k_place_orient, with the two events that tie it to the caller's:
+// made on first use, kept for the life of the process (calls on one stream follow each other in stream order, so the
+// events can be recorded again and again).  nullptr: the environment says no, or the runtime would not make one.
+struct SideStream {
+  hipStream_t stream;
+  hipEvent_t start, done;
+};
+static SideStream *side_stream_of(hipStream_t st) {
+  static const bool off = [] {
+    const char *v = getenv("R3D_PLACE_SIDE_STREAM");
+    return v && *v == '0';
+  }();
+  if (off) return nullptr;
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, SideStream *> known;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = known.find({dev, st});
+  if (it != known.end()) return it->second;
+  SideStream *s = new SideStream();
+  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&s->start, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s->done, hipEventDisableTiming) != hipSuccess) {
+    delete s;
+    s = nullptr;
+  }
+  known[{dev, st}] = s;
+  return s;
+}
+
 extern "C" size_t r3d_places_workspace_bytes(int32_t n_queries, int32_t max_boxes) {
   if (n_queries <= 0 || max_boxes < 0) return 0;
   return carve_places(n_queries, max_boxes, nullptr).total;
@@ -972,7 +1021,17 @@ extern "C" int r3d_find_possible_places(const r3d_place_query_t *queries, int32_
   const size_t qr = (size_t)n_queries * kRot;
   R3D_HIP(hipMemsetAsync(w.dmin, 0xFF, qr * sizeof(unsigned long long), st));
   R3D_HIP(hipMemsetAsync(w.hit, 0, (size_t)n_queries * 12 * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(k_place_chain, dim3((n_queries + 63) / 64), dim3(64), 0, st, queries, n_queries, w, status);
+  hipLaunchKernelGGL(k_place_centres, dim3((n_queries + 63) / 64), dim3(64), 0, st, queries, n_queries, w, status);
+  // the orientation chain beside the point passes, on the helper stream that belongs to `st` (R3D_PLACE_SIDE_STREAM=0: in line)
+  SideStream *side = side_stream_of(st);
+  if (side) {
+    R3D_HIP(hipEventRecord(side->start, st));
+    R3D_HIP(hipStreamWaitEvent(side->stream, side->start, 0));
+    hipLaunchKernelGGL(k_place_orient, dim3((n_queries + 63) / 64), dim3(64), 0, side->stream, queries, n_queries, w);
+    R3D_HIP(hipEventRecord(side->done, side->stream));
+  } else {
+    hipLaunchKernelGGL(k_place_orient, dim3((n_queries + 63) / 64), dim3(64), 0, st, queries, n_queries, w);
+  }
   if (max_boxes > 0)
     hipLaunchKernelGGL(k_place_boxes, dim3((n_queries * max_boxes + 255) / 256), dim3(256), 0, st, queries,
                        n_queries, max_boxes, w);
@@ -994,6 +1053,7 @@ extern "C" int r3d_find_possible_places(const r3d_place_query_t *queries, int32_
   hipLaunchKernelGGL(k_place_kstar, dim3((unsigned)((qr + 255) / 256)), dim3(256), 0, st, n_queries, w, rad);
   if (pb_orig > 0)
     hipLaunchKernelGGL(k_place_surface_gather, dim3(n_queries, pb_orig), dim3(kPB), 0, st, queries, w, rad);
+  if (side) R3D_HIP(hipStreamWaitEvent(st, side->done, 0));      // from here on the steps' orientations are read
   hipLaunchKernelGGL(k_place_road_level, dim3((unsigned)((qr + kPB / 64 - 1) / (kPB / 64))), dim3(kPB), 0, st, queries,
                      n_queries, w, status);
   if (pb_scene > 0)
