@@ -297,7 +297,7 @@ class AugmentPipeline:
                         max(int(srows * 1.25) + 64, caps[3]))
                 aug = aug_box[0] = None                            # free the old lanes first
                 t_setup = time.perf_counter()
-                aug = aug_box[0] = StreamedAugmenter(B, caps[1], caps[2], caps[0], caps[3], lanes=lanes, device=self.device,
+                aug = aug_box[0] = StreamedAugmenter(B, caps[1], caps[2], caps[0], caps[3], lanes=int(os.environ.get("R3D_STREAM_LANES", lanes)), device=self.device,
                                                      check_cols=self.check_cols,
                                                      collapse_keep=-1 if self.road_label is None else self.road_label,
                                                      pack_threads=pack_threads, delta=delta)
