@@ -95,9 +95,9 @@ class SceneBatch:
         if getattr(self, "_pin", None) is None:
             torch = self.torch
             self._pin = {
-                "xyzi": torch.empty((self.B, self.cap, 4), dtype=torch.float32).pin_memory(),
-                "label": torch.empty((self.B, self.cap), dtype=torch.int32).pin_memory(),
-                "n": torch.empty((self.B,), dtype=torch.int32).pin_memory(),
+                "xyzi": torch.empty((self.B, self.cap, 4), dtype=torch.float32, pin_memory=True),
+                "label": torch.empty((self.B, self.cap), dtype=torch.int32, pin_memory=True),
+                "n": torch.empty((self.B,), dtype=torch.int32, pin_memory=True),
             }
         return self._pin
 
@@ -149,15 +149,15 @@ class SceneBatch:
         torch = self.torch
         self.raise_on_status()
         if getattr(self, "_pin_out", None) is None:
-            self._pin_out = (torch.empty((self.B, self.cap, 4), dtype=torch.float32).pin_memory(),
-                             torch.empty((self.B, self.cap), dtype=torch.int32).pin_memory())
+            self._pin_out = (torch.empty((self.B, self.cap, 4), dtype=torch.float32, pin_memory=True),
+                             torch.empty((self.B, self.cap), dtype=torch.int32, pin_memory=True))
         px, pl = self._pin_out
         px.copy_(self.out_xyzi, non_blocking=True)
         pl.copy_(self.out_label, non_blocking=True)
         ck = None
         if self.check is not None:
             if getattr(self, "_pin_ck", None) is None or self._pin_ck.shape != self.check.shape:
-                self._pin_ck = torch.empty(self.check.shape, dtype=torch.float32).pin_memory()
+                self._pin_ck = torch.empty(self.check.shape, dtype=torch.float32, pin_memory=True)
             self._pin_ck.copy_(self.check, non_blocking=True)
             ck = self._pin_ck.numpy()
         n_out = self.n_out.cpu().numpy()
@@ -191,7 +191,7 @@ class SceneBatch:
         assert len(scenes5) == self.B
         if getattr(self, "_rows5", None) is None:
             self._rows5 = torch.zeros((self.B, self.cap, 5), dtype=torch.float64, device=self.device)
-            self._rows5_pin = torch.zeros((self.B, self.cap, 5), dtype=torch.float64).pin_memory()
+            self._rows5_pin = torch.zeros((self.B, self.cap, 5), dtype=torch.float64, pin_memory=True)
         host, n = self._rows5_pin.numpy(), np.zeros(self.B, dtype=np.int32)
         for s, rows in enumerate(scenes5):
             rows = np.asarray(rows, dtype=np.float64)

@@ -46,7 +46,7 @@ class _Lane:
             self.stream = torch.cuda.Stream()
             self.copy_streams = [torch.cuda.Stream() for _ in range(4)]
             self.done = torch.cuda.Event()
-            pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
+            pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
             self.in_xyzi, self.in_label, self.in_n = pin((B, cap, 4), torch.float32), pin((B, cap), torch.int32), pin((B,), torch.int32)
             self.in_rows = [pin((sample_rows, 5), torch.float64) for _ in range(K)]
             self.in_off = pin((max(K, 1), B + 1), torch.int64)
