@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MIN_POINTS = 20
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 CONFIGS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on
@@ -67,7 +67,9 @@ def scene_seed(rank, s):
 
 
 def build_scene(synth, cfg, seed):
-    return synth.make_scene(seed, n_beams=cfg["beams"], n_az=cfg["az"])
+    # cfg["shuffle"]: SURVEY.md par.8d / BASELINE.md par.4's second point order -- the same scan with its points in a random
+    # order (the reference loops over the points in whatever order they come, insertion.py:100-127)
+    return synth.make_scene(seed, n_beams=cfg["beams"], n_az=cfg["az"], shuffle=bool(cfg.get("shuffle")))
 
 
 def oracle_scene(pkg, cfg, seed):
@@ -91,7 +93,7 @@ def cpu_worker(args):
     """Child process of the one-process-per-core baseline: scenes [lo, hi) through the oracle; prints
     the seconds spent inside the oracle."""
     pkg = importlib.import_module("pcl-augmentation_amd")
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config], shuffle=args.order == "shuffled")
     lo, hi = args.cpu_worker
     spent = 0.0
     for seed in range(lo, hi):
@@ -122,7 +124,8 @@ def cpu_baselines(pkg, cfg, config_name, n_check, budget_s=20.0, all_cores=True)
     per = max(1, min(8, int(budget_s / max(spent / done, 1e-3) / 2)))
     t0 = time.perf_counter()
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--config", config_name, "--cpu-worker",
-                               str(5000 + c * per), str(5000 + (c + 1) * per)], stdout=subprocess.PIPE, text=True,
+                               str(5000 + c * per), str(5000 + (c + 1) * per)] + (["--order", "shuffled"] if cfg.get("shuffle") else []),
+                              stdout=subprocess.PIPE, text=True,
                               env={**os.environ, "OMP_NUM_THREADS": "1", "OPENBLAS_NUM_THREADS": "1", "MKL_NUM_THREADS": "1"})
              for c in range(cores)]
     outs = [p.communicate()[0] for p in procs]
@@ -292,6 +295,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region of K steps is run this many times; `value` is the first, `repeats` in the line "
                          "holds min / median / max of all of them")
+    ap.add_argument("--order", choices=["ring", "shuffled"], default="ring",
+                    help="point order of the synthetic scans: ring-major then azimuth (the order of KITTI / SemanticKITTI files), "
+                         "or the same scans with their points shuffled (SURVEY.md par.8d, BASELINE.md par.4)")
     ap.add_argument("--cpu-worker", type=int, nargs=2, metavar=("LO", "HI"), help=argparse.SUPPRESS)
     ap.add_argument("--legs-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--legs-all", action="store_true", help=argparse.SUPPRESS)
@@ -315,22 +321,26 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # before the runtime starts
 
-    cfg = dict(CONFIGS[args.config])
+    cfg = dict(CONFIGS[args.config], shuffle=args.order == "shuffled")
     B = args.scenes or cfg["scenes"]
     cfg["workload"] = cfg["workload"].replace(f"batch of {cfg['scenes']} ", f"batch of {B} ")
+    if cfg["shuffle"]:
+        cfg["workload"] += "; points of every scan in a random order"
     kinds = cfg["kinds"]
     pkg = importlib.import_module("pcl-augmentation_amd")
     synth = pkg.synth
 
-    # CPU legs first (rank 0 at N = 1 only: the other ranks would wait at the barrier), before this
-    # process starts the GPU runtime: the worker processes are plain children
+    # CPU legs first, on rank 0, before this process starts the GPU runtime: the worker processes are plain children.
+    # N > 1: a shorter single-core sample only (the other ranks wait for rank 0 in init_process_group meanwhile, and the
+    # host's cores belong to all of them), so that every --gpus N line carries `cpu_baseline` and the oracle's bytes for
+    # the parity check of rank 0's batch
     cpu_single = cpu_multi = None
     oracle_bytes = []
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         n_check = max(0, min(args.parity_scenes if args.config != "C5" else 1, B))   # a C5 scene takes the oracle ~10 s
-        budget = args.cpu_budget or (20.0 if args.config != "C5" else 30.0)
+        budget = args.cpu_budget or ((20.0 if args.config != "C5" else 30.0) if world == 1 else 10.0)
         cpu_single, cpu_multi, oracle_bytes = cpu_baselines(pkg, cfg, args.config, n_check, budget_s=budget,
-                                                            all_cores=budget >= 20.0)
+                                                            all_cores=budget >= 20.0 and world == 1)
 
     import torch
     import torch.distributed as dist
@@ -340,14 +350,21 @@ def main():
     if backend == "gloo":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under a launcher (RANK / WORLD_SIZE / MASTER_* in the environment) the process group is set up for ANY world size:
+    # `torchrun --nproc-per-node 1 bench.py --gpus 1` runs the same init / barrier / all_reduce / destroy the 8-GPU run does
+    # (tests/test_gpu_sharded.py runs it with RCCL, which wants one GPU per rank, on the one-GPU box)
+    grouped = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if grouped:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group(backend)
 
     distinct = min(args.distinct, B) if args.distinct > 0 else B
-    scenes = [build_scene(synth, cfg, scene_seed(rank, s)) for s in range(distinct)]
+    # (the generator is NumPy and releases the interpreter lock: a 1M-point scan takes 0.5 s, 64 of them 8 s on 8 threads)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(16, len(os.sched_getaffinity(0)) // max(world, 1)))) as gen:
+        scenes = list(gen.map(lambda s: build_scene(synth, cfg, scene_seed(rank, s)), range(distinct)))
     scenes = [scenes[s % distinct] for s in range(B)]
     inserts = [synth.make_inserts(scene_seed(rank, s), kinds) for s in range(B)]
     K = len(kinds)
@@ -408,14 +425,14 @@ def main():
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -423,18 +440,18 @@ def main():
     # (`value` itself is the first, the contract's, timed region)
     region_s = [elapsed]
     for _ in range(max(0, args.repeats - 1)):
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
         tr = time.perf_counter()
         for _ in range(args.steps):
             one_step()
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
         region_s.append(time.perf_counter() - tr)
-    if world > 1:
+    if grouped:
         t = torch.tensor(region_s, dtype=torch.float64, device=batch.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         region_s = [float(v) for v in t.tolist()]
@@ -612,7 +629,9 @@ def main():
                         "scenes_per_s_max": round(B * world * args.steps / min(region_s), 1)},
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["workload"],
-                       "scenes_per_gpu": B, "points_per_scene": int(n_pts / B), "inserts_per_scene": K,
+                       "scenes_per_gpu": B, "distinct_scenes": distinct, "point_order": args.order,
+                       "process_group": backend if grouped else None,
+                       "points_per_scene": int(n_pts / B), "inserts_per_scene": K,
                        "range_image": [batch.rows, batch.cols], "inserts_accepted": n_accepted, "inserts_tried": B * K,
                        "points_appended": n_appended, "points_culled": None if n_appended is None else int(n_pts + n_appended - n_out.sum()),
                        "steps_in_flight": depth, "check_rows_in_timed_region": True,
@@ -643,28 +662,53 @@ def main():
         if world == 1 and (extra or args.placement > 0 or args.e2e > 0 or args.placed or args.e2e_files):
             out.update(extra_legs_in_child(args, extra))
         if extra:
-            # BASELINE.json's stress configuration in the same line: a child process (its own batches, freed when it ends)
-            cmd = [sys.executable, os.path.abspath(__file__), "--config", "C5", "--scenes", "256", "--distinct", "8", "--steps", "4",
-                   "--warmup", "1", "--no-extra-legs", "--parity-scenes", "1", "--cpu-budget", "8"]
+            # BASELINE.json's stress configuration in the same line: a child process (its own batches, freed when it ends);
+            # 64 distinct scans (each four times in the batch of 256), 10 timed steps
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", "C5", "--scenes", "256", "--distinct", "64", "--steps", "10",
+                   "--warmup", "2", "--repeats", "2", "--no-extra-legs", "--parity-scenes", "1", "--cpu-budget", "8"]
             if args.no_cpu_baseline:
                 cmd.append("--no-cpu-baseline")
             try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
                 c5 = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
                 out["c5"] = {"scans_per_s": c5["value"], "ms_per_step": c5["ms_per_step"], "scans_per_batch": c5["config"]["scenes_per_gpu"],
+                             "distinct_scans": c5["config"].get("distinct_scenes"), "steps": c5["steps"],
                              "points_per_scan": c5["config"]["points_per_scene"], "inserts_per_scan": c5["config"]["inserts_per_scene"],
                              "range_image": c5["config"]["range_image"], "steps_in_flight": c5["config"]["steps_in_flight"],
                              "ms_per_step_one_step_in_flight": c5["config"]["ms_per_step_one_step_in_flight"],
                              "pipeline_frac_of_hbm_peak": c5["pipeline_frac_of_hbm_peak"],
                              "pipeline_frac_floor_model": c5.get("pipeline_frac_floor_model"),
                              "api_calls_ms": c5["roofline"]["api_calls_ms"], "parity_checked": c5["parity_checked"],
+                             "insert_paths_one_step": c5["config"].get("insert_paths_one_step"),
                              "cpu_baseline": c5.get("cpu_baseline"), "workload": c5["config"]["workload"],
                              "command": " ".join(cmd[1:])}
             except Exception as e:                                 # the headline must not depend on this leg
                 out["c5"] = {"error": repr(e)[:300]}
+            # ... and the headline's configuration with the points of every scan in a random order (SURVEY.md par.8d,
+            # the reference is order-agnostic, insertion.py:100-127; the chunk boxes of the incremental
+            # design lean on the order of LiDAR files)
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", "C2", "--order", "shuffled", "--steps", "10", "--warmup", "3",
+                   "--repeats", "2", "--no-extra-legs", "--parity-scenes", "2", "--cpu-budget", "2"]
+            if args.no_cpu_baseline:
+                cmd.append("--no-cpu-baseline")
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                sh = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                paths = sh["config"].get("insert_paths_one_step") or {}
+                out["shuffled"] = {"scenes_per_s": sh["value"], "ms_per_step": sh["ms_per_step"],
+                                   "step_time_vs_ring_major": round(sh["ms_per_step"] / out["ms_per_step"], 2),
+                                   "ms_per_step_one_step_in_flight": sh["config"]["ms_per_step_one_step_in_flight"],
+                                   "api_calls_ms": sh["roofline"]["api_calls_ms"],
+                                   "chunks_listed_per_pair": paths.get("chunks_listed_per_pair"),
+                                   "scenes_in_sorted_order": paths.get("scenes_in_sorted_order"),
+                                   "insert_paths_one_step": paths,
+                                   "parity_checked": sh["parity_checked"], "workload": sh["config"]["workload"],
+                                   "command": " ".join(cmd[1:])}
+            except Exception as e:
+                out["shuffled"] = {"error": repr(e)[:300]}
             out["extra_legs_seconds"] = round(time.perf_counter() - t_extra, 1)
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

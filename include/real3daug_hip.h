@@ -61,7 +61,11 @@ extern "C" {
                                      sample's per-point arrays exceed one CU's LDS (a sample that covers more
                                      than ~200 000 pixels) */
 
-#define R3D_MAX_SAMPLE 8192       /* points per insert candidate in the batched path */
+#define R3D_MAX_SAMPLE 65535      /* points per insert candidate in the batched path (16-bit indices into the sample; round 4:
+                                     8 192).  A candidate whose per-point arrays exceed a chain workgroup's LDS goes to
+                                     k_insert_big, one that exceeds a whole CU's comes back as R3D_S_WINDOW_TOO_LARGE; the
+                                     Python mirror runs a frame flagged with that bit, with R3D_S_SAMPLE_TOO_LARGE or with
+                                     R3D_S_FAR_OVERFLOW once more through Level 1, which has none of these limits */
 #define R3D_FAR_CAP 1024
 
 int r3d_version(void);

@@ -16,19 +16,23 @@ LIB_PATH = os.environ.get("R3D_LIB") or os.path.join(_HERE, "libreal3daug_hip.so
 R3D_OK = 0
 S_NONFINITE, S_ROW_RANGE, S_COL_RANGE, S_SAMPLE_TOO_LARGE, S_CAPACITY, S_FAR_OVERFLOW, S_WINDOW_TOO_LARGE = 1, 2, 4, 8, 16, 32, 64
 S_CHAIN_TIMEOUT = 128
+# limits of the batched kernels that the reference does not have (insertion.py:455-482 takes a sample of any size and any
+# number of returns beyond 500 m): a frame flagged with one of these -- and with nothing else -- is run once more, alone,
+# through the Level-1 kernels by every mirror that drives Level 2 (batch.augment_batch, streaming.StreamedAugmenter)
+S_REDO_LEVEL1 = S_WINDOW_TOO_LARGE | S_SAMPLE_TOO_LARGE | S_FAR_OVERFLOW
 STATUS_TEXT = {
     S_NONFINITE: "NaN/Inf coordinate or a point at the origin (reference: int() raises, insertion.py:104)",
     S_ROW_RANGE: "Rows in FoV went something wrong (assert insertion.py:110)",
     S_COL_RANGE: "Column in FoV went something wrong (assert insertion.py:112)",
-    S_SAMPLE_TOO_LARGE: "sample has more than R3D_MAX_SAMPLE points",
+    S_SAMPLE_TOO_LARGE: "sample has more than R3D_MAX_SAMPLE points (Level 2 only; the mirrors redo such a frame through Level 1)",
     S_CAPACITY: "merged cloud or insert log exceeds its capacity",
-    S_FAR_OVERFLOW: "more than R3D_FAR_CAP pixels deeper than 500 m",
+    S_FAR_OVERFLOW: "more than R3D_FAR_CAP pixels deeper than 500 m (Level 2 only; the mirrors redo such a frame through Level 1)",
     S_WINDOW_TOO_LARGE: "the insert's window of the range image and the sample's arrays do not fit one CU's LDS",
     S_CHAIN_TIMEOUT: "insert_many: a slot gave up waiting for the scene's previous slot",
 }
 K_BOUNDS, K_PREPARE, K_PROJECT, K_ALIVE_WRITE = 1, 2, 3, 5
 NUMROW, NUMCOLUMN = 112, 1440
-MAX_SAMPLE = 8192
+MAX_SAMPLE = 65535
 FAR_CAP = 1024
 MAX_CHAIN = 64           # insert slots one launch of the chain kernel takes (kMaxChain in csrc/r3d_batch.hpp); insert_many splits longer lists
 
@@ -188,6 +192,12 @@ def on_own_device(method):
         with on(self.device):
             return method(self, *args, **kwargs)
     return wrapped
+
+
+def needs_level1(bits) -> bool:
+    """A Level-2 status that only says "beyond this path's limits" (see S_REDO_LEVEL1)."""
+    bits = int(bits)
+    return bool(bits & S_REDO_LEVEL1) and not (bits & ~S_REDO_LEVEL1)
 
 
 def raise_status(bits: int, where: str):

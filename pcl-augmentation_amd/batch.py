@@ -24,8 +24,11 @@ def shard_indices(n_scenes: int, rank: int, world_size: int):
 
 
 class SceneBatch:
-    last_rebases = 0      # rebases counted by the most recent augment_batch (diagnostics / tests)
-    last_level1 = []      # scenes the most recent augment_batch ran through the Level-1 kernels (window too large for the LDS)
+    # diagnostics of the most recent augment_batch.  The class attributes are what a single-threaded caller (the tests)
+    # reads; augment_batch also leaves both on the batch INSTANCE it worked on, which is what holds when several threads run
+    # augment_batch at a time (AugmentPipeline.run(lanes > 1): every worker thread has its own batches)
+    last_rebases = 0      # rebases counted
+    last_level1 = []      # scenes run once more through the Level-1 kernels (_lib.S_REDO_LEVEL1)
 
     def __init__(self, B, cap, log_cap, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN, device="cuda:0",
                  exact_projection=False, debug=0):
@@ -463,12 +466,14 @@ def augment_batch(scenes, candidates, min_points, rows=_lib.NUMROW, cols=_lib.NU
     batch.begin()
     accepted = batch.run_inserts(candidates, min_points)
     batch.finish(check_cols)
-    SceneBatch.last_rebases = int(batch.rebase.sum().item())
-    SceneBatch.last_level1 = []
-    # A frame whose insert window exceeds a CU's LDS (an object a few metres from the sensor on a grid several times the
-    # reference's): once more, alone, through the Level-1 kernels -- whole range images in HBM, no such limit
+    batch.last_rebases = SceneBatch.last_rebases = int(batch.rebase.sum().item())
+    batch.last_level1 = SceneBatch.last_level1 = []
+    # A frame beyond the batched kernels' limits -- an insert window that exceeds a CU's LDS (an object a few metres from the
+    # sensor on a grid several times the reference's), a sample of more than R3D_MAX_SAMPLE points, more than R3D_FAR_CAP
+    # pixels beyond 500 m: once more, alone, through the Level-1 kernels -- whole range images in HBM, no such limit
+    # (the reference has none: insertion.py:455-482)
     status = batch.status.cpu().numpy()
-    redo = [int(s) for s in np.nonzero(status & _lib.S_WINDOW_TOO_LARGE)[0]]
+    redo = [int(s) for s in np.nonzero(status)[0] if _lib.needs_level1(status[s])]
     if redo:
         batch.status[torch_index(batch, redo)] = 0
     results = batch.results()
@@ -477,7 +482,7 @@ def augment_batch(scenes, candidates, min_points, rows=_lib.NUMROW, cols=_lib.NU
         for s in redo:
             results[s], accepted[s] = level1.augment_scene(scenes[s][0], scenes[s][1], candidates[s], min_points[s], rows, cols,
                                                            device, check_cols)
-        SceneBatch.last_level1 = redo
+        batch.last_level1 = SceneBatch.last_level1 = redo
     return results, accepted
 
 

@@ -1408,7 +1408,11 @@ struct Ins {
     RECORD_CHECK(6);                                           // evaluated
     // -- 10. accept test (insertion.py:511-517); the visible points in order; who dies -----------------
     nvis = uni(H[H_NVIS]);
-    accept = nvis > 0 && (cull_only || nvis >= need);          // (cull_only: the covered scene points are wanted, see commit)
+    // cull_only (the state a REJECTED candidate leaves, see commit): the reference culls the scene in EVERY visible pixel,
+    // also in one that holds no sample point -- a closing-filled hole of the sample in front of the scene (insertion.py:467-473
+    // runs before len(visible_sample) is looked at, :511) -- so a candidate rejected with no visible point can still leave a
+    // culled copy: any visible pixel decides, not the count
+    accept = cull_only ? uni(H[H_VRMAX]) >= 0 : (nvis > 0 && nvis >= need);
     if (accept) {
       // the visible points in sorted order: thread t takes the sorted points [t*L, t*L + L), one block scan
       {

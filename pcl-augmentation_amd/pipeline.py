@@ -184,7 +184,7 @@ class AugmentPipeline:
         finally:
             self.process = saved
 
-    def run_streamed(self, frames, inserts_for, lanes=3, label_2_for=None, pack_threads=16, io_threads=16, delta=True):
+    def run_streamed(self, frames, inserts_for, lanes=None, label_2_for=None, pack_threads=16, io_threads=16, delta=True):
         """Like ``run`` for ONE placement per insert: inserts_for(i) -> (samples, min_points) with
         samples[k] = M x 5 float64 (or None).  Batches go through ``StreamedAugmenter`` lanes: pinned
         buffers, native packing, upload / kernels / download of consecutive batches overlapped; only the delta
@@ -195,6 +195,13 @@ class AugmentPipeline:
         is handed back when its files are on disk, the other lanes keep the GPU busy meanwhile."""
         from concurrent.futures import ThreadPoolExecutor
         from .streaming import StreamedAugmenter
+        if lanes is None:
+            # (the environment only stands in for an argument that was not given; read once, before anything is started)
+            try:
+                lanes = int(os.environ.get("R3D_STREAM_LANES", "3"))
+            except ValueError:
+                raise ValueError("R3D_STREAM_LANES must be an integer") from None
+        lanes = max(1, int(lanes))
         todo = [i for i, f in enumerate(frames)
                 if not (self.resume and _outputs_exist(self.output_path, self.folder, f.name, self.write_labels))]
         stats = {"frames": len(frames), "skipped_existing": len(frames) - len(todo), "written": 0, "inserted": 0}
@@ -297,7 +304,7 @@ class AugmentPipeline:
                         max(int(srows * 1.25) + 64, caps[3]))
                 aug = aug_box[0] = None                            # free the old lanes first
                 t_setup = time.perf_counter()
-                aug = aug_box[0] = StreamedAugmenter(B, caps[1], caps[2], caps[0], caps[3], lanes=int(os.environ.get("R3D_STREAM_LANES", lanes)), device=self.device,
+                aug = aug_box[0] = StreamedAugmenter(B, caps[1], caps[2], caps[0], caps[3], lanes=lanes, device=self.device,
                                                      check_cols=self.check_cols,
                                                      collapse_keep=-1 if self.road_label is None else self.road_label,
                                                      pack_threads=pack_threads, delta=delta)
@@ -450,7 +457,7 @@ class AugmentPipeline:
 
 
 def run_sharded_files(frames, inserts_for, output_path, folder, rank=None, world_size=None, device=None, dataset="semantic",
-                      batch_size=64, lanes=3, label_2_for=None, process=None, resume=True):
+                      batch_size=64, lanes=None, label_2_for=None, process=None, resume=True):
     """BASELINE config C4 ("full sweep, scene-sharded across the GPUs of a node"): rank r of G takes frames r, r + G,
     r + 2G, ... and runs them file to file through its own GPU; no rank talks to another on the data path, every frame
     is written by exactly one rank (the reference shards by letting N copies of the script race for claim files,
@@ -475,7 +482,7 @@ def run_sharded_files(frames, inserts_for, output_path, folder, rank=None, world
         def cands64(j):
             smp, need = inserts_for(mine[j])
             return [[x] for x in smp], need
-        st = pipe.run(local, cands64, lanes=lanes)
+        st = pipe.run(local, cands64, lanes=lanes or 3)
         st.update(rank=rank, world_size=world_size, frame_indices=mine)
         return st
     if process is not None:

@@ -193,7 +193,9 @@ class PlacedInserter:
                 if self.reference_rejected_state:
                     # the sample's LAST candidate, rejected with a visible part: the driver keeps the scene it has culled
                     # (the candidate is replayed into the batch's shadow; nothing of the scene changes)
-                    last_rejected = active * still_open * (n_possible == first + j + 1).to(torch.int32) * (nv > 0).to(torch.int32)
+                    # (also one rejected WITHOUT a visible point: a closing-filled hole of the sample in front of the scene is a
+                    # visible pixel all the same and culls there, insertion.py:467-473)
+                    last_rejected = active * still_open * (n_possible == first + j + 1).to(torch.int32)
                     batch.insert_device(pb.cand[j * pb.total:], sample_off, torch.full_like(need, -1), last_rejected, new_slot=False)
             more = bool(((n_possible > first + chunk).to(torch.int32) * still_open).any().item())   # one sync per chunk
             if not more:

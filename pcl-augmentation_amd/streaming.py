@@ -265,7 +265,7 @@ class StreamedAugmenter:
             _SUM_COUNTERS["rebases"] = _SUM_COUNTERS.get("rebases", 0) + int(counts[3].sum())
         n_log = ln.h_n_log.numpy()
         n_log[:] = counts[1]
-        redo = [int(s) for s in np.nonzero(counts[2] & _lib.S_WINDOW_TOO_LARGE)[0]]   # see _redo_level1
+        redo = [int(s) for s in np.nonzero(counts[2])[0] if _lib.needs_level1(counts[2][s])]   # see _redo_level1
         for s in np.nonzero(counts[2])[0]:
             if int(s) in redo:
                 continue
@@ -304,8 +304,9 @@ class StreamedAugmenter:
         return ln.tag, results, accepted
 
     def _redo_level1(self, ln, s, n_out, n_log):
-        """Frame s of the lane came back with R3D_S_WINDOW_TOO_LARGE (an insert's window exceeds a CU's LDS: an object
-        a few metres from the sensor on a grid several times the reference's): once more, alone, through the Level-1
+        """Frame s of the lane came back beyond the batched kernels' limits (``_lib.S_REDO_LEVEL1``: an insert's window exceeds
+        a CU's LDS -- an object a few metres from the sensor on a grid several times the reference's --, a sample of more
+        than R3D_MAX_SAMPLE points, more than R3D_FAR_CAP pixels beyond 500 m): once more, alone, through the Level-1
         kernels (``level1.augment_scene``), its results into the lane's output slabs."""
         from . import level1
         bt, K = ln.bt, self.K

@@ -1,0 +1,136 @@
+"""The limits of the batched kernels that the reference does not have (-m gpu).
+
+The reference evaluates a candidate of ANY size (SS Real3DAug/insertion.py:455-461 -- semantic-kitti.yaml:9 inserts class
+18, truck: a near truck in a 64-beam scan exceeds 8 192 points) against a scene with ANY number of returns beyond 500 m
+(:99, :122-125, :467).  Level 2 has R3D_MAX_SAMPLE points per candidate and R3D_FAR_CAP far pixels per scene; a frame
+beyond either is flagged, and ``augment_batch`` / ``StreamedAugmenter.collect`` / ``AugmentPipeline.run_streamed`` run it
+once more through the Level-1 kernels instead of raising.  Every result below is compared with the oracle byte for byte.
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import real3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(xyzi, label, slots, need):
+    s5 = np.hstack((xyzi.astype(np.float64), (label & 0xFFFF).astype(np.float64)[:, None]))
+    merged, allvis, acc = O.augment_scene(s5, slots, need)
+    return O.save_bytes_semantic(merged, allvis), acc
+
+
+def _truck_cases(synth, big):
+    """Three frames, three slots each; frame 1's middle slot is a truck of `big` points 7 m from the sensor."""
+    cases = []
+    for s in range(3):
+        xyzi, label = synth.make_scene(910 + s, 48, 900)
+        slots = [[synth.make_insert(9100 + 10 * s + k, kind, rng_range=(5.0, 20.0))] for k, kind in enumerate(["pedestrian", "car", "cyclist"])]
+        if s == 1:
+            slots[1] = [synth.make_insert(9199, "car", points=big, centre_range=7.0, centre_az=0.7)]
+        cases.append((xyzi, label, slots, [20, 20, 20]))
+    return cases
+
+
+def _far_cases(synth):
+    """Two frames; frame 0 has three rings (1 800 returns, nearly as many pixels) beyond 500 m: more than R3D_FAR_CAP."""
+    cases = []
+    for s in range(2):
+        xyzi, label = synth.make_scene(930 + s, 32, 600)
+        if s == 0:
+            xyzi[:1800, :3] *= (700.0 / np.linalg.norm(xyzi[:1800, :3], axis=1, keepdims=True)).astype(np.float32)
+        slots = [[synth.make_insert(9300 + 10 * s + k, kind, rng_range=(5.0, 15.0))] for k, kind in enumerate(["car", "pedestrian"])]
+        cases.append((xyzi, label, slots, [10, 10]))
+    return cases
+
+
+def _through_augment_batch(pkg, cases, expect_level1):
+    res, acc = pkg.augment_batch([(c[0], c[1]) for c in cases], [c[2] for c in cases], [c[3] for c in cases])
+    if expect_level1 is not None:
+        assert pkg.SceneBatch.last_level1 == expect_level1
+    for i, c in enumerate(cases):
+        (vb, lb, cb), oacc = _oracle(*c)
+        assert list(acc[i]) == list(oacc), i
+        assert res[i][0].tobytes() == vb and res[i][1].tobytes() == lb and res[i][2].tobytes() == cb, i
+    return pkg.SceneBatch.last_level1
+
+
+def _through_lane(pkg, cases, expect_redo):
+    streaming = importlib.import_module("pcl-augmentation_amd.streaming")
+    K = max(len(c[2]) for c in cases)
+    n_max = max(len(c[0]) for c in cases)
+    grow = max(sum(len(slot[0]) for slot in c[2]) for c in cases)
+    srows = max(sum(len(c[2][k][0]) for c in cases if k < len(c[2])) for k in range(K))
+    for delta in (True, False):
+        aug = streaming.StreamedAugmenter(len(cases), n_max, grow, K, srows, lanes=1, delta=delta)
+        aug.submit(0, [(c[0], c[1]) for c in cases], [[slot[0] for slot in c[2]] for c in cases], [c[3] for c in cases])
+        _, results, accepted = aug.collect(0)
+        if expect_redo is not None:
+            assert getattr(aug, "level1_frames", 0) == expect_redo
+        for i, c in enumerate(cases):
+            (vb, lb, cb), oacc = _oracle(*c)
+            assert list(accepted[i][:len(oacc)]) == [0 if a >= 0 else -1 for a in oacc], (delta, i)
+            assert results[i][0].tobytes() == vb and results[i][1].tobytes() == lb and results[i][2].tobytes() == cb, (delta, i)
+
+
+def _through_files(pkg, cases, tmp_path, tag):
+    root = tmp_path / tag
+    (root / "in" / "velodyne").mkdir(parents=True)
+    (root / "in" / "labels").mkdir(parents=True)
+    frames = []
+    for i, c in enumerate(cases):
+        c[0].tofile(root / "in" / "velodyne" / f"{i:06d}.bin")
+        c[1].astype(np.uint32).tofile(root / "in" / "labels" / f"{i:06d}.label")
+        frames.append(pkg.Frame(str(root / "in" / "velodyne" / f"{i:06d}.bin"), str(root / "in" / "labels" / f"{i:06d}.label")))
+    pipe = pkg.AugmentPipeline(str(root / "out"), "run", batch_size=len(cases))
+    st = pipe.run_streamed(frames, lambda i: ([slot[0] for slot in cases[i][2]], cases[i][3]), lanes=2)
+    assert st["written"] == len(cases)
+    for i, c in enumerate(cases):
+        (vb, lb, cb), _ = _oracle(*c)
+        assert (root / "out" / "run" / "velodyne" / f"{i:06d}.bin").read_bytes() == vb, i
+        assert (root / "out" / "run" / "labels" / f"{i:06d}.label").read_bytes() == lb, i
+        assert (root / "out" / "run" / "check" / f"{i:06d}.bin").read_bytes() == cb, i
+
+
+def test_a_truck_of_12000_points(pkg, synth, tmp_path):
+    """A candidate of 12 000 points (round 4: ValueError, R3D_S_SAMPLE_TOO_LARGE above 8 192).  Its per-point arrays exceed
+    a chain workgroup's LDS: the pair goes to k_insert_big, and if that does not hold it either the frame goes through
+    Level 1 -- the route is the library's business, the bytes are the reference's."""
+    cases = _truck_cases(synth, 12000)
+    assert len(cases[1][2][1][0]) == 12000
+    (vb, lb, cb), oacc = _oracle(*cases[1])
+    assert oacc[1] == 0 and len(cb) > 20 * 3000                       # the truck is accepted with thousands of visible points
+    _through_augment_batch(pkg, cases, None)
+    _through_lane(pkg, cases, None)
+    _through_files(pkg, cases, tmp_path, "truck")
+
+
+def test_a_sample_beyond_the_16_bit_indices(pkg, synth, tmp_path):
+    """70 000 points in one candidate: beyond R3D_MAX_SAMPLE (the sample's sorted order is kept in 16-bit indices): the
+    frame is flagged R3D_S_SAMPLE_TOO_LARGE and redone through Level 1; its neighbours in the batch are not."""
+    cases = _truck_cases(synth, 70000)
+    assert _through_augment_batch(pkg, cases, [1]) == [1]
+    _through_lane(pkg, cases, 1)
+    _through_files(pkg, cases, tmp_path, "huge")
+
+
+def test_more_far_pixels_than_the_far_list_holds(pkg, synth, tmp_path):
+    """More than R3D_FAR_CAP pixels with a return beyond 500 m (round 4: ValueError, R3D_S_FAR_OVERFLOW): every one of them
+    is visible to every accepted insert whose sample is empty there (500 < depth: insertion.py:99, :467) and is culled."""
+    cases = _far_cases(synth)
+    (vb, lb, cb), oacc = _oracle(*cases[0])
+    assert list(oacc) == [0, 0] and len(vb) // 16 < len(cases[0][0]) - 1500 + len(cb) // 20     # the far returns are gone
+    assert _through_augment_batch(pkg, cases, [0]) == [0]
+    _through_lane(pkg, cases, 1)
+    _through_files(pkg, cases, tmp_path, "far")
+
+
+def test_a_status_that_is_an_error_still_raises(pkg, synth):
+    """Only the three 'beyond this path's limits' bits are redone; a NaN coordinate (the reference's int() raises,
+    insertion.py:104) stays an exception, also when the same frame carries a redo bit."""
+    cases = _truck_cases(synth, 70000)
+    cases[1][0][5, 0] = np.nan
+    with pytest.raises(ValueError):
+        pkg.augment_batch([(c[0], c[1]) for c in cases], [c[2] for c in cases], [c[3] for c in cases])

@@ -289,8 +289,7 @@ def test_placed_chain_with_the_reference_rejected_candidate_state(P, synth):
                 out, visible, _ = O.evaluate_candidate(scene, s_train, max_el, min_el, cand)   # from the backup (:453)
                 leak = None
                 if len(visible) == 0 or len(visible) < needs[k]:
-                    if len(visible):
-                        leak = out
+                    leak = out            # (also without a visible POINT: :467-473 cull in every visible pixel before :511 counts)
                     continue
                 scene = np.append(out, visible, axis=0)
                 all_visible = np.append(all_visible, visible, axis=0)

@@ -98,7 +98,8 @@ def test_bench_command_with_two_ranks():
     (R3D_DIST_BACKEND=gloo: RCCL wants one GPU per rank).  One JSON line, n_gpus 2, parity keys present."""
     env = {**os.environ, "R3D_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scenes", "64",
-                        "--repeats", "2", "--e2e", "256", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+                        "--repeats", "2", "--e2e", "256", "--cpu-budget", "3", "--parity-scenes", "2"], capture_output=True, text=True,
+                       timeout=900, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -107,3 +108,29 @@ def test_bench_command_with_two_ranks():
     assert out["config"]["scenes_per_gpu"] == 64 and out["repeats"]["regions"] == 2
     assert out["parity_of_overlapped_run"]["lanes_byte_equal_to_lane0"] == 2 and "parity_checked" in out
     assert out["roofline"]["frac"] > 0 and out["e2e_all_ranks"]["ranks"] == 2 and out["e2e_all_ranks"]["frames_per_s_all_ranks"] > 0
+    # every --gpus N line carries the CPU baseline (rank 0 times the oracle before it starts its GPU runtime) and rank 0's
+    # batch is compared with the oracle's bytes
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["kind"] == "port"
+    assert out["parity_checked"] == 2 and out["parity_of_overlapped_run"]["scenes_vs_oracle_lane0"] == 2
+
+
+def test_bench_under_torchrun_with_rccl_world_of_one():
+    """The code the 8-GPU driver executes, once, on the one GPU this box has: `torchrun --nproc-per-node 1 bench.py --gpus 1`
+    with the default backend ("nccl" = RCCL): init_process_group with device_id, barriers around the timed region, all_reduce
+    (MAX) of a GPU tensor, destroy_process_group.  (No scaling is measured here; `n_gpus` is 1.)"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    env.pop("R3D_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--scenes", "64",
+           "--repeats", "2", "--no-extra-legs", "--cpu-budget", "2", "--parity-scenes", "1"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = lines[0]
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0 and out["config"]["process_group"] == "nccl"
+    assert out["cpu_baseline"]["value"] > 0 and out["roofline"]["frac"] > 0 and out["parity_checked"] == 1
