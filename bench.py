@@ -422,6 +422,8 @@ def main():
         settle += 1
         if len(recent) == 3 and max(recent) <= 1.1 * min(recent):
             break
+    for bt, _, _ in lanes:
+        bt.raise_on_status()              # (every lane has run at least once; SceneBatch also learns its clouds' point order here)
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()

@@ -61,6 +61,7 @@ extern "C" {
                                      sample's per-point arrays exceed one CU's LDS (a sample that covers more
                                      than ~200 000 pixels) */
 
+#define R3D_B_FILE_ORDER 2048     /* r3d_batch_t.reserved: the clouds come in a LiDAR file order (see r3d_batch_export_pix below) */
 #define R3D_MAX_SAMPLE 65535      /* points per insert candidate in the batched path (16-bit indices into the sample; round 4:
                                      8 192).  A candidate whose per-point arrays exceed a chain workgroup's LDS goes to
                                      k_insert_big, one that exceeds a whole CU's comes back as R3D_S_WINDOW_TOO_LARGE; the
@@ -276,8 +277,31 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream);
  * [6] scenes handed to k_insert_big; [7] rebases inside the chain kernel; [8..11] rebases by reason: a visible sample point
  * outside the elevation bounds / a culled point held a bound / the same found by the far-pixel pass / none of these (must stay 0);
  * [12..15] index checks a diagnostic build (-DR3D_CHECK) saw fail.  reset: bit 0 clears the counters after the copy; bit 1:
- * host_out16 holds 32 values, [16..31] are the notes such a build keeps about the first failed check. */
+ * host_out16 holds 32 values, [16..31] are the notes such a build keeps about the first failed check; bit 2: it holds 64
+ * values, [32..] are round 5's counters: [32] pairs committed by the workgroup that evaluated them, [33] chunks those pairs
+ * listed in all, [34] / [35] pairs whose evaluator found their predecessors still at work and left them -- with a record of
+ * the evaluation / as they came -- to the workgroup that finishes slot k - 1 (nobody waits: csrc/r3d_insert.hip), [36] pairs
+ * committed from such a record, [37] scenes whose points were put into virtual order at step 0 (below). */
 int r3d_batch_debug_counters(const r3d_batch_t *b, int32_t *host_out16, int32_t reset, void *stream);
+
+/* Point order.  The incremental state of Level 2 is kept per 64 consecutive points (alive word, bounding box of their
+ * pixels), which is cheap when consecutive points are neighbours in the range image -- every LiDAR file order is like that:
+ * ring-major (KITTI, SemanticKITTI), firing sequence by firing sequence (all lasers of one azimuth, then the next).  The
+ * reference does not care about the order (insertion.py:100-127 loops over the points as they come), and neither do the
+ * results here: r3d_batch_begin looks at the boxes it has just built and, for a scene whose mean box exceeds 1 024 pixels (and
+ * that has 4 096 points or more), numbers the points anew by (row, band of 64 columns) -- internally: slabs, log and the
+ * order of every output are untouched.  R3D_VIRTUAL_ORDER=0 / 2 in the environment: never / every scene; bit 1024 of
+ * `reserved`: every scene of this batch (tests).  The look costs a begin four small launches (~20 us per 256 scenes); a caller
+ * who knows that its clouds come in a file order says so with R3D_B_FILE_ORDER in `reserved` and saves them -- a cloud that
+ * does not keep the promise costs time (every insert then walks the whole cloud), never results.  The Python mirror
+ * (SceneBatch) sets the bit by itself once a batch has come through without an unordered scene, and looks again now and then.
+ *
+ * r3d_batch_export_pix: the pixel id of every point of every scene, in the order of the slabs, as the reference numbers
+ * it (row * cols + column, insertion.py:116; `pix` itself holds (row << 16) | column in the internal numbering). */
+int r3d_batch_export_pix(const r3d_batch_t *b, int32_t *pix_ids /* [B*cap] */, void *stream);
+/* r3d_batch_point_order: per scene, how many of its points the last r3d_batch_begin numbered anew (0: the scene keeps the order
+ * of its slab), into DEVICE memory -- what a caller that sets R3D_B_FILE_ORDER by itself looks at (SceneBatch does). */
+int r3d_batch_point_order(const r3d_batch_t *b, int32_t *virtual_order /* [B], device */, void *stream);
 
 /* =====================================================================================
  * Level 3 -- placement search.

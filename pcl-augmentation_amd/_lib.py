@@ -34,6 +34,7 @@ K_BOUNDS, K_PREPARE, K_PROJECT, K_ALIVE_WRITE = 1, 2, 3, 5
 NUMROW, NUMCOLUMN = 112, 1440
 MAX_SAMPLE = 65535
 FAR_CAP = 1024
+B_FILE_ORDER = 2048      # r3d_batch_t.reserved: the clouds come in a LiDAR file order (no look at the chunk boxes, no virtual order)
 MAX_CHAIN = 64           # insert slots one launch of the chain kernel takes (kMaxChain in csrc/r3d_batch.hpp); insert_many splits longer lists
 
 
@@ -107,6 +108,8 @@ _SIGNATURES = {
     "r3d_batch_debug_counters": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int32, _P]),
     "r3d_batch_insert_many": (C.c_int, [C.POINTER(BatchDesc), C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "r3d_batch_export_rows": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P]),
+    "r3d_batch_export_pix": (C.c_int, [C.POINTER(BatchDesc), _P, _P]),
+    "r3d_batch_point_order": (C.c_int, [C.POINTER(BatchDesc), _P, _P]),
     "r3d_batch_adopt_rejected": (C.c_int, [C.POINTER(BatchDesc), _P, _P]),
     "r3d_places_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "r3d_cut_boxes_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),

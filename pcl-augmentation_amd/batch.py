@@ -31,11 +31,20 @@ class SceneBatch:
     last_level1 = []      # scenes run once more through the Level-1 kernels (_lib.S_REDO_LEVEL1)
 
     def __init__(self, B, cap, log_cap, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN, device="cuda:0",
-                 exact_projection=False, debug=0):
+                 exact_projection=False, debug=0, order="auto"):
+        """order: the point order of the clouds this batch will see -- "file" (ring-major, firing sequences: any order in
+        which consecutive points are neighbours in the range image; nothing is looked at), "any" (every ``begin`` looks at
+        the chunk boxes it has built and numbers the points of an unordered cloud anew, internally: four small launches),
+        "auto" (default): as "any" until a batch has come through without an unordered scene, then as "file", with a
+        look every 64th ``begin`` -- datasets do not change their order from frame to frame.  The results never depend on
+        it; a wrong "file" costs time (every insert then walks the whole cloud)."""
         torch = _lib.require_gpu()
         self.torch = torch
         self.lib = _lib.load()
         self.device = torch.device(device)
+        if order not in ("auto", "file", "any"):
+            raise ValueError("order: 'auto', 'file' or 'any'")
+        self.order, self._begins, self._looked = order, 0, False
         with _lib.on(self.device):
             self._init(B, cap, log_cap, rows, cols, exact_projection, debug)
 
@@ -177,10 +186,42 @@ class SceneBatch:
         self._loaded_from_staging = False
 
     # -- the three phases -----------------------------------------------------------------------
+    def _order_bit(self):
+        """Sets / clears R3D_B_FILE_ORDER in the descriptor for the begin that follows (see ``order`` of the constructor)."""
+        if self.order == "file":
+            look = False
+        elif self.order == "any":
+            look = True
+        else:
+            # what the last look found arrives with the next status read-back (note_point_order); until one has: look
+            look = not getattr(self, "_file_order_seen", False) or self._begins % 64 == 0
+        self._begins += 1
+        self._looked = look
+        if look:
+            self.desc.reserved &= ~_lib.B_FILE_ORDER
+        else:
+            self.desc.reserved |= _lib.B_FILE_ORDER
+
+    def note_point_order(self, n_virtual):
+        """What the last ``begin`` that looked has found, read back by whoever synchronises anyway (``raise_on_status``, the
+        streamed lanes' collect): n_virtual[s] > 0 = scene s was numbered anew."""
+        if self._looked:
+            self._file_order_seen = not bool(np.any(np.asarray(n_virtual) > 0))
+
+    @_lib.on_own_device
+    def point_order_device(self):
+        """Device tensor [B] int32: the points of scene s the last ``begin`` numbered anew (0: slab order kept)."""
+        if getattr(self, "_n_virtual", None) is None:
+            self._n_virtual = self.torch.zeros((self.B,), dtype=self.torch.int32, device=self.device)
+        _lib.check(self.lib.r3d_batch_point_order(C.byref(self.desc), C.c_void_p(self._n_virtual.data_ptr()), _lib.stream_ptr()),
+                   "r3d_batch_point_order")
+        return self._n_virtual
+
     @_lib.on_own_device
     def begin(self):
         self.step = 0
         self._rebegin = self.begin                      # how run_inserts' time-out fallback starts the batch again
+        self._order_bit()
         _lib.check(self.lib.r3d_batch_begin(C.byref(self.desc), C.c_void_p(self.n_points.data_ptr()),
                                             _lib.stream_ptr()), "r3d_batch_begin")
 
@@ -212,6 +253,7 @@ class SceneBatch:
         ``run_inserts``: the rows and counts are untouched by the inserts)."""
         self.step = 0
         self._rebegin = self._begin_rows5
+        self._order_bit()
         self.n_points.copy_(self.torch.from_numpy(self.n_frame))
         _lib.check(self.lib.r3d_batch_begin_f64(C.byref(self.desc), C.c_void_p(self._rows5.data_ptr()),
                                                 C.c_void_p(self.n_points.data_ptr()), _lib.stream_ptr()),
@@ -344,8 +386,8 @@ class SceneBatch:
     @_lib.on_own_device
     def debug_counters(self, reset=True):
         """The insert kernels' diagnostic counters (r3d_batch_debug_counters) as a dict."""
-        out = (C.c_int32 * 32)()
-        _lib.check(self.lib.r3d_batch_debug_counters(C.byref(self.desc), out, (1 if reset else 0) | 2, _lib.stream_ptr()),
+        out = (C.c_int32 * 64)()
+        _lib.check(self.lib.r3d_batch_debug_counters(C.byref(self.desc), out, (1 if reset else 0) | 2 | 4, _lib.stream_ptr()),
                    "r3d_batch_debug_counters")
         names = ["pool_exhausted", "tiles_pooled", "evaluated_twice", "verify_runs", "verify_mismatch", "hits_overflow", "deferred_scenes",
                  "rebases_in_chain", "rebase_for_sample_point_outside_bounds", "rebase_for_culled_holder", "rebase_from_far_pass",
@@ -354,18 +396,31 @@ class SceneBatch:
         if any(out[12:16]):              # a diagnostic build (-DR3D_CHECK) counted index checks that failed: [12 + (code & 3)]
             d["check_failures"] = list(out[12:16])
             d["check_notes"] = list(out[16:32])               # ... and what it noted about the first one (csrc/r3d_insert.hip)
+        # round 5 (no workgroup waits for another): pairs committed by the workgroup that evaluated them, pairs left to the
+        # workgroup that finishes their predecessor (with / without a record), pairs committed from such a record
+        pairs, listed = int(out[32]), int(out[33])
+        d.update(pairs_committed_by_their_evaluator=pairs, parked_with_record=int(out[34]), parked_unevaluated=int(out[35]),
+                 committed_from_record=int(out[36]), scenes_in_sorted_order=int(out[37]),
+                 chunks_listed_per_pair=round(listed / pairs, 1) if pairs else None)
         return d
 
+    @_lib.on_own_device
     def pixel_ids(self):
-        """The pixel id of every point as the reference numbers it (row * cols + col, insertion.py:116): the batch keeps
-        (row << 16) | column."""
-        p = self.pix.cpu().numpy().view(np.uint32)
-        return ((p >> 16).astype(np.int64) * self.cols + (p & 0xFFFF)).astype(np.int32)
+        """The pixel id of every point, in the order of the slabs, as the reference numbers it (row * cols + col,
+        insertion.py:116): the batch keeps (row << 16) | column, for a scene in virtual order under another point numbering
+        (``r3d_batch_export_pix``)."""
+        out = self.torch.zeros((self.B, self.cap), dtype=self.torch.int32, device=self.device)
+        _lib.check(self.lib.r3d_batch_export_pix(C.byref(self.desc), C.c_void_p(out.data_ptr()), _lib.stream_ptr()), "r3d_batch_export_pix")
+        return out.cpu().numpy()
 
     # -- results --------------------------------------------------------------------------------
     @_lib.on_own_device
     def raise_on_status(self):
+        if self._looked:
+            nv = self.point_order_device()
         st = self.status.cpu().numpy()
+        if self._looked:
+            self.note_point_order(nv.cpu().numpy())
         for s in np.nonzero(st)[0]:
             _lib.raise_status(int(st[s]), f"scene {s}")
 
@@ -472,7 +527,10 @@ def augment_batch(scenes, candidates, min_points, rows=_lib.NUMROW, cols=_lib.NU
     # sensor on a grid several times the reference's), a sample of more than R3D_MAX_SAMPLE points, more than R3D_FAR_CAP
     # pixels beyond 500 m: once more, alone, through the Level-1 kernels -- whole range images in HBM, no such limit
     # (the reference has none: insertion.py:455-482)
+    order = batch.point_order_device() if batch._looked else None
     status = batch.status.cpu().numpy()
+    if order is not None:
+        batch.note_point_order(order.cpu().numpy())
     redo = [int(s) for s in np.nonzero(status)[0] if _lib.needs_level1(status[s])]
     if redo:
         batch.status[torch_index(batch, redo)] = 0

@@ -37,6 +37,8 @@ __global__ void k_begin_init(r3d_batch_t b, const int32_t *n_points, BatchWs w, 
   b.n_out[s] = 0;
   w.all_list[s] = s;
   w.shadow_valid[s] = 0;
+  w.n_virt[s] = 0;
+  w.box_area[s] = 0;
   w.qkeys[2 * s + 0] = ~0ull;   // running min of z/r
   w.qkeys[2 * s + 1] = 0ull;    // running max of z/r
 }
@@ -290,6 +292,7 @@ __global__ void k_col_table(r3d_batch_t b, BatchWs w) {
 //         cross product; it has to clear 1e-6 * (|x| + |y|), the float64 test needs 1e-12 * (|x|+|y|+|z|)
 //         and |z| < 71 * hypot(x, y) away from the poles.
 //   ss must be a normal float32 far from overflow / flush-to-zero (1e-30 < ss < 1e30).
+constexpr int kVirtAreaCap = 4096;           // pixels of a chunk's box that count towards box_area (k_virt_hist)
 __global__ void __launch_bounds__(kPT)
 k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int chunks) {
   extern __shared__ __align__(16) float s_tabf[];          // [(cols+1)*2] column edges, [(rows+2)*2] row limits
@@ -309,7 +312,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
     const float elo = (float)(bn.min_el + 0.00001);
     const double *row_cc = w.row_q + (int64_t)s * (b.rows + 2);
     uint32_t *queue = w.cand + (int64_t)s * w.cand_stride;  // insert scratch, free during step 0
-    int flags = 0;
+    int flags = 0, area = 0;
     // 8 points per thread and tile; unconfirmed points are queued for k_project_slow.  A block walks
     // several tiles so that the tables are staged once.  Points are requested two rounds ahead of their use
     // (indices clamped to the scene: no branch around a load).
@@ -392,6 +395,11 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
       }
       unsigned long long living = __ballot(i < n);           // every point of the frame is alive at step 0
       int i0 = t0 + k * kPT + (threadIdx.x & ~63);
+      if (i0 < n) {                                            // (wave-uniform: the box is the wave's)
+        const int r0 = (int)(packed & 0xFFFF), r1 = (int)((packed >> 16) & 0xFFFF), c0 = (int)((packed >> 32) & 0xFFFF), c1 = (int)((packed >> 48) & 0xFFFF);
+        const int a = r0 > r1 ? 0 : (r1 - r0 + 1) * (c0 <= c1 ? c1 - c0 + 1 : b.cols - c0 + c1 + 1);
+        area += a > kVirtAreaCap ? kVirtAreaCap : a;
+      }
       if ((threadIdx.x & 63) == 0 && i0 < n) {
         w.chunk_box[(int64_t)s * chunks + (i0 >> 6)] = packed;
         w.alive[(int64_t)s * chunks + (i0 >> 6)] = living;
@@ -400,6 +408,8 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
     }
     flags = wave_or_i32(flags);
     if ((threadIdx.x & 63) == 0 && flags) atomicOr(&b.status[s], flags);
+    // how large are this scene's chunk boxes?  (k_virt_hist: a scene whose points come in no file order)
+    if ((threadIdx.x & 63) == 0 && area) atomicAdd(&w.box_area[s], area);
   }
 }
 
@@ -477,6 +487,219 @@ k_super_rows(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w
   }
 }
 
+// ---- virtual order (r3d_batch.hpp): a cloud whose points come in no LiDAR file order ---------------------------------
+// Is the mean box of a scene's chunks large?  A scan in ring order has boxes of one row by ~50 columns, a firing-sequence
+// order (all lasers of one azimuth, then the next) one column by every row; a shuffled cloud has the whole image in every
+// box, every chunk then sits in every insert's list and an insert costs a pass over the cloud (config C2 shuffled, round 5
+// before this: 1.51 ms per launch of 5 slots against 0.32).  k_project leaves the sum of the boxes' areas (each capped at
+// kVirtAreaCap pixels: a chunk with a point on the slow path has the whole image as box until k_fix_boxes) in box_area[s].
+// If so: a counting sort of the point NUMBERS by (group of rows, band of columns) -- at most kVirtBins bins of a few hundred
+// points each, finer ones than a chunk would buy nothing -- in three streaming kernels: k_virt_hist (a histogram per block
+// of kVirtBlock points), k_virt_scan (counts -> every block's first place per bin), k_virt_scatter ({pixel,
+// point} to its place, inv), k_virt_finish (pixel ids and perm in the new order, the chunk boxes over it).  The order inside
+// a bin is whatever the atomics give: nothing that is computed afterwards depends on it (minima per pixel, kills per pixel,
+// the output in slab order).  (First form, one 1024-thread workgroup per scene with the bins in LDS: 1.42 ms per 256 scenes
+// of 120 000 points -- more than the inserts of config C2 gain.)
+constexpr int kVirtMeanArea = 1024;          // pixels (kVirtAreaCap, the cap per chunk: in front of k_project)
+constexpr int kVirtBins = 512;
+constexpr int kVirtPer = 16;
+constexpr int kVirtBlock = kPT * kVirtPer;   // points per block of the histogram / scatter kernels
+constexpr int kDbgVirtual = 1024;            // r3d_batch_t.reserved: every scene in virtual order (tests)
+struct VirtShape {
+  int mode, gh, cshift, nbands, nbins, nblk;
+};
+inline int virt_blocks(const r3d_batch_t &b) { return (int)((b.cap + kVirtBlock - 1) / kVirtBlock); }
+__device__ __forceinline__ int virt_bin(const VirtShape &v, uint32_t p) { return (pix_row(p) / v.gh) * v.nbands + (pix_col(p) >> v.cshift); }
+
+// does the scene get a virtual order?  (the same answer in k_virt_hist and k_virt_scan)
+__device__ __forceinline__ bool virt_wanted(const r3d_batch_t &b, const BatchWs &w, const VirtShape &v, int s, int n) {
+  if (b.status[s] & (R3D_S_ROW_RANGE | R3D_S_COL_RANGE | R3D_S_NONFINITE)) return false;   // (a point without a pixel)
+  if (v.mode == 2 || (b.reserved & kDbgVirtual)) return n > 0;
+  return n >= 4096 && (long long)w.box_area[s] > (long long)kVirtMeanArea * ((n + 63) >> 6);
+}
+
+__global__ void __launch_bounds__(kPT)
+k_virt_hist(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, VirtShape v) {
+  __shared__ uint32_t s_hist[kVirtBins];
+  const int tid = threadIdx.x;
+  const int cnt = *count;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    const int s = list[li];
+    const int n = b.n_total[s];
+    const int blk = (int)blockIdx.x;
+    if (blk * kVirtBlock >= n || !virt_wanted(b, w, v, s, n)) continue;
+    __syncthreads();
+    for (int e = tid; e < v.nbins; e += kPT) s_hist[e] = 0u;
+    __syncthreads();
+    const int32_t *pix = b.pix + (int64_t)s * b.cap;
+    uint32_t p[kVirtPer];
+#pragma unroll
+    for (int u = 0; u < kVirtPer; ++u) {
+      const int i = blk * kVirtBlock + u * kPT + tid;
+      p[u] = i < n ? (uint32_t)pix[i] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < kVirtPer; ++u)
+      if (p[u] != 0xFFFFFFFFu) atomicAdd(&s_hist[virt_bin(v, p[u])], 1u);
+    __syncthreads();
+    uint32_t *off = w.sort_off + ((int64_t)s * v.nblk + blk) * kVirtBins;
+    for (int e = tid; e < v.nbins; e += kPT) off[e] = s_hist[e];
+  }
+}
+
+// counts -> every block's first place per bin (bin-major: all of bin 0, then bin 1, ...); one block per scene.  (A kernel of
+// its own: the scene's last histogram block doing this needs an agent-scope release per block -- an L2 write-back on this
+// part, 1 us each and one after the other per XCD: 0.9 ms for the 7 680 blocks of config C2.)
+constexpr int kVirtScanNT = 512;
+__global__ void __launch_bounds__(kVirtScanNT)
+k_virt_scan(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, VirtShape v) {
+  static_assert(kVirtBins <= kVirtScanNT, "a bin per thread");
+  __shared__ int s_scan[kVirtScanNT / 64 + 1];
+  const int tid = threadIdx.x;
+  const int cnt = *count;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    const int s = list[li];
+    const int n = b.n_total[s], nblk = (n + kVirtBlock - 1) / kVirtBlock;
+    if (!virt_wanted(b, w, v, s, n)) continue;
+    uint32_t *all = w.sort_off + (int64_t)s * v.nblk * kVirtBins;
+    int total = 0;
+    if (tid < v.nbins) {
+#pragma unroll 8
+      for (int bl = 0; bl < nblk; ++bl) total += (int)all[(int64_t)bl * kVirtBins + tid];
+    }
+    int tot;
+    int run = block_escan_i32(total, s_scan, tot);
+    if (tid < v.nbins) {
+#pragma unroll 8
+      for (int bl = 0; bl < nblk; ++bl) {
+        const int c = (int)all[(int64_t)bl * kVirtBins + tid];
+        all[(int64_t)bl * kVirtBins + tid] = (uint32_t)run;
+        run += c;
+      }
+    }
+    if (tid == 0) {
+      w.n_virt[s] = n;
+      atomicAdd(&w.dbg[37], 1);                              // (D_VIRTUAL of the insert kernels' counters)
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kPT)
+k_virt_scatter(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, VirtShape v) {
+  __shared__ uint32_t s_cur[kVirtBins];
+  const int tid = threadIdx.x;
+  const int cnt = *count;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    const int s = list[li];
+    const int n = w.n_virt[s];
+    const int blk = (int)blockIdx.x;
+    if (blk * kVirtBlock >= n) continue;                     // (n_virt = 0: the scene keeps its order)
+    __syncthreads();
+    const uint32_t *off = w.sort_off + ((int64_t)s * v.nblk + blk) * kVirtBins;
+    for (int e = tid; e < v.nbins; e += kPT) s_cur[e] = off[e];
+    __syncthreads();
+    const int32_t *pix = b.pix + (int64_t)s * b.cap;
+    uint2 *tmp = reinterpret_cast<uint2 *>(b.out_xyzi) + (int64_t)s * b.cap * 2;   // (the output slab: scratch until r3d_batch_finish)
+    uint32_t *inv = w.inv + (int64_t)s * b.cap;
+    uint32_t p[kVirtPer];
+#pragma unroll
+    for (int u = 0; u < kVirtPer; ++u) {
+      const int i = blk * kVirtBlock + u * kPT + tid;
+      p[u] = i < n ? (uint32_t)pix[i] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < kVirtPer; ++u) {
+      if (p[u] == 0xFFFFFFFFu) continue;
+      const int i = blk * kVirtBlock + u * kPT + tid;
+      const uint32_t j = atomicAdd(&s_cur[virt_bin(v, p[u])], 1u);
+      tmp[j] = make_uint2(p[u], (uint32_t)i);
+      inv[i] = j;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kPT)
+k_virt_finish(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int chunks) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int cnt = *count;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    const int s = list[li];
+    const int n = w.n_virt[s];
+    const int t0 = (int)blockIdx.x * kTile;
+    if (t0 >= n) continue;
+    int32_t *pix = b.pix + (int64_t)s * b.cap;
+    const uint2 *tmp = reinterpret_cast<const uint2 *>(b.out_xyzi) + (int64_t)s * b.cap * 2;
+    uint32_t *perm = w.perm + (int64_t)s * b.cap;
+    uint2 e[kPerThread];
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+      const int j = t0 + u * kPT + tid;
+      e[u] = j < n ? tmp[j] : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+      const int j = t0 + u * kPT + tid;
+      BoxAcc box;
+      if (j < n) {
+        pix[j] = (int32_t)e[u].x;
+        perm[j] = e[u].y;
+        box.add(pix_row(e[u].x), pix_col(e[u].x));
+      }
+      const unsigned long long packed = box.wave_pack_arc(j < n ? pix_col(e[u].x) : -1, b.cols);
+      if (lane == 0 && (t0 + u * kPT + (tid & ~63)) < n) w.chunk_box[(int64_t)s * chunks + (j >> 6)] = packed;
+    }
+  }
+}
+
+// A scene in virtual order: its alive bits back in slab order (what the compaction, the delta and the float64 rows are made
+// from), and the living points per 2048-point tile of the slabs.  One block per tile; the other scenes are left alone.
+template <bool ROWS4>
+__global__ void __launch_bounds__(kPT)
+k_unvirtual(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles, int chunks) {
+  __shared__ int s_cnt;
+  const int cnt = *count;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    const int s = list[li];
+    const int n_virt = w.n_virt[s];
+    if (!n_virt) continue;
+    const int n = b.n_total[s], t0 = blockIdx.x * kTile;
+    if (t0 >= n) continue;
+    const bool shadow = ROWS4 && w.shadow_valid[s] != 0;     // (what k_alive_write<ROWS4> shows)
+    const unsigned long long *alive = (shadow ? w.alive_shadow : w.alive) + (int64_t)s * chunks;
+    const uint32_t *inv = w.inv + (int64_t)s * b.cap;
+    __syncthreads();
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    int living = 0;
+    for (int c = (t0 >> 6) + wave; c < ((t0 + kTile) >> 6) && (c << 6) < n; c += kPT / 64) {
+      const int i = (c << 6) + lane;
+      bool on = false;
+      if (i < n) {
+        const int j = i < n_virt ? (int)inv[i] : i;
+        on = (alive[j >> 6] >> (j & 63)) & 1ull;
+      }
+      const unsigned long long word = __ballot(on);
+      if (lane == 0) w.alive_o[(int64_t)s * chunks + c] = word;
+      living += __popcll(word);
+    }
+    if (lane == 0 && living) atomicAdd(&s_cnt, living);
+    __syncthreads();
+    if (threadIdx.x == 0) w.tile_o[(int64_t)s * tiles + blockIdx.x] = s_cnt;
+  }
+}
+
+// SceneBatch.pixel_ids(): the pixel id of every point in slab order as the reference numbers it (row * cols + col)
+__global__ void k_export_pix(r3d_batch_t b, BatchWs w, int32_t *out) {
+  const int s = blockIdx.y;
+  const int n = b.n_total[s], n_virt = w.n_virt[s];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int j = i < n_virt ? (int)w.inv[(int64_t)s * b.cap + i] : i;
+    const uint32_t p = (uint32_t)b.pix[(int64_t)s * b.cap + j];
+    out[(int64_t)s * b.cap + i] = pix_row(p) * b.cols + pix_col(p);
+  }
+}
+
 // Survivors in original order (insertion.py:472-473 applied once for all steps), float4 + label
 // straight into the output arrays.  A wave owns 8 consecutive chunks (512 points) of its block's tile and
 // needs nobody else: its output offset is the sum of the living counts of the scene's preceding tiles
@@ -500,8 +723,9 @@ k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
     if (t0 >= n) continue;
     // (r3d_batch_export_rows shows the copy a rejected candidate has left, while there is one: BatchWs::shadow_valid)
     const bool shadow = ROWS4 && w.shadow_valid[s] != 0;
-    const int32_t *tile_alive = (shadow ? w.tile_shadow : w.tile_alive) + (int64_t)s * tiles;
-    const unsigned long long *alive = (shadow ? w.alive_shadow : w.alive) + (int64_t)s * chunks;
+    const bool virt = w.n_virt[s] != 0;                       // (virtual order: the bits k_unvirtual has put back into slab order)
+    const int32_t *tile_alive = (virt ? w.tile_o : (shadow ? w.tile_shadow : w.tile_alive)) + (int64_t)s * tiles;
+    const unsigned long long *alive = (virt ? w.alive_o : (shadow ? w.alive_shadow : w.alive)) + (int64_t)s * chunks;
     int pre = 0;
     for (int t = lane; t < (int)blockIdx.x; t += 64) pre += tile_alive[t];
     const int first = wave * kWaveChunks;                    // my first chunk within the tile
@@ -633,7 +857,7 @@ __global__ void k_export_delta(r3d_batch_t b, BatchWs w, int chunks, unsigned lo
   }
   const int n_words = (n_total + 63) >> 6;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += gridDim.x * blockDim.x) {
-    unsigned long long a = c < n_words ? w.alive[(int64_t)s * chunks + c] : 0ull;
+    unsigned long long a = c < n_words ? (w.n_virt[s] ? w.alive_o : w.alive)[(int64_t)s * chunks + c] : 0ull;
     const int left = n_total - (c << 6);
     if (left < 64) a = left > 0 ? a & ((1ull << left) - 1ull) : 0ull;
     alive_out[(int64_t)s * chunks + c] = a;
@@ -691,6 +915,31 @@ static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_
                      count, w, chunks_of(b));
   hipLaunchKernelGGL(k_project_slow, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_fix_boxes, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w, chunks_of(b));
+  {
+    // R3D_VIRTUAL_ORDER: 0 never, 1 (default) the scenes whose chunk boxes say that their points come in no file order, 2 all
+    static const int mode = [] {
+      const char *v = getenv("R3D_VIRTUAL_ORDER");
+      return v && *v ? atoi(v) : 1;
+    }();
+    // bit 2048 of `reserved` (R3D_B_FILE_ORDER): the caller says that the clouds come in a LiDAR file order -- nothing is
+    // looked at, nothing sorted (a cloud that does not keep the promise costs time, not results)
+    if (mode && (!(b.reserved & R3D_B_FILE_ORDER) || mode == 2 || (b.reserved & kDbgVirtual))) {
+      VirtShape v;
+      v.mode = mode;
+      v.cshift = 6;                                            // bands of 64 columns, groups of rows: at most kVirtBins bins
+      while (((b.cols + (1 << v.cshift) - 1) >> v.cshift) > kVirtBins) ++v.cshift;
+      v.nbands = (b.cols + (1 << v.cshift) - 1) >> v.cshift;
+      int groups = kVirtBins / v.nbands;
+      groups = groups > b.rows ? b.rows : (groups < 1 ? 1 : groups);
+      v.gh = (b.rows + groups - 1) / groups;
+      v.nbins = ((b.rows + v.gh - 1) / v.gh) * v.nbands;
+      v.nblk = virt_blocks(b);
+      hipLaunchKernelGGL(k_virt_hist, dim3(v.nblk, rows), dim3(kPT), 0, st, b, list, count, w, v);
+      hipLaunchKernelGGL(k_virt_scan, dim3(1, rows), dim3(kVirtScanNT), 0, st, b, list, count, w, v);
+      hipLaunchKernelGGL(k_virt_scatter, dim3(v.nblk, rows), dim3(kPT), 0, st, b, list, count, w, v);
+      hipLaunchKernelGGL(k_virt_finish, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, chunks_of(b));
+    }
+  }
   if (supers_on(b, chunks_of(b)))
     hipLaunchKernelGGL(k_super_rows, dim3((supers_of(b) + kPT / 64 - 1) / (kPT / 64), rows), dim3(kPT), 0, st, b, list, count, w,
                        chunks_of(b));
@@ -704,10 +953,14 @@ static int launch_compact(const r3d_batch_t &b, const BatchWs &w, const int32_t 
   int tiles = tiles_of(b);
   dim3 grid(tiles, rows), blk(kPT);
   // non-temporal loads and stores: nothing of the cloud is read again before r3d_batch_begin overwrites the state
-  if (rows4)
+  // (scenes in virtual order: their alive bits back in slab order first; a block of the others returns at once)
+  if (rows4) {
+    hipLaunchKernelGGL((k_unvirtual<true>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b));
     hipLaunchKernelGGL((k_alive_write<true, false>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b), rows4, n_rows);
-  else
+  } else {
+    hipLaunchKernelGGL((k_unvirtual<false>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b));
     hipLaunchKernelGGL((k_alive_write<false, true>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b), rows4, n_rows);
+  }
   R3D_LAUNCHED("compaction kernel");
   return R3D_OK;
 }
@@ -729,7 +982,7 @@ int r3d_batch_create(const r3d_batch_t *b, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   BatchWs w = carve_batch(*b, b->workspace);
   hipLaunchKernelGGL(k_col_table, dim3((b->cols + 1 + 255) / 256), dim3(256), 0, st, *b, w);
-  R3D_HIP(hipMemsetAsync(w.dbg, 0, 32 * sizeof(int32_t), st));
+  R3D_HIP(hipMemsetAsync(w.dbg, 0, 64 * sizeof(int32_t), st));
   R3D_LAUNCHED("k_col_table");
   return R3D_OK;
 }
@@ -799,12 +1052,33 @@ int r3d_batch_export_rows(const r3d_batch_t *b, double *rows4, int32_t *n_rows, 
   return launch_compact(*b, w, w.all_list, w.all_count, b->B, (hipStream_t)stream, rows4, n_rows);
 }
 
+int r3d_batch_point_order(const r3d_batch_t *b, int32_t *virtual_order, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  if (!virtual_order) return fail(R3D_E_ARG, "batch_point_order: null output");
+  BatchWs w = carve_batch(*b, b->workspace);
+  R3D_HIP(hipMemcpyAsync(virtual_order, w.n_virt, (size_t)b->B * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return R3D_OK;
+}
+
+int r3d_batch_export_pix(const r3d_batch_t *b, int32_t *pix_ids, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  if (!pix_ids) return fail(R3D_E_ARG, "batch_export_pix: null output");
+  BatchWs w = carve_batch(*b, b->workspace);
+  hipLaunchKernelGGL(k_export_pix, dim3(32, b->B), dim3(256), 0, (hipStream_t)stream, *b, w, pix_ids);
+  R3D_LAUNCHED("k_export_pix");
+  return R3D_OK;
+}
+
 int r3d_batch_export_delta(const r3d_batch_t *b, uint64_t *alive, float *tail_xyzi, uint32_t *tail_label, int64_t tail_stride,
                            int32_t *counts, void *stream) {
   int rc = check_batch(b);
   if (rc != R3D_OK) return rc;
   if (!alive || !tail_xyzi || !tail_label || !counts || tail_stride <= 0) return fail(R3D_E_ARG, "batch_export_delta: null output or stride");
   BatchWs w = carve_batch(*b, b->workspace);
+  hipLaunchKernelGGL((k_unvirtual<false>), dim3(tiles_of(*b), b->B), dim3(kPT), 0, (hipStream_t)stream, *b, w.all_list, w.all_count, w,
+                     tiles_of(*b), chunks_of(*b));
   hipLaunchKernelGGL(k_export_delta, dim3(8, b->B), dim3(256), 0, (hipStream_t)stream, *b, w, chunks_of(*b),
                      reinterpret_cast<unsigned long long *>(alive), tail_xyzi, tail_label, tail_stride, counts);
   R3D_LAUNCHED("k_export_delta");

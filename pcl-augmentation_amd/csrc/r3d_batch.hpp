@@ -8,6 +8,12 @@
 //                  turns visible for an accepted insert (insertion.py:472-473), set for appended points
 //   chunk_box[c]   row / column bounding box of the pixels of chunk c (all of its points, dead or alive)
 //   tile_alive[t]  living points of the 2048-point tile t: the compaction's offsets without a counting pass
+// Round 5, VIRTUAL ORDER: all of the above lean on the point order of LiDAR files (64 consecutive points = a piece of one ring:
+// a chunk's box is one row by ~50 columns).  A cloud whose points come in no such order (the reference does not care:
+// insertion.py:100-127) gets, at step 0, a permutation of its points by (row, 64-column band) -- n_virt[s] > 0 --, and point
+// number j < n_virt[s] of everything above (pix, alive, chunk_box, tile_alive) is point perm[j] of the slabs; the slabs, the
+// log and the OUTPUT ORDER are untouched: r3d_batch_finish / export_delta / export_rows first put the alive bits back
+// into slab order (k_unvirtual: alive_o, tile_o).
 #pragma once
 
 #include <cstdlib>
@@ -23,6 +29,7 @@ constexpr int kTile = kPT * kPerThread;   // points per block tile
 constexpr int kKeyCap = R3D_MAX_SAMPLE;
 constexpr int kMaxChain = 64;        // insert slots of one k_insert_chain launch
 constexpr int kRecInts = 16;         // int32 words of a published slot record
+constexpr int kParkInts = 32;        // int32 words of the header a parked pair leaves (r3d_insert.hip)
 constexpr int kEntry = 32;           // bytes of a chunk-list entry of the insert kernels (r3d_insert.hip)
 
 struct BatchWs {
@@ -42,21 +49,33 @@ struct BatchWs {
   int32_t *chain_progress;      // [B] slots of the scene completed by the running k_insert_chain (< 0: see r3d_insert.hip)
   int32_t *n_total0;            // [B] n_total when the running k_insert_chain was launched
   int32_t *defer_from;          // [B] first slot of the launch left to k_insert_big (n_slots: none)
-  int32_t *claim_next;          // [B] next slot of the scene a workgroup of k_insert_chain may claim (queue modes 3 / 4)
   unsigned long long *alive_shadow; // [B*chunks] the alive bits of the culled copy a REJECTED candidate leaves (min_points < 0)
   int32_t *tile_shadow;         // [B*tiles] ... and its living points per tile
   int32_t *shadow_valid;        // [B] 1: r3d_batch_export_rows shows that copy; r3d_batch_adopt_rejected makes it the scene
   int32_t *super_rows;          // [B*supers*2] first / last row over the boxes of 64 consecutive chunks (clouds of kSuperMinChunks
                                 // chunks and more: the chunk list looks at a chunk's box only when its super-box reaches the window)
   int32_t *recs;                // [B*kMaxChain*kRecInts] what every finished slot of the launch publishes
+  int32_t *park;                // [B*kMaxChain] hand-over word of every pair of the running launch: its evaluator leaves "parked"
+                                // there, the workgroup that finishes the scene's previous slot "predecessor done" -- whoever
+                                // comes second carries on with the pair (r3d_insert.hip: nobody ever waits)
+  int32_t *park_hdr;            // [B*kMaxChain*kParkInts] what a parked pair leaves for the workgroup that commits it
+  int32_t *slot_order;          // [kMaxChain] the order in which the running launch hands out its slots
+  int32_t *n_virt;              // [B] > 0: the scene's first n_virt points are in virtual order (see the top of this file)
+  int32_t *box_area;            // [B] sum of the areas of the scene's chunk boxes as k_project built them (each capped)
+  uint32_t *sort_off;           // [B*sort_blocks*512] per block of 4 096 points and bin: count, then first place (k_virt_hist)
+  uint32_t *perm;               // [B*cap] virtual point number -> point of the slabs (first n_virt entries of a scene)
+  uint32_t *inv;                // [B*cap] point of the slabs -> virtual point number
+  unsigned long long *alive_o;  // [B*chunks] alive words of a scene in virtual order, put back into slab order (k_unvirtual)
+  int32_t *tile_o;              // [B*tiles] ... and the living points per tile in slab order
   unsigned char *glist;         // [B*chunks*kEntry] k_insert_big's chunk lists, one area per scene (a pair of k_insert_chain whose
                                 // list exceeds its LDS takes room from the pool)
   unsigned char *tile_pool;     // [pool_bytes] the launch's bump pool: depth tiles / candidate lists / chunk lists / scratch images
                                 // of the pairs whose window exceeds a workgroup's LDS
   unsigned long long *pool_head; // [1] bytes handed out in the running launch
   int32_t *queue_next;          // [16] the running k_insert_chain's work queues: next pair of XCD x's queue in [x] (all pairs: [0])
-  int32_t *dbg;                 // [32] diagnostic counters of the insert kernels (r3d_batch_debug_counters: the first 16;
-                                // [16..31]: what a diagnostic build notes about the first failed check, `reset` bit 1 asks for them)
+  int32_t *dbg;                 // [64] diagnostic counters of the insert kernels (r3d_batch_debug_counters: the first 16;
+                                // [16..31]: what a diagnostic build notes about the first failed check, `reset` bit 1 asks for them;
+                                // [32..63]: round 5's counters, `reset` bit 2)
   int64_t pool_bytes;
   int64_t cand_stride;          // uint32 entries of `cand` per scene
   size_t total;
@@ -102,12 +121,21 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.chain_progress = c.take<int32_t>((size_t)b.B);
   w.n_total0 = c.take<int32_t>((size_t)b.B);
   w.defer_from = c.take<int32_t>((size_t)b.B);
-  w.claim_next = c.take<int32_t>((size_t)b.B);
   w.super_rows = c.take<int32_t>((size_t)b.B * supers_of(b) * 2);
   w.alive_shadow = c.take<unsigned long long>((size_t)b.B * chunks_of(b));
   w.tile_shadow = c.take<int32_t>((size_t)b.B * tiles);
   w.shadow_valid = c.take<int32_t>((size_t)b.B);
   w.recs = c.take<int32_t>((size_t)b.B * kMaxChain * kRecInts);
+  w.park = c.take<int32_t>((size_t)b.B * kMaxChain);
+  w.park_hdr = c.take<int32_t>((size_t)b.B * kMaxChain * kParkInts);
+  w.slot_order = c.take<int32_t>(kMaxChain);
+  w.n_virt = c.take<int32_t>((size_t)b.B);
+  w.box_area = c.take<int32_t>((size_t)b.B);
+  w.sort_off = c.take<uint32_t>((size_t)b.B * ((b.cap + 4095) / 4096) * 512);
+  w.perm = c.take<uint32_t>((size_t)b.B * b.cap);
+  w.inv = c.take<uint32_t>((size_t)b.B * b.cap);
+  w.alive_o = c.take<unsigned long long>((size_t)b.B * chunks_of(b));
+  w.tile_o = c.take<int32_t>((size_t)b.B * tiles);
   w.glist = c.take<unsigned char>((size_t)b.B * chunks_of(b) * kEntry);
   // The launch's pool: depth tiles, candidate lists, chunk lists and scratch images of the pairs whose window exceeds a
   // workgroup's LDS (on the reference's grid a few per cent of the pairs, 10-60 KB each; on a range image several times
@@ -125,7 +153,7 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.tile_pool = c.take<unsigned char>((size_t)w.pool_bytes);
   w.pool_head = c.take<unsigned long long>(1);
   w.queue_next = c.take<int32_t>(16);
-  w.dbg = c.take<int32_t>(32);
+  w.dbg = c.take<int32_t>(64);
   w.total = c.off;
   return w;
 }
@@ -277,6 +305,11 @@ __device__ __forceinline__ int project_point(const r3d_batch_t &b, int s, const 
   return p;
 }
 
+// Point number j of the insert kernels' numbering -> point of the slabs (n_virt: BatchWs::n_virt[s], 0 for a scene in file order)
+__device__ __forceinline__ int orig_of(const BatchWs &w, const r3d_batch_t &b, int s, int n_virt, int j) {
+  return j < n_virt ? (int)w.perm[(int64_t)s * b.cap + j] : j;
+}
+
 __device__ __forceinline__ bool alive_bit(const BatchWs &w, int chunks, int s, int i) {
   return (w.alive[(int64_t)s * chunks + (i >> 6)] >> (i & 63)) & 1ull;
 }
@@ -338,7 +371,7 @@ __device__ __forceinline__ void rebase_scene(const r3d_batch_t &b, const BatchWs
   // (the caller has fenced; the scalar cache is dropped as well: the counts below may travel through it, and this
   // workgroup read the older ones before its commit)
   asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-  const int n = b.n_total[s], n_head = b.n_head[s];
+  const int n = b.n_total[s], n_head = b.n_head[s], n_virt = w.n_virt[s];
   int32_t *pix = b.pix + (int64_t)s * b.cap;
   // (a) bounds (insertion.py:78-79) via the extreme z/r of the living
   unsigned long long lmin = ~0ull, lmax = 0ull;
@@ -346,7 +379,7 @@ __device__ __forceinline__ void rebase_scene(const r3d_batch_t &b, const BatchWs
   for (int i = tid; i < n; i += NT) {
     if (!alive_bit(w, chunks, s, i)) continue;
     double x, y, z;
-    load_point(b, s, i, n_head, x, y, z);
+    load_point(b, s, orig_of(w, b, s, n_virt, i), n_head, x, y, z);
     double q = z / sqrt(x * x + y * y + z * z);
     if (!(q >= -1.0 && q <= 1.0)) bad = 1;
     else {
@@ -400,7 +433,7 @@ __device__ __forceinline__ void rebase_scene(const r3d_batch_t &b, const BatchWs
     BoxAcc box;
     if (i < n && alive_bit(w, chunks, s, i)) {
       double x, y, z;
-      load_point(b, s, i, n_head, x, y, z);
+      load_point(b, s, orig_of(w, b, s, n_virt, i), n_head, x, y, z);
       pix[i] = project_point(b, s, bn, x, y, z, flags, box);
     }
     unsigned long long packed = box.wave_pack();

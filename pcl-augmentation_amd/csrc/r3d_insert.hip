@@ -25,16 +25,24 @@
 // Otherwise it evaluates again, now after its predecessors.  The chain of a scene therefore costs one
 // evaluation plus K commits instead of K evaluations.
 //
-// Hand-off between the slots of a scene (cdna_hip_programming.md, Guideline 16; correct for any
-// placement of the workgroups): every storing wave drains (s_waitcnt vmcnt(0)), barrier, ONE lane does
-// the agent-scope release, waits again and stores the scene's progress word (relaxed, agent scope);
-// the consumer polls that word relaxed from ONE lane, then ONE agent-scope acquire + wait, barrier,
-// scalar cache dropped.  Reads of a speculative evaluation race with the commits of the scene's
-// running predecessors by design: those only write points and bits the evaluation either does not
-// look at (indices >= its base count) or that lie in pixels whose change is detected afterwards.
-// Liveness leans on in-order dispatch (workgroups are numbered slot-major, and a scene's slots stay
-// on block ids of one residue mod 8, i.e. on one XCD's queue); the wait is bounded by wall clock
-// all the same: R3D_S_CHAIN_TIMEOUT flags the scene, its later slots are skipped.
+// Hand-off between the slots of a scene: NOBODY WAITS (round 5).  A pair whose predecessors are still at work when its
+// speculative evaluation is done PARKS it: what the commit needs -- {sample index, pixel} of every visible point in order,
+// {chunk, mask} of every chunk that loses points, the boxes the conflict test looks at -- goes to a piece of the launch's
+// pool, a header to BatchWs::park_hdr, and the workgroup moves on to its next pair.  The workgroup that finishes slot k - 1
+// of the scene finds slot k parked, checks the records of the slots the evaluation did not know for a conflict and commits
+// it from the record (or evaluates it again, now after its predecessors), then slot k + 1, and so on.  Who carries on is
+// decided by ONE atomic exchange each on the pair's hand-over word (BatchWs::park): the evaluator leaves "parked", the
+// workgroup that has published slot k - 1 leaves "predecessor done"; whoever finds the other's mark there continues with
+// the pair.  Rounds 2-4 had the evaluator spin on the scene's progress word instead (11-14 % of a pair's time, a whole CU
+// idle on large range images), which also tied liveness to the order in which workgroups are dispatched -- a workgroup could
+// only wait for lower block ids -- and needed a wall-clock time-out; now any order of dispatch is correct, so the launch
+// hands out its heaviest slot first when the chain is short (k_chain_init: slot_order).
+// Memory ordering (cdna_hip_programming.md, Guideline 16; correct for any placement of the workgroups): every storing wave
+// drains (s_waitcnt vmcnt(0)), barrier, ONE lane does the agent-scope release, waits again, then the relaxed agent-scope
+// atomic (progress word, hand-over word); the side that finds the other's mark does ONE agent-scope acquire + wait,
+// barrier, scalar cache dropped.  Reads of a speculative evaluation race with the commits of the scene's running
+// predecessors by design: those only write points and bits the evaluation either does not look at (indices >= its base
+// count) or that lie in pixels whose change is detected afterwards.
 //
 // Working set: everything lives in the workgroup's LDS (`lds_cap` bytes, a few workgroups per CU).
 // A pair whose depth tile, candidate list or chunk list does not fit uses the scene's global
@@ -89,7 +97,14 @@ struct ChainSlots {
 // published record of a finished slot
 enum { REC_FLAGS = 0, REC_NTOTAL, REC_RLO, REC_RHI, REC_CLO0, REC_CHI0, REC_CLO1, REC_CHI1 };
 constexpr int kRecAccepted = 1, kRecRebased = 2, kRecFar = 4;
-constexpr int kProgTimeout = -1, kProgDeferred = -2;
+constexpr int kProgDeferred = -2;                        // (-1: round 4's time-out mark, no longer written)
+// hand-over word of a pair (BatchWs::park) and the header a parked pair leaves (BatchWs::park_hdr, kParkInts words)
+constexpr int kParkNone = 0, kParkParked = 1, kParkPredDone = 2;
+constexpr int kParkRaw = 0, kParkEvaluated = 1;      // PK_KIND: nothing usable was left (evaluate after the predecessors) | a record
+enum { PK_KIND = 0, PK_P0, PK_NVALID, PK_NVIS, PK_ACCEPT, PK_REBASE, PK_FLAGS, PK_NKILL, PK_OFF_LO, PK_OFF_HI,
+       PK_RMIN, PK_RMAX, PK_CMIN0, PK_CMIN1, PK_CMAX0, PK_CMAX1, PK_VRMIN, PK_VRMAX, PK_VCMIN0, PK_VCMIN1, PK_VCMAX0, PK_VCMAX1,
+       PK_SIG_LO, PK_SIG_HI, PK_VERIFY };
+static_assert(PK_VERIFY < kParkInts, "the header of a parked pair");
 
 // ---- window of the range image: rows [r_lo, r_hi] x one or two column intervals of whole 32-pixel
 // words (two when the object straddles the azimuth seam) ---------------------------------------------
@@ -217,16 +232,24 @@ enum {
   H_NVALID = 0, H_NCAND, H_REBASE, H_FLAGS, H_RMIN, H_RMAX, H_CMIN0, H_CMIN1, H_CMAX0, H_CMAX1,
   H_NLIST, H_CARRY, H_EXT0, H_EXT1, H_NOCC, H_NVIS, H_VRMIN, H_VRMAX, H_VCMIN0, H_VCMIN1, H_VCMAX0,
   H_VCMAX1, H_FARADD, H_FILL, H_NHIT, H_HITEND,
-  H_SIG = 26,         // two words: the signature's 64-bit sum (diagnostic bit 64)
-  H_GO = 30,          // chain logic: broadcast cells [H_GO - 2, H_GO + 1] (not touched by the phases)
-  H_SCAN = 32         // block scan cells [NT/64 + 1]
+  H_SFAR,             // the sample has a point beyond 500 m (its commit may add to the far list: such a pair is never parked as a record)
+  H_SIG = 28,         // two words: the signature's 64-bit sum (diagnostic bit 64)
+  H_PHASE_END = 30,   // the cells below belong to the phases (sample_phase clears them)
+  H_GO = 32,          // chain logic: broadcast cells [H_GO, H_GO + 1] (not touched by the phases)
+  H_SCAN = 36         // block scan cells [NT/64 + 1]
 };
+static_assert(H_SFAR < H_SIG && (H_SIG & 1) == 0, "header cells");
 constexpr int kHdrBytes = 512;
 
 enum { kOk = 0, kNoFit = 1, kNeedSerial = 2, kStale = 3 };
 // diagnostic counters (BatchWs::dbg; r3d_batch_debug_counters)
 enum { D_POOL_FULL = 0, D_TILE_POOLED, D_EVAL_TWICE, D_VERIFY_RUNS, D_VERIFY_MISMATCH, D_HITS_OVERFLOW, D_DEFERRED, D_REBASE,
-       D_REBASE_OOB, D_REBASE_HOLDER, D_REBASE_FAR, D_REBASE_OTHER };     // (a diagnostic build, -DR3D_CHECK, counts its failed checks from [12] on)
+       D_REBASE_OOB, D_REBASE_HOLDER, D_REBASE_FAR, D_REBASE_OTHER,       // (a diagnostic build, -DR3D_CHECK, counts its failed checks in [12 .. 15], notes in [16 .. 31])
+       // round 5, [32 ..]: pairs committed from their own evaluation and the chunks they listed; pairs left to whoever finishes
+       // their predecessors -- with a record of the evaluation / as they came --; parked pairs committed from their record
+       D_PAIRS = 32, D_CHUNKS_LISTED, D_PARKED, D_PARKED_RAW, D_TAKEOVER_COMMIT,
+       D_VIRTUAL /* scenes put into virtual order at step 0: counted by k_virtual_order, r3d_batch.hip */ };
+constexpr int kDbgInts = 64;
 
 // Diagnostic builds (-DR3D_CHECK): the index of every access the gather / kill / commit code derives from data is
 // checked against its array; a violation is counted in BatchWs::dbg[8 + code] and the access skipped.
@@ -560,7 +583,7 @@ struct Ins {
     if (carve > lds_cap) return kNoFit;
     __syncthreads();                                         // the previous use of this LDS is over
     for (int i = tid; i < ((m + 31) >> 5); i += NT) s_oob[i] = 0u;
-    if (tid < H_GO)
+    if (tid < H_PHASE_END)
       H[tid] = (tid == H_RMIN || tid == H_CMIN0 || tid == H_CMIN1 || tid == H_VRMIN || tid == H_VCMIN0 || tid == H_VCMIN1)
                    ? 0x7FFFFFFF
                    : (tid == H_RMAX || tid == H_CMAX0 || tid == H_CMAX1 || tid == H_EXT0 || tid == H_EXT1 ||
@@ -737,8 +760,10 @@ struct Ins {
       s_F[a + before] = (uint16_t)j;
       const double *q = rows5 + (int64_t)j * 5;
       double x = q[0], y = q[1], zc = q[2];
-      unsigned long long key = depth_key(sqrt(x * x + y * y + zc * zc));
+      const double rr = sqrt(x * x + y * y + zc * zc);
+      unsigned long long key = depth_key(rr);
       atomicMin(&s_sdepth[rk], key);
+      if (rr > R3D_EMPTY_DEPTH) H[H_SFAR] = 1;                 // (every writer writes 1)
     }
     __syncthreads();
 
@@ -849,7 +874,7 @@ struct Ins {
   // and pooled tiles: the occupancy of the whole window is needed up front).
   __device__ __forceinline__ void gather(bool all_rows_bits, const uint16_t *sub, int nsub) {
     constexpr int kPer = NT == 1024 ? R3D_GATHER_PER_BIG : R3D_GATHER_PER;    // (one workgroup per CU: nothing else hides the loads)
-    const int n_head = uni(b.n_head[s]);
+    const int n_head = uni(b.n_head[s]), n_virt = uni(w.n_virt[s]);
     const uint32_t *pixs = reinterpret_cast<const uint32_t *>(b.pix) + (int64_t)s * b.cap;
     const float4 *xyzi = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
     const int nitems = (sub ? nsub : nlist) << 6;           // sub: the entries whose rows reach the band
@@ -907,6 +932,12 @@ struct Ins {
 #pragma unroll
       for (int h = 0; h < kPer; h += 4) {
         float4 f[4];
+        // (a scene in virtual order: the point of the slabs behind the listed point number -- one more dependent load,
+        // for such scenes only)
+        if (n_virt)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (dl[h + u] >= 0) idx[h + u] = orig_of(w, b, s, n_virt, idx[h + u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           f[u] = make_float4(1.f, 0.f, 0.f, 0.f);
@@ -935,7 +966,7 @@ struct Ins {
   // trips to memory however long the list is.  A wave whose hits do not fit the room fetches its coordinates right away.
   __device__ __forceinline__ void gather_flat(bool all_rows_bits) {
     constexpr int kU = 8;
-    const int n_head = uni(b.n_head[s]);
+    const int n_head = uni(b.n_head[s]), n_virt = uni(w.n_virt[s]);
     const uint32_t *pixs = reinterpret_cast<const uint32_t *>(b.pix) + (int64_t)s * b.cap;
     const float4 *xyzi = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
     const int nitems = nlist << 6;
@@ -1002,7 +1033,7 @@ struct Ins {
         for (int u = 0; u < kU; ++u) {
           if (code[u] == 0xFFFFFFFFu) continue;
           double x, y, z;
-          load_point(b, s, idx[u], n_head, x, y, z);
+          load_point(b, s, orig_of(w, b, s, n_virt, idx[u]), n_head, x, y, z);
           const unsigned long long key = depth_key(x * x + y * y + z * z);
           if (g_dtile) atomicMin(&g_dtile[code[u] >> 16], key);
           else atomicMin(&s_dtile[code[u] >> 16], key);
@@ -1021,9 +1052,15 @@ struct Ins {
         hv[u] = h < nh ? s_hit[h] : make_uint2(0xFFFFFFFFu, 0u);
       }
 #pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (hv[u].x != 0xFFFFFFFFu && !CHK((int)hv[u].x < n_base && (int)(hv[u].y >> 16) < dt.npx, 3)) hv[u].x = 0xFFFFFFFFu;
+      if (n_virt)                                              // (virtual order: the point of the slabs behind the hit)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (hv[u].x != 0xFFFFFFFFu) hv[u].x = (uint32_t)orig_of(w, b, s, n_virt, (int)hv[u].x);
+#pragma unroll
       for (int u = 0; u < 4; ++u) {
         f[u] = make_float4(1.f, 0.f, 0.f, 0.f);
-        if (hv[u].x != 0xFFFFFFFFu && !CHK((int)hv[u].x < n_base && (int)(hv[u].y >> 16) < dt.npx, 3)) hv[u].x = 0xFFFFFFFFu;
         if (hv[u].x != 0xFFFFFFFFu && (int)hv[u].x < n_head) f[u] = xyzi[hv[u].x];
       }
 #pragma unroll
@@ -1182,6 +1219,7 @@ struct Ins {
     // band, the evaluation reads the tile through L2); in row bands in LDS only when the pool is exhausted
     g_dtile = nullptr;
     g_cand = nullptr;
+    // (round 5, measured on config C5: such tiles in row bands in LDS instead -- 30.1 against 5.07 ms per launch)
     if (!single && !(b.reserved & kDbgBands) && pool_off != -2) {
       if (pool_off == -1) {
         pool_off = pool_take((((long long)dt.npx * 8 + 255) & ~255ll) + (long long)ncand * 4);
@@ -1505,7 +1543,7 @@ struct Ins {
             const int i = e >> 6;
             if (!((l_kill(i) >> (e & 63)) & 1ull)) continue;
             double x, y, z;
-            load_point(b, s, (int)(l_chunk(i) << 6) + (e & 63), n_head, x, y, z);
+            load_point(b, s, orig_of(w, b, s, uni(w.n_virt[s]), (int)(l_chunk(i) << 6) + (e & 63)), n_head, x, y, z);
             const double q = z / sqrt(x * x + y * y + z * z);
             if (q == q_min || q == q_max) atomicOr(&H[H_REBASE], 2);
           }
@@ -1522,9 +1560,77 @@ struct Ins {
   // commit of an accepted candidate: append (insertion.py:526), cull (:470-473).  Returns true when
   // the scene must be re-based (the elevation bounds may have moved).  `flags_out`: kRec* bits.
   // ================================================================================================
+  // What a commit is made from: the evaluation's structures in this workgroup's LDS (FromLds), or the record a parked pair
+  // has left in the pool (FromRecord; written by park_write() through the very accessors of FromLds).
+  struct FromLds {
+    static constexpr bool kLds = true;
+    const Ins &I;
+    __device__ __forceinline__ void vis(int o, int &j, int &row, int &col) const {     // visible point o, in (pixel, index) order
+      j = I.s_F[I.s_V[o]];
+      const int lp = (int)I.s_lp[j];
+      I.win.row_word(lp >> 5, row, col);
+      col = (col << 5) + (lp & 31);
+    }
+    __device__ __forceinline__ int n_kill() const { return I.nlist; }
+    __device__ __forceinline__ bool kill(int i, int &c, unsigned long long &mask) const {   // false: the chunk loses nobody
+      mask = I.l_kill(i);
+      c = (int)I.l_chunk(i);
+      return mask != 0ull;
+    }
+  };
+  struct FromRecord {
+    static constexpr bool kLds = false;
+    const uint2 *v;                 // {sample index, packed pixel} per visible point
+    const ulonglong2 *kl;           // {chunk, mask}
+    int nkill;
+    __device__ __forceinline__ void vis(int o, int &j, int &row, int &col) const {
+      const uint2 e = v[o];
+      j = (int)e.x;
+      row = pix_row(e.y);
+      col = pix_col(e.y);
+    }
+    __device__ __forceinline__ int n_kill() const { return nkill; }
+    __device__ __forceinline__ bool kill(int i, int &c, unsigned long long &mask) const {
+      const ulonglong2 e = kl[i];
+      c = (int)e.x;
+      mask = e.y;
+      return mask != 0ull;
+    }
+  };
+  static __device__ __forceinline__ long long park_vis_bytes(int nvis_) { return ((long long)nvis_ * 8 + 15) & ~15ll; }
+
+  // Leaves what commit() needs of this (accepted) evaluation in a piece of the launch's pool.  Returns its offset, -1 when
+  // the pool is exhausted; `n_kill_out`: entries of the kill list.  Whole workgroup.
+  __device__ __forceinline__ long long park_write(int &n_kill_out) {
+    n_kill_out = 0;
+    if (!accept) return 0;
+    const long long off = pool_take(park_vis_bytes(nvis) + (long long)nlist * 16);
+    if (off < 0) return -1;
+    uint2 *v = reinterpret_cast<uint2 *>(w.tile_pool + off);
+    ulonglong2 *kl = reinterpret_cast<ulonglong2 *>(w.tile_pool + off + park_vis_bytes(nvis));
+    const FromLds src{*this};
+    for (int o = tid; o < nvis; o += NT) {
+      int j, row, col;
+      src.vis(o, j, row, col);
+      v[o] = make_uint2((uint32_t)j, pack_pix(row, col));
+    }
+    if (tid == 0) H[H_CARRY] = 0;
+    __syncthreads();
+    for (int i = tid; i < nlist; i += NT) {
+      int c;
+      unsigned long long mask;
+      if (src.kill(i, c, mask)) kl[atomicAdd(&H[H_CARRY], 1)] = make_ulonglong2((unsigned long long)(uint32_t)c, mask);
+    }
+    __syncthreads();
+    n_kill_out = uni(H[H_CARRY]);
+    return off;
+  }
+  __device__ __forceinline__ bool sample_far() const { return uni(H[H_SFAR]) != 0; }
+
   // n_total_in / n_head_in: the scene's counts when the caller already holds them (the chain kernel: from the
   // predecessor's record), -1 = read them here.  The log holds one row per appended point: n_log = n_total - n_head.
-  __device__ __forceinline__ bool commit(int &flags_out, int &n_total_after, int n_total_in = -1, int n_head_in = -1) {
+  template <class SRC>
+  __device__ __forceinline__ bool commit(const SRC &src, int &flags_out, int &n_total_after, int n_total_in = -1, int n_head_in = -1) {
     const int lane = tid & 63, wave = tid >> 6;
     const int n_head = n_head_in >= 0 ? n_head_in : uni(b.n_head[s]);
     const int n_total = n_total_in >= 0 ? n_total_in : uni(b.n_total[s]);
@@ -1551,15 +1657,16 @@ struct Ins {
       for (int t = tid; t < tiles; t += NT) ts[t] = tile_alive[t];
       phase_sync();
       if (accept) {
-        for (int i = tid; i < nlist; i += NT) {
-          const unsigned long long mask = l_kill(i);
-          if (!mask) continue;
-          const int c = (int)l_chunk(i);
+        for (int i = tid; i < src.n_kill(); i += NT) {
+          int c;
+          unsigned long long mask;
+          if (!src.kill(i, c, mask)) continue;
           if (!CHK(c < chunks, 5)) continue;
           atomicAnd(&sh[c], ~mask);
           atomicSub(&ts[(c << 6) / kTile], __popcll(mask));
         }
-        if (n_far > 0) far_pass(n_total, sh, ts);
+        if constexpr (SRC::kLds)
+          if (n_far > 0) far_pass(n_total, sh, ts);
       }
       __syncthreads();
       if (tid == 0) w.shadow_valid[s] = accept ? 1 : 0;
@@ -1577,23 +1684,21 @@ struct Ins {
         bool valid = o >= 0 && o < nvis;
         BoxAcc box;
 #ifdef R3D_CHECK
-        if (valid) {                                          // which of the three: room | the visible list | the sorted order
-          const bool c_room = dst < b.cap && n_log + o < b.log_cap && dst >= n_head;
-          const bool c_v = (int)s_V[o] < nvalid;
-          const bool c_f = c_v && (int)s_F[s_V[o]] < m;
-          if (!c_room) atomicAdd(&w.dbg[14], 1);
-          if (!c_v || !c_f) {
-            atomicAdd(&w.dbg[14], 1);
+        if constexpr (SRC::kLds)
+          if (valid) {                                          // which of the three: room | the visible list | the sorted order
+            const bool c_room = dst < b.cap && n_log + o < b.log_cap && dst >= n_head;
+            const bool c_v = (int)s_V[o] < nvalid;
+            const bool c_f = c_v && (int)s_F[s_V[o]] < m;
+            if (!c_room) atomicAdd(&w.dbg[14], 1);
+            if (!c_v || !c_f) {
+              atomicAdd(&w.dbg[14], 1);
+            }
+            if (!c_room || !c_v || !c_f) valid = false;
           }
-          if (!c_room || !c_v || !c_f) valid = false;
-        }
 #endif
         if (valid) {
-          int j = s_F[s_V[o]];
-          int lp = (int)s_lp[j];
-          int row, col;
-          win.row_word(lp >> 5, row, col);
-          col = (col << 5) + (lp & 31);
+          int j, row, col;
+          src.vis(o, j, row, col);
           const double *q = rows5 + (int64_t)j * 5;
           double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
           int lr = n_log + o;
@@ -1634,10 +1739,10 @@ struct Ins {
     }
     STAMP(23);
     // -- the scene points in visible pixels die
-    for (int i = tid; i < nlist; i += NT) {
-      unsigned long long mask = l_kill(i);
-      if (!mask) continue;
-      int c = (int)l_chunk(i);
+    for (int i = tid; i < src.n_kill(); i += NT) {
+      int c;
+      unsigned long long mask;
+      if (!src.kill(i, c, mask)) continue;
       if (!CHK(c < chunks, 5)) continue;
 #ifdef R3D_CHECK
       {
@@ -1650,22 +1755,26 @@ struct Ins {
       atomicSub(&tile_alive[(c << 6) / kTile], __popcll(mask));
     }
     STAMP(24);
-    // -- pixels that now hold a return beyond 500 m join the far list
-    for (int o = tid; o < nvis; o += NT) {
-      int k = s_V[o];
-      int lp = (int)s_lp[s_F[k]];
-      int rk = rank_of(lp);
-      if (k != (int)s_start[rk]) continue;                    // once per pixel
-      if (key_depth(s_sdepth[rk]) > R3D_EMPTY_DEPTH) {
-        int f = atomicAdd(&b.n_far[s], 1);
-        if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = global_pix(lp);
-        else atomicOr(&b.status[s], R3D_S_FAR_OVERFLOW);
-        H[H_FARADD] = 1;
-      }
+    if constexpr (SRC::kLds) {
+      // -- pixels that now hold a return beyond 500 m join the far list (a sample with such a point is never committed
+      // from a record: sample_far())
+      if (uni(H[H_SFAR]))
+        for (int o = tid; o < nvis; o += NT) {
+          int k = s_V[o];
+          int lp = (int)s_lp[s_F[k]];
+          int rk = rank_of(lp);
+          if (k != (int)s_start[rk]) continue;                    // once per pixel
+          if (key_depth(s_sdepth[rk]) > R3D_EMPTY_DEPTH) {
+            int f = atomicAdd(&b.n_far[s], 1);
+            if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = global_pix(lp);
+            else atomicOr(&b.status[s], R3D_S_FAR_OVERFLOW);
+            H[H_FARADD] = 1;
+          }
+        }
+      // -- scene pixels deeper than 500 m are visible to any accepted insert whose sample is empty there
+      // (500 < depth, insertion.py:99,:467): not a matter of the window.  Rare: two passes over the cloud.
+      if (n_far > 0) far_pass(n_total);
     }
-    // -- scene pixels deeper than 500 m are visible to any accepted insert whose sample is empty there
-    // (500 < depth, insertion.py:99,:467): not a matter of the window.  Rare: two passes over the cloud.
-    if (n_far > 0) far_pass(n_total);
     __syncthreads();
     STAMP(25);
     const bool rebase = uni(H[H_REBASE]) != 0;
@@ -1745,7 +1854,7 @@ struct Ins {
             }
           if (hit >= 0) {
             double x, y, z;
-            load_point(b, s, i, n_head, x, y, z);
+            load_point(b, s, orig_of(w, b, s, w.n_virt[s], i), n_head, x, y, z);
             double r = sqrt(x * x + y * y + z * z);
             if (pass == 0) atomicMin(&fmin[hit], depth_key(r));
             else if (key_depth(__hip_atomic_load(&fmin[hit], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > R3D_EMPTY_DEPTH) {
@@ -1814,39 +1923,33 @@ __device__ __forceinline__ int conflict_with(const BatchWs &w, int s, int j0, in
   return wave_or_i32(out);
 }
 
-// One (slot, scene) pair of the chain kernel.  Returns 1 when the pair does not fit this flavour's LDS and nothing
-// has been done for it yet (the caller then tries the POOL flavour; LAST: there is none, the scene's chain goes to
-// k_insert_big from here), else 0.
+// What becomes of a pair a workgroup has picked up (run_pair's result): done with it (committed and published, parked,
+// left to k_insert_big, ...) | it does not fit this flavour's LDS and nothing has been done for it (the caller tries the
+// POOL flavour) | done, and the scene's next slot was found parked: the caller carries on with that one.
+enum { kPairDone = 0, kPairAgain = 1, kPairNextParked = 2 };
+// How a workgroup comes to a pair: off the queue / by its block id | as the workgroup that has just finished the scene's
+// previous slot and found this one parked | the same, the parked record is not to be used (the POOL flavour's turn).
+enum { kFresh = 0, kTakeover = 1, kTakeoverEvaluate = 2 };
+
+// One (slot k, scene s) pair of the chain kernel.  LAST: there is no further flavour to try, a pair that does not fit sends
+// the rest of its scene's chain to k_insert_big.
 template <int NT, bool POOL, bool LAST>
-__device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots &slots, int nk, int first_step, const BatchWs &w,
-                                          int chunks, int lds_cap, long long timeout_ticks, int B8, unsigned char *smem, int pair_id) {
-  // B8 > 0: slot-major numbering (slot k of every scene, then slot k + 1; a scene's slots on one residue of the
-  // pair id mod 8); B8 == 0: scene-major (the slots of scene 0, then those of scene 1, ...)
-  const int k = B8 ? pair_id / B8 : pair_id % nk, s = B8 ? pair_id % B8 : pair_id / nk;
-  if (s >= b.B) return 0;
+__device__ __forceinline__ int run_pair(const r3d_batch_t &b, const ChainSlots &slots, int nk, int first_step, const BatchWs &w,
+                                        int chunks, int lds_cap, unsigned char *smem, const int k, const int s, const int mode) {
+  if (s >= b.B) return kPairDone;
   const int tid = threadIdx.x, slot_no = k;
   (void)slot_no;
   int *H = reinterpret_cast<int *>(smem);
-  Ins<NT, POOL> I(b, w, smem, lds_cap, s, chunks, k, false);
+  typedef Ins<NT, POOL> InsT;
+  InsT I(b, w, smem, lds_cap, s, chunks, k, false);
+  const int64_t pair_at = (int64_t)s * kMaxChain + k;
 
-  // wait until `want` slots of the scene are done (or the chain is abandoned); ONE lane polls relaxed,
-  // then ONE agent-scope acquire; the scalar cache is dropped as well (counters travel through it)
-  auto wait_for = [&](int want) -> int {
+  // how many slots of the scene are done (negative: the chain was given up / left to k_insert_big); never waits.  ONE
+  // lane reads relaxed, then ONE agent-scope acquire; the scalar cache is dropped as well (counters travel through it)
+  auto progress_now = [&]() -> int {
     __syncthreads();
     if (tid == 0) {
-      int seen = 0;
-      const long long t0 = wall_clock64();
-      for (;;) {
-        seen = __hip_atomic_load(&w.chain_progress[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen < 0 || seen >= want) break;
-        if (wall_clock64() - t0 > timeout_ticks) {
-          seen = kProgTimeout;
-          atomicOr(&b.status[s], R3D_S_CHAIN_TIMEOUT);
-          __hip_atomic_store(&w.chain_progress[s], kProgTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-      }
+      const int seen = __hip_atomic_load(&w.chain_progress[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (seen > 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1854,17 +1957,20 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
       H[H_GO] = seen;
     }
     __syncthreads();
-    int seen = uni(H[H_GO]);
+    const int seen = uni(H[H_GO]);
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     return seen;
   };
-  auto publish = [&](int flags, int n_total_after) {
+  // Slot k is done: its record, the scene's progress word, and the hand-over word of slot k + 1.  Returns 1 when that slot
+  // was found parked -- this workgroup carries on with it (its evaluator has gone on to other pairs).
+  auto publish = [&](int flags, int n_total_after) -> int {
     // every storing wave drains its stores, the workgroup meets, ONE lane releases (then waits again:
     // the order fence -> wait -> flag matters) and stores the progress word relaxed
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      int *rec = w.recs + ((int64_t)s * kMaxChain + k) * kRecInts;
+      int nxt = 0;
+      int *rec = w.recs + pair_at * kRecInts;
       rec[REC_FLAGS] = flags;
       rec[REC_NTOTAL] = n_total_after;
       rec[REC_RLO] = H[H_VRMIN];
@@ -1873,15 +1979,71 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
       rec[REC_CHI0] = H[H_VCMAX0];
       rec[REC_CLO1] = H[H_VCMIN1];
       rec[REC_CHI1] = H[H_VCMAX1];
-      if ((b.reserved & kDbgDropPublish) && k == 0 && s == 0 && nk > 1) return;
+      // (diagnostic bit 16: slot 0 of scene 0 never publishes -- its successors stay parked, k_insert_big flags the scene)
+      if (!((b.reserved & kDbgDropPublish) && k == 0 && s == 0 && nk > 1)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // k -> k + 1 and nothing else: a negative mark (the chain left to k_insert_big) stays
+        int expect = k;
+        __hip_atomic_compare_exchange_strong(&w.chain_progress[s], &expect, k + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+        if (k + 1 < nk) {
+          const int old = __hip_atomic_exchange(&w.park[pair_at + 1], kParkPredDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (old == kParkParked) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            nxt = 1;
+          }
+        }
+      }
+      H[H_GO] = nxt;
+    }
+    __syncthreads();
+    const int nxt = uni(H[H_GO]);
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    return nxt;
+  };
+  // The predecessors are still at work: leave the pair -- with a record of its evaluation (kind kParkEvaluated: `off`,
+  // `n_kill`, the header cells) or without (kParkRaw) -- to the workgroup that finishes slot k - 1.  true: parked, this
+  // workgroup is done with the pair; false: slot k - 1 has been published meanwhile, carry on as after a wait.
+  auto park_try = [&](int kind, long long off, int n_kill, int base_slots, unsigned long long sig, int verify) -> bool {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the record's stores, every wave
+    __syncthreads();
+    if (tid == 0) {
+      int *hdr = w.park_hdr + pair_at * kParkInts;
+      hdr[PK_KIND] = kind;
+      if (kind == kParkEvaluated) {
+        hdr[PK_P0] = base_slots;
+        hdr[PK_NVALID] = I.nvalid;
+        hdr[PK_NVIS] = I.nvis;
+        hdr[PK_ACCEPT] = I.accept ? 1 : 0;
+        hdr[PK_REBASE] = H[H_REBASE];
+        hdr[PK_FLAGS] = H[H_FLAGS];
+        hdr[PK_NKILL] = n_kill;
+        hdr[PK_OFF_LO] = (int)(uint32_t)off;
+        hdr[PK_OFF_HI] = (int)(uint32_t)((unsigned long long)off >> 32);
+        hdr[PK_RMIN] = H[H_RMIN], hdr[PK_RMAX] = H[H_RMAX];
+        hdr[PK_CMIN0] = H[H_CMIN0], hdr[PK_CMIN1] = H[H_CMIN1], hdr[PK_CMAX0] = H[H_CMAX0], hdr[PK_CMAX1] = H[H_CMAX1];
+        hdr[PK_VRMIN] = H[H_VRMIN], hdr[PK_VRMAX] = H[H_VRMAX];
+        hdr[PK_VCMIN0] = H[H_VCMIN0], hdr[PK_VCMIN1] = H[H_VCMIN1], hdr[PK_VCMAX0] = H[H_VCMAX0], hdr[PK_VCMAX1] = H[H_VCMAX1];
+        hdr[PK_SIG_LO] = (int)(uint32_t)sig, hdr[PK_SIG_HI] = (int)(uint32_t)(sig >> 32);
+        hdr[PK_VERIFY] = verify;
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      // k -> k + 1 and nothing else: a successor that gave up has left a negative mark there, which stays (a late
-      // publish must not revive the chain: the later slots would then wait their full time-out one after the other)
-      int expect = k;
-      __hip_atomic_compare_exchange_strong(&w.chain_progress[s], &expect, k + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+      const int old = __hip_atomic_exchange(&w.park[pair_at], kParkParked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == kParkPredDone) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+        atomicAdd(&w.dbg[kind == kParkEvaluated ? D_PARKED : D_PARKED_RAW], 1);
+      }
+      H[H_GO] = old;
     }
+    __syncthreads();
+    const int old = uni(H[H_GO]);
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    return old != kParkPredDone;
   };
   auto outputs = [&](int nv, int acc) {
     if (tid == 0) {
@@ -1889,179 +2051,241 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
       slots.accepted[k][s] = acc;
     }
   };
+  auto bounds_moved = [&](int j0, int j1) -> bool {          // did a slot of [j0, j1) re-base the scene?
+    bool moved = false;
+    for (int j = j0; j < j1; ++j)
+      if ((w.recs[((int64_t)s * kMaxChain + j) * kRecInts + REC_FLAGS] & (kRecAccepted | kRecRebased)) == (kRecAccepted | kRecRebased))
+        moved = true;
+    return moved;
+  };
 
   const int n_head0 = uni(b.n_head[s]);                     // fixed for the launch
-  // the scene's point count when this pair commits: what its predecessor published (read once the wait is over)
-  auto count_now = [&]() -> int {
-    return k > 0 ? uni(w.recs[((int64_t)s * kMaxChain + k - 1) * kRecInts + REC_NTOTAL]) : uni(w.n_total0[s]);
+  // the scene's point count after its first j slots (what slot j - 1 published)
+  auto count_after = [&](int j) -> int {
+    return j > 0 ? uni(w.recs[((int64_t)s * kMaxChain + j - 1) * kRecInts + REC_NTOTAL]) : uni(w.n_total0[s]);
   };
+  const bool on = load_slot(I, b, slots, k, s, first_step);
+  // (diagnostic bit 2: never evaluate ahead of the predecessors -- the pair is left, unevaluated, to whoever finishes them)
+  const bool speculate = !(b.reserved & kDbgSerial);
+  bool need_sample = true, sample_ok = false, speculative = false, verified = false, committed = false, rebase = false;
+  unsigned long long sig0 = 0ull;
+  int rc = kOk, attempts = 0, flags = 0, n_after = 0;
+
   // 1. where does the scene stand?  p0 slots are done: the evaluation builds on them
-  int p0 = 0;
-  if (k > 0) {
-    p0 = wait_for(0);
-    if (p0 == kProgDeferred) return 0;                      // k_insert_big does this slot
+  int p0 = k;
+  bool waited = true;
+  if (mode == kFresh) {
+    p0 = k > 0 ? progress_now() : 0;
+    if (p0 == kProgDeferred) return kPairDone;              // k_insert_big does this slot
     if (p0 < 0) {
       outputs(0, 0);
-      return 0;
+      return kPairDone;
+    }
+    waited = p0 >= k;
+    if (!waited && (!speculate || !on)) {
+      if (park_try(kParkRaw, 0, 0, 0, 0ull, 0)) return kPairDone;
+      waited = true;
+      p0 = k;
+    }
+  } else if (mode == kTakeover) {
+    // This workgroup has just published slot k - 1 and found slot k parked.  A record: did one of the slots its evaluation did
+    // not know (p0 .. k - 1) change a pixel it read, the bounds, the far list?  No: commit it from the record.
+    const int *hdr = w.park_hdr + pair_at * kParkInts;
+    if (uni(hdr[PK_KIND]) == kParkEvaluated) {
+      const int hp0 = uni(hdr[PK_P0]), hnvalid = uni(hdr[PK_NVALID]), verify = uni(hdr[PK_VERIFY]);
+      __syncthreads();
+      if (tid == 0) {
+        H[H_RMIN] = hdr[PK_RMIN], H[H_RMAX] = hdr[PK_RMAX];
+        H[H_CMIN0] = hdr[PK_CMIN0], H[H_CMIN1] = hdr[PK_CMIN1], H[H_CMAX0] = hdr[PK_CMAX0], H[H_CMAX1] = hdr[PK_CMAX1];
+        H[H_VRMIN] = hdr[PK_VRMIN], H[H_VRMAX] = hdr[PK_VRMAX];
+        H[H_VCMIN0] = hdr[PK_VCMIN0], H[H_VCMIN1] = hdr[PK_VCMIN1], H[H_VCMAX0] = hdr[PK_VCMAX0], H[H_VCMAX1] = hdr[PK_VCMAX1];
+        H[H_REBASE] = hdr[PK_REBASE];
+        H[H_FLAGS] = hdr[PK_FLAGS];
+        H[H_FARADD] = 0;
+        H[H_SFAR] = 0;
+      }
+      __syncthreads();
+      int cf = 0;
+      if (hnvalid > 0) cf = conflict_with(w, s, hp0, k, H, b.rows, b.cols);
+      else if (bounds_moved(hp0, k)) cf = 3;                 // nothing projected: only new bounds could change that
+      if (verify) {
+        sig0 = (unsigned long long)(uint32_t)uni(hdr[PK_SIG_LO]) | ((unsigned long long)(uint32_t)uni(hdr[PK_SIG_HI]) << 32);
+        verified = !cf;                                      // (a detected conflict: nothing to compare, the evaluation is redone anyway)
+        if (tid == 0 && !cf) atomicAdd(&w.dbg[D_VERIFY_RUNS], 1);
+      }
+      if (!cf && !verify) {
+        I.nvalid = hnvalid;
+        I.nvis = uni(hdr[PK_NVIS]);
+        I.accept = uni(hdr[PK_ACCEPT]) != 0;
+        I.n_far = 0;
+        const long long off = (long long)((unsigned long long)(uint32_t)uni(hdr[PK_OFF_LO]) | ((unsigned long long)(uint32_t)uni(hdr[PK_OFF_HI]) << 32));
+        typename InsT::FromRecord src;
+        src.v = reinterpret_cast<const uint2 *>(w.tile_pool + off);
+        src.kl = reinterpret_cast<const ulonglong2 *>(w.tile_pool + off + InsT::park_vis_bytes(I.nvis));
+        src.nkill = uni(hdr[PK_NKILL]);
+        rebase = I.commit(src, flags, n_after, count_after(k), n_head0);
+        outputs(I.nvis, I.accept ? 1 : 0);
+        committed = true;
+        if (tid == 0) atomicAdd(&w.dbg[D_TAKEOVER_COMMIT], 1);
+      } else if (cf) {
+        attempts = 1;                                          // (the first evaluation was somebody else's)
+      }
     }
   }
-  bool waited = p0 >= k;
-  // (diagnostic bit 2: never evaluate ahead of the predecessors -- the sample is prepared, then the pair waits)
-  const bool speculate = !(b.reserved & kDbgSerial);
-  int n_base = p0 > 0 ? w.recs[((int64_t)s * kMaxChain + p0 - 1) * kRecInts + REC_NTOTAL]
-                      : (k > 0 ? w.n_total0[s] : b.n_total[s]);
-  const bool on = load_slot(I, b, slots, k, s, first_step);
-  bool need_sample = true, sample_ok = false, speculative = false, verified = false;
-  unsigned long long sig0 = 0ull;
-  int rc = kOk, attempts = 0;
-  if (on) {
-    for (;;) {
-      rc = kOk;
-      ++attempts;
-      if (need_sample) {
-        rc = (b.reserved & kDbgDefer) ? kNoFit : I.sample_phase();
-        sample_ok = rc == kOk;
-        // The scene may have moved on while the sample was prepared: build on the freshest state, so that fewer
-        // slots remain that can invalidate the evaluation (a big pair that has to evaluate twice is the tail
-        // of the launch).  New bounds in between: the sample is projected again.
-        if (rc == kOk && !waited) {
-          const int p1 = wait_for(speculate ? 0 : k);         // not speculating: the sample is ready, now the predecessors
-          if (p1 == kProgDeferred) return 0;
-          if (p1 < 0) {
+
+  if (!committed) {
+    int n_base = count_after(p0);
+    if (on) {
+      for (;;) {
+        rc = kOk;
+        ++attempts;
+        if (need_sample) {
+          rc = (b.reserved & kDbgDefer) ? kNoFit : I.sample_phase();
+          sample_ok = rc == kOk;
+          // The scene may have moved on while the sample was prepared: build on the freshest state, so that fewer
+          // slots remain that can invalidate the evaluation (a big pair that has to evaluate twice is the tail
+          // of the launch).  New bounds in between: the sample is projected again.
+          if (rc == kOk && !waited) {
+            const int p1 = progress_now();
+            if (p1 == kProgDeferred) return kPairDone;
+            if (p1 < 0) {
+              outputs(0, 0);
+              return kPairDone;
+            }
+            if (p1 > p0) {
+              const bool moved = bounds_moved(p0, p1);
+              p0 = p1;
+              n_base = count_after(p0);
+              waited = p0 >= k;
+              if (moved) continue;
+            }
+          }
+        }
+        // while it speculates, the evaluation looks twice whether a slot that finished meanwhile has already
+        // invalidated it: a doomed evaluation of a big pair is given up early and restarted on the fresher state
+        int gone = 0, stale_cf = 0;
+        speculative = !waited;
+        if (rc == kOk)
+          rc = I.scene_phase(n_base, waited, [&]() -> bool {
+            const int p1 = progress_now();
+            if (p1 < 0) {
+              gone = p1;
+              return true;
+            }
+            if (p1 > p0) {
+              stale_cf = I.nvalid > 0 ? conflict_with(w, s, p0, p1, H, b.rows, b.cols) : (bounds_moved(p0, p1) ? 3 : 0);
+              p0 = p1;                                         // slots below p1 are accounted for from here on
+              if (stale_cf) return true;
+            }
+            return false;
+          });
+        if (rc == kStale) {
+          if (gone == kProgDeferred) return kPairDone;
+          if (gone < 0) {
             outputs(0, 0);
-            return 0;
+            return kPairDone;
           }
-          if (p1 > p0) {
-            bool moved = false;
-            for (int j = p0; j < p1; ++j)
-              if ((w.recs[((int64_t)s * kMaxChain + j) * kRecInts + REC_FLAGS] & (kRecAccepted | kRecRebased)) ==
-                  (kRecAccepted | kRecRebased))
-                moved = true;
-            p0 = p1;
-            n_base = w.recs[((int64_t)s * kMaxChain + p0 - 1) * kRecInts + REC_NTOTAL];
-            waited = p0 >= k;
-            if (moved) continue;
+          n_base = count_after(p0);
+          waited = p0 >= k;
+          need_sample = (stale_cf & 2) != 0;
+          continue;
+        }
+        if (rc == kNoFit) break;
+        if (!waited) {
+          const int seen = progress_now();
+          if (seen == kProgDeferred) return kPairDone;
+          if (seen < 0) {
+            outputs(0, 0);
+            return kPairDone;
+          }
+          if (seen < k) {
+            // The predecessors are still at work: nobody waits for them.  The evaluation is left to the workgroup that
+            // finishes slot k - 1 -- as a record when a commit can be made from one (no far pixels in play: their pass
+            // over the cloud reads this workgroup's LDS), else the pair as it came.
+            int kind = kParkEvaluated, n_kill = 0, verify = 0;
+            long long off = 0;
+            unsigned long long sig = 0ull;
+            if (rc == kNeedSerial || I.sample_far()) {
+              kind = kParkRaw;
+            } else {
+              if (b.reserved & kDbgVerify) {
+                sig = I.signature();
+                verify = 1;
+              }
+              off = I.park_write(n_kill);
+              if (off < 0) kind = kParkRaw;
+            }
+            if (park_try(kind, off, n_kill, p0, sig, verify)) return kPairDone;
+          }
+          waited = true;
+          STAMP(13);
+          int cf = rc == kNeedSerial ? 1 : 0;
+          if (sample_ok && I.nvalid > 0) cf |= conflict_with(w, s, p0, k, H, b.rows, b.cols);
+          else if (bounds_moved(p0, k)) cf |= 3;               // nothing projected: only new bounds could change that
+          if (cf) {
+            n_base = count_after(k);
+            need_sample = !sample_ok || (cf & 2) != 0;
+            p0 = k;
+            continue;
           }
         }
-      }
-      // while it speculates, the evaluation looks twice whether a slot that finished meanwhile has already
-      // invalidated it: a doomed evaluation of a big pair is given up early and restarted on the fresher state
-      int gone = 0, stale_cf = 0;
-      speculative = !waited;
-      if (rc == kOk)
-        rc = I.scene_phase(n_base, waited, [&]() -> bool {
-          const int p1 = wait_for(0);
-          if (p1 < 0) {
-            gone = p1;
-            return true;
+        // Diagnostic bit 64: an evaluation that ran ahead of its predecessors and is about to be committed is done again,
+        // now after them, and the two are compared -- the invariant of the speculation (no detected conflict => the same
+        // visible points and the same culled points).  The later one is what is committed.  (A parked evaluation: its
+        // digest travels in the record, the workgroup that takes the pair over evaluates and compares.)
+        if ((b.reserved & kDbgVerify) && rc == kOk) {
+          if (verified) {
+            const unsigned long long sig1 = I.signature();
+            if (tid == 0 && sig0 != sig1) atomicAdd(&w.dbg[D_VERIFY_MISMATCH], 1);
+          } else if (speculative) {
+            sig0 = I.signature();
+            verified = true;
+            if (tid == 0) atomicAdd(&w.dbg[D_VERIFY_RUNS], 1);
+            n_base = count_after(k);
+            need_sample = false;
+            p0 = k;
+            --attempts;
+            continue;
           }
-          if (p1 > p0) {
-            stale_cf = I.nvalid > 0 ? conflict_with(w, s, p0, p1, H, b.rows, b.cols) : 0;
-            if (I.nvalid == 0)
-              for (int j = p0; j < p1; ++j)
-                if ((w.recs[((int64_t)s * kMaxChain + j) * kRecInts + REC_FLAGS] & (kRecAccepted | kRecRebased)) ==
-                    (kRecAccepted | kRecRebased))
-                  stale_cf |= 3;
-            p0 = p1;                                         // slots below p1 are accounted for from here on
-            if (stale_cf) return true;
-          }
-          return false;
-        });
-      if (rc == kStale) {
-        if (gone == kProgDeferred) return 0;
-        if (gone < 0) {
-          outputs(0, 0);
-          return 0;
         }
-        n_base = w.recs[((int64_t)s * kMaxChain + p0 - 1) * kRecInts + REC_NTOTAL];
-        waited = p0 >= k;
-        need_sample = (stale_cf & 2) != 0;
-        continue;
+        break;
       }
-      if (rc == kNoFit) break;
+    }
+    if (on && rc == kNoFit) {
+      if (!LAST) return kPairAgain;                           // once more with the scratch images in the pool
+      // the rest of this scene's chain goes to k_insert_big; the predecessors must be done first, so that nobody
+      // overwrites the mark: if they are not, whoever finishes them comes back to this pair and leaves the mark
       if (!waited) {
-        int seen = wait_for(k);
-        if (seen == kProgDeferred) return 0;
+        const int seen = progress_now();
+        if (seen == kProgDeferred) return kPairDone;
         if (seen < 0) {
           outputs(0, 0);
-          return 0;
+          return kPairDone;
         }
-        waited = true;
-        STAMP(13);
-        int cf = rc == kNeedSerial ? 1 : 0;
-        if (sample_ok && I.nvalid > 0) cf |= conflict_with(w, s, p0, k, H, b.rows, b.cols);
-        else {
-          for (int j = p0; j < k; ++j)                     // nothing projected: only new bounds could change that
-            if ((w.recs[((int64_t)s * kMaxChain + j) * kRecInts + REC_FLAGS] & (kRecAccepted | kRecRebased)) ==
-                (kRecAccepted | kRecRebased))
-              cf |= 3;
-        }
-        if (cf) {
-          n_base = b.n_total[s];
-          need_sample = !sample_ok || (cf & 2) != 0;
-          p0 = k;
-          continue;
-        }
+        if (seen < k && park_try(kParkRaw, 0, 0, 0, 0ull, 0)) return kPairDone;
       }
-      // Diagnostic bit 64: an evaluation that ran ahead of its predecessors and is about to be committed is done again,
-      // now after them, and the two are compared -- the invariant of the speculation (no detected conflict => the same
-      // visible points and the same culled points).  The later one is what is committed.
-      if ((b.reserved & kDbgVerify) && rc == kOk) {
-        if (verified) {
-          const unsigned long long sig1 = I.signature();
-          if (tid == 0 && sig0 != sig1) atomicAdd(&w.dbg[D_VERIFY_MISMATCH], 1);
-        } else if (speculative) {
-          sig0 = I.signature();
-          verified = true;
-          if (tid == 0) atomicAdd(&w.dbg[D_VERIFY_RUNS], 1);
-          n_base = b.n_total[s];
-          need_sample = false;
-          p0 = k;
-          --attempts;
-          continue;
-        }
+      if (tid == 0) {
+        w.defer_from[s] = k;
+        atomicAdd(&w.dbg[D_DEFERRED], 1);
+        __hip_atomic_store(&w.chain_progress[s], kProgDeferred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      break;
+      return kPairDone;
     }
-  } else if (!waited) {
-    int seen = wait_for(k);
-    if (seen == kProgDeferred) return 0;
-    if (seen < 0) {
+    if (on && attempts > 1 && tid == 0) atomicAdd(&w.dbg[D_EVAL_TWICE], 1);
+    // 2. commit
+    const int n_now = count_after(k);
+    n_after = !on ? n_now : 0;
+    if (on) {
+      if (tid == 0) {
+        atomicAdd(&w.dbg[D_PAIRS], 1);
+        atomicAdd(&w.dbg[D_CHUNKS_LISTED], I.nlist);
+      }
+      rebase = I.commit(typename InsT::FromLds{I}, flags, n_after, n_now, n_head0);
+      outputs(I.nvis, I.accept ? 1 : 0);
+      STAMP(14);
+    } else {
       outputs(0, 0);
-      return 0;
     }
-    waited = true;
-  }
-  if (on && rc == kNoFit) {
-    if (!LAST) return 1;                                    // once more with the scratch images in the pool
-    // the rest of this scene's chain goes to k_insert_big; the predecessors must be done first, so
-    // that nobody overwrites the mark
-    if (!waited) {
-      int seen = wait_for(k);
-      if (seen == kProgDeferred) return 0;
-      if (seen < 0) {
-        outputs(0, 0);
-        return 0;
-      }
-    }
-    if (tid == 0) {
-      w.defer_from[s] = k;
-      atomicAdd(&w.dbg[D_DEFERRED], 1);
-      __hip_atomic_store(&w.chain_progress[s], kProgDeferred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return 0;
-  }
-  if (on && attempts > 1 && tid == 0) atomicAdd(&w.dbg[D_EVAL_TWICE], 1);
-  // 2. commit, publish
-  const int n_now = count_now();
-  int flags = 0, n_after = waited && !on ? n_now : 0;
-  bool rebase = false;
-  if (on) {
-    rebase = I.commit(flags, n_after, n_now, n_head0);
-    outputs(I.nvis, I.accept ? 1 : 0);
-    STAMP(14);
-  } else {
-    outputs(0, 0);
   }
   if (rebase) {
     __syncthreads();
@@ -2071,7 +2295,9 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
     rebase_scene<NT>(b, w, chunks, s, s_min, s_max);
     if (tid == 0) atomicAdd(&w.dbg[D_REBASE], 1);
   }
-  if (nk > 1) publish(flags, n_after);
+  // 3. publish; the scene's next slot may be waiting for exactly this
+  int nxt = 0;
+  if (nk > 1) nxt = publish(flags, n_after);
   STAMP(15);
 #ifdef R3D_STAMPS
   if (tid == 0)
@@ -2079,7 +2305,7 @@ __device__ __forceinline__ int chain_pair(const r3d_batch_t &b, const ChainSlots
         (long long)attempts | ((long long)(rc == kOk ? 1 : 0) << 8) | ((long long)I.ww << 16) | ((long long)I.nlist << 32) |
         ((long long)(I.dt.npx >> 4) << 48);
 #endif
-  return 0;
+  return nxt ? kPairNextParked : kPairDone;
 }
 
 // Everything the chain kernel is given, as ONE kernel argument.  The kernel reads it through the kernarg segment
@@ -2091,14 +2317,60 @@ struct ChainArgs {
   r3d_batch_t b;
   ChainSlots slots;
   BatchWs w;
-  long long timeout_ticks;
-  int nk, first_step, chunks, lds_cap, B8, queue_mode, lead;
+  int nk, first_step, chunks, lds_cap, B8, queue_mode;
 };
 
 // Range images of KITTI's size never need the pool for their scratch images; on large ones a window can exceed the
 // LDS (a car a few metres from the sensor on 448 x 2880).  The POOL flavour reaches those images through flat
 // accesses -- 35 % slower on config C5 when every pair takes it -- so a pair runs it only after the LDS flavour
 // has turned it down.
+typedef const __attribute__((address_space(4))) ChainArgs *ChainArgsPtr;
+
+// A pair, then the slots of its scene that are found parked behind it, one after the other.  (The arguments are taken
+// afresh through the kernarg pointer for every pair: nothing of them stays in registers across pairs.)
+template <int NT>
+__device__ __forceinline__ void run_pairs_from(unsigned char *smem, int pair_id) {
+  int k, s, mode = kFresh;
+  {
+    ChainArgsPtr ap = (ChainArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap));
+    const ChainArgs &a = *(const ChainArgs *)ap;
+    // B8 > 0: slot-major numbering (every scene's first slot, then every scene's second; a scene's slots on one residue of
+    // the pair id mod 8), the slots in the launch's order (BatchWs::slot_order); B8 == 0: scene-major
+    const int B8 = a.B8, nk = a.nk;
+    k = B8 ? uni(a.w.slot_order[pair_id / B8]) : pair_id % nk;
+    s = B8 ? pair_id % B8 : pair_id / nk;
+  }
+  for (;;) {
+    ChainArgsPtr ap = (ChainArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap));
+    const ChainArgs &a = *(const ChainArgs *)ap;
+#ifdef R3D_STAMPS
+    long long *cell = s < a.b.B ? reinterpret_cast<long long *>(a.b.out_xyzi + (int64_t)s * a.b.cap * 4) + k * 32 : nullptr;
+    if (cell && threadIdx.x == 0) {
+      cell[28] = wall_clock64();                               // this workgroup takes the pair
+      if (mode == kFresh) cell[21] = cell[28];                 // ... off the queue (a parked pair is taken a second time)
+      cell[20] = (long long)blockIdx.x | ((long long)mode << 32);
+    }
+#endif
+    // (only the shape for large range images carries the POOL flavour: half the code for the others)
+    int st = uni(run_pair<NT, false, NT != 1024>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, smem, k, s, mode));
+#ifdef R3D_STAMPS
+    if (cell && threadIdx.x == 0) cell[29] = st == kPairAgain ? wall_clock64() : 0;   // the LDS flavour turned the pair down here
+#endif
+    if (NT == 1024 && st == kPairAgain)
+      st = uni(run_pair<NT, true, true>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, smem, k, s,
+                                        mode == kFresh ? kFresh : kTakeoverEvaluate));
+#ifdef R3D_STAMPS
+    __syncthreads();
+    if (cell && threadIdx.x == 0) cell[30] = wall_clock64();   // ... and is done with it
+#endif
+    if (st != kPairNextParked) return;
+    ++k;
+    mode = kTakeover;
+  }
+}
+
 template <int NT, bool QUEUE>
 __global__ void __launch_bounds__(NT, NT == 1024 ? R3D_BIG_WAVES : R3D_CHAIN_WAVES)
 k_insert_chain(ChainArgs args) {
@@ -2106,142 +2378,42 @@ k_insert_chain(ChainArgs args) {
   // QUEUE false: one workgroup per pair, pair = block id.  QUEUE true: the launch holds only as many workgroups as the
   // device keeps resident and each takes pairs off a queue until it is empty -- queue_mode 1: one queue, pairs in id
   // order; 2: a queue per XCD (workgroups go to the XCDs round robin, a scene's pairs share a residue mod 8: a scene
-  // stays with one XCD's L2), an XCD that runs dry helps the others.  A pair still waits only for pairs with lower
-  // ids of its own queue, which a running workgroup has taken before.  Why: the hardware hands workgroups to the XCDs
+  // stays with one XCD's L2), an XCD that runs dry helps the others.  Why: the hardware hands workgroups to the XCDs
   // strictly round robin, so with one workgroup per pair an XCD whose pairs run long stalls the hand-out to all the
-  // others (a third of the CUs idle on config C5, tools/stamps_insert.py).
-  typedef const __attribute__((address_space(4))) ChainArgs *ArgsPtr;
+  // others (a third of the CUs idle on config C5, tools/stamps_insert.py).  Either way a workgroup never waits for
+  // another one (see the top of the file): any order in which the pairs are taken is correct.
   if (!QUEUE) {
-    ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ap));
-    const ChainArgs &a = *(const ChainArgs *)ap;
-    // (only the shape for large range images carries the POOL flavour: half the code for the others)
-    const int again = chain_pair<NT, false, NT != 1024>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks,
-                                                        a.B8, smem, (int)blockIdx.x);
-    if (NT == 1024 && uni(again))
-      chain_pair<NT, true, true>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8, smem, (int)blockIdx.x);
+    run_pairs_from<NT>(smem, (int)blockIdx.x);
     return;
   }
   int *H = reinterpret_cast<int *>(smem);
-  // queue_mode 3 / 4: the queues hold SCENES, and a scene hands out its slots one at a time (BatchWs::claim_next).  A
-  // workgroup takes a scene and claims slot after slot of it: every wait finds its predecessor done, nothing is evaluated
-  // twice, the scene stays with one CU.  Mode 4: a workgroup that finds the queues empty joins the scene with the most
-  // unclaimed slots and claims from it too (its pairs then run ahead of the owner's, like any pair of mode 2).  A pair
-  // still waits only for pairs claimed before it, by workgroups that are running.
   const int queue_mode = args.queue_mode;
-  const bool owner = queue_mode >= 3, help = queue_mode == 4;
-  const int total = (args.B8 ? args.B8 : args.b.B) * (owner ? 1 : args.nk);
+  const int total = (args.B8 ? args.B8 : args.b.B) * args.nk;
   const int home = queue_mode >= 2 ? (int)(blockIdx.x & 7) : 0;
   int turn = 0;                                              // queues this workgroup has found empty
-  int own = -1;                                              // modes 3 / 4: the scene this workgroup is claiming from
   for (;;) {
-    // (the pointer is taken afresh for every pair: nothing of the arguments stays in registers across pairs)
-    ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ap));
-    const ChainArgs &a = *(const ChainArgs *)ap;
     __syncthreads();
-    if (threadIdx.x < 64) {                                    // wave 0 decides (lane 0 claims, the wave scans)
-      const int lane = (int)threadIdx.x;
-      int id = total, kk = 0;
-      auto claim = [&](int32_t *cell) -> int {
-        int v = 0;
-        if (lane == 0) v = atomicAdd(cell, 1);
-        return __builtin_amdgcn_readfirstlane(v);
-      };
-      if (!owner) {
-        while (turn < (queue_mode == 2 ? 8 : 1)) {
-          const int q = (home + turn) & 7;
-          const int n = claim(&a.w.queue_next[q]);
-          id = queue_mode == 2 ? n * 8 + q : n;
-          if (id < total) break;
-          id = total;
-          ++turn;
-        }
-      } else {
-        const int nk = a.nk, B = a.b.B;
-        // mode 4: the scene with the most unclaimed slots, looked up before every claim -- a workgroup whose own scene is
-        // more than `lead` slots ahead of it (or has none left) claims from that one instead
-        int behind = -1, behind_left = 0;
-        if (help) {
-          int key = -1;
-          for (int sc = lane; sc < B; sc += 64) {
-            const int left = nk - __hip_atomic_load(&a.w.claim_next[sc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int cand = left > 0 ? (left << 20) | sc : -1;
-            key = cand > key ? cand : key;
-          }
-          key = wave_max_i32(key);
-          if (key >= 0) behind = key & 0xFFFFF, behind_left = key >> 20;
-        }
-        if (own >= 0) {                                        // the next slot of the scene in hand
-          int left_own = 0;
-          if (help && behind >= 0 && behind != own)
-            left_own = nk - __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.w.claim_next[own], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          if (help && behind >= 0 && behind != own && left_own > 0 && behind_left > left_own + a.lead) {
-            const int k = claim(&a.w.claim_next[behind]);      // (own stays: the workgroup comes back to it)
-            if (k < nk) id = behind, kk = k;
-          }
-          if (id == total) {
-            const int k = claim(&a.w.claim_next[own]);
-            if (k < nk) id = own, kk = k;
-            else own = -1;
-          }
-        }
-        while (id == total && turn < 8) {                      // a scene nobody has started
-          const int q = (home + turn) & 7;
-          const int sc = claim(&a.w.queue_next[q]) * 8 + q;
-          if (sc >= total) {
-            ++turn;
-            continue;
-          }
-          if (sc >= B) continue;                               // (the batch rounded up to eight)
-          const int k = claim(&a.w.claim_next[sc]);
-          if (k < nk) own = id = sc, kk = k;
-        }
-        for (int tries = 0; help && id == total && tries < 64; ++tries) {   // nothing of its own: join the scene furthest behind
-          if (tries) {
-            int key = -1;
-            for (int sc = lane; sc < B; sc += 64) {
-              const int left = nk - __hip_atomic_load(&a.w.claim_next[sc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              const int cand = left > 0 ? (left << 20) | sc : -1;
-              key = cand > key ? cand : key;
-            }
-            key = wave_max_i32(key);
-            behind = key >= 0 ? key & 0xFFFFF : -1;
-          }
-          if (behind < 0) break;                               // every slot of every scene is claimed
-          const int k = claim(&a.w.claim_next[behind]);
-          if (k < nk) own = id = behind, kk = k;
-        }
+    if (threadIdx.x == 0) {
+      ChainArgsPtr ap = (ChainArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(ap));
+      const ChainArgs &a = *(const ChainArgs *)ap;
+      int id = total;
+      while (turn < (queue_mode >= 2 ? 8 : 1)) {
+        const int q = (home + turn) & 7;
+        const int n = atomicAdd(&a.w.queue_next[q], 1);
+        id = queue_mode >= 2 ? n * 8 + q : n;
+        if (id < total) break;
+        id = total;
+        ++turn;
       }
-      if (lane == 0) {
-        H[H_GO] = id;
-        H[H_GO + 1] = turn;
-        H[H_GO - 2] = kk;
-        H[H_GO - 1] = own;
-      }
+      H[H_GO] = id;
+      H[H_GO + 1] = turn;
     }
     __syncthreads();
     const int taken = uni(H[H_GO]);
     turn = uni(H[H_GO + 1]);
-    own = uni(H[H_GO - 1]);
     if (taken >= total) return;
-    const int pair_id = owner ? uni(H[H_GO - 2]) * a.B8 + taken : taken;
-#ifdef R3D_STAMPS
-    const int k_ = a.B8 ? pair_id / a.B8 : pair_id % a.nk, s_ = a.B8 ? pair_id % a.B8 : pair_id / a.nk;
-    long long *cell = s_ < a.b.B ? reinterpret_cast<long long *>(a.b.out_xyzi + (int64_t)s_ * a.b.cap * 4) + k_ * 32 : nullptr;
-    if (cell && threadIdx.x == 0) cell[28] = wall_clock64();   // this workgroup takes the pair
-#endif
-    const int again = chain_pair<NT, false, NT != 1024>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8,
-                                                        smem, pair_id);
-#ifdef R3D_STAMPS
-    if (cell && threadIdx.x == 0) cell[29] = uni(again) ? wall_clock64() : 0;   // the LDS flavour turned the pair down here
-#endif
-    if (NT == 1024 && uni(again))
-      chain_pair<NT, true, true>(a.b, a.slots, a.nk, a.first_step, a.w, a.chunks, a.lds_cap, a.timeout_ticks, a.B8, smem, pair_id);
-#ifdef R3D_STAMPS
-    __syncthreads();
-    if (cell && threadIdx.x == 0) cell[30] = wall_clock64();   // ... and is done with it
-#endif
+    run_pairs_from<NT>(smem, taken);
   }
 }
 
@@ -2253,6 +2425,17 @@ k_insert_big(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w,
   const int s = (int)blockIdx.x;
   const int tid = threadIdx.x;
   const int k0 = w.defer_from[s];
+  // A chain the chain kernel neither finished nor handed over (a slot that never published: diagnostic bit 16; nothing
+  // else is known to get there): the scene is flagged, its remaining slots report nothing, the caller redoes the batch
+  // slot by slot (SceneBatch.run_inserts)
+  if (k0 >= nk) {
+    const int done = w.chain_progress[s];
+    if (nk > 1 && done >= 0 && done < nk && tid == 0) {
+      atomicOr(&b.status[s], R3D_S_CHAIN_TIMEOUT);
+      for (int k = done; k < nk; ++k) slots.n_visible[k][s] = 0, slots.accepted[k][s] = 0;
+    }
+    return;
+  }
   for (int k = k0; k < nk; ++k) {
     Ins<NT, true> I(b, w, smem, lds_cap, s, chunks, k, true);
     const bool on = load_slot(I, b, slots, k, s, first_step);
@@ -2264,7 +2447,7 @@ k_insert_big(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w,
         if (tid == 0) atomicOr(&b.status[s], R3D_S_WINDOW_TOO_LARGE);     // not even a whole CU's LDS holds it
       } else {
         int flags, n_after;
-        bool rebase = I.commit(flags, n_after);
+        bool rebase = I.commit(typename Ins<NT, true>::FromLds{I}, flags, n_after);
         nv = I.nvis;
         acc = I.accept ? 1 : 0;
         if (rebase) {
@@ -2282,17 +2465,45 @@ k_insert_big(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w,
   }
 }
 
-__global__ void k_chain_init(r3d_batch_t b, BatchWs w, int nk) {
+// Before a chain launch: progress / hand-over words, the pool, the queues -- and the ORDER in which the launch hands out
+// its slots.  Nobody waits for anybody (see the top of the file), so any order is correct.  A slot much heavier than the
+// others (sample rows >= 1.8 x the mean: the car among pedestrians and cyclists) is handed out up to `kPromote` places
+// earlier: it then evaluates while its predecessors run, is found parked when they are done, and the launch no longer ends
+// with "the slowest car, started after two slots had been through the device, plus what queued behind it" (config C2: the
+// scene with the slowest car ended at 334 us, its car taken at 69 us and evaluated for 206).  Not further: a slot evaluated
+// far ahead of its predecessors conflicts with one of them almost surely and is evaluated again by whoever commits it -- on
+// the scene's critical path.  (Tried: all slots by weight, heaviest first -- slot 0 then starts at 100 us and every chain
+// queues behind it: 0.42 ms per launch against 0.35.)  `order_mode`: 0 keep the caller's order, 1 promote (chains of <= 8 slots).
+constexpr int kPromote = 2;
+__global__ void k_chain_init(r3d_batch_t b, BatchWs w, ChainSlots slots, int nk, int order_mode) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= b.B) return;
   if (s == 0) {
     *w.pool_head = 0ull;
     for (int q = 0; q < 16; ++q) w.queue_next[q] = 0;
+    long long rows_of[kMaxChain], sum = 0;
+    for (int k = 0; k < nk; ++k) {
+      w.slot_order[k] = k;
+      rows_of[k] = slots.sample_off[k][b.B];
+      sum += rows_of[k];
+    }
+    if (order_mode == 1 && nk <= 8)
+      for (int k = 1; k < nk; ++k) {
+        if (rows_of[k] * 10 * nk < 18 * sum) continue;         // not a heavy slot
+        int at = 0;
+        while (w.slot_order[at] != k) ++at;
+        for (int hop = 0; hop < kPromote && at > 0; ++hop, --at) {
+          const int before = w.slot_order[at - 1];
+          if (rows_of[before] * 10 * nk >= 18 * sum) break;    // (heavy slots keep their order among themselves)
+          w.slot_order[at - 1] = k;
+          w.slot_order[at] = before;
+        }
+      }
   }
   w.chain_progress[s] = 0;
-  w.claim_next[s] = 0;
   w.n_total0[s] = b.n_total[s];
   w.defer_from[s] = nk;
+  for (int k = 0; k < nk; ++k) w.park[(int64_t)s * kMaxChain + k] = kParkNone;
 }
 
 constexpr int kSmallNT = 256;
@@ -2320,11 +2531,11 @@ static void chain_shape(const r3d_batch_t &b, int &nt, int &lds) {
 
 template <int NT, bool QUEUE>
 static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step, int lds,
-                          long long timeout_ticks, int B8, int queue_mode, hipStream_t st) {
+                          int B8, int queue_mode, hipStream_t st) {
   // per device, every call: the attribute belongs to the current device's copy of the kernel
   R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_chain<NT, QUEUE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  const int total = (B8 ? B8 : b.B) * nk;                     // (modes 3 / 4: as many workgroups as pairs at most, too)
+  const int total = (B8 ? B8 : b.B) * nk;
   int grid = total;
   if (QUEUE && queue_mode) {
     // how many workgroups of this shape the device keeps resident: asked once per (device, LDS size) and kernel flavour
@@ -2352,10 +2563,7 @@ static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlo
   args.b = b;
   args.slots = sl;
   args.w = w;
-  args.timeout_ticks = timeout_ticks;
   args.nk = nk, args.first_step = first_step, args.chunks = chunks_of(b), args.lds_cap = lds, args.B8 = B8, args.queue_mode = queue_mode;
-  static const int lead_env = env_int("R3D_CHAIN_LEAD", 4);
-  args.lead = lead_env;
   hipLaunchKernelGGL((k_insert_chain<NT, QUEUE>), dim3(grid), dim3(NT), lds, st, args);
   R3D_LAUNCHED("k_insert_chain");
   return R3D_OK;
@@ -2363,34 +2571,36 @@ static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlo
 
 template <int NT>
 static int launch_chain(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step, int lds,
-                        long long timeout_ticks, hipStream_t st) {
-  // measured on config C2: scene-major numbering is 10-40 % slower (the big pairs of all scenes no longer start together)
+                        hipStream_t st) {
+  // measured on config C2 (round 2): scene-major numbering is 10-40 % slower (the big pairs of all scenes no longer start together)
   static const bool scene_major = getenv("R3D_CHAIN_ORDER") && std::string(getenv("R3D_CHAIN_ORDER")) == "scene";
   const int B8 = scene_major ? 0 : (b.B + 7) & ~7;            // a scene's slots on one residue of the pair id mod 8
   // R3D_CHAIN_QUEUE: 0 one workgroup per pair; 1 resident workgroups that take pairs off one queue; 2 ... off a queue per
-  // XCD; 3 ... scenes off a queue per XCD, slot after slot; 4 as 3, and idle workgroups join the scenes that are behind
-  // (see k_insert_chain).  Default: 2 on large range images (config C5: 6.4 -> 4.8 ms per 128 scans x 50 slots), 0 otherwise.
+  // XCD (see k_insert_chain).  Default: 2 on large range images (config C5: 6.4 -> 4.8 ms per 128 scans x 50 slots), 0 otherwise.
   static const int queue_env = env_int("R3D_CHAIN_QUEUE", -1);
   const bool large = (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN;
-  int queue_mode = queue_env >= 0 ? queue_env : (large ? 2 : 0);
+  int queue_mode = queue_env >= 0 ? (queue_env > 2 ? 2 : queue_env) : (large ? 2 : 0);
   if ((scene_major || B8 >= (1 << 20)) && queue_mode >= 2) queue_mode = 1;
-  return queue_mode ? launch_chain_q<NT, true>(b, w, sl, nk, first_step, lds, timeout_ticks, B8, queue_mode, st)
-                    : launch_chain_q<NT, false>(b, w, sl, nk, first_step, lds, timeout_ticks, B8, 0, st);
+  return queue_mode ? launch_chain_q<NT, true>(b, w, sl, nk, first_step, lds, B8, queue_mode, st)
+                    : launch_chain_q<NT, false>(b, w, sl, nk, first_step, lds, B8, 0, st);
 }
 
 // One launch of the chain kernel for the slots of `sl`, k_insert_big behind it for what it left (idle otherwise).
 static int launch_slots(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step,
                         hipStream_t st) {
-  static const int timeout_ms = env_int("R3D_CHAIN_TIMEOUT_MS", 2000);
+  // R3D_SLOT_ORDER: 0 (default) the slots in the caller's order, 1 a heavy slot up to two places earlier (k_chain_init: measured
+  // on config C2, 0.43 against 0.35 ms per launch -- the car then evaluates against a state two slots old, a tenth of the cars
+  // conflict with one of them and start over, and the launch ends with the slowest of THOSE; the bulk is bound by
+  // workgroup-time either way)
+  static const int order_mode = env_int("R3D_SLOT_ORDER", 0);
   int nt, lds;
   chain_shape(b, nt, lds);
   R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_big<kBigNT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
-  hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, nk);
-  const long long tt = (long long)timeout_ms * 100000ll;
-  int rc = nt == 1024  ? launch_chain<1024>(b, w, sl, nk, first_step, lds, tt, st)
-           : nt == 512 ? launch_chain<512>(b, w, sl, nk, first_step, lds, tt, st)
-                       : launch_chain<kSmallNT>(b, w, sl, nk, first_step, lds, tt, st);
+  hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, sl, nk, order_mode);
+  int rc = nt == 1024  ? launch_chain<1024>(b, w, sl, nk, first_step, lds, st)
+           : nt == 512 ? launch_chain<512>(b, w, sl, nk, first_step, lds, st)
+                       : launch_chain<kSmallNT>(b, w, sl, nk, first_step, lds, st);
   if (rc != R3D_OK) return rc;
   hipLaunchKernelGGL(k_insert_big<kBigNT>, dim3(b.B), dim3(kBigNT), kBigLds, st, b, sl, nk, first_step, w,
                      chunks_of(b), kBigLds);
@@ -2458,9 +2668,10 @@ int r3d_batch_debug_counters(const r3d_batch_t *b, int32_t *host_out16, int32_t 
   if (rc != R3D_OK) return rc;
   if (!host_out16) return fail(R3D_E_ARG, "batch_debug_counters: null output");
   BatchWs w = carve_batch(*b, b->workspace);
-  const size_t n = (reset & 2) ? 32 : 16;                      // (bit 1: the caller's array holds 32, the notes of a diagnostic build too)
+  // (bit 1: the caller's array holds 32, the notes of a diagnostic build too; bit 2: it holds all 64, round 5's counters too)
+  const size_t n = (reset & 4) ? kDbgInts : ((reset & 2) ? 32 : 16);
   R3D_HIP(hipMemcpyAsync(host_out16, w.dbg, n * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
-  if (reset & 1) R3D_HIP(hipMemsetAsync(w.dbg, 0, 32 * sizeof(int32_t), (hipStream_t)stream));
+  if (reset & 1) R3D_HIP(hipMemsetAsync(w.dbg, 0, kDbgInts * sizeof(int32_t), (hipStream_t)stream));
   R3D_HIP(hipStreamSynchronize((hipStream_t)stream));
   return R3D_OK;
 }

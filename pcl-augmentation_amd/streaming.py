@@ -54,7 +54,7 @@ class _Lane:
             self.d_rows = [torch.empty((sample_rows, 5), dtype=torch.float64, device=device) for _ in range(K)]
             self.d_off = torch.zeros((max(K, 1), B + 1), dtype=torch.int64, device=device)
             self.d_need = torch.zeros((max(K, 1), B), dtype=torch.int32, device=device)
-            self.out_counts = pin((4, B), torch.int32)                  # n_out, n_log, status, rebases
+            self.out_counts = pin((5, B), torch.int32)                  # n_out, n_log, status, rebases, points numbered anew
             self.out_acc = pin((max(K, 1), B), torch.int32)
             if delta:
                 # the delta on the device and in pinned memory; the merged results in plain host memory
@@ -242,6 +242,9 @@ class StreamedAugmenter:
             ln.out_counts[1].copy_(bt.n_log, non_blocking=True)
             ln.out_counts[2].copy_(bt.status, non_blocking=True)
             ln.out_counts[3].copy_(bt.rebase, non_blocking=True)
+            ln.looked = bt._looked                                  # (did this begin look at the point order?  SceneBatch.order)
+            if ln.looked:
+                ln.out_counts[4].copy_(bt.point_order_device(), non_blocking=True)
             ln.done.record(ln.stream)
         ln.busy, ln.tag = True, tag
         self.times["enqueue"] += time.perf_counter() - t_enq
@@ -263,6 +266,8 @@ class StreamedAugmenter:
             for k, v in ln.bt.debug_counters(reset=True).items():
                 _SUM_COUNTERS[k] = (_SUM_COUNTERS.get(k, 0) + v) if not isinstance(v, list) else [a + b for a, b in zip(_SUM_COUNTERS.get(k, [0] * len(v)), v)]
             _SUM_COUNTERS["rebases"] = _SUM_COUNTERS.get("rebases", 0) + int(counts[3].sum())
+        if getattr(ln, "looked", False):
+            ln.bt.note_point_order(counts[4])
         n_log = ln.h_n_log.numpy()
         n_log[:] = counts[1]
         redo = [int(s) for s in np.nonzero(counts[2])[0] if _lib.needs_level1(counts[2][s])]   # see _redo_level1

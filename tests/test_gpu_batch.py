@@ -208,10 +208,14 @@ def test_status_is_raised(P, synth):
     xyzi[5, :3] = 0.0                                     # a point at the origin
     with pytest.raises(ValueError):
         P.augment_batch([(xyzi, label)], [[[synth.make_insert(1, "pedestrian")]]], [[10]])
+    # (round 4 raised for a sample of more than 8 192 points; the reference takes any size, insertion.py:455-461, and so
+    # does this path now: tests/test_gpu_limits.py)
     big = synth.make_insert(1, "car", points=9000)
     xyzi, label = synth.make_scene(3, 8, 100)
-    with pytest.raises(ValueError):
-        P.augment_batch([(xyzi, label)], [[[big]]], [[10]])
+    res, acc = P.augment_batch([(xyzi, label)], [[[big]]], [[10]])
+    vb, lb, cb, oacc = _oracle_chain(xyzi, label, [[big]], [10])
+    assert acc[0] == oacc
+    _check_scene(res[0], vb, lb, cb)
 
 
 def test_full_size_properties(P, synth):
@@ -526,14 +530,14 @@ def test_insert_many_reports_the_same_status_as_single_calls(P, synth):
     B, K = 8, 4
     scenes = [synth.make_scene(90 + s, 32, 500) for s in range(B)]
     ins = [[synth.make_insert(900 + 10 * s + k, "pedestrian", rng_range=(5.0, 15.0)) for k in range(K)] for s in range(B)]
-    ins[1][1] = np.tile(ins[1][1], (21, 1))[:8200]                      # > 8192 points
+    ins[1][1] = np.tile(ins[1][1], (170, 1))[:65600]                    # > R3D_MAX_SAMPLE = 65 535 points
     ins[2][0] = ins[2][0].copy()
     ins[2][0][5, 0] = np.nan                                           # NaN coordinate
     ins[3] = [synth.make_insert(950 + k, "car", rng_range=(5.0, 9.0)) for k in range(K)]   # 4 x 1500 points: log too small
     n = max(len(x) for x, _ in scenes)
     out = []
     for mode in ("many", "single"):
-        batch = P.SceneBatch(B, n + 9000, 4000)
+        batch = P.SceneBatch(B, n + 70000, 4000)
         batch.load(scenes)
         batch.begin()
         packed = [batch.pack_samples([ins[s][k] for s in range(B)]) for k in range(K)]
