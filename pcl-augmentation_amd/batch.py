@@ -178,6 +178,55 @@ class SceneBatch:
         return px.numpy(), pl.numpy().view(np.uint32), ck, n_out, n_log
 
     @_lib.on_own_device
+    def download_delta_views(self, check_cols=5, threads=16):
+        """``finish`` + ``download_views`` for a batch whose frames the host still holds (``load``: the pinned staging):
+        only the DELTA comes back from the device -- one alive bit per point, the inserted points, counters: 0.1 MB per
+        frame instead of 2.5 MB -- and the merged clouds, labels and check rows are put together on the host
+        (``r3d_host_merge_frames``: the bytes ``r3d_batch_finish`` would have written).  No compaction runs on the device.
+        Returns what ``download_views`` returns; the views are valid until the next call."""
+        torch = self.torch
+        if not getattr(self, "_loaded_from_staging", False):
+            self.finish(check_cols)
+            return self.download_views()
+        B, cap, log_cap, chunks = self.B, self.cap, self.log_cap, (self.cap + 63) // 64
+        cc = max(int(check_cols), 4)
+        d = getattr(self, "_delta", None)
+        if d is None or d["cc"] != cc:
+            pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
+            z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.device)
+            d = self._delta = {
+                "cc": cc,
+                "d_alive": z((B, chunks), torch.int64), "d_tail_xyzi": z((B, log_cap, 4), torch.float32),
+                "d_tail_label": z((B, log_cap), torch.int32), "d_counts": z((2, B), torch.int32),
+                "h_alive": pin((B, chunks), torch.int64), "h_tail_xyzi": pin((B, log_cap, 4), torch.float32),
+                "h_tail_label": pin((B, log_cap), torch.int32), "h_counts": pin((2, B), torch.int32),
+                "h_status": pin((B,), torch.int32), "h_n_log": pin((B,), torch.int32),
+                "out_xyzi": torch.empty((B, cap, 4), dtype=torch.float32), "out_label": torch.empty((B, cap), dtype=torch.int32),
+                "out_check": torch.empty((B, log_cap, cc), dtype=torch.float32), "n_out": torch.zeros((B,), dtype=torch.int32),
+            }
+        _lib.check(self.lib.r3d_batch_export_delta(C.byref(self.desc), d["d_alive"].data_ptr(), d["d_tail_xyzi"].data_ptr(),
+                                                   d["d_tail_label"].data_ptr(), log_cap, d["d_counts"].data_ptr(), _lib.stream_ptr()),
+                   "r3d_batch_export_delta")
+        for h, dv in (("h_alive", "d_alive"), ("h_tail_xyzi", "d_tail_xyzi"), ("h_tail_label", "d_tail_label"), ("h_counts", "d_counts")):
+            d[h].copy_(d[dv], non_blocking=True)
+        d["h_status"].copy_(self.status, non_blocking=True)
+        d["h_n_log"].copy_(self.n_log, non_blocking=True)
+        order = self.point_order_device().cpu() if self._looked else None
+        torch.cuda.current_stream().synchronize()
+        if order is not None:
+            self.note_point_order(order.numpy())
+        st = d["h_status"].numpy()
+        for s in np.nonzero(st)[0]:
+            _lib.raise_status(int(st[s]), f"scene {s}")
+        pin_in = self._staging()
+        _lib.check(self.lib.r3d_host_merge_frames(
+            pin_in["xyzi"].data_ptr(), pin_in["label"].data_ptr(), cap, d["h_alive"].data_ptr(), chunks, d["h_tail_xyzi"].data_ptr(),
+            d["h_tail_label"].data_ptr(), log_cap, d["h_counts"].data_ptr(), B, d["out_xyzi"].data_ptr(), d["out_label"].data_ptr(), cap,
+            d["n_out"].data_ptr(), d["out_check"].data_ptr() if check_cols else None, log_cap, cc, int(threads)), "r3d_host_merge_frames")
+        ck = d["out_check"].numpy()[:, :, :check_cols] if check_cols else None
+        return d["out_xyzi"].numpy(), d["out_label"].numpy().view(np.uint32), ck, d["n_out"].numpy(), d["h_n_log"].numpy()
+
+    @_lib.on_own_device
     def load_device(self, xyzi, label, n_points):
         """Same from tensors already on the device (copied into the batch slabs)."""
         self.xyzi.copy_(xyzi)
@@ -425,9 +474,10 @@ class SceneBatch:
             _lib.raise_status(int(st[s]), f"scene {s}")
 
     @_lib.on_own_device
-    def results(self):
-        """Per scene: (xyzi float32 [n,4], label uint32 [n], check float32 [m,cols]), copies."""
-        ox, ol, ck, n_out, n_log = self.download_views()
+    def results(self, delta_check_cols=None):
+        """Per scene: (xyzi float32 [n,4], label uint32 [n], check float32 [m,cols]), copies.  After ``finish``; or, with
+        ``delta_check_cols`` (4 / 5 / 0) INSTEAD of ``finish``: by the delta and the host merge (``download_delta_views``)."""
+        ox, ol, ck, n_out, n_log = self.download_views() if delta_check_cols is None else self.download_delta_views(delta_check_cols)
         one = lambda s: (ox[s, :n_out[s]].copy(), ol[s, :n_out[s]].copy(), ck[s, :n_log[s]].copy() if ck is not None else None)
         if self.B < 16:
             return [one(s) for s in range(self.B)]

@@ -430,11 +430,12 @@ __global__ __launch_bounds__(kPB) void k_place_road_min(const r3d_place_query_t 
 
 // First radius of the growing search that holds surface (find_spot.py:121-140).
 __global__ void k_place_kstar(int nq, PlaceWs w, Radii rad) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nq * kRot) return;
+  const int t_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = t_raw < nq * kRot;                        // (nobody leaves: the wave reductions below want every lane)
+  const int t = live ? t_raw : nq * kRot - 1;
   unsigned long long key = w.dmin[t];
   int k = -1;
-  if (key != R3D_SENT) {
+  if (live && key != R3D_SENT) {
     double d2 = key_depth(key);
     for (int j = 0; j < rad.n; ++j)
       if (d2 <= rad.sq[j]) {
@@ -442,13 +443,26 @@ __global__ void k_place_kstar(int nq, PlaceWs w, Radii rad) {
         break;
       }
   }
-  w.kstar[t] = k;
-  w.surf_n[t] = 0;
-  w.surf_sum[t] = 0.0;
-  w.surf_abs[t] = 0.0;
-  w.surf_lsb[t] = INT32_MAX;
-  w.surf_list_n[t] = 0;
-  if (k >= 0) atomicMax(&w.gather_sq[t / kRot], depth_key(rad.sq[k]));
+  if (live) {
+    w.kstar[t] = k;
+    w.surf_n[t] = 0;
+    w.surf_sum[t] = 0.0;
+    w.surf_abs[t] = 0.0;
+    w.surf_lsb[t] = INT32_MAX;
+    w.surf_list_n[t] = 0;
+  }
+  // (the largest radius any step of the query needs.  A wave of 64 steps belongs to at most two queries, lane 0's and lane
+  // 63's: one maximum each, one atomic each -- 360 atomics on one address per query took their turns in L2: 42 us for 320
+  // queries)
+  const unsigned long long mine = k >= 0 ? depth_key(rad.sq[k]) : 0ull;
+  const int q = t / kRot;
+  const int q_first = __shfl(q, 0, 64), q_last = __shfl(q, 63, 64);
+  const unsigned long long m_first = wave_max_u64(q == q_first ? mine : 0ull);
+  const unsigned long long m_last = wave_max_u64(q == q_last ? mine : 0ull);
+  if ((threadIdx.x & 63) == 0) {
+    if (m_first) atomicMax(&w.gather_sq[q_first], m_first);
+    if (q_last != q_first && m_last) atomicMax(&w.gather_sq[q_last], m_last);
+  }
 }
 
 // Exponent of the last set mantissa bit of a finite non-zero double: v is a multiple of 2^that.
@@ -663,9 +677,15 @@ __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_quer
 }
 
 // Points per thread with which the sample chain takes a sample of m points.
+// (as few as the workgroup's 512 threads allow: a step of the chain is the instruction stream of ONE wave -- its points'
+// float64 chains, some 100 instructions per point -- and a workgroup's waves run side by side on the CU's four SIMDs; with 4
+// points per lane a pedestrian was two waves of 550 instructions per step, 2.0 us)
 __host__ __device__ inline int chain_class(int m) {
   int need = (m + kCB - 1) / kCB;
-  return need <= 4 ? 4 : need <= 8 ? 8 : 16;
+  // measured per class on 320 queries (us per launch, 4 points per lane -> this choice): pedestrians of 400 points 717 -> 591
+  // with one point per lane (7 waves), cars of 1 500 points 1 046 -> 991 with three (8 waves); cyclists of 600 points are
+  // better off with four per lane on three waves (819) than with two on five (881): more waves, longer barriers
+  return need <= 1 ? 1 : need == 3 ? 3 : need <= 4 ? 4 : need <= 8 ? 8 : 16;
 }
 // threads of the sample chain's workgroup that take part: whole waves, PPT points per lane
 template <int PPT>
@@ -692,7 +712,12 @@ struct ChainLds {
   float red[2][kCB / 64];
 };
 
-template <int PPT>
+// The chain's per-step agreement travels through LDS only: wait for the LDS counter and meet.  (__syncthreads() also waits
+// for every global store in flight -- the candidate clouds a possible step has just written, a microsecond or two each
+// time, 96 times per query on the bench's frames.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int PPT, bool POINTWISE>
 __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_query_t *Q, const PlaceWs &w, int max_boxes,
                                              uint8_t *flags, int32_t *n_possible, int32_t *rot_out,
                                              double *anno_out, double *cand, int32_t first_cand, int32_t *status) {
@@ -706,7 +731,7 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
   unsigned short *s_rot = lds.rot;
   uint32_t *s_hit = lds.hit;
   float(*s_red)[kCB / 64] = lds.red;
-  double x[PPT], y[PPT], z[PPT];
+  double x[PPT], y[PPT], z[PPT], c3[PPT], c4[PPT];   // (c3, c4: intensity and label, written with every candidate)
   bool valid[PPT];
   int bad_input = 0;
   float rho2 = 0.f, ext2 = 0.f;                     // largest distance^2 from the sensor / from the box centre
@@ -719,12 +744,14 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
 #pragma unroll
   for (int u = 0; u < PPT; ++u) {
     int i = tid + u * T;
-    x[u] = y[u] = z[u] = 0.0;
+    x[u] = y[u] = z[u] = c3[u] = c4[u] = 0.0;
     valid[u] = i < m && tid < T;
     if (valid[u]) {
       x[u] = in_global(qq.sample)[(size_t)i * 5 + 0];
       y[u] = in_global(qq.sample)[(size_t)i * 5 + 1];
       z[u] = in_global(qq.sample)[(size_t)i * 5 + 2];
+      c3[u] = in_global(qq.sample)[(size_t)i * 5 + 3];
+      c4[u] = in_global(qq.sample)[(size_t)i * 5 + 4];
       if (!(isfinite(x[u]) && isfinite(y[u]) && isfinite(z[u]))) bad_input = 1;
       rho2 = fmaxf(rho2, (float)(x[u] * x[u] + y[u] * y[u]));
       ext2 = fmaxf(ext2, (float)((x[u] - ax) * (x[u] - ax) + (y[u] - ay) * (y[u] - ay)));
@@ -765,12 +792,11 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
     uint64_t wv = v < 64 ? okm0 : v < 128 ? okm1 : v < 192 ? okm2 : okm3;
     return (wv >> (v & 63)) & 1ull;
   };
-  const bool pointwise = qq.flavour & R3D_PQ_POINTWISE_ROTATION, od_map = qq.flavour & R3D_PQ_MAP_NEEDS_POINT;
+  const bool od_map = qq.flavour & R3D_PQ_MAP_NEEDS_POINT;
   const double map_lo = od_map ? 0.0 : -1.0;         // OD: 0 <= position; SS: int() of (-1, 0) is cell 0
   const int cand_cap = qq.cand_cap;
   const int64_t cand_stride = qq.cand_stride;
   double *cand_q = cand + qq.cand_off;
-  InGlobal<double> sample = in_global(qq.sample);
   float rho = 0.f, ext = 0.f;
   for (int i = 0; i < kCB / 64; ++i) {
     rho = fmaxf(rho, s_red[0][i]);
@@ -808,17 +834,31 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
     s_allowed[wi] = bits;
   }
   __syncthreads();
+  // Whole waves leave here (T is a multiple of 64: act_threads), the others go on meeting at s_barrier: the hardware's
+  // barrier counts the waves of the workgroup that have not ended (CDNA ISA, s_barrier: "waves that have terminated are not
+  // waited for"), which the HIP programming model does not promise -- hence the barriers below are spelled as the
+  // instruction (lds_barrier), not as __syncthreads(), and the two facts they rest on are checked where they are made.
+  static_assert(kCB % 64 == 0, "the sample chain's workgroup is whole waves");
+  if ((T & 63) != 0 || (long long)PPT * T < m) {              // (cannot happen: chain_class / act_threads)
+    if (tid == 0) atomicOr(&status[q], R3D_PS_NONFINITE);
+    return;
+  }
   if (tid >= T) return;
   double anno_z = qq.anno[2];
   int n_out = 0;
+  // (od_map as arithmetic on compare results, the rotation's flavour as a template parameter, the rare map cell outside the
+  // LDS patch behind ONE branch after the PPT points: a branch inside the per-point code keeps the compiler from
+  // interleaving the points' float64 chains -- each then runs at its full latency, 2.0 us per step for a pedestrian)
+  const int od_i = od_map ? 1 : 0;
   for (int r = 0; r < kRot; ++r) {
-    int bad = 0, in_any_map = 0;
+    int bad = 0, in_any_map = 0, slow = 0;
+    double g0[PPT], g1[PPT];
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
       // SS :72  bbox_pcl[:, :3] = (z_rot_matrix @ bbox_pcl[:, :3].T).T   (matrix product: a0*b0, fma, fma)
       // OD :94-99  np.dot(z_rot_matrix, column) per point             (matrix x vector: fma(a2,b2, fma(a0,b0, a1*b1)))
       double nx, ny, nz;
-      if (pointwise) {
+      if (POINTWISE) {
         nx = fma(0.0, z[u], fma(kCos1, x[u], -kSin1 * y[u]));
         ny = fma(0.0, z[u], fma(kSin1, x[u], kCos1 * y[u]));
         nz = fma(1.0, z[u], fma(0.0, x[u], 0.0 * y[u]));
@@ -831,23 +871,42 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
       y[u] = ny;
       z[u] = nz;
       // transformation_matrix @ [x y z 1], minus map_move, astype(int): :234-238
-      double g0 = fma(T03, 1.0, fma(T02, nz, fma(T01, ny, T00 * nx))) - mv0;
-      double g1 = fma(T13, 1.0, fma(T12, nz, fma(T11, ny, T10 * nx))) - mv1;
-      // int() truncates: the index is in [0, rows) exactly when -1 < g0 < rows (:240-243)
-      const bool in_map = (od_map ? g0 >= map_lo : g0 > map_lo) && g0 < (double)rows &&
-                          (od_map ? g1 >= map_lo : g1 > map_lo) && g1 < (double)cols;
-      in_any_map |= (valid[u] && in_map) ? 1 : 0;
-      const int i0 = in_map ? (int)g0 : 0, i1 = in_map ? (int)g1 : 0;
-      const int a = i0 - wr0, b = i1 - wc0;
-      const bool in_win = a >= 0 && a < wh && b >= 0 && b < ww;
-      const int c = in_win ? a * ww + b : 0;
-      bool ok = (s_allowed[c >> 5] >> (c & 31)) & 1u;
-      if (in_map && !in_win && valid[u]) ok = allowed(map[(size_t)i0 * cols + i1]);   // outside the patch: rare
-      bad |= (valid[u] && in_map && !ok) ? 1 : 0;                 // :245-248
+      g0[u] = fma(T03, 1.0, fma(T02, nz, fma(T01, ny, T00 * nx))) - mv0;
+      g1[u] = fma(T13, 1.0, fma(T12, nz, fma(T11, ny, T10 * nx))) - mv1;
+    }
+    int cell[PPT], i0s[PPT], i1s[PPT];
+    int inmap[PPT], inwin[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      // int() truncates: the index is in [0, rows) exactly when -1 < g0 < rows (:240-243); OD: 0 <= position
+      const int lo0 = (int)(g0[u] > map_lo) | (od_i & (int)(g0[u] == map_lo));
+      const int lo1 = (int)(g1[u] > map_lo) | (od_i & (int)(g1[u] == map_lo));
+      inmap[u] = lo0 & (int)(g0[u] < (double)rows) & lo1 & (int)(g1[u] < (double)cols);
+      i0s[u] = inmap[u] ? (int)g0[u] : 0;
+      i1s[u] = inmap[u] ? (int)g1[u] : 0;
+      const int a = i0s[u] - wr0, b = i1s[u] - wc0;
+      inwin[u] = (int)(a >= 0) & (int)(a < wh) & (int)(b >= 0) & (int)(b < ww);
+      cell[u] = inwin[u] ? a * ww + b : 0;
+    }
+    uint32_t wd[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) wd[u] = s_allowed[cell[u] >> 5];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      const int v = valid[u] ? 1 : 0;
+      const int ok = (int)((wd[u] >> (cell[u] & 31)) & 1u);
+      in_any_map |= v & inmap[u];
+      bad |= v & inmap[u] & inwin[u] & (ok ^ 1);                  // :245-248
+      slow |= v & inmap[u] & (inwin[u] ^ 1);
+    }
+    if (slow) {                                                   // a cell outside the patch in LDS: rare
+#pragma unroll
+      for (int u = 0; u < PPT; ++u)
+        if (valid[u] && inmap[u] && !inwin[u] && !allowed(map[(size_t)i0s[u] * cols + i1s[u]])) bad = 1;
     }
     if (bad) s_vote[0][r] = 1;                                    // one slot per step: no reset, one barrier
     if (od_map && in_any_map) s_vote[2][r] = 1;
-    __syncthreads();
+    lds_barrier();
     const bool on_surface = !s_vote[0][r] && (!od_map || s_vote[2][r]);
     const bool near = s_near[r];
     if (on_surface && near) {                                     // correct_height, :142-148
@@ -877,7 +936,7 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
       else test_boxes(gboxes);
       if (tested) {
         if (in_any) s_vote[1][r] = 1;
-        __syncthreads();
+        lds_barrier();
         sample_hit = s_vote[1][r];
       }
     }
@@ -897,15 +956,15 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
           out[(size_t)i * 5 + 0] = x[u];
           out[(size_t)i * 5 + 1] = y[u];
           out[(size_t)i * 5 + 2] = z[u];
-          out[(size_t)i * 5 + 3] = sample[(size_t)i * 5 + 3];
-          out[(size_t)i * 5 + 4] = sample[(size_t)i * 5 + 4];
+          out[(size_t)i * 5 + 3] = c3[u];                        // (from registers: a load here waits for every store
+          out[(size_t)i * 5 + 4] = c4[u];                        // of the steps before -- loads and stores share a counter)
         }
       }
       if (tid == 0) s_rot[n_out] = (unsigned short)r;
       ++n_out;
     }
   }
-  __syncthreads();
+  lds_barrier();                                                  // (s_flags / s_rot of thread 0; surviving waves only)
   // the annotation of a possible placement: centre (cx, cy, road level of that step), orientation
   for (int r = tid; r < kRot; r += T) flags[(size_t)q * kRot + r] = s_flags[r];
   for (int j = tid; j < n_out; j += T) {
@@ -927,8 +986,17 @@ __global__ __launch_bounds__(kCB) void k_place_sample_chain(const r3d_place_quer
                                                            double *anno_out, double *cand, int32_t first_cand,
                                                            int32_t *status) {
   __shared__ ChainLds lds;
+  const bool pointwise = Q[blockIdx.x].flavour & R3D_PQ_POINTWISE_ROTATION;
   switch (chain_class(Q[blockIdx.x].m)) {
-    case 4: sample_chain<4>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
+#define R3D_CHAIN_CASE(P)                                                                                                  \
+  case P:                                                                                                                   \
+    if (pointwise) sample_chain<P, true>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); \
+    else sample_chain<P, false>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status);      \
+    break;
+    R3D_CHAIN_CASE(1)
+    R3D_CHAIN_CASE(3)
+    R3D_CHAIN_CASE(4)
+#undef R3D_CHAIN_CASE
     default: break;
   }
 }
@@ -938,9 +1006,16 @@ __global__ __launch_bounds__(kCB) void k_place_sample_chain_large(const r3d_plac
                                                                  int32_t *rot_out, double *anno_out, double *cand,
                                                                  int32_t first_cand, int32_t *status) {
   __shared__ ChainLds lds;
+  const bool pointwise = Q[blockIdx.x].flavour & R3D_PQ_POINTWISE_ROTATION;
   switch (chain_class(Q[blockIdx.x].m)) {
-    case 8: sample_chain<8>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
-    case 16: sample_chain<16>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status); break;
+    case 8:
+      if (pointwise) sample_chain<8, true>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status);
+      else sample_chain<8, false>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status);
+      break;
+    case 16:
+      if (pointwise) sample_chain<16, true>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status);
+      else sample_chain<16, false>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status);
+      break;
     default: break;
   }
 }
@@ -1039,7 +1114,10 @@ extern "C" int r3d_find_possible_places(const r3d_place_query_t *queries, int32_
   const int pb_scene = (int)((max_n_scene + kPointsPerBlock - 1) / kPointsPerBlock);
   // distance passes of growing reach (metres); a pass only serves the steps whose minimum the
   // previous one could not settle (nothing found within its reach)
-  const double reach_of_pass[3] = {0.6, 1.8, sqrt(reach_max)};
+  // (round 5: 0.6 m, then the full reach for the steps still open -- the 1.8 m pass in between cost more than it saved the
+  // last one: 1.80 -> 1.75 ms per 320 queries, 4.10 -> 3.94 per 1 280; R3D_PLACE_TWO_PASS=0 brings it back)
+  static const int two_pass = [] { const char *v = getenv("R3D_PLACE_TWO_PASS"); return v && *v == '0' ? 0 : 1; }();
+  const double reach_of_pass[3] = {0.6, two_pass ? sqrt(reach_max) : 1.8, sqrt(reach_max)};
   if (pb_orig > 0) {
     double settled = 0.0;
     for (int pass = 0; pass < 3; ++pass) {

@@ -153,8 +153,8 @@ class AugmentPipeline:
             for s in range(B):
                 if have[s]:
                     chosen[s].append(rot[s])
-        batch.finish(self.check_cols)
-        return batch.results(), chosen
+        # (the delta instead of the merged clouds: the frames are still in the pinned staging `load` filled)
+        return batch.results(delta_check_cols=self.check_cols), chosen
 
     def run_placed(self, frames, scene_info_for, slots_for, lanes=1):
         """Frames with the placement search in the loop: scene_info_for(i) -> (rich_map, map_move,

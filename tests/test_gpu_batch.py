@@ -912,3 +912,37 @@ def test_window_larger_than_the_lds_images_on_448x2880(P, synth, monkeypatch):
     vb, lb, cb, oacc = _oracle_chain(xyzi, label, sl, nd)
     assert acc[0] == oacc and oacc[0] == 0
     _check_scene(res[0], vb, lb, cb)
+
+
+def test_delta_download_equals_finish(P, synth):
+    """``SceneBatch.download_delta_views`` (alive bits + inserted points back, the merged files' bytes put together on the
+    host from the frames the pinned staging still holds) against ``finish`` + ``download_views`` (compaction on the device,
+    whole clouds back) and against the oracle; ragged frames, a rejected slot, a frame in virtual order."""
+    cases = []
+    for s in range(5):
+        xyzi, label = synth.make_scene(610 + s, 40, 400 + 50 * s, shuffle=(s == 3))
+        label = label | (np.uint32(s + 1) << 16)                         # instance bits: dropped on the way (datasets.py:56)
+        ins = [synth.make_insert(6100 + 10 * s + k, kind, rng_range=(4.0, 20.0)) for k, kind in enumerate(["car", "pedestrian", "cyclist"])]
+        cases.append((xyzi, label, [[x] for x in ins], [20, 10 ** 6 if s == 1 else 20, 20]))
+    B = len(cases)
+    grow = sum(max(len(c[2][k][0]) for c in cases) for k in range(3))
+    for check_cols in (5, 4):
+        outs = []
+        for delta in (False, True):
+            batch = P.SceneBatch(B, max(len(c[0]) for c in cases) + grow, grow)
+            batch.load([(c[0], c[1]) for c in cases])
+            batch.begin()
+            batch.run_inserts([c[2] for c in cases], [c[3] for c in cases])
+            if delta:
+                ox, ol, ck, n_out, n_log = batch.download_delta_views(check_cols)
+            else:
+                batch.finish(check_cols)
+                ox, ol, ck, n_out, n_log = batch.download_views()
+            outs.append([(ox[s, :n_out[s]].copy(), ol[s, :n_out[s]].copy(), ck[s, :n_log[s]].copy()) for s in range(B)])
+        for s in range(B):
+            for a, b in zip(outs[0][s], outs[1][s]):
+                assert a.tobytes() == b.tobytes(), (check_cols, s)
+        if check_cols == 5:
+            for s, c in enumerate(cases):
+                vb, lb, cb, _ = _oracle_chain(c[0], c[1] & 0xFFFF, c[2], c[3])
+                _check_scene(outs[1][s], vb, lb, cb)

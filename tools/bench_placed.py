@@ -51,8 +51,11 @@ def measure(pkg, B=256, K=5, reps=3, profile=False, lanes=2):
             placed += sum(1 for r in rot if r > 0)
         torch.cuda.current_stream().synchronize()
         t2 = time.perf_counter()
-        batch.finish()
-        batch.download_views()                                   # merged clouds, labels, check rows in pinned host memory
+        if os.environ.get("R3D_PLACED_WHOLE_CLOUDS"):
+            batch.finish()
+            batch.download_views()                               # merged clouds, labels, check rows in pinned host memory
+        else:
+            batch.download_delta_views(5)                        # the delta back, merged clouds / labels / check rows put together on the host
         t3 = time.perf_counter()
         if times is not None:
             times.update(load_begin_setup=round(1e3 * (t1 - t0), 1), placed_slots=round(1e3 * (t2 - t1), 1),

@@ -40,7 +40,7 @@ def main():
     K = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     cap = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     n_boxes = int(sys.argv[4]) if len(sys.argv) > 4 else 6
-    kinds = pkg.synth.CONFIG_INSERTS["C2"]
+    kinds = os.environ.get("R3D_KINDS", "").split(",") if os.environ.get("R3D_KINDS") else pkg.synth.CONFIG_INSERTS["C2"]
     t0 = time.time()
     scenes = [make_scene(s, n_boxes) for s in range(B)]
     queries = [make_query(scenes[s], s * 100 + k, kinds[k % len(kinds)]) for s in range(B) for k in range(K)]
