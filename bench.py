@@ -326,6 +326,9 @@ def main():
     cfg["workload"] = cfg["workload"].replace(f"batch of {cfg['scenes']} ", f"batch of {B} ")
     if cfg["shuffle"]:
         cfg["workload"] += "; points of every scan in a random order"
+    if os.environ.get("R3D_BENCH_KINDS"):                             # (experiments: another mix of inserts, same count)
+        mix = os.environ["R3D_BENCH_KINDS"].split(",")
+        cfg["kinds"] = [mix[k % len(mix)] for k in range(len(cfg["kinds"]))]
     kinds = cfg["kinds"]
     pkg = importlib.import_module("pcl-augmentation_amd")
     synth = pkg.synth

@@ -486,6 +486,17 @@ int r3d_host_write_frames(const char *const *velodyne_paths, const char *const *
                           const float *xyzi, const uint32_t *label, int64_t cap, const int32_t *n_out, const float *check,
                           int64_t check_stride, int32_t check_cols, const int32_t *n_check, int32_t threads);
 
+/* HOST: the same files straight from what the host already holds -- the frames in the staging slab the upload was made from
+ * (in_xyzi, in_label: the layout of r3d_host_pack_frames / r3d_host_read_frames) and the delta of r3d_batch_export_delta
+ * (alive, tail_xyzi, tail_label, counts) -- without the merged clouds in between: velodyne and label files are written
+ * run by run of surviving points (writev), then the surviving inserted points; check/{f}.bin = every inserted point.  Byte
+ * for byte what r3d_host_merge_frames followed by r3d_host_write_frames writes; n_out [B] (may be NULL) = points per
+ * merged cloud.  label_paths / check_paths / their entries may be NULL as there. */
+int r3d_host_write_delta_frames(const char *const *velodyne_paths, const char *const *label_paths, const char *const *check_paths,
+                                int32_t B, const float *in_xyzi, const uint32_t *in_label, int64_t cap, const uint64_t *alive,
+                                int64_t chunks, const float *tail_xyzi, const uint32_t *tail_label, int64_t tail_stride,
+                                const int32_t *counts, int32_t check_cols, int32_t *n_out, int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -689,6 +689,37 @@ k_unvirtual(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w,
   }
 }
 
+// Clouds of many tiles (config C5: 489 per scan): the living points in front of every tile, once per scene, instead of every
+// block of the compaction adding up the counts of the tiles before it (up to 8 dependent loads per lane at its start).
+constexpr int kPrefixMinTiles = 128;
+template <bool ROWS4>
+__global__ void __launch_bounds__(1024)
+k_tile_prefix(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles) {
+  __shared__ int s_scan[1024 / 64 + 1];
+  __shared__ int s_carry;
+  const int cnt = *count, tid = threadIdx.x;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    const int s = list[li];
+    const bool shadow = ROWS4 && w.shadow_valid[s] != 0, virt = w.n_virt[s] != 0;
+    const int32_t *src = (virt ? w.tile_o : (shadow ? w.tile_shadow : w.tile_alive)) + (int64_t)s * tiles;
+    const int used = (b.n_total[s] + kTile - 1) / kTile;
+    __syncthreads();
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < used; base += 1024) {
+      const int t = base + tid;
+      const int c = t < used ? src[t] : 0;
+      int tot;
+      const int ex = block_escan_i32(c, s_scan, tot);
+      const int carry = s_carry;
+      if (t < used) w.tile_pre[(int64_t)s * tiles + t] = carry + ex;
+      __syncthreads();
+      if (tid == 0) s_carry = carry + tot;
+      __syncthreads();
+    }
+  }
+}
+
 // SceneBatch.pixel_ids(): the pixel id of every point in slab order as the reference numbers it (row * cols + col)
 __global__ void k_export_pix(r3d_batch_t b, BatchWs w, int32_t *out) {
   const int s = blockIdx.y;
@@ -727,7 +758,9 @@ k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
     const int32_t *tile_alive = (virt ? w.tile_o : (shadow ? w.tile_shadow : w.tile_alive)) + (int64_t)s * tiles;
     const unsigned long long *alive = (virt ? w.alive_o : (shadow ? w.alive_shadow : w.alive)) + (int64_t)s * chunks;
     int pre = 0;
-    for (int t = lane; t < (int)blockIdx.x; t += 64) pre += tile_alive[t];
+    if (tiles >= kPrefixMinTiles) pre = lane == 0 ? w.tile_pre[(int64_t)s * tiles + blockIdx.x] : 0;   // (k_tile_prefix)
+    else
+      for (int t = lane; t < (int)blockIdx.x; t += 64) pre += tile_alive[t];
     const int first = wave * kWaveChunks;                    // my first chunk within the tile
     unsigned long long m = 0ull;                             // lane c: alive word of chunk c of the tile
     if (lane < first + kWaveChunks && t0 + lane * 64 < n) m = alive[(t0 >> 6) + lane];
@@ -956,9 +989,11 @@ static int launch_compact(const r3d_batch_t &b, const BatchWs &w, const int32_t 
   // (scenes in virtual order: their alive bits back in slab order first; a block of the others returns at once)
   if (rows4) {
     hipLaunchKernelGGL((k_unvirtual<true>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b));
+    if (tiles >= kPrefixMinTiles) hipLaunchKernelGGL((k_tile_prefix<true>), dim3(1, rows), dim3(1024), 0, st, b, list, count, w, tiles);
     hipLaunchKernelGGL((k_alive_write<true, false>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b), rows4, n_rows);
   } else {
     hipLaunchKernelGGL((k_unvirtual<false>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b));
+    if (tiles >= kPrefixMinTiles) hipLaunchKernelGGL((k_tile_prefix<false>), dim3(1, rows), dim3(1024), 0, st, b, list, count, w, tiles);
     hipLaunchKernelGGL((k_alive_write<false, true>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b), rows4, n_rows);
   }
   R3D_LAUNCHED("compaction kernel");

@@ -67,6 +67,7 @@ struct BatchWs {
   uint32_t *inv;                // [B*cap] point of the slabs -> virtual point number
   unsigned long long *alive_o;  // [B*chunks] alive words of a scene in virtual order, put back into slab order (k_unvirtual)
   int32_t *tile_o;              // [B*tiles] ... and the living points per tile in slab order
+  int32_t *tile_pre;            // [B*tiles] living points in front of every tile (k_tile_prefix: clouds of many tiles)
   unsigned char *glist;         // [B*chunks*kEntry] k_insert_big's chunk lists, one area per scene (a pair of k_insert_chain whose
                                 // list exceeds its LDS takes room from the pool)
   unsigned char *tile_pool;     // [pool_bytes] the launch's bump pool: depth tiles / candidate lists / chunk lists / scratch images
@@ -136,6 +137,7 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.inv = c.take<uint32_t>((size_t)b.B * b.cap);
   w.alive_o = c.take<unsigned long long>((size_t)b.B * chunks_of(b));
   w.tile_o = c.take<int32_t>((size_t)b.B * tiles);
+  w.tile_pre = c.take<int32_t>((size_t)b.B * tiles);
   w.glist = c.take<unsigned char>((size_t)b.B * chunks_of(b) * kEntry);
   // The launch's pool: depth tiles, candidate lists, chunk lists and scratch images of the pairs whose window exceeds a
   // workgroup's LDS (on the reference's grid a few per cent of the pairs, 10-60 KB each; on a range image several times

@@ -3,6 +3,7 @@
 // (std::thread), no HIP: the copies into HBM are the caller's (hipMemcpyAsync on its copy streams).
 #include <cerrno>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -10,7 +11,9 @@
 
 #include <emmintrin.h>
 #include <fcntl.h>
+#include <limits.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 
 #include "r3d_host.hpp"
@@ -290,6 +293,183 @@ int r3d_host_write_frames(const char *const *velodyne_paths, const char *const *
       }
       if (!ok) {
         err[t] = std::string("host_write_frames: could not write ") + velodyne_paths[s] + " (" + std::strerror(errno) + ")";
+        return;
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+  work(0);
+  for (auto &th : pool) th.join();
+  for (int t = 0; t < threads; ++t)
+    if (!err[t].empty()) return r3d::fail(R3D_E_ARG, err[t].c_str());
+  return R3D_OK;
+}
+
+// The files of B frames straight from what the host already holds -- the frames in the staging slab the upload was made
+// from, and the delta the device exported (r3d_batch_export_delta) -- without materialising the merged clouds first:
+// velodyne/{f}.bin = the surviving frame points, run by run (writev over the staging slab), then the surviving inserted
+// points; labels/{f}.label the same over the label slab; check/{f}.bin = every inserted point (SS tools/datasets.py:73-75,
+// :80-89; OD :86-93).  The same bytes r3d_host_merge_frames + r3d_host_write_frames write, at half the host's memory traffic
+// (the merge read and wrote every frame once more before the writers read it again: the file legs are bound by exactly that).
+}  // extern "C"
+
+namespace {
+
+// runs of set bits of a frame's alive words over [lo, hi), as (first point, count); `emit` returns false to stop
+template <class Emit>
+bool alive_runs(const uint64_t *aw, int64_t lo, int64_t hi, Emit &&emit) {
+  int64_t run0 = -1;
+  for (int64_t c = lo >> 6; (c << 6) < hi; ++c) {
+    uint64_t m = aw[c];
+    const int64_t base = c << 6;
+    if (base < lo) m &= ~0ull << (lo - base);
+    if (base + 64 > hi) m &= (hi - base) >= 64 ? ~0ull : ((1ull << (hi - base)) - 1ull);
+    if (m == ~0ull) {                                                  // the usual word: the run goes on
+      if (run0 < 0) run0 = base;
+      continue;
+    }
+    int64_t at = base;                                                 // next point of the word not looked at yet
+    while (true) {
+      if (run0 >= 0) {                                                 // inside a run: where does it end?
+        const uint64_t rest = ~m & (at - base >= 64 ? 0ull : (~0ull << (at - base)));
+        if (!rest) break;                                              // ... not in this word
+        const int64_t end = base + __builtin_ctzll(rest);
+        if (!emit(run0, end - run0)) return false;
+        run0 = -1;
+        at = end;
+      } else {                                                         // outside: where does the next one start?
+        const uint64_t rest = m & (at - base >= 64 ? 0ull : (~0ull << (at - base)));
+        if (!rest) break;
+        run0 = base + __builtin_ctzll(rest);
+        at = run0;
+      }
+    }
+  }
+  if (run0 >= 0) {
+    const int64_t end = hi;
+    if (end > run0 && !emit(run0, end - run0)) return false;
+  }
+  return true;
+}
+
+struct IovFile {
+  int fd = -1;
+  std::vector<iovec> iov;
+  bool ok = true;
+  bool flush() {
+    size_t done = 0;
+    while (ok && done < iov.size()) {
+      const int n = (int)std::min<size_t>(iov.size() - done, IOV_MAX);
+      ssize_t want = 0;
+      for (int i = 0; i < n; ++i) want += (ssize_t)iov[done + i].iov_len;
+      ssize_t put = ::writev(fd, iov.data() + done, n);
+      if (put < 0 && errno == EINTR) continue;
+      if (put == want) {
+        done += (size_t)n;
+        continue;
+      }
+      if (put < 0) {
+        ok = false;
+        break;
+      }
+      // a short write: skip what went out, go on from there
+      size_t i = done;
+      while (put > 0 && (size_t)put >= iov[i].iov_len) put -= (ssize_t)iov[i++].iov_len;
+      if (put > 0) {
+        iov[i].iov_base = static_cast<char *>(iov[i].iov_base) + put;
+        iov[i].iov_len -= (size_t)put;
+      }
+      done = i;
+    }
+    iov.clear();
+    return ok;
+  }
+  void add(const void *p, size_t bytes) {
+    if (!bytes) return;
+    if (!iov.empty() && static_cast<char *>(iov.back().iov_base) + iov.back().iov_len == p) iov.back().iov_len += bytes;
+    else iov.push_back(iovec{const_cast<void *>(p), bytes});
+    if (iov.size() >= 4096) flush();
+  }
+};
+
+bool open_tmp(const char *path, IovFile &f) {
+  std::string tmp = std::string(path) + ".tmp";
+  f.fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  return f.fd >= 0;
+}
+bool close_commit(const char *path, IovFile &f) {
+  bool ok = f.flush();
+  ok = (::close(f.fd) == 0) && ok;
+  f.fd = -1;
+  if (ok) ok = ::rename((std::string(path) + ".tmp").c_str(), path) == 0;
+  return ok;
+}
+
+}  // namespace
+
+extern "C" {
+
+int r3d_host_write_delta_frames(const char *const *velodyne_paths, const char *const *label_paths, const char *const *check_paths,
+                                int32_t B, const float *in_xyzi, const uint32_t *in_label, int64_t cap, const uint64_t *alive,
+                                int64_t chunks, const float *tail_xyzi, const uint32_t *tail_label, int64_t tail_stride,
+                                const int32_t *counts, int32_t check_cols, int32_t *n_out, int32_t threads) {
+  if (!velodyne_paths || !in_xyzi || !alive || !tail_xyzi || !tail_label || !counts || B <= 0 || cap <= 0)
+    return r3d::fail(R3D_E_ARG, "host_write_delta_frames: null pointer or shape");
+  if (label_paths && !in_label) return r3d::fail(R3D_E_ARG, "host_write_delta_frames: labels missing");
+  if (check_paths && check_cols != 4 && check_cols != 5) return r3d::fail(R3D_E_ARG, "host_write_delta_frames: check_cols");
+  for (int s = 0; s < B; ++s) {
+    const int64_t n_head = counts[s], n_total = counts[B + s];
+    if (n_head < 0 || n_total < n_head || n_total > cap || n_total - n_head > tail_stride || (n_total + 63) / 64 > chunks)
+      return r3d::fail(R3D_E_ARG, "host_write_delta_frames: counts exceed the buffers");
+  }
+  if (threads < 1) threads = 1;
+  if (threads > B) threads = B;
+  std::vector<std::string> err(threads);
+  auto work = [&](int t) {
+    std::vector<float> ck5;
+    for (int s = t; s < B; s += threads) {
+      const int64_t n_head = counts[s], n_total = counts[B + s], n_tail = n_total - n_head;
+      const uint64_t *aw = alive + (int64_t)s * chunks;
+      const float *hx = in_xyzi + (int64_t)s * cap * 4, *tx = tail_xyzi + (int64_t)s * tail_stride * 4;
+      const uint32_t *hl = in_label ? in_label + (int64_t)s * cap : nullptr, *tl = tail_label + (int64_t)s * tail_stride;
+      int64_t survivors = 0;
+      alive_runs(aw, 0, n_total, [&](int64_t, int64_t n) { survivors += n; return true; });
+      if (n_out) n_out[s] = (int32_t)survivors;
+      if (!velodyne_paths[s]) continue;                                            // (a padded slot of the last batch)
+      bool ok = true;
+      {
+        IovFile f;
+        ok = open_tmp(velodyne_paths[s], f);
+        if (ok) {
+          alive_runs(aw, 0, n_head, [&](int64_t i, int64_t n) { f.add(hx + i * 4, (size_t)n * 16); return f.ok; });
+          alive_runs(aw, n_head, n_total, [&](int64_t i, int64_t n) { f.add(tx + (i - n_head) * 4, (size_t)n * 16); return f.ok; });
+          ok = close_commit(velodyne_paths[s], f);
+        }
+      }
+      if (ok && label_paths && label_paths[s]) {
+        IovFile f;
+        ok = open_tmp(label_paths[s], f);
+        if (ok) {
+          alive_runs(aw, 0, n_head, [&](int64_t i, int64_t n) { f.add(hl + i, (size_t)n * 4); return f.ok; });
+          alive_runs(aw, n_head, n_total, [&](int64_t i, int64_t n) { f.add(tl + (i - n_head), (size_t)n * 4); return f.ok; });
+          ok = close_commit(label_paths[s], f);
+        }
+      }
+      if (ok && check_paths && check_paths[s]) {
+        const void *data = tx;
+        if (check_cols == 5) {
+          ck5.resize((size_t)n_tail * 5);
+          for (int64_t j = 0; j < n_tail; ++j) {
+            std::memcpy(ck5.data() + j * 5, tx + j * 4, 4 * sizeof(float));
+            ck5[(size_t)j * 5 + 4] = (float)tl[j];
+          }
+          data = ck5.data();
+        }
+        ok = commit_file(check_paths[s], data, (size_t)n_tail * check_cols * 4);
+      }
+      if (!ok) {
+        err[t] = std::string("host_write_delta_frames: could not write ") + velodyne_paths[s] + " (" + std::strerror(errno) + ")";
         return;
       }
     }

@@ -308,6 +308,7 @@ class AugmentPipeline:
                                                      check_cols=self.check_cols,
                                                      collapse_keep=-1 if self.road_label is None else self.road_label,
                                                      pack_threads=pack_threads, delta=delta)
+                aug.merge_on_collect = False                       # (files only: written from the pinned input and the delta)
                 stats["t_setup"] = stats.get("t_setup", 0.0) + time.perf_counter() - t_setup   # lanes: device + pinned memory
                 aug.run(segment(), consume)
                 for k, v in aug.times.items():

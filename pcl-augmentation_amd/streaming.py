@@ -102,6 +102,10 @@ class StreamedAugmenter:
         self.lanes = [_Lane(B, n_max + grow, max(grow, 1), self.K, max(int(sample_rows), 1), rows, cols, device, self.check_cols,
                             self.delta) for _ in range(lanes)]
         self.device = device
+        # delta mode: False = `collect` leaves the merged clouds unmade (results come back as None) for a caller that only
+        # writes files -- `write_files` then writes them straight from the lane's pinned input and the delta, run by run of
+        # surviving points (r3d_host_write_delta_frames: no merged copy in between); AugmentPipeline.run_streamed does that
+        self.merge_on_collect = True
         self.bytes_h2d = self.bytes_d2h = 0
         # seconds spent per stage, summed over the batches (submitting thread: read / pack, enqueue; drain thread: wait for
         # the device, host merge, the caller's consume)
@@ -156,6 +160,14 @@ class StreamedAugmenter:
         ln = self.lanes[lane_no]
         B = self.B
         enc = lambda paths: None if paths is None else (C.c_char_p * B)(*[None if p is None else str(p).encode() for p in paths])
+        if self.delta and not getattr(ln, "merged", True):
+            bt = ln.bt
+            _lib.check(self.lib.r3d_host_write_delta_frames(
+                enc(velodyne_files), enc(label_files), enc(check_files) if ln.check_cols else None, B, ln.in_xyzi.data_ptr(),
+                ln.in_label.data_ptr(), bt.cap, ln.h_alive.data_ptr(), ln.chunks, ln.h_tail_xyzi.data_ptr(), ln.h_tail_label.data_ptr(),
+                bt.log_cap, ln.h_dcounts.data_ptr(), ln.check_cols or 4, ln.h_n_out.data_ptr(), self.pack_threads),
+                "r3d_host_write_delta_frames")
+            return
         n_out = ln.h_n_out if self.delta else ln.out_counts[0]
         cc = max(ln.check_cols, 4)
         _lib.check(self.lib.r3d_host_write_frames(
@@ -282,6 +294,14 @@ class StreamedAugmenter:
             _lib.raise_status(int(counts[2][s]), f"scene {s} of the batch (status {int(counts[2][s])}, {int(counts[3][s])} rebases, "
                                                  f"{int(counts[1][s])} inserted points; counters {why})")
         cc = max(ln.check_cols, 4)
+        ln.merged = True
+        if self.delta and not self.merge_on_collect and not redo:
+            # (the files are written from the pinned input and the delta: write_files)
+            ln.merged = False
+            acc = ln.out_acc.numpy()
+            accepted = [[0 if acc[k, s] else -1 for k in range(self.K)] for s in range(self.B)]
+            ln.busy = False
+            return ln.tag, [None] * self.B, accepted
         if self.delta:
             bt = ln.bt
             _lib.check(self.lib.r3d_host_merge_frames(

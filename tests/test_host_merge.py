@@ -104,3 +104,67 @@ def test_native_file_readers_and_writers(pkg, tmp_path):
     assert (tmp_path / "c0.bin").read_bytes() == ck[0, :16].tobytes() and (tmp_path / "c2.bin").read_bytes() == ck[2, :3].tobytes()
     assert (tmp_path / "o3.bin").read_bytes() == b"" and not (tmp_path / "o2.label").exists() and not (tmp_path / "o1.bin").exists()
     assert not list(tmp_path.glob("*.tmp"))
+
+
+@pytest.mark.parametrize("check_cols", [5, 4])
+def test_delta_writer_writes_what_merge_and_write_do(pkg, tmp_path, check_cols):
+    """r3d_host_write_delta_frames (files straight from the staging slab + the delta, run by run of surviving points)
+    against r3d_host_merge_frames followed by r3d_host_write_frames: the same bytes in every file, for alive patterns that
+    put runs across word boundaries, whole words, single points, empty frames and frames that lose everything."""
+    lib = pkg._lib.load()
+    rng = np.random.default_rng(11)
+    B, cap, tail_stride = 9, 1500, 200
+    chunks = (cap + 63) // 64
+    in_x = rng.random((B, cap, 4), dtype=np.float32)
+    in_l = rng.integers(0, 60000, (B, cap)).astype(np.uint32)
+    tail_x = rng.random((B, tail_stride, 4), dtype=np.float32)
+    tail_l = rng.integers(0, 80000, (B, tail_stride)).astype(np.uint32)
+    n_head = np.array([1300, 64, 0, 129, 640, 1000, 1, 777, 1200], dtype=np.int32)
+    n_tail = np.array([200, 0, 50, 7, 64, 0, 0, 199, 13], dtype=np.int32)
+    counts = np.stack([n_head, n_head + n_tail]).astype(np.int32)
+    bits = rng.random((B, chunks * 64)) < 0.97
+    bits[3, :] = True                                            # nobody dies: one run
+    bits[4, :] = rng.random(chunks * 64) < 0.5                   # runs of a point or two
+    bits[5, :] = False                                           # nobody lives: an empty file
+    bits[5, 63:65] = True                                        # ... but a run across a word boundary
+    bits[7, :] = True
+    bits[7, 64:128] = False                                      # a whole word dead
+    bits[8, 1199] = False                                        # the frame's last point dead, the first inserted alive
+    for s in range(B):
+        bits[s, counts[1, s]:] = rng.random(chunks * 64 - counts[1, s]) < 0.5     # garbage beyond n_total must not matter
+    alive = np.packbits(bits.reshape(B, chunks, 64), axis=2, bitorder="little").view(np.uint64).reshape(B, chunks)
+    clean = bits.copy()
+    for s in range(B):
+        clean[s, counts[1, s]:] = False
+    alive_clean = np.packbits(clean.reshape(B, chunks, 64), axis=2, bitorder="little").view(np.uint64).reshape(B, chunks)
+    P = lambda a: a.ctypes.data
+    enc = lambda sub, ext, skip=(): (C.c_char_p * B)(*[None if s in skip else str(tmp_path / sub / f"{s}.{ext}").encode() for s in range(B)])
+    for sub in ("a", "b"):
+        (tmp_path / sub).mkdir()
+    # the two-step way (it wants clean bits beyond n_total: r3d_batch_export_delta delivers them that way)
+    out_x, out_l, n_out = np.zeros((B, cap, 4), np.float32), np.zeros((B, cap), np.uint32), np.zeros(B, np.int32)
+    check = np.zeros((B, tail_stride, check_cols), np.float32)
+    assert lib.r3d_host_merge_frames(P(in_x), P(in_l), cap, P(alive_clean), chunks, P(tail_x), P(tail_l), tail_stride, P(counts), B,
+                                     P(out_x), P(out_l), cap, P(n_out), P(check), tail_stride, check_cols, 3) == 0
+    n_ck = n_tail.astype(np.int32)
+    assert lib.r3d_host_write_frames(enc("a", "bin", (2,)), enc("a", "label", (2, 6)), enc("a", "check", (2,)), B, P(out_x), P(out_l), cap,
+                                     P(n_out), P(check), tail_stride, check_cols, P(n_ck), 3) == 0
+    n_out2 = np.zeros(B, np.int32)
+    rc = lib.r3d_host_write_delta_frames(enc("b", "bin", (2,)), enc("b", "label", (2, 6)), enc("b", "check", (2,)), B, P(in_x), P(in_l), cap,
+                                         P(alive), chunks, P(tail_x), P(tail_l), tail_stride, P(counts), check_cols, P(n_out2), 4)
+    assert rc == 0, lib.r3d_last_error()
+    assert np.array_equal(n_out, n_out2)
+    names = sorted(p.name for p in (tmp_path / "a").iterdir())
+    assert names == sorted(p.name for p in (tmp_path / "b").iterdir()) and len(names) == 3 * 8 - 1 and not any(n.endswith(".tmp") for n in names)
+    for n in names:
+        assert (tmp_path / "a" / n).read_bytes() == (tmp_path / "b" / n).read_bytes(), n
+    assert (tmp_path / "b" / "5.bin").stat().st_size == 2 * 16 and (tmp_path / "b" / "3.bin").stat().st_size == 136 * 16
+    # refused: counts beyond the buffers; a path that cannot be written is named
+    bad = counts.copy()
+    bad[1, 0] = cap + 1
+    assert lib.r3d_host_write_delta_frames(enc("b", "bin"), None, None, B, P(in_x), P(in_l), cap, P(alive), chunks, P(tail_x), P(tail_l),
+                                           tail_stride, P(bad), check_cols, None, 2) < 0
+    nowhere = (C.c_char_p * B)(*[str(tmp_path / "no" / "dir" / f"{s}.bin").encode() for s in range(B)])
+    assert lib.r3d_host_write_delta_frames(nowhere, None, None, B, P(in_x), P(in_l), cap, P(alive), chunks, P(tail_x), P(tail_l),
+                                           tail_stride, P(counts), check_cols, None, 2) < 0
+    assert b"no/dir" in lib.r3d_last_error()
