@@ -36,7 +36,11 @@
 extern "C" {
 #endif
 
-#define R3D_VERSION 0x00020003   /* 2.3: min_points < 0 (the state a rejected candidate leaves), r3d_batch_adopt_rejected; 2.2: r3d_batch_t.pix / far_pix
+#define R3D_VERSION 0x00020004   /* 2.4: R3D_MAX_SAMPLE 65 535; R3D_B_FILE_ORDER, r3d_batch_export_pix, r3d_batch_point_order (clouds in no
+                                  * file order are numbered anew internally); r3d_host_write_delta_frames; r3d_batch_debug_counters
+                                  * holds 64 values; R3D_S_CHAIN_TIMEOUT now means "a scene's chain was left unfinished" (no slot
+                                  * waits for another any more); the workspace of a batch grew (r3d_batch_workspace_bytes);
+                                  * 2.3: min_points < 0 (the state a rejected candidate leaves), r3d_batch_adopt_rejected; 2.2: r3d_batch_t.pix / far_pix
                                   * hold (row << 16) | column; r3d_batch_debug_trace is gone; r3d_build_info */
 
 #define R3D_NUMROW 112        /* insertion.py:22 */
@@ -56,7 +60,8 @@ extern "C" {
 #define R3D_S_SAMPLE_TOO_LARGE 8  /* batched path: sample exceeds R3D_MAX_SAMPLE points */
 #define R3D_S_CAPACITY 16         /* batched path: merged cloud / log would exceed its capacity */
 #define R3D_S_FAR_OVERFLOW 32     /* batched path: more than R3D_FAR_CAP pixels beyond 500 m */
-#define R3D_S_CHAIN_TIMEOUT 128   /* r3d_batch_insert_many: a slot gave up waiting for the scene's previous slot */
+#define R3D_S_CHAIN_TIMEOUT 128   /* r3d_batch_insert_many: the chain of the scene's slots was left unfinished (a slot never
+                                     published; the name is round 2's, when slots waited for each other against a clock) */
 #define R3D_S_WINDOW_TOO_LARGE 64 /* batched path: the bit images of the insert's window of the range image plus the
                                      sample's per-point arrays exceed one CU's LDS (a sample that covers more
                                      than ~200 000 pixels) */

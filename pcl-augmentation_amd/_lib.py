@@ -28,7 +28,7 @@ STATUS_TEXT = {
     S_CAPACITY: "merged cloud or insert log exceeds its capacity",
     S_FAR_OVERFLOW: "more than R3D_FAR_CAP pixels deeper than 500 m (Level 2 only; the mirrors redo such a frame through Level 1)",
     S_WINDOW_TOO_LARGE: "the insert's window of the range image and the sample's arrays do not fit one CU's LDS",
-    S_CHAIN_TIMEOUT: "insert_many: a slot gave up waiting for the scene's previous slot",
+    S_CHAIN_TIMEOUT: "insert_many: the chain of a scene's slots was left unfinished",
 }
 K_BOUNDS, K_PREPARE, K_PROJECT, K_ALIVE_WRITE = 1, 2, 3, 5
 NUMROW, NUMCOLUMN = 112, 1440

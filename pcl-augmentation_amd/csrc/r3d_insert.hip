@@ -2350,7 +2350,7 @@ __device__ __forceinline__ void run_pairs_from(unsigned char *smem, int pair_id)
     if (cell && threadIdx.x == 0) {
       cell[28] = wall_clock64();                               // this workgroup takes the pair
       if (mode == kFresh) cell[21] = cell[28];                 // ... off the queue (a parked pair is taken a second time)
-      cell[20] = (long long)blockIdx.x | ((long long)mode << 32);
+      cell[16] = (long long)blockIdx.x | ((long long)mode << 32);   // (17 .. 20: the gather loop's accumulators)
     }
 #endif
     // (only the shape for large range images carries the POOL flavour: half the code for the others)

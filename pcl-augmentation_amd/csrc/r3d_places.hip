@@ -1098,12 +1098,30 @@ extern "C" int r3d_find_possible_places(const r3d_place_query_t *queries, int32_
   R3D_HIP(hipMemsetAsync(w.hit, 0, (size_t)n_queries * 12 * sizeof(uint32_t), st));
   hipLaunchKernelGGL(k_place_centres, dim3((n_queries + 63) / 64), dim3(64), 0, st, queries, n_queries, w, status);
   // the orientation chain beside the point passes, on the helper stream that belongs to `st` (R3D_PLACE_SIDE_STREAM=0: in line)
+  // (calls that share one stream must come from one host thread at a time: the two events of the stream's helper are
+  // recorded again by every call)
   SideStream *side = side_stream_of(st);
+  // whatever way this function is left once the side launch is out, the caller's stream waits for it: the workspace and the
+  // queries must not be freed or reused while k_place_orient still writes w.quat
+  struct JoinSide {
+    SideStream *side;
+    hipStream_t st;
+    bool armed = false, joined = false;
+    void join() {
+      if (armed && !joined) (void)hipStreamWaitEvent(st, side->done, 0);
+      joined = true;
+    }
+    ~JoinSide() { join(); }
+  } join_side{side, st};
   if (side) {
     R3D_HIP(hipEventRecord(side->start, st));
     R3D_HIP(hipStreamWaitEvent(side->stream, side->start, 0));
     hipLaunchKernelGGL(k_place_orient, dim3((n_queries + 63) / 64), dim3(64), 0, side->stream, queries, n_queries, w);
-    R3D_HIP(hipEventRecord(side->done, side->stream));
+    if (hipEventRecord(side->done, side->stream) != hipSuccess) {
+      (void)hipStreamSynchronize(side->stream);                  // (no event to wait for: wait here)
+      return fail(R3D_E_HIP, "places: hipEventRecord on the helper stream");
+    }
+    join_side.armed = true;
   } else {
     hipLaunchKernelGGL(k_place_orient, dim3((n_queries + 63) / 64), dim3(64), 0, st, queries, n_queries, w);
   }
@@ -1131,7 +1149,10 @@ extern "C" int r3d_find_possible_places(const r3d_place_query_t *queries, int32_
   hipLaunchKernelGGL(k_place_kstar, dim3((unsigned)((qr + 255) / 256)), dim3(256), 0, st, n_queries, w, rad);
   if (pb_orig > 0)
     hipLaunchKernelGGL(k_place_surface_gather, dim3(n_queries, pb_orig), dim3(kPB), 0, st, queries, w, rad);
-  if (side) R3D_HIP(hipStreamWaitEvent(st, side->done, 0));      // from here on the steps' orientations are read
+  if (side) {                                                      // from here on the steps' orientations are read
+    join_side.joined = true;
+    R3D_HIP(hipStreamWaitEvent(st, side->done, 0));
+  }
   hipLaunchKernelGGL(k_place_road_level, dim3((unsigned)((qr + kPB / 64 - 1) / (kPB / 64))), dim3(kPB), 0, st, queries,
                      n_queries, w, status);
   if (pb_scene > 0)

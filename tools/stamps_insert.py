@@ -33,9 +33,11 @@ batch = pkg.SceneBatch(B, max(len(x) for x, _ in scenes) + grow, grow, **shape)
 batch.load(scenes)
 need = torch.full((B,), 20, dtype=torch.int32, device=batch.device)
 packed = [batch.pack_samples([inserts[s][k] for s in range(B)]) for k in range(K)]
+# ("hand-over": round 5 -- nobody waits; what is left between the end of the evaluation and the commit is the look at the
+# progress word, the conflict test and, for a pair that parks, the record it leaves)
 names = ["project sample", "window + re-key", "occupancy + rank", "counting sort + depths", "sample closing + count",
          "scene set-up", "chunk list", "candidates + gather (first band)", "scene bits + closing", "evaluate (+ further bands)",
-         "visible list + kill masks", "wait for predecessor", "commit", "publish"]
+         "visible list + kill masks", "hand-over", "commit", "publish"]
 edges = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10), (10, 11), (11, 13), (13, 14), (14, 15)]
 for rep in range(3):
     batch.begin()
@@ -78,7 +80,8 @@ print("gather loop, thread 0, us per pair (mean / max): " + "; ".join(
     f"{n} {g[:, :, i].mean():.2f} / {g[:, :, i].max():.2f}" for i, n in enumerate(["list + pixel ids", "place in tile", "coordinates", "sqrt + min"])))
 c = raw.astype(np.float64)
 if (raw[:, :, 22] > 0).any():
-    m = raw[:, :, 22] > 0
+    # (pairs committed by the workgroup that evaluated them: a parked pair's commit stamps are its taker's, its stamp 14 is not set)
+    m = (raw[:, :, 22] > 0) & (raw[:, :, 14] > raw[:, :, 25]) & (raw[:, :, 22] >= st[:, :, 13].astype(np.int64))
     print("commit (accepted pairs), us: header %.2f; append %.2f; kills %.2f; far list + barrier %.2f; tail %.2f" % (
         ((c[:, :, 22] - st[:, :, 13]) / 100)[m].mean(), ((c[:, :, 23] - c[:, :, 22]) / 100)[m].mean(),
         ((c[:, :, 24] - c[:, :, 23]) / 100)[m].mean(), ((c[:, :, 25] - c[:, :, 24]) / 100)[m].mean(),
@@ -94,10 +97,11 @@ if (raw[:, :, 26] > 0).any():
         sel = once & (npx >= lo) & (npx < hi) & (raw[:, :, 26] > 0)
         if not sel.any():
             continue
-        f = lambda a, z: ((st[:, :, z] - st[:, :, a]) / 100.0)[sel].mean()
+        f = lambda a, z, sl=None: ((st[:, :, z] - st[:, :, a]) / 100.0)[sel if sl is None else sl].mean()
+        acc = sel & (raw[:, :, 31] > 0)                            # (stamp 31, "visible list made", exists for accepted pairs only)
+        vis = f"visible list {f(10, 31, acc):.1f}, kill masks {f(31, 11, acc):.1f} ({acc.sum()} accepted)" if acc.any() else "no accepted pair"
         print(f"{lab}: {sel.sum()} pairs, total {tot[sel].mean():.1f} us ({100 * tot[sel].sum() / tot[once].sum():.0f} % of all pair time) | "
-              f"list candidates + clear {f(7, 26):.1f}, gather {f(26, 27):.1f}, roots + bits {f(27, 8):.1f}, evaluate {f(9, 10):.1f}, "
-              f"visible list {f(10, 31):.1f}, kill masks {f(31, 11):.1f}")
+              f"list candidates + clear {f(7, 26):.1f}, gather {f(26, 27):.1f}, roots + bits {f(27, 8):.1f}, evaluate {f(9, 10):.1f}, {vis}")
 # the workgroup's own span (kernel entry -> exit) against the phases' span, and how long a CU stays empty between two workgroups
 if raw.shape[2] > 30 and raw[:, :, 28].any():
     ent, ext, retry = raw[:, :, 28].astype(np.float64), raw[:, :, 30].astype(np.float64), raw[:, :, 29]

@@ -42,7 +42,7 @@ print(batch.debug_counters())
 t0 = raw[:, :, 21][raw[:, :, 21] > 0].min()
 us = lambda a: (a - t0) / 100.0
 take, last_take, done, pub = us(raw[:, :, 21]), us(raw[:, :, 28]), us(raw[:, :, 30]), us(raw[:, :, 15])
-who, mode = raw[:, :, 20] & 0xFFFFFFFF, raw[:, :, 20] >> 32
+who, mode = raw[:, :, 16] & 0xFFFFFFFF, raw[:, :, 16] >> 32
 ev_end = us(raw[:, :, 11])
 print(f"{cfg}: {B} scenes x {K} slots; launch span {pub.max():.1f} us")
 print("slot kind        take mean/max      eval-end mean    publish mean/max   taken over   mean busy")
