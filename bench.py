@@ -498,8 +498,10 @@ def main():
     else:
         serial_elapsed = elapsed
     batch.debug_counters(reset=True)
+    batch.count_pairs(True)                               # (the per-pair counters cost atomics on the chain's critical path: this step only)
     enqueue_serial()
     insert_paths = batch.debug_counters(reset=True)       # which way every pair of one step went
+    batch.count_pairs(False)
     n_out = batch.n_out.cpu().numpy()
     n_accepted = int(batch.last_acc.sum().item())
     n_appended = int((batch.last_vis * batch.last_acc).sum().item()) if hasattr(batch, "last_vis") else None

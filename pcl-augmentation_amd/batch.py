@@ -432,6 +432,14 @@ class SceneBatch:
         _lib.check(self.lib.r3d_batch_finish(C.byref(self.desc), cp, int(check_cols or 5), _lib.stream_ptr()),
                    "r3d_batch_finish")
 
+    def count_pairs(self, on=True):
+        """Descriptor bit 4096: the insert kernels count per pair (pairs, chunks listed, parked, committed from a record) --
+        atomics of every pair on a few addresses, hence off unless somebody reads them (``debug_counters``)."""
+        if on:
+            self.desc.reserved |= 4096
+        else:
+            self.desc.reserved &= ~4096
+
     @_lib.on_own_device
     def debug_counters(self, reset=True):
         """The insert kernels' diagnostic counters (r3d_batch_debug_counters) as a dict."""

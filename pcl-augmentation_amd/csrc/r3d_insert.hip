@@ -81,6 +81,9 @@ constexpr int kDbgDefer = 8;         // every pair is left to k_insert_big
 constexpr int kDbgDropPublish = 16;  // slot 0 of scene 0 does not publish: its successors time out
 constexpr int kDbgPoolTile = 32;     // every pair's depth tile and candidate list in the global pool
 constexpr int kDbgNoHits = 128;      // the kill masks from the pixel ids in global memory for every chunk (no hits kept in LDS)
+constexpr int kDbgCount = 4096;      // count per pair (D_PAIRS .. D_TAKEOVER_COMMIT): two to four atomics of every pair on the same few
+                                     // addresses, on the chain's critical path -- only when somebody wants to read them (bench.py's
+                                     // insert_paths step, the tests)
 constexpr int kDbgVerify = 64;       // a speculative evaluation that is about to be committed is done again, now after its
                                      // predecessors, and compared (visible count, accept, visible pixels, kill masks):
                                      // counters D_VERIFY_RUNS / D_VERIFY_MISMATCH (tests/test_gpu_batch.py soaks on them)
@@ -2035,7 +2038,7 @@ __device__ __forceinline__ int run_pair(const r3d_batch_t &b, const ChainSlots &
       if (old == kParkPredDone) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      } else {
+      } else if (b.reserved & kDbgCount) {
         atomicAdd(&w.dbg[kind == kParkEvaluated ? D_PARKED : D_PARKED_RAW], 1);
       }
       H[H_GO] = old;
@@ -2126,7 +2129,7 @@ __device__ __forceinline__ int run_pair(const r3d_batch_t &b, const ChainSlots &
         rebase = I.commit(src, flags, n_after, count_after(k), n_head0);
         outputs(I.nvis, I.accept ? 1 : 0);
         committed = true;
-        if (tid == 0) atomicAdd(&w.dbg[D_TAKEOVER_COMMIT], 1);
+        if (tid == 0 && (b.reserved & kDbgCount)) atomicAdd(&w.dbg[D_TAKEOVER_COMMIT], 1);
       } else if (cf) {
         attempts = 1;                                          // (the first evaluation was somebody else's)
       }
@@ -2276,7 +2279,7 @@ __device__ __forceinline__ int run_pair(const r3d_batch_t &b, const ChainSlots &
     const int n_now = count_after(k);
     n_after = !on ? n_now : 0;
     if (on) {
-      if (tid == 0) {
+      if (tid == 0 && (b.reserved & kDbgCount)) {
         atomicAdd(&w.dbg[D_PAIRS], 1);
         atomicAdd(&w.dbg[D_CHUNKS_LISTED], I.nlist);
       }

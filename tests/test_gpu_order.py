@@ -37,6 +37,7 @@ def test_shuffled_scans_at_full_size(pkg, synth):
     grow = sum(max(len(c[2][k][0]) for c in cases) for k in range(len(kinds)))
     batch = pkg.SceneBatch(B, max(len(c[0]) for c in cases) + grow, grow)
     batch.load([(c[0], c[1]) for c in cases])
+    batch.count_pairs(True)
     batch.debug_counters(reset=True)
     batch.begin()
     assert batch.debug_counters(reset=True)["scenes_in_sorted_order"] == 3

@@ -11,7 +11,7 @@ for setting in "$@"; do
 import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 p = d["config"]["insert_paths_one_step"]
-print(f"{sys.argv[2]:40s} step {d['ms_per_step']:.3f} ms  ({min(d['repeats']['ms_per_step']):.3f}-{max(d['repeats']['ms_per_step']):.3f}); alone {d['config']['ms_per_step_one_step_in_flight']:.3f}; "
+print(f"{sys.argv[2][-40:]:40s} step {d['ms_per_step']:.3f} ms  ({min(d['repeats']['ms_per_step']):.3f}-{max(d['repeats']['ms_per_step']):.3f}); alone {d['config']['ms_per_step_one_step_in_flight']:.3f}; "
       f"{d['roofline']['api_calls_ms']}; twice {p['evaluated_twice']}, parked {p.get('parked_with_record')}/{p.get('parked_unevaluated')}, from record {p.get('committed_from_record')}, pooled {p['tiles_pooled']}")
 PY
 done

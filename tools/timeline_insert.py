@@ -30,6 +30,7 @@ inserts = [synth.make_inserts(s, KINDS) for s in range(B)]
 grow = sum(max(len(inserts[s][k]) for s in range(B)) for k in range(K))
 batch = pkg.SceneBatch(B, max(len(x) for x, _ in scenes) + grow, grow, **shape)
 batch.load(scenes)
+batch.count_pairs(True)
 need = torch.full((B,), 20, dtype=torch.int32, device=batch.device)
 packed = [batch.pack_samples([inserts[s][k] for s in range(B)]) for k in range(K)]
 for rep in range(3):
