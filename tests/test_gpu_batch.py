@@ -672,13 +672,13 @@ def test_large_sample_and_overlapping_chain(P, synth):
 
 
 def test_chain_timeout_is_reported(P, synth):
-    """A slot whose predecessor never publishes gives up after the wall-clock bound (diagnostic bit 16
-    makes slot 0 of scene 0 skip its publish): R3D_S_CHAIN_TIMEOUT on that scene, its later slots
-    are not run, the other scene is untouched by it, nothing hangs."""
+    """A chain that is never finished (diagnostic bit 16 makes slot 0 of scene 0 skip its publish; nobody waits for it --
+    its successors leave their evaluations parked and the launch ends): R3D_S_CHAIN_TIMEOUT on that scene (the name is from
+    the rounds in which slots waited against a clock), its later slots report nothing, the other scene is untouched by it."""
     import os
     import torch
     if os.environ.get("R3D_NO_CHAIN"):
-        pytest.skip("R3D_NO_CHAIN: one launch per slot, nothing waits inside a kernel")
+        pytest.skip("R3D_NO_CHAIN: one launch per slot, no chain inside a kernel")
     scenes = [synth.make_scene(50 + s, 32, 500) for s in range(2)]
     ins = [[synth.make_insert(500 + 10 * s + k, "pedestrian", rng_range=(5.0, 15.0)) for k in range(3)] for s in range(2)]
     n = max(len(x) for x, _ in scenes)
@@ -691,7 +691,7 @@ def test_chain_timeout_is_reported(P, synth):
     st = batch.status.cpu().numpy()
     assert st[0] & P._lib.S_CHAIN_TIMEOUT and not st[1]
     assert acc.cpu().numpy()[:, 1].tolist() == [1, 1, 1] and acc.cpu().numpy()[1:, 0].tolist() == [0, 0]
-    with pytest.raises(ValueError, match="waiting"):
+    with pytest.raises(ValueError, match="unfinished"):
         batch.raise_on_status()
 
 
