@@ -60,7 +60,12 @@ def main():
     torch.cuda.synchronize()
     ref = fingerprint(0, acc)
     bad = 0
+    import time
+    t_last = time.time()
     for it in range(n_iter):
+        if time.time() - t_last > 45:                          # (a sign of life for whoever watches the run)
+            print(f"... iteration {it} of {n_iter}, {bad} with a mismatch so far", flush=True)
+            t_last = time.time()
         for _ in range(depth):
             accs = [step(lane) for lane in range(n_lanes)]    # the batches in flight
         torch.cuda.synchronize()
