@@ -579,7 +579,7 @@ k_virt_scan(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w,
     }
     if (tid == 0) {
       w.n_virt[s] = n;
-      atomicAdd(&w.dbg[37], 1);                              // (D_VIRTUAL of the insert kernels' counters)
+      atomicAdd(&w.dbg[kCntVirtual], 1);
     }
   }
 }

@@ -92,6 +92,7 @@ inline int chunks_of(const r3d_batch_t &b) { return (int)((b.cap + 63) / 64); }
 #endif
 constexpr int kSuperMinChunks = R3D_SUPER_MIN_CHUNKS;
 constexpr int kDbgSuper = 256;
+constexpr int kCntVirtual = 37;      // BatchWs::dbg: scenes put into virtual order at step 0 (D_VIRTUAL of r3d_insert.hip's counters)
 inline int supers_of(const r3d_batch_t &b) { return (chunks_of(b) + 63) / 64; }
 #ifdef __HIPCC__
 __host__ __device__

@@ -251,7 +251,8 @@ enum { D_POOL_FULL = 0, D_TILE_POOLED, D_EVAL_TWICE, D_VERIFY_RUNS, D_VERIFY_MIS
        // round 5, [32 ..]: pairs committed from their own evaluation and the chunks they listed; pairs left to whoever finishes
        // their predecessors -- with a record of the evaluation / as they came --; parked pairs committed from their record
        D_PAIRS = 32, D_CHUNKS_LISTED, D_PARKED, D_PARKED_RAW, D_TAKEOVER_COMMIT,
-       D_VIRTUAL /* scenes put into virtual order at step 0: counted by k_virtual_order, r3d_batch.hip */ };
+       D_VIRTUAL /* scenes put into virtual order at step 0: counted by k_virt_scan, r3d_batch.hip */ };
+static_assert(D_VIRTUAL == kCntVirtual, "the counter r3d_batch.hip writes");
 constexpr int kDbgInts = 64;
 
 // Diagnostic builds (-DR3D_CHECK): the index of every access the gather / kill / commit code derives from data is

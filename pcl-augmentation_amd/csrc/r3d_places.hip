@@ -40,7 +40,16 @@ constexpr int kRot = R3D_PLACE_ROTATIONS;
 constexpr int kCap = R3D_PLACE_SURFACE_CAP;
 constexpr int kPB = 256;                 // threads per block
 constexpr int kCB = 512;                 // threads per block of the sample chain
-constexpr int kPointsPerBlock = 4096;    // points of one query handled by one block of the point passes
+#ifndef R3D_PLACE_BLOCK
+#define R3D_PLACE_BLOCK 4096
+#endif
+#ifndef R3D_PLACE_TURNS
+#define R3D_PLACE_TURNS 1
+#endif
+constexpr int kPointsPerBlock = R3D_PLACE_BLOCK;    // points of one query per turn of a block of the point passes (one ballot lists its chunks)
+constexpr int kTurns = R3D_PLACE_TURNS;                // turns per block: a block stages its query's tables (centres, minima, boxes of the 360
+                                         // steps: 9-25 KB) once for 16 384 points -- at 320 queries the passes were bound by
+                                         // exactly that staging, 9 600 blocks of it per pass
 constexpr int kBoxD = 18;                // 3x3 matrix, upper planes, lower planes, centre x y, bounding radius
 constexpr int kLdsBoxes = 32;            // scene boxes of a query kept in LDS by the sample chain
 constexpr double kCos1 = 0x1.ffec097f5af8ap-1;   // np.cos(np.deg2rad(1)), find_spot.py:52-59
@@ -348,7 +357,7 @@ __device__ __forceinline__ bool chunk_out_of_reach(const float *ranges, int64_t 
 
 // The chunks of a block's 4096 points that are within reach, listed in LDS by the first wave with one
 // coalesced load of the ranges (a serial skip test per chunk would pay one memory latency each).
-static_assert(kPointsPerBlock == 64 * 64, "one ballot covers the chunks of a block");
+static_assert(kPointsPerBlock <= 64 * 64 && kPointsPerBlock % 64 == 0, "one ballot covers the chunks of a block");
 __device__ __forceinline__ int list_chunks_in_reach(const float *ranges, int64_t start, int64_t end, float rho_c,
                                                     float reach, unsigned char *s_chunk, int *s_count) {
   if (threadIdx.x < 64) {
@@ -382,8 +391,8 @@ __device__ __forceinline__ void stage_query(r3d_place_query_t &dst, const r3d_pl
 __global__ __launch_bounds__(kPB) void k_place_road_min(const r3d_place_query_t *Q, PlaceWs w, float reach, int mode,
                                                         double resolved_sq) {
   const int q = blockIdx.x, tid = threadIdx.x;        // queries of one scene are neighbours: they share the chunk in L2
-  const int64_t n = Q[q].n_orig, start = (int64_t)blockIdx.y * kPointsPerBlock;
-  if (start >= n) return;
+  const int64_t n = Q[q].n_orig, start0 = (int64_t)blockIdx.y * kPointsPerBlock * kTurns;
+  if (start0 >= n) return;
   __shared__ r3d_place_query_t qq;
   __shared__ unsigned char s_chunk[64];
   __shared__ int s_nchunk;
@@ -403,24 +412,29 @@ __global__ __launch_bounds__(kPB) void k_place_road_min(const r3d_place_query_t 
   if (!__syncthreads_or(any)) return;
   stage_query(qq, Q + q);
   const float rho_c = sqrtf((float)(s_cx[0] * s_cx[0] + s_cy[0] * s_cy[0])), th1 = atan2f((float)s_cy[0], (float)s_cx[0]);
-  const int64_t end = start + kPointsPerBlock < n ? start + kPointsPerBlock : n;
-  const int n_chunks = list_chunks_in_reach(qq.orig_ranges, start, end, rho_c, reach, s_chunk, &s_nchunk);
-  for (int a = tid >> 6; a < n_chunks; a += kPB / 64) {           // one 64-point chunk per wave and turn
-    const int64_t i = start + (int64_t)s_chunk[a] * 64 + (tid & 63);
-    if (i >= end) continue;
-    const Pt p = load_point(qq.orig, i, qq.orig_ld, qq.orig_label_col);
-    const double x = p.x, y = p.y;
-    if (!(p.z > -3.0)) continue;                                  // :133-134
-    if (label_rank(qq, p.label) < 0) continue;                    // :125-131
-    int first, count;
-    if (!steps_in_reach((float)x, (float)y, rho_c, th1, reach, first, count)) continue;
-    for (int t = 0; t < count; ++t) {
-      int r = first + t;
-      r = r >= kRot ? r - kRot : r;
-      if (!s_need[r]) continue;
-      double dx = x - s_cx[r], dy = y - s_cy[r];
-      unsigned long long key = depth_key(dx * dx + dy * dy);     // :123, non-negative: bits are ordered
-      if (key < s_min[r]) atomicMin(&s_min[r], key);
+  for (int turn = 0; turn < kTurns; ++turn) {
+    const int64_t start = start0 + (int64_t)turn * kPointsPerBlock;
+    if (start >= n) break;
+    const int64_t end = start + kPointsPerBlock < n ? start + kPointsPerBlock : n;
+    __syncthreads();                                              // (the previous turn's chunk list is no longer read)
+    const int n_chunks = list_chunks_in_reach(qq.orig_ranges, start, end, rho_c, reach, s_chunk, &s_nchunk);
+    for (int a = tid >> 6; a < n_chunks; a += kPB / 64) {         // one 64-point chunk per wave and turn
+      const int64_t i = start + (int64_t)s_chunk[a] * 64 + (tid & 63);
+      if (i >= end) continue;
+      const Pt p = load_point(qq.orig, i, qq.orig_ld, qq.orig_label_col);
+      const double x = p.x, y = p.y;
+      if (!(p.z > -3.0)) continue;                                // :133-134
+      if (label_rank(qq, p.label) < 0) continue;                  // :125-131
+      int first, count;
+      if (!steps_in_reach((float)x, (float)y, rho_c, th1, reach, first, count)) continue;
+      for (int t = 0; t < count; ++t) {
+        int r = first + t;
+        r = r >= kRot ? r - kRot : r;
+        if (!s_need[r]) continue;
+        double dx = x - s_cx[r], dy = y - s_cy[r];
+        unsigned long long key = depth_key(dx * dx + dy * dy);   // :123, non-negative: bits are ordered
+        if (key < s_min[r]) atomicMin(&s_min[r], key);
+      }
     }
   }
   __syncthreads();
@@ -482,8 +496,8 @@ __device__ __forceinline__ int last_bit_exponent(double v) {
 // which are float32 values of similar size).  The ordered list is kept for the other case.
 __global__ __launch_bounds__(kPB) void k_place_surface_gather(const r3d_place_query_t *Q, PlaceWs w, Radii rad) {
   const int q = blockIdx.x, tid = threadIdx.x;        // queries of one scene are neighbours: they share the chunk in L2
-  const int64_t n = Q[q].n_orig, start = (int64_t)blockIdx.y * kPointsPerBlock;
-  if (start >= n) return;
+  const int64_t n = Q[q].n_orig, start0 = (int64_t)blockIdx.y * kPointsPerBlock * kTurns;
+  if (start0 >= n) return;
   const double reach_sq = key_depth(w.gather_sq[q]);
   if (!(reach_sq > 0.0)) return;                                  // no step found surface
   __shared__ r3d_place_query_t qq;
@@ -504,7 +518,11 @@ __global__ __launch_bounds__(kPB) void k_place_surface_gather(const r3d_place_qu
   stage_query(qq, Q + q);
   const float reach = (float)sqrt(reach_sq) * 1.01f + 0.05f;
   const float rho_c = sqrtf((float)(s_cx[0] * s_cx[0] + s_cy[0] * s_cy[0])), th1 = atan2f((float)s_cy[0], (float)s_cx[0]);
+  for (int turn = 0; turn < kTurns; ++turn) {
+  const int64_t start = start0 + (int64_t)turn * kPointsPerBlock;
+  if (start >= n) break;
   const int64_t end = start + kPointsPerBlock < n ? start + kPointsPerBlock : n;
+  __syncthreads();                                                // (the previous turn's chunk list is no longer read)
   const int n_chunks = list_chunks_in_reach(qq.orig_ranges, start, end, rho_c, reach, s_chunk, &s_nchunk);
   for (int a = tid >> 6; a < n_chunks; a += kPB / 64) {
     const int64_t i = start + (int64_t)s_chunk[a] * 64 + (tid & 63);
@@ -532,6 +550,7 @@ __global__ __launch_bounds__(kPB) void k_place_surface_gather(const r3d_place_qu
         if (slot < kCap) w.surf[o * kCap + slot] = ((unsigned long long)rank << 40) | (unsigned long long)i;
       }
     }
+  }
   }
   __syncthreads();
   for (int r = tid; r < kRot; r += kPB) {
@@ -609,8 +628,8 @@ __global__ __launch_bounds__(kPB) void k_place_road_level(const r3d_place_query_
 // ---- k_place_scene_in_box: cut_bounding_box(scene_pcl, sample_anno) minus surface (:91-97) --------
 __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_query_t *Q, PlaceWs w) {
   const int q = blockIdx.x, tid = threadIdx.x;
-  const int64_t n = Q[q].n_scene, start = (int64_t)blockIdx.y * kPointsPerBlock;
-  if (start >= n) return;
+  const int64_t n = Q[q].n_scene, start0 = (int64_t)blockIdx.y * kPointsPerBlock * kTurns;
+  if (start0 >= n) return;
   __shared__ r3d_place_query_t qq;
   __shared__ unsigned char s_chunk[64];
   __shared__ int s_nchunk;
@@ -643,7 +662,11 @@ __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_quer
   // float32 rounding of coordinates up to ~100 m is ~1e-5 m; the planes sit at |column|^2 * size, within
   // 1e-12 of size for the unit quaternions of the chain
   const float slack = 1e-3f + 1e-5f * (rho_c + reach + (float)fabs(qq.anno[2]) + 10.f);
+  for (int turn = 0; turn < kTurns; ++turn) {
+  const int64_t start = start0 + (int64_t)turn * kPointsPerBlock;
+  if (start >= n) break;
   const int64_t end = start + kPointsPerBlock < n ? start + kPointsPerBlock : n;
+  __syncthreads();                                                // (the previous turn's chunk list is no longer read)
   const int n_chunks = list_chunks_in_reach(qq.scene_ranges, start, end, rho_c, reach, s_chunk, &s_nchunk);
   for (int a = tid >> 6; a < n_chunks; a += kPB / 64) {
     const int64_t i = start + (int64_t)s_chunk[a] * 64 + (tid & 63);
@@ -671,6 +694,7 @@ __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_quer
       if (inside_box(w.rotm + o * 9, w.planes + o * 6, w.planes + o * 6 + 3, x, y, z))
         atomicOr(&s_hit[r >> 5], 1u << (r & 31));
     }
+  }
   }
   __syncthreads();
   if (tid < 12 && s_hit[tid]) atomicOr(&w.hit[(size_t)q * 12 + tid], s_hit[tid]);
@@ -1128,8 +1152,9 @@ extern "C" int r3d_find_possible_places(const r3d_place_query_t *queries, int32_
   if (max_boxes > 0)
     hipLaunchKernelGGL(k_place_boxes, dim3((n_queries * max_boxes + 255) / 256), dim3(256), 0, st, queries,
                        n_queries, max_boxes, w);
-  const int pb_orig = (int)((max_n_orig + kPointsPerBlock - 1) / kPointsPerBlock);
-  const int pb_scene = (int)((max_n_scene + kPointsPerBlock - 1) / kPointsPerBlock);
+  const int64_t per_block = (int64_t)kPointsPerBlock * kTurns;
+  const int pb_orig = (int)((max_n_orig + per_block - 1) / per_block);
+  const int pb_scene = (int)((max_n_scene + per_block - 1) / per_block);
   // distance passes of growing reach (metres); a pass only serves the steps whose minimum the
   // previous one could not settle (nothing found within its reach)
   // (round 5: 0.6 m, then the full reach for the steps still open -- the 1.8 m pass in between cost more than it saved the
