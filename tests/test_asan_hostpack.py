@@ -1,4 +1,4 @@
-"""CPU: the host half of the streamed driver (r3d_hostpack.cpp: r3d_host_pack_frames, r3d_host_merge_frames) built with
+"""CPU: the host half of the streamed driver (r3d_hostpack.cpp: r3d_host_pack_frames, r3d_host_merge_frames, r3d_host_write_delta_frames) built with
 g++ -fsanitize=address,undefined and driven through ctypes the way streaming.py does, edge cases included (empty
 frames, counts at chunk boundaries, refused arguments).  GPU sanitizers are not available on the pool; this covers
 the native host code of the path."""
@@ -22,6 +22,7 @@ DRIVER = textwrap.dedent("""
     lib.r3d_host_pack_frames.argtypes = [P, P, P, C.c_int32, C.c_int64, P, P, C.c_int32, C.c_int32]
     lib.r3d_host_merge_frames.argtypes = [P, P, C.c_int64, P, C.c_int64, P, P, C.c_int64, P, C.c_int32, P, P, C.c_int64, P, P,
                                           C.c_int64, C.c_int32, C.c_int32]
+    lib.r3d_host_write_delta_frames.argtypes = [P, P, P, C.c_int32, P, P, C.c_int64, P, C.c_int64, P, P, C.c_int64, P, C.c_int32, P, C.c_int32]
     rng = np.random.default_rng(1)
     for B, cap, tail in ((1, 64, 1), (3, 130, 17), (7, 1000, 64)):
         chunks = (cap + 63) // 64
@@ -55,6 +56,27 @@ DRIVER = textwrap.dedent("""
                                          tail, counts.ctypes.data, B, ox.ctypes.data, ol.ctypes.data, cap, no.ctypes.data, None, tail, 5, 2) < 0
         big = n.copy(); big[-1] = cap + 1
         assert lib.r3d_host_pack_frames(px, pl, big.ctypes.data, B, cap, sx.ctypes.data, sl.ctypes.data, -1, 2) < 0
+        # the delta writer (files straight from the staging slab + the delta, run by run): the bytes of merge + the counts above,
+        # with garbage in the alive bits beyond n_total (it masks them itself)
+        import os, tempfile
+        dirty = bits.copy()
+        for s in range(B):
+            dirty[s, counts[1, s]:] = rng.random(chunks * 64 - counts[1, s]) < 0.5
+        alive_d = np.packbits(dirty.reshape(B, chunks, 64), axis=2, bitorder="little").view(np.uint64).reshape(B, chunks).copy()
+        with tempfile.TemporaryDirectory() as d:
+            enc = lambda ext: (C.c_char_p * B)(*[os.path.join(d, f"{s}.{ext}").encode() for s in range(B)])
+            no2 = np.zeros(B, np.int32)
+            for cols in (5, 4):
+                rc = lib.r3d_host_write_delta_frames(enc("bin"), enc("label"), enc("check"), B, sx.ctypes.data, sl.ctypes.data, cap,
+                                                     alive_d.ctypes.data, chunks, tx.ctypes.data, tl.ctypes.data, tail, counts.ctypes.data,
+                                                     cols, no2.ctypes.data, 3)
+                assert rc == 0 and list(no2) == list(no)
+                for s in range(B):
+                    assert open(os.path.join(d, f"{s}.bin"), "rb").read() == ox[s, :no[s]].tobytes()
+                    assert open(os.path.join(d, f"{s}.label"), "rb").read() == ol[s, :no[s]].tobytes()
+                    assert os.path.getsize(os.path.join(d, f"{s}.check")) == int(n_tail[s]) * cols * 4
+            assert lib.r3d_host_write_delta_frames(enc("bin"), None, None, B, sx.ctypes.data, sl.ctypes.data, cap, alive_d.ctypes.data, chunks,
+                                                   tx.ctypes.data, tl.ctypes.data, tail, bad.ctypes.data, 5, None, 2) < 0
     print("asan driver ok")
 """)
 
