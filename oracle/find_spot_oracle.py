@@ -19,6 +19,8 @@ Third-party arithmetic the reference calls on this path and that is not under /r
   Its kernels accumulate a dot product with fused multiply-adds in a fixed order:
   matrix x matrix  ``acc = a0*b0; acc = fma(a1, b1, acc); acc = fma(a2, b2, acc) ...``
   3x3 x column     ``fma(a2, b2, fma(a0, b0, a1*b1))``
+  4x4 x column     ``(a0*b0 + a2*b2) + (a1*b1 + a3*b3)``, every product and sum rounded
+  (the two column forms are also what ``@`` does at :72 and :236 for a sample of ONE point)
   (measured here; a BLAS without FMA gives results 1 ULP away for ~3 % of the points).  The
   restatement reproduces exactly that with an emulated FMA, so it does not depend on the BLAS of
   the machine the tests run on.
@@ -84,6 +86,13 @@ def blas_matvec3(A, v):
     """np.dot(A (3,3), v (3,1)) the way the BLAS gemv kernel accumulates."""
     v = np.asarray(v, dtype=np.float64).reshape(3)
     return fma(A[:, 2], v[2], fma(A[:, 0], v[0], A[:, 1] * v[1]))
+
+
+def blas_matvec4(A, v):
+    """A (4,4) @ v (4,1): the gemv kernel's row dot products, two partial sums (even and odd terms)
+    of rounded products added at the end."""
+    v = np.asarray(v, dtype=np.float64).reshape(4)
+    return (A[:, 0] * v[0] + A[:, 2] * v[2]) + (A[:, 1] * v[1] + A[:, 3] * v[3])
 
 
 # ---- scipy.spatial.transform.Rotation, the four calls on the path --------------------------------
@@ -164,7 +173,10 @@ def rotate_bounding_box_2(bbox_pcl, annotation):
     rot = quat_to_matrix(quat_normalize(anno_quat(annotation)))             # :53-55
     q = matrix_to_quat(blas_matmul(rot, Z1))                                # :61-65
     c = blas_matvec3(Z1, anno_center(annotation))                           # :66-70
-    bbox_pcl[:, :3] = blas_matmul(Z1, bbox_pcl[:, :3].T).T                  # :72
+    if len(bbox_pcl) == 1:                                                  # :72 with one column: matrix x vector
+        bbox_pcl[0, :3] = blas_matvec3(Z1, bbox_pcl[0, :3])
+    else:
+        bbox_pcl[:, :3] = blas_matmul(Z1, bbox_pcl[:, :3].T).T              # :72
     return bbox_pcl, make_annotation(c, q, annotation["length"], annotation["width"], annotation["height"],
                                      annotation["class"])
 
@@ -242,7 +254,8 @@ def on_allowed_surface(sample_pcl, map_, map_move, transformation_matrix, ok_map
     """find_spot.py:234-248: every sample point that falls inside the map lies on an allowed cell
     (vacuously true when none does)."""
     hom = np.hstack((sample_pcl[:, :3], np.ones((len(sample_pcl), 1)))).T
-    g = blas_matmul(np.asarray(transformation_matrix, dtype=np.float64), hom)     # :235
+    T = np.asarray(transformation_matrix, dtype=np.float64)
+    g = blas_matvec4(T, hom[:, 0])[:, None] if hom.shape[1] == 1 else blas_matmul(T, hom)   # :235
     g = (g - map_move).astype(np.int64)                                            # :237-238 (np.int)
     g = g[:, g[0] < len(map_)]
     g = g[:, g[0] > -1]

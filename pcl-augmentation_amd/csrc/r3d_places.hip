@@ -741,7 +741,7 @@ struct ChainLds {
 // time, 96 times per query on the bench's frames.)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int PPT, bool POINTWISE>
+template <int PPT, bool POINTWISE, bool ONE = false>
 __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_query_t *Q, const PlaceWs &w, int max_boxes,
                                              uint8_t *flags, int32_t *n_possible, int32_t *rot_out,
                                              double *anno_out, double *cand, int32_t first_cand, int32_t *status) {
@@ -895,8 +895,16 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
       y[u] = ny;
       z[u] = nz;
       // transformation_matrix @ [x y z 1], minus map_move, astype(int): :234-238
-      g0[u] = fma(T03, 1.0, fma(T02, nz, fma(T01, ny, T00 * nx))) - mv0;
-      g1[u] = fma(T13, 1.0, fma(T12, nz, fma(T11, ny, T10 * nx))) - mv1;
+      if (ONE) {
+        // a sample of ONE point: both products have a single column and numpy hands them to the matrix x vector
+        // routine -- :72 then accumulates as OD's per-point product does (POINTWISE), and the 4 x 4 one as two partial
+        // sums of rounded products (even and odd terms) added at the end (oracle/find_spot_oracle.py: blas_matvec4)
+        g0[u] = __dadd_rn(__dadd_rn(__dmul_rn(T00, nx), __dmul_rn(T02, nz)), __dadd_rn(__dmul_rn(T01, ny), T03)) - mv0;
+        g1[u] = __dadd_rn(__dadd_rn(__dmul_rn(T10, nx), __dmul_rn(T12, nz)), __dadd_rn(__dmul_rn(T11, ny), T13)) - mv1;
+      } else {
+        g0[u] = fma(T03, 1.0, fma(T02, nz, fma(T01, ny, T00 * nx))) - mv0;
+        g1[u] = fma(T13, 1.0, fma(T12, nz, fma(T11, ny, T10 * nx))) - mv1;
+      }
     }
     int cell[PPT], i0s[PPT], i1s[PPT];
     int inmap[PPT], inwin[PPT];
@@ -1011,6 +1019,10 @@ __global__ __launch_bounds__(kCB) void k_place_sample_chain(const r3d_place_quer
                                                            int32_t *status) {
   __shared__ ChainLds lds;
   const bool pointwise = Q[blockIdx.x].flavour & R3D_PQ_POINTWISE_ROTATION;
+  if (Q[blockIdx.x].m == 1) {                                     // one column: the matrix x vector arithmetic throughout
+    sample_chain<1, true, true>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status);
+    return;
+  }
   switch (chain_class(Q[blockIdx.x].m)) {
 #define R3D_CHAIN_CASE(P)                                                                                                  \
   case P:                                                                                                                   \

@@ -152,6 +152,7 @@ CASES = {
     "places_cyclist": dict(seed=11, cls=31),
     "places_pedestrian": dict(seed=12, cls=30),
     "places_car_smallmap": dict(seed=13, cls=18, small_map=True, tilt=False),
+    "places_one_point": dict(seed=12, cls=30, m_points=1),      # one column: numpy takes the matrix x vector routine (:72, :236)
 }
 
 

@@ -10,7 +10,7 @@ from oracle import real3d_oracle as O
 
 PLACEMENT = {11: [1, 3], 15: [1, 3], 18: [1, 3], 30: [2], 31: [1, 3], 32: [1, 3], 253: [1, 3], 255: [1, 3]}
 PLACEMENT_LABELS = {1: [40, 60], 2: [48], 3: [44]}
-CASES = ["places_cyclist.npz", "places_pedestrian.npz", "places_car_smallmap.npz"]
+CASES = ["places_cyclist.npz", "places_pedestrian.npz", "places_car_smallmap.npz", "places_one_point.npz"]
 
 
 def oracle_inputs(g):

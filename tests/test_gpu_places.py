@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 PLACEMENT = {11: [1, 3], 15: [1, 3], 18: [1, 3], 30: [2], 31: [1, 3], 32: [1, 3], 253: [1, 3], 255: [1, 3]}
 PLACEMENT_LABELS = {1: [40, 60], 2: [48], 3: [44]}
 CONFIG = {"insertion": {"placement": PLACEMENT, "placement_labels": PLACEMENT_LABELS}}
-CASES = ["places_cyclist.npz", "places_pedestrian.npz", "places_car_smallmap.npz"]
+CASES = ["places_cyclist.npz", "places_pedestrian.npz", "places_car_smallmap.npz", "places_one_point.npz"]
 
 
 @pytest.fixture(scope="module")
@@ -50,7 +50,7 @@ def test_function_level_drop_in_equals_reference(P, name):
     assert np.array_equal(got_q, g["out_quat"])
 
 
-def _random_query(synth, seed, cls, n_boxes, beams=32, n_az=500, dist=None):
+def _random_query(synth, seed, cls, n_boxes, beams=32, n_az=500, dist=None, m=None):
     rng = np.random.default_rng(seed)
     xyzi, label = synth.make_scene(seed, beams, n_az, shuffle=bool(seed & 1))
     label = label.copy()
@@ -73,7 +73,7 @@ def _random_query(synth, seed, cls, n_boxes, beams=32, n_az=500, dist=None):
         rich[world[0][sel], world[1][sel]] = value
     kind = {30: "pedestrian", 31: "cyclist", 18: "car"}[cls]
     length, width, height, _, _ = synth.INSERT_KINDS[kind]
-    m = int(rng.integers(20, 700))
+    m = int(rng.integers(20, 700)) if m is None else m
     dist0, phi, yaw = rng.uniform(4, 14), rng.uniform(-np.pi, np.pi), rng.uniform(-np.pi, np.pi)
     dist = dist0 if dist is None else dist
     p = rng.uniform(-0.5, 0.5, size=(m, 3)) * [length, width, height]
@@ -100,6 +100,8 @@ def test_batch_of_queries_equals_oracle(P, synth):
     specs = [(21, 31, 2), (22, 30, 0), (23, 18, 4), (24, 31, 1)]
     cases = [_random_query(synth, *s) for s in specs]
     cases.append(_random_query(synth, 25, 30, 1, dist=9.2))       # walks through the patch without surface points
+    cases.append(_random_query(synth, 26, 31, 2, m=1))            # one point: numpy's matrix x vector arithmetic (:72, :236)
+    cases.append(_random_query(synth, 27, 30, 1, m=2))
     queries = []
     for c in cases:
         annos = [fs.read_label_line(l) for l in c["lines"]]
