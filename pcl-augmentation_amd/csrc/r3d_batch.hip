@@ -11,6 +11,9 @@
 #include "r3d_batch.hpp"
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace r3d {
 
@@ -293,93 +296,167 @@ __global__ void k_col_table(r3d_batch_t b, BatchWs w) {
 //         and |z| < 71 * hypot(x, y) away from the poles.
 //   ss must be a normal float32 far from overflow / flush-to-zero (1e-30 < ss < 1e30).
 constexpr int kVirtAreaCap = 4096;           // pixels of a chunk's box that count towards box_area (k_virt_hist)
-__global__ void __launch_bounds__(kPT)
+// The kernel is bound by its vector instructions (profiles/r05_sq.csv), so the per-point code is counted in them:
+//   * the points come through a buffer descriptor per tile (base = the tile's first point, records = what is left of the
+//     scene): the lane's offset is a constant, the round's a scalar, past the end reads zeros -- no address arithmetic;
+//   * angle guesses and clamps in float32 (v_med3 before the conversion), octant by selects (no fmax / fmin: those
+//     canonicalise their operands first);
+//   * the row limits of a bin side by side in LDS ({upper, lower} at the row's index: one read, no select for row 0);
+//   * the chunk's box is only reduced when the 64 points are not one ascending run of a row (lane 0's and lane 63's pixel
+//     otherwise); its store address is scalar.
+#ifndef R3D_PROJECT_WAVES
+#define R3D_PROJECT_WAVES
+#endif
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+// The grid is what the device holds at once (project_grid(): CUs x resident workgroups); the tiles of all the scenes of
+// (list, count), counted from their n_total, are dealt out evenly: a workgroup takes tiles [lo, hi) of that sequence, as
+// segments (scene, first tile, last tile) it finds itself with a block scan of the scenes' tile counts.  It stages the
+// column table once and a scene's row table per segment, and its point loads run on across the tiles of a segment (one
+// descriptor per segment, the round's offset in the scalar operand): measured on 256 scenes of 120 000 points, a
+// workgroup's start (tables, scene parameters, the first loads) cost as much as one and a half tiles of work.
+#ifndef R3D_PROJECT_AHEAD
+#define R3D_PROJECT_AHEAD 4
+#endif
+// Rounds (256 points) requested ahead of their use.  What is in flight bounds the rate: with two rounds, 1 536 resident
+// workgroups had 12.6 MB under way -- at the ~3.7 us a load takes here that is 3.4 TB/s, the rate the kernel ran at
+// whatever its instruction count.
+constexpr int kProjectAhead = R3D_PROJECT_AHEAD;
+static_assert(kPerThread % kProjectAhead == 0, "the rounds' registers rotate with the unrolled tile loop");
+constexpr int kSegCap = 64;                   // tiles of a workgroup's range looked at per pass (segments <= tiles)
+__global__ void __launch_bounds__(kPT) R3D_PROJECT_WAVES
 k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int chunks) {
-  extern __shared__ __align__(16) float s_tabf[];          // [(cols+1)*2] column edges, [(rows+2)*2] row limits
+  extern __shared__ __align__(16) float s_tabf[];          // [(cols+1)*2] column edges, [rows*2] row limits
+  __shared__ int s_scan[kPT / 64 + 1], s_seg[kSegCap * 3], s_nseg;
   float2 *s_col = reinterpret_cast<float2 *>(s_tabf), *s_row = s_col + (b.cols + 1);
   for (int e = threadIdx.x; e < b.cols + 1; e += kPT) s_col[e] = reinterpret_cast<const float2 *>(w.col_dirf)[e];
-  int cnt = *count;
-  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
-    int s = list[li];
-    int n = b.n_total[s], n_head = b.n_head[s];
+  const int cnt = *count;
+  const int lane_off = (int)threadIdx.x * 16;
+  const int wave_base = __builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63);
+  const float row_top = (float)(b.rows - 1), col_top = (float)(b.cols - 1);
+  auto tiles_at = [&](int e) { return e < cnt ? (b.n_total[list[e]] + kTile - 1) / kTile : 0; };
+  int all_tiles;
+  {
+    int mine = 0;
+    for (int e = threadIdx.x; e < cnt; e += kPT) mine += tiles_at(e);
+    block_escan_i32(mine, s_scan, all_tiles);
+  }
+  const int lo = (int)((long long)blockIdx.x * all_tiles / gridDim.x);
+  const int hi = (int)((long long)(blockIdx.x + 1) * all_tiles / gridDim.x);
+  for (int sub = lo; sub < hi; sub += kSegCap) {
+  const int sub_hi = sub + kSegCap < hi ? sub + kSegCap : hi;
+  if (threadIdx.x == 0) s_nseg = 0;
+  __syncthreads();
+  for (int base = 0, running = 0; base < cnt && running < sub_hi; base += kPT) {
+    const int e = base + (int)threadIdx.x, t = tiles_at(e);
+    int total;
+    const int pre = running + block_escan_i32(t, s_scan, total);
+    const int a = pre > sub ? pre : sub, z = pre + t < sub_hi ? pre + t : sub_hi;
+    if (a < z) {
+      const int g = atomicAdd(&s_nseg, 1);
+      s_seg[3 * g + 0] = e, s_seg[3 * g + 1] = a - pre, s_seg[3 * g + 2] = z - pre;
+    }
+    running += total;
+  }
+  __syncthreads();
+  const int n_seg = __builtin_amdgcn_readfirstlane(s_nseg);
+  for (int g = 0; g < n_seg; ++g) {
+    const int s = list[__builtin_amdgcn_readfirstlane(s_seg[3 * g + 0])];
+    const int tile_lo = __builtin_amdgcn_readfirstlane(s_seg[3 * g + 1]), tile_hi = __builtin_amdgcn_readfirstlane(s_seg[3 * g + 2]);
+    const int n = b.n_total[s], n_head = b.n_head[s];
     __syncthreads();                                       // previous scene's row table is no longer read
-    for (int e = threadIdx.x; e < b.rows + 2; e += kPT)
-      s_row[e] = reinterpret_cast<const float2 *>(w.row_qf)[(int64_t)s * (b.rows + 2) + e];
+    {
+      const float2 *rq = reinterpret_cast<const float2 *>(w.row_qf) + (int64_t)s * (b.rows + 2);
+      for (int e = threadIdx.x; e < b.rows; e += kPT) s_row[e] = make_float2(rq[e == 0 ? 0 : e + 1].x, rq[e + 2].y);
+    }
     __syncthreads();
     Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
-    const bool exact = b.reserved & 1;                       // diagnostic: reference formula only
+    // diagnostic: reference formula only; a scene with float64 points (r3d_batch_begin_f64): the float32 slab gives the
+    // guess, the float64 confirmation decides on the exact coordinates from the log (the float32 screen is a statement
+    // about float32-exact inputs)
+    const bool exact = b.reserved & 1, any64 = n_head < n;
     const float inv_del = (float)(1.0 / bn.d_el), inv_daz = (float)(1.0 / bn.d_az);
     const float elo = (float)(bn.min_el + 0.00001);
     const double *row_cc = w.row_q + (int64_t)s * (b.rows + 2);
     uint32_t *queue = w.cand + (int64_t)s * w.cand_stride;  // insert scratch, free during step 0
     int flags = 0, area = 0;
     // 8 points per thread and tile; unconfirmed points are queued for k_project_slow.  A block walks
-    // several tiles so that the tables are staged once.  Points are requested two rounds ahead of their use
-    // (indices clamped to the scene: no branch around a load).
-    const float4 *__restrict__ src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
-    const unsigned int last = (unsigned int)(n > 0 ? n - 1 : 0);   // (the slab holds the float32 rounding of float64 points)
-    auto fetch = [&](int i) {
-      unsigned int j = (unsigned int)i < last ? (unsigned int)i : last;
-      return src[j];
-    };
-    for (int t0 = blockIdx.x * kTile; t0 < n; t0 += gridDim.x * kTile) {
-    float4 pt = fetch(t0 + threadIdx.x), pt1 = fetch(t0 + kPT + threadIdx.x);
+    // several tiles so that the tables are staged once.  Points are requested kProjectAhead rounds ahead of their use.
+    const float *scene_xyzi = b.xyzi + (int64_t)s * b.cap * 4;   // (the slab holds the float32 rounding of float64 points)
+    const int first = tile_lo * kTile, left = n - first, span = (tile_hi - tile_lo) * kTile;
+    const __amdgpu_buffer_rsrc_t seg_xyzi = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(scene_xyzi + (int64_t)first * 4), 0, (left < span ? left : span) * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t seg_pix = __builtin_amdgcn_make_buffer_rsrc(
+        b.pix + (int64_t)s * b.cap + first, 0, (left < span ? left : span) * 4, 0x00020000);
+    // (past the segment's end the loads return zeros: the rounds requested ahead at its last tile)
+    auto fetch = [&](int round) { return __builtin_amdgcn_raw_buffer_load_b96(seg_xyzi, lane_off, round * kPT * 16, 0); };
+    u32x3 ahead[kProjectAhead];
+#pragma unroll
+    for (int k = 0; k < kProjectAhead; ++k) ahead[k] = fetch(k);
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int t0 = tile * kTile, round0 = (tile - tile_lo) * kPerThread;
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
-      int i = t0 + k * kPT + threadIdx.x;
-      float4 pt2 = pt1;
-      if (k + 2 < kPerThread) pt2 = fetch(t0 + (k + 2) * kPT + threadIdx.x);
-      BoxAcc box;
+      const int i = t0 + k * kPT + (int)threadIdx.x;
+      const u32x3 pt = ahead[k % kProjectAhead];
+      ahead[k % kProjectAhead] = fetch(round0 + k + kProjectAhead);
+      const float px = __uint_as_float(pt.x), py = __uint_as_float(pt.y), pz = __uint_as_float(pt.z);
       int row = 0, col = 0;
       bool placed = false;
-      if (i < n) {
-        // (inserted float64 points, which only exist when a re-based scene is projected by this kernel,
-        // take the queue)
-        // bin guess (about 1e-5 rad off at worst, a few per mille of a bin)
-        float ssf = fmaf(pt.x, pt.x, fmaf(pt.y, pt.y, pt.z * pt.z));
-        float qf = pt.z * __frsqrt_rn(ssf);
+      const bool live = i < n;
+      if (live) {
+        // bin guess (a few 1e-7 rad off at worst, a fraction of a per mille of a bin)
+        const float ssf = fmaf(px, px, fmaf(py, py, pz * pz));
+        float qf = pz * __frsqrt_rn(ssf);
         qf = __builtin_amdgcn_fmed3f(qf, -1.f, 1.f);
-        row = (int)floorf((guess_acosf(qf) - elo) * inv_del);
-        col = (int)((guess_atan2f(pt.y, pt.x) + 3.14159274f) * inv_daz);
-        row = max(0, min(row, bn.rows - 1));
-        col = max(0, min(col, bn.cols - 1));
+        const float rowf = floorf((guess_acosf(qf) - elo) * inv_del);
+        const float ax = fabsf(px), ay = fabsf(py);
+        const bool steep = ay > ax;
+        const float mx = steep ? ay : ax, mn = steep ? ax : ay;
+        const float t = mn * __builtin_amdgcn_rcpf(mx), t2 = t * t;   // atan on [0, 1], odd polynomial (v_rcp_f32: 1 ulp)
+        float pa = fmaf(-0.0047804345f, t2, 0.024557052f);
+        pa = fmaf(pa, t2, -0.059904616f);
+        pa = fmaf(pa, t2, 0.09942752f);
+        pa = fmaf(pa, t2, -0.14029418f);
+        pa = fmaf(pa, t2, 0.19971375f);
+        pa = fmaf(pa, t2, -0.33332095f);
+        pa = fmaf(pa, t2, 0.99999994f);
+        float az = pa * t;
+        az = steep ? 1.57079637f - az : az;
+        az = px < 0.f ? 3.14159274f - az : az;
+        az = py < 0.f ? -az : az;
+        row = (int)__builtin_amdgcn_fmed3f(rowf, 0.f, row_top);
+        col = (int)__builtin_amdgcn_fmed3f((az + 3.14159274f) * inv_daz, 0.f, col_top);
         // float32 screen
-        float2 ea = s_col[col], eb = s_col[col + 1];
-        float mcf = 1e-6f * (fabsf(pt.x) + fabsf(pt.y));
-        int ok = (int)(ssf > 1e-30f) & (int)(ssf < 1e30f) & (int)(fabsf(qf) < 0.9999f) &
-                 (int)(qf < s_row[row == 0 ? 0 : row + 1].x) & (int)(qf > s_row[row + 2].y) &
-                 (int)(fmaf(ea.x, pt.y, -(ea.y * pt.x)) > mcf) & (int)(fmaf(eb.x, pt.y, -(eb.y * pt.x)) < -mcf);
+        const float2 ea = s_col[col], eb = s_col[col + 1], rq = s_row[row];
+        const float mcf = 1e-6f * (ax + ay);
+        // (ss up to 249 000: r below 499; beyond, the float64 part below looks at r > 500)
+        int ok = (int)(ssf > 1e-30f) & (int)(ssf <= 249000.f) & (int)(fabsf(qf) < 0.9999f) & (int)(qf < rq.x) &
+                 (int)(qf > rq.y) & (int)(fmaf(ea.x, py, -(ea.y * px)) > mcf) & (int)(fmaf(eb.x, py, -(eb.y * px)) < -mcf) &
+                 (int)(!any64);
         bool far = false;
-        // A point with genuine float64 coordinates (r3d_batch_begin_f64; an inserted point of a re-projected scene):
-        // the float32 slab gave the guess, the float64 confirmation decides on the exact coordinates from the log
-        // (the float32 screen is a statement about float32-exact inputs).
-        const bool is64 = i >= n_head;
-        if (is64) ok = 0;
-        if (!ok | (ssf > 249000.f)) {                        // undecided in float32, or r near / above 500
-          double x = (double)pt.x, y = (double)pt.y, z = (double)pt.z;
-          if (is64) load_point(b, s, i, n_head, x, y, z);
+#ifdef R3D_EXP_NOCOLD
+        ok = 1;
+#endif
+        if (!ok) {                                           // undecided in float32, or r near / above 500
+          double x = (double)px, y = (double)py, z = (double)pz;
+          if (i >= n_head) load_point(b, s, i, n_head, x, y, z);
           double ss = x * x + y * y + z * z;
-          if (!ok) ok = confirm_bin(row_cc, w.col_dir, row, col, x, y, z, ss);
+          ok = confirm_bin(row_cc, w.col_dir, row, col, x, y, z, ss);
           far = ss > R3D_EMPTY_DEPTH * R3D_EMPTY_DEPTH;      // r > 500 (or rounds to it): far list
         }
         if (ok & (int)(!exact)) {
           int p = (int)pack_pix(row, col);
-          box.add(row, col);
           placed = true;
           if (far) {
             int f = atomicAdd(&b.n_far[s], 1);
             if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
             else flags |= R3D_S_FAR_OVERFLOW;
           }
-          b.pix[(int64_t)s * b.cap + i] = p;
+          __builtin_amdgcn_raw_buffer_store_b32((unsigned int)p, seg_pix, lane_off >> 2, (round0 + k) * kPT * 4, 0);
         } else {
           queue[atomicAdd(&w.n_slow[s], 1)] = (uint32_t)i;
-          box.add(0, 0);                                     // unknown pixel: the chunk's box covers
-          box.add(b.rows - 1, b.cols - 1);                   // the whole image
         }
       }
-      pt = pt1;
-      pt1 = pt2;
       // the chunk's box.  A scan in ring order gives 64 points of one row whose columns rise with the lane:
       // then the box is lane 0's and lane 63's pixel (checked, not assumed); anything else takes the reduction.
       unsigned long long packed;
@@ -387,22 +464,31 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
         const int before = __builtin_amdgcn_update_dpp(col, col, 0x138, 0xF, 0xF, false);   // wave_shr:1; lane 0 keeps its own
         const int row0 = __builtin_amdgcn_readfirstlane(row);
         const bool in_order = placed & (row == row0) & (col >= before);
-        if (__ballot(in_order) == ~0ull)
+        if (__ballot(in_order) == ~0ull) {
           packed = pack_box(row0, row0, __builtin_amdgcn_readfirstlane(col), __builtin_amdgcn_readlane(col, 63));
-        else
-          // (a point queued for k_project_slow has made the box the whole image: no arc then)
-          packed = __ballot((i < n) & !placed) ? box.wave_pack() : box.wave_pack_arc(placed ? col : -1, b.cols);
+        } else {
+          BoxAcc box;
+          if (live) {
+            if (placed) {
+              box.add(row, col);
+            } else {                                           // unknown pixel (queued for k_project_slow): the chunk's
+              box.add(0, 0);                                   // box covers the whole image until k_fix_boxes
+              box.add(b.rows - 1, b.cols - 1);
+            }
+          }
+          packed = __ballot(live & !placed) ? box.wave_pack() : box.wave_pack_arc(placed ? col : -1, b.cols);
+        }
       }
-      unsigned long long living = __ballot(i < n);           // every point of the frame is alive at step 0
-      int i0 = t0 + k * kPT + (threadIdx.x & ~63);
-      if (i0 < n) {                                            // (wave-uniform: the box is the wave's)
+      const int i0 = t0 + k * kPT + wave_base;                 // the wave's first point (scalar)
+      if (i0 < n) {
         const int r0 = (int)(packed & 0xFFFF), r1 = (int)((packed >> 16) & 0xFFFF), c0 = (int)((packed >> 32) & 0xFFFF), c1 = (int)((packed >> 48) & 0xFFFF);
         const int a = r0 > r1 ? 0 : (r1 - r0 + 1) * (c0 <= c1 ? c1 - c0 + 1 : b.cols - c0 + c1 + 1);
         area += a > kVirtAreaCap ? kVirtAreaCap : a;
-      }
-      if ((threadIdx.x & 63) == 0 && i0 < n) {
-        w.chunk_box[(int64_t)s * chunks + (i0 >> 6)] = packed;
-        w.alive[(int64_t)s * chunks + (i0 >> 6)] = living;
+        const unsigned long long living = __ballot(live);     // every point of the frame is alive at step 0
+        if ((threadIdx.x & 63) == 0) {
+          w.chunk_box[(int64_t)s * chunks + (i0 >> 6)] = packed;
+          w.alive[(int64_t)s * chunks + (i0 >> 6)] = living;
+        }
       }
     }
     }
@@ -410,6 +496,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
     if ((threadIdx.x & 63) == 0 && flags) atomicOr(&b.status[s], flags);
     // how large are this scene's chunk boxes?  (k_virt_hist: a scene whose points come in no file order)
     if ((threadIdx.x & 63) == 0 && area) atomicAdd(&w.box_area[s], area);
+  }
   }
 }
 
@@ -926,15 +1013,37 @@ int check_batch(const r3d_batch_t *b) {
   return R3D_OK;
 }
 
-// blocks per scene of k_project: each walks ~4 tiles, at least ~2048 blocks in a 256-scene launch
-static int project_blocks(const r3d_batch_t &b) {
-  int t = tiles_of(b);
-  int per = (t + 3) / 4;
-  return per < 1 ? 1 : per;
-}
-
 static size_t project_lds_bytes(const r3d_batch_t &b) {
   return ((size_t)(b.cols + 1) + b.rows + 2) * 2 * sizeof(float);
+}
+
+// k_project's grid: the workgroups the device holds at once (they deal the tiles out among themselves), but no more than
+// there can be tiles.  R3D_PROJECT_GRID: workgroups per CU instead of what the occupancy query says (experiments).
+static int project_grid(const r3d_batch_t &b) {
+  static std::mutex mu;
+  static std::map<std::pair<int, size_t>, int> known;      // (device, LDS bytes) -> resident workgroups
+  static const int per_cu_env = [] {
+    const char *v = getenv("R3D_PROJECT_GRID");
+    return v && atoi(v) > 0 ? atoi(v) : 0;
+  }();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const size_t lds = project_lds_bytes(b);
+  int resident;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = known.find({dev, lds});
+    if (it == known.end()) {
+      int cus = 0, per_cu = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_project, kPT, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
+      if (per_cu_env) per_cu = per_cu_env;
+      it = known.emplace(std::make_pair(dev, lds), cus * per_cu).first;
+    }
+    resident = it->second;
+  }
+  const long long most = (long long)b.B * tiles_of(b);
+  return (int)(most < resident ? (most > 0 ? most : 1) : resident);
 }
 
 // bounds -> tables -> project for the scenes of (list, count); rows = block rows of the launches.
@@ -944,8 +1053,8 @@ static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_
   hipLaunchKernelGGL(k_bounds_sample, dim3((tiles + kPT / 64 - 1) / (kPT / 64), rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_bounds, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_prepare, dim3(1, rows), dim3(kPT), 0, st, b, list, count, w, tiles);
-  hipLaunchKernelGGL(k_project, dim3(project_blocks(b), rows), dim3(kPT), project_lds_bytes(b), st, b, list,
-                     count, w, chunks_of(b));
+  hipLaunchKernelGGL(k_project, dim3(project_grid(b)), dim3(kPT), project_lds_bytes(b), st, b, list, count, w,
+                     chunks_of(b));
   hipLaunchKernelGGL(k_project_slow, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_fix_boxes, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w, chunks_of(b));
   {
@@ -1058,7 +1167,7 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream) {
       hipLaunchKernelGGL(k_prepare, dim3(1, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w, tiles);
       break;
     case R3D_K_PROJECT:
-      hipLaunchKernelGGL(k_project, dim3(project_blocks(*b), b->B), dim3(kPT), project_lds_bytes(*b), st, *b,
+      hipLaunchKernelGGL(k_project, dim3(project_grid(*b)), dim3(kPT), project_lds_bytes(*b), st, *b,
                          w.all_list, w.all_count, w, chunks_of(*b));
       break;
     case R3D_K_ALIVE_WRITE:
