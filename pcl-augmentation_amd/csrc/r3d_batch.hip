@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 
 namespace r3d {
@@ -308,12 +309,26 @@ constexpr int kVirtAreaCap = 4096;           // pixels of a chunk's box that cou
 #define R3D_PROJECT_WAVES
 #endif
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ int box_area_capped(unsigned long long packed, int cols) {
+  const int r0 = (int)(packed & 0xFFFF), r1 = (int)((packed >> 16) & 0xFFFF), c0 = (int)((packed >> 32) & 0xFFFF), c1 = (int)((packed >> 48) & 0xFFFF);
+  const int a = r0 > r1 ? 0 : (r1 - r0 + 1) * (c0 <= c1 ? c1 - c0 + 1 : cols - c0 + c1 + 1);
+  return a > kVirtAreaCap ? kVirtAreaCap : a;
+}
 // The grid is what the device holds at once (project_grid(): CUs x resident workgroups); the tiles of all the scenes of
 // (list, count), counted from their n_total, are dealt out evenly: a workgroup takes tiles [lo, hi) of that sequence, as
 // segments (scene, first tile, last tile) it finds itself with a block scan of the scenes' tile counts.  It stages the
 // column table once and a scene's row table per segment, and its point loads run on across the tiles of a segment (one
 // descriptor per segment, the round's offset in the scalar operand): measured on 256 scenes of 120 000 points, a
 // workgroup's start (tables, scene parameters, the first loads) cost as much as one and a half tiles of work.
+// R3D_PROJECT_BURST (the default; -DR3D_PROJECT_ROLLING for the other): a tile's eight rounds are requested together, a
+// tile ahead of their use, instead of one round per round R3D_PROJECT_AHEAD rounds ahead: 0.142 -> 0.136 ms per 256 scenes
+// (a workgroup's 32 KB arrive at the memory as one run of addresses).
+#if !defined(R3D_PROJECT_ROLLING) && !defined(R3D_PROJECT_BURST)
+#define R3D_PROJECT_BURST
+#endif
+#ifdef R3D_PROJECT_BURST
+#define R3D_PROJECT_AHEAD 8
+#endif
 #ifndef R3D_PROJECT_AHEAD
 #define R3D_PROJECT_AHEAD 4
 #endif
@@ -324,21 +339,30 @@ constexpr int kProjectAhead = R3D_PROJECT_AHEAD;
 static_assert(kPerThread % kProjectAhead == 0, "the rounds' registers rotate with the unrolled tile loop");
 constexpr int kSegCap = 64;                   // tiles of a workgroup's range looked at per pass (segments <= tiles)
 __global__ void __launch_bounds__(kPT) R3D_PROJECT_WAVES
-k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int chunks) {
+k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_count, BatchWs w, int chunks) {
   extern __shared__ __align__(16) float s_tabf[];          // [(cols+1)*2] column edges, [rows*2] row limits
-  __shared__ int s_scan[kPT / 64 + 1], s_seg[kSegCap * 3], s_nseg;
+  __shared__ int s_scan[kPT / 64 + 1], s_seg[kSegCap * 4], s_nseg;
   float2 *s_col = reinterpret_cast<float2 *>(s_tabf), *s_row = s_col + (b.cols + 1);
+#ifdef R3D_EXP_STAMP
+  const unsigned long long stamp0 = wall_clock64();
+  unsigned long long stamp1 = 0;
+#endif
   for (int e = threadIdx.x; e < b.cols + 1; e += kPT) s_col[e] = reinterpret_cast<const float2 *>(w.col_dirf)[e];
-  const int cnt = *count;
+  const int cnt = known_count >= 0 ? known_count : *count;
   const int lane_off = (int)threadIdx.x * 16;
   const int wave_base = __builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63);
   const float row_top = (float)(b.rows - 1), col_top = (float)(b.cols - 1);
-  auto tiles_at = [&](int e) { return e < cnt ? (b.n_total[list[e]] + kTile - 1) / kTile : 0; };
-  int all_tiles;
+  // a launch of up to kPT scenes (the usual one): a scene per thread, one scan, nothing read twice
+  const bool few = cnt <= kPT;
+  int my_s = 0, my_n = 0, my_pre = 0, all_tiles;
   {
     int mine = 0;
-    for (int e = threadIdx.x; e < cnt; e += kPT) mine += tiles_at(e);
-    block_escan_i32(mine, s_scan, all_tiles);
+    if (few) {
+      if ((int)threadIdx.x < cnt) my_s = list[threadIdx.x], my_n = b.n_total[my_s], mine = (my_n + kTile - 1) / kTile;
+    } else {
+      for (int e = threadIdx.x; e < cnt; e += kPT) mine += (b.n_total[list[e]] + kTile - 1) / kTile;
+    }
+    my_pre = block_escan_i32(mine, s_scan, all_tiles);
   }
   const int lo = (int)((long long)blockIdx.x * all_tiles / gridDim.x);
   const int hi = (int)((long long)(blockIdx.x + 1) * all_tiles / gridDim.x);
@@ -346,27 +370,37 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
   const int sub_hi = sub + kSegCap < hi ? sub + kSegCap : hi;
   if (threadIdx.x == 0) s_nseg = 0;
   __syncthreads();
-  for (int base = 0, running = 0; base < cnt && running < sub_hi; base += kPT) {
-    const int e = base + (int)threadIdx.x, t = tiles_at(e);
-    int total;
-    const int pre = running + block_escan_i32(t, s_scan, total);
+  auto offer = [&](int s_e, int n_e, int pre) {               // the part of a scene's tiles [pre, pre + t) inside [sub, sub_hi)
+    const int t = (n_e + kTile - 1) / kTile;
     const int a = pre > sub ? pre : sub, z = pre + t < sub_hi ? pre + t : sub_hi;
     if (a < z) {
       const int g = atomicAdd(&s_nseg, 1);
-      s_seg[3 * g + 0] = e, s_seg[3 * g + 1] = a - pre, s_seg[3 * g + 2] = z - pre;
+      s_seg[4 * g + 0] = s_e, s_seg[4 * g + 1] = n_e, s_seg[4 * g + 2] = a - pre, s_seg[4 * g + 3] = z - pre;
     }
-    running += total;
+  };
+  if (few) {
+    offer(my_s, my_n, my_pre);
+  } else {
+    for (int base = 0, running = 0; base < cnt && running < sub_hi; base += kPT) {
+      const int e = base + (int)threadIdx.x;
+      const int s_e = e < cnt ? list[e] : 0, n_e = e < cnt ? b.n_total[s_e] : 0;
+      int total;
+      const int pre = running + block_escan_i32((n_e + kTile - 1) / kTile, s_scan, total);
+      offer(s_e, n_e, pre);
+      running += total;
+    }
   }
   __syncthreads();
   const int n_seg = __builtin_amdgcn_readfirstlane(s_nseg);
   for (int g = 0; g < n_seg; ++g) {
-    const int s = list[__builtin_amdgcn_readfirstlane(s_seg[3 * g + 0])];
-    const int tile_lo = __builtin_amdgcn_readfirstlane(s_seg[3 * g + 1]), tile_hi = __builtin_amdgcn_readfirstlane(s_seg[3 * g + 2]);
-    const int n = b.n_total[s], n_head = b.n_head[s];
+    const int s = __builtin_amdgcn_readfirstlane(s_seg[4 * g + 0]), n = __builtin_amdgcn_readfirstlane(s_seg[4 * g + 1]);
+    const int tile_lo = __builtin_amdgcn_readfirstlane(s_seg[4 * g + 2]), tile_hi = __builtin_amdgcn_readfirstlane(s_seg[4 * g + 3]);
+    const int n_head = b.n_head[s];
     __syncthreads();                                       // previous scene's row table is no longer read
     {
       const float2 *rq = reinterpret_cast<const float2 *>(w.row_qf) + (int64_t)s * (b.rows + 2);
-      for (int e = threadIdx.x; e < b.rows; e += kPT) s_row[e] = make_float2(rq[e == 0 ? 0 : e + 1].x, rq[e + 2].y);
+      for (int e = threadIdx.x; e < b.rows; e += kPT)          // (+-0.9999: the screen's pole test, folded into the limits)
+        s_row[e] = make_float2(fminf(rq[e == 0 ? 0 : e + 1].x, 0.9999f), fmaxf(rq[e + 2].y, -0.9999f));
     }
     __syncthreads();
     Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
@@ -388,55 +422,35 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
     const __amdgpu_buffer_rsrc_t seg_pix = __builtin_amdgcn_make_buffer_rsrc(
         b.pix + (int64_t)s * b.cap + first, 0, (left < span ? left : span) * 4, 0x00020000);
     // (past the segment's end the loads return zeros: the rounds requested ahead at its last tile)
+#ifdef R3D_EXP_L2
+    auto fetch = [&](int round) { return __builtin_amdgcn_raw_buffer_load_b96(seg_xyzi, lane_off, (round & 7) * kPT * 16, 0); };
+#else
     auto fetch = [&](int round) { return __builtin_amdgcn_raw_buffer_load_b96(seg_xyzi, lane_off, round * kPT * 16, 0); };
+#endif
     u32x3 ahead[kProjectAhead];
 #pragma unroll
     for (int k = 0; k < kProjectAhead; ++k) ahead[k] = fetch(k);
-    for (int tile = tile_lo; tile < tile_hi; ++tile) {
-    const int t0 = tile * kTile, round0 = (tile - tile_lo) * kPerThread;
-#pragma unroll
-    for (int k = 0; k < kPerThread; ++k) {
+    // One round: 256 points, one per lane.  round_any: the general form (lanes past the scene's end, float64 points, the
+    // diagnostic mode).
+    auto round_any = [&](const int t0, const int round0, const int k, const u32x3 pt) {
       const int i = t0 + k * kPT + (int)threadIdx.x;
-      const u32x3 pt = ahead[k % kProjectAhead];
-      ahead[k % kProjectAhead] = fetch(round0 + k + kProjectAhead);
       const float px = __uint_as_float(pt.x), py = __uint_as_float(pt.y), pz = __uint_as_float(pt.z);
       int row = 0, col = 0;
       bool placed = false;
       const bool live = i < n;
       if (live) {
-        // bin guess (a few 1e-7 rad off at worst, a fraction of a per mille of a bin)
         const float ssf = fmaf(px, px, fmaf(py, py, pz * pz));
         float qf = pz * __frsqrt_rn(ssf);
         qf = __builtin_amdgcn_fmed3f(qf, -1.f, 1.f);
-        const float rowf = floorf((guess_acosf(qf) - elo) * inv_del);
-        const float ax = fabsf(px), ay = fabsf(py);
-        const bool steep = ay > ax;
-        const float mx = steep ? ay : ax, mn = steep ? ax : ay;
-        const float t = mn * __builtin_amdgcn_rcpf(mx), t2 = t * t;   // atan on [0, 1], odd polynomial (v_rcp_f32: 1 ulp)
-        float pa = fmaf(-0.0047804345f, t2, 0.024557052f);
-        pa = fmaf(pa, t2, -0.059904616f);
-        pa = fmaf(pa, t2, 0.09942752f);
-        pa = fmaf(pa, t2, -0.14029418f);
-        pa = fmaf(pa, t2, 0.19971375f);
-        pa = fmaf(pa, t2, -0.33332095f);
-        pa = fmaf(pa, t2, 0.99999994f);
-        float az = pa * t;
-        az = steep ? 1.57079637f - az : az;
-        az = px < 0.f ? 3.14159274f - az : az;
-        az = py < 0.f ? -az : az;
-        row = (int)__builtin_amdgcn_fmed3f(rowf, 0.f, row_top);
-        col = (int)__builtin_amdgcn_fmed3f((az + 3.14159274f) * inv_daz, 0.f, col_top);
-        // float32 screen
+        row = (int)floorf((guess_acosf(qf) - elo) * inv_del);
+        col = (int)((guess_atan2f(py, px) + 3.14159274f) * inv_daz);
+        row = max(0, min(row, bn.rows - 1));
+        col = max(0, min(col, bn.cols - 1));
         const float2 ea = s_col[col], eb = s_col[col + 1], rq = s_row[row];
-        const float mcf = 1e-6f * (ax + ay);
-        // (ss up to 249 000: r below 499; beyond, the float64 part below looks at r > 500)
-        int ok = (int)(ssf > 1e-30f) & (int)(ssf <= 249000.f) & (int)(fabsf(qf) < 0.9999f) & (int)(qf < rq.x) &
-                 (int)(qf > rq.y) & (int)(fmaf(ea.x, py, -(ea.y * px)) > mcf) & (int)(fmaf(eb.x, py, -(eb.y * px)) < -mcf) &
-                 (int)(!any64);
+        const float mcf = 1e-6f * (fabsf(px) + fabsf(py));
+        int ok = (int)(ssf > 1e-30f) & (int)(ssf <= 249000.f) & (int)(qf < rq.x) & (int)(qf > rq.y) &
+                 (int)(fmaf(ea.x, py, -(ea.y * px)) > mcf) & (int)(fmaf(eb.x, py, -(eb.y * px)) < -mcf) & (int)(!any64);
         bool far = false;
-#ifdef R3D_EXP_NOCOLD
-        ok = 1;
-#endif
         if (!ok) {                                           // undecided in float32, or r near / above 500
           double x = (double)px, y = (double)py, z = (double)pz;
           if (i >= n_head) load_point(b, s, i, n_head, x, y, z);
@@ -481,16 +495,146 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
       }
       const int i0 = t0 + k * kPT + wave_base;                 // the wave's first point (scalar)
       if (i0 < n) {
-        const int r0 = (int)(packed & 0xFFFF), r1 = (int)((packed >> 16) & 0xFFFF), c0 = (int)((packed >> 32) & 0xFFFF), c1 = (int)((packed >> 48) & 0xFFFF);
-        const int a = r0 > r1 ? 0 : (r1 - r0 + 1) * (c0 <= c1 ? c1 - c0 + 1 : b.cols - c0 + c1 + 1);
-        area += a > kVirtAreaCap ? kVirtAreaCap : a;
+        if ((k & 3) == 0) area += 4 * box_area_capped(packed, b.cols);
         const unsigned long long living = __ballot(live);     // every point of the frame is alive at step 0
         if ((threadIdx.x & 63) == 0) {
           w.chunk_box[(int64_t)s * chunks + (i0 >> 6)] = packed;
           w.alive[(int64_t)s * chunks + (i0 >> 6)] = living;
         }
       }
-    }
+    };
+    // round_whole: every lane has a point and the scene is plain float32.  No "is there a point" mask; the float32 screen
+    // and the test for an ascending run of one row are ONE chain of v_cmpx (each narrows EXEC, none needs a scalar AND;
+    // EXEC is put back inside the statement); everything about the lanes the screen leaves undecided sits behind one
+    // uniform branch.
+    auto round_whole = [&](const int t0, const int round0, const int k, const u32x3 pt) {
+      const float px = __uint_as_float(pt.x), py = __uint_as_float(pt.y), pz = __uint_as_float(pt.z);
+      // bin guess (about 1e-5 rad off at worst, a few per mille of a bin)
+      const float ssf = fmaf(px, px, fmaf(py, py, pz * pz));
+      float qf = pz * __frsqrt_rn(ssf);
+      qf = __builtin_amdgcn_fmed3f(qf, -1.f, 1.f);
+      const float rowf = floorf((guess_acosf(qf) - elo) * inv_del);
+      const float ax = fabsf(px), ay = fabsf(py);
+      const bool steep = ay > ax;                              // octant by selects (fmax / fmin canonicalise their operands first)
+      const float mx = steep ? ay : ax, mn = steep ? ax : ay;
+      const float t = mn * __builtin_amdgcn_rcpf(mx), t2 = t * t;   // atan on [0, 1], odd polynomial (v_rcp_f32: 1 ulp)
+      float pa = fmaf(-0.01172120f, t2, 0.05265332f);
+      pa = fmaf(pa, t2, -0.11643287f);
+      pa = fmaf(pa, t2, 0.19354346f);
+      pa = fmaf(pa, t2, -0.33262347f);
+      pa = fmaf(pa, t2, 0.99997726f);
+      float az = pa * t;
+      az = steep ? 1.57079637f - az : az;
+      az = px < 0.f ? 3.14159274f - az : az;
+      az = py < 0.f ? -az : az;
+      const int row = (int)__builtin_amdgcn_fmed3f(rowf, 0.f, row_top);
+      const int col = (int)__builtin_amdgcn_fmed3f((az + 3.14159274f) * inv_daz, 0.f, col_top);
+      const float2 ea = s_col[col], eb = s_col[col + 1], rq = s_row[row];
+      const float mcf = 1e-6f * (ax + ay);
+      const float c1 = fmaf(ea.x, py, -(ea.y * px)), c2 = fmaf(eb.x, py, -(eb.y * px));
+      const int before = __builtin_amdgcn_update_dpp(col, col, 0x138, 0xF, 0xF, false);   // wave_shr:1; lane 0 keeps its own
+      const int row0 = __builtin_amdgcn_readfirstlane(row);
+      // (ss up to 249 000: r below 499; the row limits in LDS stay within +-0.9999: the pole test)
+      unsigned long long ok_mask, run_mask, saved;
+      asm volatile("s_mov_b64 %[sv], exec\n\t"
+                   "v_cmpx_lt_f32_e32 vcc, 0x0da24260, %[ss]\n\t"          // 1e-30 < ss
+                   "v_cmpx_ge_f32_e32 vcc, 0x48732a00, %[ss]\n\t"          // 249 000 >= ss
+                   "v_cmpx_gt_f32_e32 vcc, %[hi], %[q]\n\t"
+                   "v_cmpx_lt_f32_e32 vcc, %[lo], %[q]\n\t"
+                   "v_cmpx_gt_f32_e32 vcc, %[c1], %[m]\n\t"
+                   "v_cmpx_lt_f32_e64 vcc, %[c2], -%[m]\n\t"
+                   "s_mov_b64 %[ok], exec\n\t"
+                   "v_cmpx_eq_u32_e32 vcc, %[row0], %[row]\n\t"
+                   "v_cmpx_le_i32_e32 vcc, %[bef], %[col]\n\t"
+                   "s_mov_b64 %[run], exec\n\t"
+                   "s_mov_b64 exec, %[sv]\n\t"
+                   "s_nop 2"                                             // (a DPP operation may follow: 5 states after the last v_cmpx)
+                   : [ok] "=&s"(ok_mask), [run] "=&s"(run_mask), [sv] "=&s"(saved)
+                   : [ss] "v"(ssf), [q] "v"(qf), [hi] "v"(rq.x), [lo] "v"(rq.y), [c1] "v"(c1), [c2] "v"(c2), [m] "v"(mcf),
+                     [row0] "s"(row0), [row] "v"(row), [bef] "v"(before), [col] "v"(col)
+                   : "vcc");
+      const int p = (int)pack_pix(row, col);
+      unsigned long long packed, placed_mask = ~0ull;
+      if (ok_mask == ~0ull) {
+#ifndef R3D_EXP_NOSTORE
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned int)p, seg_pix, lane_off >> 2, (round0 + k) * kPT * 4, 0);
+#endif
+      } else {                                                 // some lane undecided in float32, or r near / above 500
+        bool ok = __builtin_amdgcn_inverse_ballot_w64(ok_mask), far = false;
+        if (!ok) {
+          const double x = (double)px, y = (double)py, z = (double)pz, ss = x * x + y * y + z * z;
+          ok = confirm_bin(row_cc, w.col_dir, row, col, x, y, z, ss);
+          far = ss > R3D_EMPTY_DEPTH * R3D_EMPTY_DEPTH;        // r > 500 (or rounds to it): far list
+        }
+        if (ok) {
+          if (far) {
+            int f = atomicAdd(&b.n_far[s], 1);
+            if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
+            else flags |= R3D_S_FAR_OVERFLOW;
+          }
+          __builtin_amdgcn_raw_buffer_store_b32((unsigned int)p, seg_pix, lane_off >> 2, (round0 + k) * kPT * 4, 0);
+        } else {
+          queue[atomicAdd(&w.n_slow[s], 1)] = (uint32_t)(t0 + k * kPT + (int)threadIdx.x);
+        }
+        placed_mask = __ballot(ok);
+      }
+      if (run_mask == ~0ull) {                                 // (all decided by the screen, one row, columns ascending)
+        packed = pack_box(row0, row0, __builtin_amdgcn_readfirstlane(col), __builtin_amdgcn_readlane(col, 63));
+      } else {
+        const bool placed = __builtin_amdgcn_inverse_ballot_w64(placed_mask);
+        BoxAcc box;
+        if (placed) {
+          box.add(row, col);
+        } else {                                               // unknown pixel (queued for k_project_slow): the chunk's
+          box.add(0, 0);                                       // box covers the whole image until k_fix_boxes
+          box.add(b.rows - 1, b.cols - 1);
+        }
+        packed = placed_mask != ~0ull ? box.wave_pack() : box.wave_pack_arc(col, b.cols);
+      }
+      // the boxes' areas (k_virt_hist: is this a scene whose points come in no file order?): every fourth round's
+      if ((k & 3) == 0) area += 4 * box_area_capped(packed, b.cols);
+      if ((threadIdx.x & 63) == 0) {
+        const int c = (t0 + k * kPT + wave_base) >> 6;
+        w.chunk_box[(int64_t)s * chunks + c] = packed;
+        w.alive[(int64_t)s * chunks + c] = ~0ull;              // every point of the frame is alive at step 0
+      }
+    };
+    const bool plain = !any64 && !exact;
+#ifdef R3D_EXP_STAMP
+    if (!stamp1) stamp1 = wall_clock64();
+#endif
+#ifdef R3D_PROJECT_BURST
+    u32x3 nxt[kPerThread];
+#endif
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+      const int t0 = tile * kTile, round0 = (tile - tile_lo) * kPerThread;
+#ifdef R3D_PROJECT_BURST
+#pragma unroll
+      for (int k = 0; k < kPerThread; ++k) nxt[k] = fetch(round0 + kPerThread + k);
+#define R3D_NEXT_ROUND(k) const u32x3 pt = ahead[k];
+#else
+#define R3D_NEXT_ROUND(k)                        \
+  const u32x3 pt = ahead[k % kProjectAhead]; \
+  ahead[k % kProjectAhead] = fetch(round0 + k + kProjectAhead);
+#endif
+      if (plain && t0 + kTile <= n) {
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+          R3D_NEXT_ROUND(k)
+          round_whole(t0, round0, k, pt);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+          R3D_NEXT_ROUND(k)
+          round_any(t0, round0, k, pt);
+        }
+      }
+#undef R3D_NEXT_ROUND
+#ifdef R3D_PROJECT_BURST
+#pragma unroll
+      for (int k = 0; k < kPerThread; ++k) ahead[k] = nxt[k];
+#endif
     }
     flags = wave_or_i32(flags);
     if ((threadIdx.x & 63) == 0 && flags) atomicOr(&b.status[s], flags);
@@ -498,6 +642,16 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, i
     if ((threadIdx.x & 63) == 0 && area) atomicAdd(&w.box_area[s], area);
   }
   }
+#ifdef R3D_EXP_STAMP
+  if (threadIdx.x == 0) {
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(b.out_xyzi) + (size_t)blockIdx.x * 4;
+    unsigned int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned int hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    o[0] = stamp0, o[1] = stamp1, o[2] = wall_clock64(), o[3] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
 }
 
 // The reference formula (insertion.py:74-76, :104-116) for the points k_project could not confirm:
@@ -1053,8 +1207,9 @@ static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_
   hipLaunchKernelGGL(k_bounds_sample, dim3((tiles + kPT / 64 - 1) / (kPT / 64), rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_bounds, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_prepare, dim3(1, rows), dim3(kPT), 0, st, b, list, count, w, tiles);
-  hipLaunchKernelGGL(k_project, dim3(project_grid(b)), dim3(kPT), project_lds_bytes(b), st, b, list, count, w,
-                     chunks_of(b));
+  // (known_count: the list is all_list of a batch that has just begun -- its count is B, no need to wait for the word)
+  hipLaunchKernelGGL(k_project, dim3(project_grid(b)), dim3(kPT), project_lds_bytes(b), st, b, list, count,
+                     list == w.all_list ? b.B : -1, w, chunks_of(b));
   hipLaunchKernelGGL(k_project_slow, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_fix_boxes, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w, chunks_of(b));
   {
@@ -1168,7 +1323,7 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream) {
       break;
     case R3D_K_PROJECT:
       hipLaunchKernelGGL(k_project, dim3(project_grid(*b)), dim3(kPT), project_lds_bytes(*b), st, *b,
-                         w.all_list, w.all_count, w, chunks_of(*b));
+                         w.all_list, w.all_count, b->B, w, chunks_of(*b));
       break;
     case R3D_K_ALIVE_WRITE:
       return launch_compact(*b, w, w.all_list, w.all_count, b->B, st);
