@@ -314,53 +314,45 @@ __device__ __forceinline__ int box_area_capped(unsigned long long packed, int co
   const int a = r0 > r1 ? 0 : (r1 - r0 + 1) * (c0 <= c1 ? c1 - c0 + 1 : cols - c0 + c1 + 1);
   return a > kVirtAreaCap ? kVirtAreaCap : a;
 }
-// The grid is what the device holds at once (project_grid(): CUs x resident workgroups); the tiles of all the scenes of
-// (list, count), counted from their n_total, are dealt out evenly: a workgroup takes tiles [lo, hi) of that sequence, as
-// segments (scene, first tile, last tile) it finds itself with a block scan of the scenes' tile counts.  It stages the
-// column table once and a scene's row table per segment, and its point loads run on across the tiles of a segment (one
-// descriptor per segment, the round's offset in the scalar operand): measured on 256 scenes of 120 000 points, a
-// workgroup's start (tables, scene parameters, the first loads) cost as much as one and a half tiles of work.
-// R3D_PROJECT_BURST (the default; -DR3D_PROJECT_ROLLING for the other): a tile's eight rounds are requested together, a
-// tile ahead of their use, instead of one round per round R3D_PROJECT_AHEAD rounds ahead: 0.142 -> 0.136 ms per 256 scenes
-// (a workgroup's 32 KB arrive at the memory as one run of addresses).
-#if !defined(R3D_PROJECT_ROLLING) && !defined(R3D_PROJECT_BURST)
-#define R3D_PROJECT_BURST
-#endif
-#ifdef R3D_PROJECT_BURST
-#define R3D_PROJECT_AHEAD 8
-#endif
-#ifndef R3D_PROJECT_AHEAD
-#define R3D_PROJECT_AHEAD 4
-#endif
-// Rounds (256 points) requested ahead of their use.  What is in flight bounds the rate: with two rounds, 1 536 resident
-// workgroups had 12.6 MB under way -- at the ~3.7 us a load takes here that is 3.4 TB/s, the rate the kernel ran at
-// whatever its instruction count.
-constexpr int kProjectAhead = R3D_PROJECT_AHEAD;
-static_assert(kPerThread % kProjectAhead == 0, "the rounds' registers rotate with the unrolled tile loop");
-constexpr int kSegCap = 64;                   // tiles of a workgroup's range looked at per pass (segments <= tiles)
-__global__ void __launch_bounds__(kPT) R3D_PROJECT_WAVES
+// The grid is what the device holds at once (project_grid(): one workgroup of 1 024 threads per CU); the scenes of (list,
+// count) are cut into units of 512 consecutive points, counted from their n_total, and the units are dealt out evenly: a
+// workgroup takes units [lo, hi) of that sequence, as segments (scene, first unit, last unit) it finds itself with a block
+// scan of the scenes' unit counts.  It stages the column table once and a scene's row table per segment; inside a segment
+// its sixteen waves take the units one at a time from a counter in LDS and need no barrier: a wave's eight rounds of 64
+// points are its own (chunk boxes and alive words are per 64 points).  Measured on 256 scenes of 120 000 points:
+//   * a workgroup's start (tables, scene parameters, first loads) costs 6-10 us -- as much as a tile of 2 048 points took
+//     when every 4 tiles had a workgroup of their own (0.170 ms per launch; 1 / 2 / 8 tiles: 0.297 / 0.199 / 0.182);
+//   * four persistent workgroups of 256 threads per CU with equal shares ended 97 / 106 / 115 / 125 us after the launch,
+//     in the order the CU had received them (the older waves are served first): 0.137-0.143 ms; the waves of ONE
+//     workgroup sharing the CU's range end together;
+//   * what is in flight bounds the rate of a load-per-round scheme (two rounds ahead: 12.6 MB under way); a unit's eight
+//     rounds are requested together, a unit ahead of their use (one descriptor per segment, the round's offset in the
+//     scalar operand, past the segment's end zeros).
+constexpr int kSegCap = 256;                  // units of a workgroup's range looked at per pass (segments <= units)
+constexpr int kProjNT = 1024;                 // one workgroup per CU: its sixteen waves share the work of the CU's range
+constexpr int kUnit = 64 * kPerThread;        // points a wave takes at a time: eight rounds of 64 consecutive points
+__global__ void __launch_bounds__(kProjNT) R3D_PROJECT_WAVES
 k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_count, BatchWs w, int chunks) {
   extern __shared__ __align__(16) float s_tabf[];          // [(cols+1)*2] column edges, [rows*2] row limits
-  __shared__ int s_scan[kPT / 64 + 1], s_seg[kSegCap * 4], s_nseg;
+  __shared__ int s_scan[kProjNT / 64 + 1], s_seg[kSegCap * 4], s_nseg, s_next;
   float2 *s_col = reinterpret_cast<float2 *>(s_tabf), *s_row = s_col + (b.cols + 1);
 #ifdef R3D_EXP_STAMP
   const unsigned long long stamp0 = wall_clock64();
   unsigned long long stamp1 = 0;
 #endif
-  for (int e = threadIdx.x; e < b.cols + 1; e += kPT) s_col[e] = reinterpret_cast<const float2 *>(w.col_dirf)[e];
+  for (int e = threadIdx.x; e < b.cols + 1; e += kProjNT) s_col[e] = reinterpret_cast<const float2 *>(w.col_dirf)[e];
   const int cnt = known_count >= 0 ? known_count : *count;
-  const int lane_off = (int)threadIdx.x * 16;
-  const int wave_base = __builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63);
+  const int lane = (int)threadIdx.x & 63, lane_off = lane * 16;
   const float row_top = (float)(b.rows - 1), col_top = (float)(b.cols - 1);
-  // a launch of up to kPT scenes (the usual one): a scene per thread, one scan, nothing read twice
-  const bool few = cnt <= kPT;
+  // a launch of up to kProjNT scenes (the usual one): a scene per thread, one scan, nothing read twice
+  const bool few = cnt <= kProjNT;
   int my_s = 0, my_n = 0, my_pre = 0, all_tiles;
   {
     int mine = 0;
     if (few) {
-      if ((int)threadIdx.x < cnt) my_s = list[threadIdx.x], my_n = b.n_total[my_s], mine = (my_n + kTile - 1) / kTile;
+      if ((int)threadIdx.x < cnt) my_s = list[threadIdx.x], my_n = b.n_total[my_s], mine = (my_n + kUnit - 1) / kUnit;
     } else {
-      for (int e = threadIdx.x; e < cnt; e += kPT) mine += (b.n_total[list[e]] + kTile - 1) / kTile;
+      for (int e = threadIdx.x; e < cnt; e += kProjNT) mine += (b.n_total[list[e]] + kUnit - 1) / kUnit;
     }
     my_pre = block_escan_i32(mine, s_scan, all_tiles);
   }
@@ -371,7 +363,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
   if (threadIdx.x == 0) s_nseg = 0;
   __syncthreads();
   auto offer = [&](int s_e, int n_e, int pre) {               // the part of a scene's tiles [pre, pre + t) inside [sub, sub_hi)
-    const int t = (n_e + kTile - 1) / kTile;
+    const int t = (n_e + kUnit - 1) / kUnit;
     const int a = pre > sub ? pre : sub, z = pre + t < sub_hi ? pre + t : sub_hi;
     if (a < z) {
       const int g = atomicAdd(&s_nseg, 1);
@@ -381,11 +373,11 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
   if (few) {
     offer(my_s, my_n, my_pre);
   } else {
-    for (int base = 0, running = 0; base < cnt && running < sub_hi; base += kPT) {
+    for (int base = 0, running = 0; base < cnt && running < sub_hi; base += kProjNT) {
       const int e = base + (int)threadIdx.x;
       const int s_e = e < cnt ? list[e] : 0, n_e = e < cnt ? b.n_total[s_e] : 0;
       int total;
-      const int pre = running + block_escan_i32((n_e + kTile - 1) / kTile, s_scan, total);
+      const int pre = running + block_escan_i32((n_e + kUnit - 1) / kUnit, s_scan, total);
       offer(s_e, n_e, pre);
       running += total;
     }
@@ -399,8 +391,9 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
     __syncthreads();                                       // previous scene's row table is no longer read
     {
       const float2 *rq = reinterpret_cast<const float2 *>(w.row_qf) + (int64_t)s * (b.rows + 2);
-      for (int e = threadIdx.x; e < b.rows; e += kPT)          // (+-0.9999: the screen's pole test, folded into the limits)
+      for (int e = threadIdx.x; e < b.rows; e += kProjNT)      // (+-0.9999: the screen's pole test, folded into the limits)
         s_row[e] = make_float2(fminf(rq[e == 0 ? 0 : e + 1].x, 0.9999f), fmaxf(rq[e + 2].y, -0.9999f));
+      if (threadIdx.x == 0) s_next = tile_lo;                  // the segment's units, taken by the waves one at a time
     }
     __syncthreads();
     Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
@@ -413,27 +406,23 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
     const double *row_cc = w.row_q + (int64_t)s * (b.rows + 2);
     uint32_t *queue = w.cand + (int64_t)s * w.cand_stride;  // insert scratch, free during step 0
     int flags = 0, area = 0;
-    // 8 points per thread and tile; unconfirmed points are queued for k_project_slow.  A block walks
-    // several tiles so that the tables are staged once.  Points are requested kProjectAhead rounds ahead of their use.
+    // unconfirmed points are queued for k_project_slow
     const float *scene_xyzi = b.xyzi + (int64_t)s * b.cap * 4;   // (the slab holds the float32 rounding of float64 points)
-    const int first = tile_lo * kTile, left = n - first, span = (tile_hi - tile_lo) * kTile;
+    const int first = tile_lo * kUnit, left = n - first, span = (tile_hi - tile_lo) * kUnit;
     const __amdgpu_buffer_rsrc_t seg_xyzi = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(scene_xyzi + (int64_t)first * 4), 0, (left < span ? left : span) * 16, 0x00020000);
     const __amdgpu_buffer_rsrc_t seg_pix = __builtin_amdgcn_make_buffer_rsrc(
         b.pix + (int64_t)s * b.cap + first, 0, (left < span ? left : span) * 4, 0x00020000);
     // (past the segment's end the loads return zeros: the rounds requested ahead at its last tile)
 #ifdef R3D_EXP_L2
-    auto fetch = [&](int round) { return __builtin_amdgcn_raw_buffer_load_b96(seg_xyzi, lane_off, (round & 7) * kPT * 16, 0); };
+    auto fetch = [&](int round) { return __builtin_amdgcn_raw_buffer_load_b96(seg_xyzi, lane_off, (round & 7) * 1024, 0); };
 #else
-    auto fetch = [&](int round) { return __builtin_amdgcn_raw_buffer_load_b96(seg_xyzi, lane_off, round * kPT * 16, 0); };
+    auto fetch = [&](int round) { return __builtin_amdgcn_raw_buffer_load_b96(seg_xyzi, lane_off, round * 1024, 0); };
 #endif
-    u32x3 ahead[kProjectAhead];
-#pragma unroll
-    for (int k = 0; k < kProjectAhead; ++k) ahead[k] = fetch(k);
     // One round: 256 points, one per lane.  round_any: the general form (lanes past the scene's end, float64 points, the
     // diagnostic mode).
     auto round_any = [&](const int t0, const int round0, const int k, const u32x3 pt) {
-      const int i = t0 + k * kPT + (int)threadIdx.x;
+      const int i = t0 + k * 64 + lane;
       const float px = __uint_as_float(pt.x), py = __uint_as_float(pt.y), pz = __uint_as_float(pt.z);
       int row = 0, col = 0;
       bool placed = false;
@@ -466,7 +455,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
             if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
             else flags |= R3D_S_FAR_OVERFLOW;
           }
-          __builtin_amdgcn_raw_buffer_store_b32((unsigned int)p, seg_pix, lane_off >> 2, (round0 + k) * kPT * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b32((unsigned int)p, seg_pix, lane_off >> 2, (round0 + k) * 256, 0);
         } else {
           queue[atomicAdd(&w.n_slow[s], 1)] = (uint32_t)i;
         }
@@ -493,7 +482,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
           packed = __ballot(live & !placed) ? box.wave_pack() : box.wave_pack_arc(placed ? col : -1, b.cols);
         }
       }
-      const int i0 = t0 + k * kPT + wave_base;                 // the wave's first point (scalar)
+      const int i0 = t0 + k * 64;                              // the wave's first point (scalar)
       if (i0 < n) {
         if ((k & 3) == 0) area += 4 * box_area_capped(packed, b.cols);
         const unsigned long long living = __ballot(live);     // every point of the frame is alive at step 0
@@ -557,7 +546,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
       unsigned long long packed, placed_mask = ~0ull;
       if (ok_mask == ~0ull) {
 #ifndef R3D_EXP_NOSTORE
-        __builtin_amdgcn_raw_buffer_store_b32((unsigned int)p, seg_pix, lane_off >> 2, (round0 + k) * kPT * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned int)p, seg_pix, lane_off >> 2, (round0 + k) * 256, 0);
 #endif
       } else {                                                 // some lane undecided in float32, or r near / above 500
         bool ok = __builtin_amdgcn_inverse_ballot_w64(ok_mask), far = false;
@@ -572,9 +561,9 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
             if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
             else flags |= R3D_S_FAR_OVERFLOW;
           }
-          __builtin_amdgcn_raw_buffer_store_b32((unsigned int)p, seg_pix, lane_off >> 2, (round0 + k) * kPT * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b32((unsigned int)p, seg_pix, lane_off >> 2, (round0 + k) * 256, 0);
         } else {
-          queue[atomicAdd(&w.n_slow[s], 1)] = (uint32_t)(t0 + k * kPT + (int)threadIdx.x);
+          queue[atomicAdd(&w.n_slow[s], 1)] = (uint32_t)(t0 + k * 64 + lane);
         }
         placed_mask = __ballot(ok);
       }
@@ -594,7 +583,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
       // the boxes' areas (k_virt_hist: is this a scene whose points come in no file order?): every fourth round's
       if ((k & 3) == 0) area += 4 * box_area_capped(packed, b.cols);
       if ((threadIdx.x & 63) == 0) {
-        const int c = (t0 + k * kPT + wave_base) >> 6;
+        const int c = (t0 >> 6) + k;
         w.chunk_box[(int64_t)s * chunks + c] = packed;
         w.alive[(int64_t)s * chunks + c] = ~0ull;              // every point of the frame is alive at step 0
       }
@@ -603,38 +592,37 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
 #ifdef R3D_EXP_STAMP
     if (!stamp1) stamp1 = wall_clock64();
 #endif
-#ifdef R3D_PROJECT_BURST
-    u32x3 nxt[kPerThread];
-#endif
-    for (int tile = tile_lo; tile < tile_hi; ++tile) {
-      const int t0 = tile * kTile, round0 = (tile - tile_lo) * kPerThread;
-#ifdef R3D_PROJECT_BURST
+    // A wave takes the segment's units one at a time from the counter in LDS (the sixteen waves of the CU finish together:
+    // four workgroups of 256 threads with their own ranges ended 97 / 106 / 115 / 125 us after the launch, in the order
+    // the CU had received them -- the older waves are served first); the next unit is taken, and its eight rounds are
+    // requested, before the current one is worked on.
+    auto claim = [&]() {
+      int u = 0;
+      if (lane == 0) u = atomicAdd(&s_next, 1);
+      return __builtin_amdgcn_readfirstlane(u);
+    };
+    int unit = claim();
+    if (unit < tile_hi) {
+      u32x3 cur[kPerThread], nxt[kPerThread];
 #pragma unroll
-      for (int k = 0; k < kPerThread; ++k) nxt[k] = fetch(round0 + kPerThread + k);
-#define R3D_NEXT_ROUND(k) const u32x3 pt = ahead[k];
-#else
-#define R3D_NEXT_ROUND(k)                        \
-  const u32x3 pt = ahead[k % kProjectAhead]; \
-  ahead[k % kProjectAhead] = fetch(round0 + k + kProjectAhead);
-#endif
-      if (plain && t0 + kTile <= n) {
+      for (int k = 0; k < kPerThread; ++k) cur[k] = fetch((unit - tile_lo) * kPerThread + k);
+      while (unit < tile_hi) {
+        const int unit_next = claim();
+        // (past the segment's end the loads return zeros)
 #pragma unroll
-        for (int k = 0; k < kPerThread; ++k) {
-          R3D_NEXT_ROUND(k)
-          round_whole(t0, round0, k, pt);
+        for (int k = 0; k < kPerThread; ++k) nxt[k] = fetch((unit_next - tile_lo) * kPerThread + k);
+        const int t0 = unit * kUnit, round0 = (unit - tile_lo) * kPerThread;
+        if (plain && t0 + kUnit <= n) {
+#pragma unroll
+          for (int k = 0; k < kPerThread; ++k) round_whole(t0, round0, k, cur[k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < kPerThread; ++k) round_any(t0, round0, k, cur[k]);
         }
-      } else {
 #pragma unroll
-        for (int k = 0; k < kPerThread; ++k) {
-          R3D_NEXT_ROUND(k)
-          round_any(t0, round0, k, pt);
-        }
+        for (int k = 0; k < kPerThread; ++k) cur[k] = nxt[k];
+        unit = unit_next;
       }
-#undef R3D_NEXT_ROUND
-#ifdef R3D_PROJECT_BURST
-#pragma unroll
-      for (int k = 0; k < kPerThread; ++k) ahead[k] = nxt[k];
-#endif
     }
     flags = wave_or_i32(flags);
     if ((threadIdx.x & 63) == 0 && flags) atomicOr(&b.status[s], flags);
@@ -1190,13 +1178,13 @@ static int project_grid(const r3d_batch_t &b) {
     if (it == known.end()) {
       int cus = 0, per_cu = 0;
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_project, kPT, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_project, kProjNT, lds) != hipSuccess || per_cu <= 0) per_cu = 1;
       if (per_cu_env) per_cu = per_cu_env;
       it = known.emplace(std::make_pair(dev, lds), cus * per_cu).first;
     }
     resident = it->second;
   }
-  const long long most = (long long)b.B * tiles_of(b);
+  const long long most = (long long)b.B * ((b.cap + kUnit - 1) / kUnit);
   return (int)(most < resident ? (most > 0 ? most : 1) : resident);
 }
 
@@ -1208,7 +1196,7 @@ static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_
   hipLaunchKernelGGL(k_bounds, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_prepare, dim3(1, rows), dim3(kPT), 0, st, b, list, count, w, tiles);
   // (known_count: the list is all_list of a batch that has just begun -- its count is B, no need to wait for the word)
-  hipLaunchKernelGGL(k_project, dim3(project_grid(b)), dim3(kPT), project_lds_bytes(b), st, b, list, count,
+  hipLaunchKernelGGL(k_project, dim3(project_grid(b)), dim3(kProjNT), project_lds_bytes(b), st, b, list, count,
                      list == w.all_list ? b.B : -1, w, chunks_of(b));
   hipLaunchKernelGGL(k_project_slow, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_fix_boxes, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w, chunks_of(b));
@@ -1322,7 +1310,7 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream) {
       hipLaunchKernelGGL(k_prepare, dim3(1, b->B), dim3(kPT), 0, st, *b, w.all_list, w.all_count, w, tiles);
       break;
     case R3D_K_PROJECT:
-      hipLaunchKernelGGL(k_project, dim3(project_grid(*b)), dim3(kPT), project_lds_bytes(*b), st, *b,
+      hipLaunchKernelGGL(k_project, dim3(project_grid(*b)), dim3(kProjNT), project_lds_bytes(*b), st, *b,
                          w.all_list, w.all_count, b->B, w, chunks_of(*b));
       break;
     case R3D_K_ALIVE_WRITE:

@@ -80,6 +80,7 @@ constexpr int kDbgBands = 4;         // the depth tile in bands of at most 3 can
 constexpr int kDbgDefer = 8;         // every pair is left to k_insert_big
 constexpr int kDbgDropPublish = 16;  // slot 0 of scene 0 does not publish: its successors time out
 constexpr int kDbgPoolTile = 32;     // every pair's depth tile and candidate list in the global pool
+constexpr int kDbgNoPoolTile = 8192; // a depth tile beyond the LDS in row bands in LDS, never in the pool (R3D_TILE_BANDS=1)
 constexpr int kDbgNoHits = 128;      // the kill masks from the pixel ids in global memory for every chunk (no hits kept in LDS)
 constexpr int kDbgCount = 4096;      // count per pair (D_PAIRS .. D_TAKEOVER_COMMIT): two to four atomics of every pair on the same few
                                      // addresses, on the chain's critical path -- only when somebody wants to read them (bench.py's
@@ -1224,7 +1225,7 @@ struct Ins {
     g_dtile = nullptr;
     g_cand = nullptr;
     // (round 5, measured on config C5: such tiles in row bands in LDS instead -- 30.1 against 5.07 ms per launch)
-    if (!single && !(b.reserved & kDbgBands) && pool_off != -2) {
+    if (!single && !(b.reserved & (kDbgBands | kDbgNoPoolTile)) && pool_off != -2) {
       if (pool_off == -1) {
         pool_off = pool_take((((long long)dt.npx * 8 + 255) & ~255ll) + (long long)ncand * 4);
         if (pool_off < 0) pool_off = -2;
@@ -2565,6 +2566,8 @@ static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlo
   }
   ChainArgs args;
   args.b = b;
+  static const int tile_bands = env_int("R3D_TILE_BANDS", 0);
+  if (tile_bands) args.b.reserved |= kDbgNoPoolTile;
   args.slots = sl;
   args.w = w;
   args.nk = nk, args.first_step = first_step, args.chunks = chunks_of(b), args.lds_cap = lds, args.B8 = B8, args.queue_mode = queue_mode;

@@ -29,3 +29,13 @@ cu = (hw >> 8) & 0xF; se = (hw >> 13) & 0x7; sh = (hw >> 12) & 1
 key = xcc * 1000 + se * 100 + sh * 20 + cu
 u, c = np.unique(key, return_counts=True)
 print("workgroups per CU: ", np.bincount(c))
+# do the four workgroups of a CU end together (a slow CU) or apart (slow tiles)?
+spread_in_cu = np.array([en[key == k].max() - en[key == k].min() for k in u])
+mean_of_cu = np.array([en[key == k].mean() for k in u])
+print(f"end spread inside a CU: p50 {np.percentile(spread_in_cu,50):.1f} p90 {np.percentile(spread_in_cu,90):.1f} us; CU means: p10 {np.percentile(mean_of_cu,10):.1f} "
+      f"p50 {np.percentile(mean_of_cu,50):.1f} p90 {np.percentile(mean_of_cu,90):.1f} max {mean_of_cu.max():.1f} us")
+order = np.argsort(raw[:, 0] * 0 + np.arange(len(raw)))          # workgroup index = position in the tile sequence
+blk = np.arange(len(raw))
+for lo in range(0, len(raw), len(raw) // 8):
+    m = (blk >= lo) & (blk < lo + len(raw) // 8)
+    print(f"workgroups {lo:4d}..{lo + len(raw) // 8 - 1:4d} (consecutive tiles): life mean {(en - st)[m].mean():6.1f} us")
