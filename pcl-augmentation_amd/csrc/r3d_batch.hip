@@ -297,9 +297,9 @@ __global__ void k_col_table(r3d_batch_t b, BatchWs w) {
 //         and |z| < 71 * hypot(x, y) away from the poles.
 //   ss must be a normal float32 far from overflow / flush-to-zero (1e-30 < ss < 1e30).
 constexpr int kVirtAreaCap = 4096;           // pixels of a chunk's box that count towards box_area (k_virt_hist)
-// The kernel is bound by its vector instructions (profiles/r05_sq.csv), so the per-point code is counted in them:
-//   * the points come through a buffer descriptor per tile (base = the tile's first point, records = what is left of the
-//     scene): the lane's offset is a constant, the round's a scalar, past the end reads zeros -- no address arithmetic;
+// The per-point code, counted in vector instructions (round 4: 141 per 64 points; now 69 on the usual path):
+//   * the points come through a buffer descriptor per segment (base = the segment's first point, records = what is left
+//     of the scene): the lane's offset is a constant, the round's a scalar, past the end reads zeros -- no address arithmetic;
 //   * angle guesses and clamps in float32 (v_med3 before the conversion), octant by selects (no fmax / fmin: those
 //     canonicalise their operands first);
 //   * the row limits of a bin side by side in LDS ({upper, lower} at the row's index: one read, no select for row 0);
