@@ -37,7 +37,7 @@ extern "C" {
 #endif
 
 #define R3D_VERSION 0x00020004   /* 2.4: R3D_MAX_SAMPLE 65 535; R3D_B_FILE_ORDER, r3d_batch_export_pix, r3d_batch_point_order (clouds in no
-                                  * file order are numbered anew internally); r3d_host_write_delta_frames; r3d_batch_debug_counters
+                                  * file order are numbered anew internally); r3d_host_write_delta_frames, r3d_host_append_text_files; r3d_batch_debug_counters
                                   * holds 64 values; R3D_S_CHAIN_TIMEOUT now means "a scene's chain was left unfinished" (no slot
                                   * waits for another any more); the workspace of a batch grew (r3d_batch_workspace_bytes);
                                   * 2.3: min_points < 0 (the state a rejected candidate leaves), r3d_batch_adopt_rejected; 2.2: r3d_batch_t.pix / far_pix
@@ -501,6 +501,12 @@ int r3d_host_write_delta_frames(const char *const *velodyne_paths, const char *c
                                 int32_t B, const float *in_xyzi, const uint32_t *in_label, int64_t cap, const uint64_t *alive,
                                 int64_t chunks, const float *tail_xyzi, const uint32_t *tail_label, int64_t tail_stride,
                                 const int32_t *counts, int32_t check_cols, int32_t *n_out, int32_t threads);
+
+/* HOST: object_detection/Real3DAug/tools/datasets.py:20-37 (create_annotation, called by save_data :81-84) for the n frames
+ * of a batch: dst[i] = the bytes of the frame's label_2 file src[i] followed by extra[i] (the lines of the inserted objects,
+ * one zero-terminated string per frame; NULL adds nothing), written to dst[i].tmp and renamed.  A NULL dst[i] is skipped. */
+int r3d_host_append_text_files(const char *const *src, const char *const *dst, const char *const *extra, int32_t n,
+                               int32_t threads);
 
 #ifdef __cplusplus
 }

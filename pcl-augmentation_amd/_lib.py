@@ -127,6 +127,7 @@ _SIGNATURES = {
     "r3d_host_write_frames": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P, C.c_int32]),
     "r3d_host_write_delta_frames": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int32, _P,
                                               C.c_int32]),
+    "r3d_host_append_text_files": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32]),
     "r3d_batch_export_delta": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P, C.c_int64, _P, _P]),
     "r3d_host_merge_frames": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int32, _P, _P, C.c_int64, _P, _P,
                                         C.c_int64, C.c_int32, C.c_int32]),

@@ -483,4 +483,55 @@ int r3d_host_write_delta_frames(const char *const *velodyne_paths, const char *c
   return R3D_OK;
 }
 
+
+// OD tools/datasets.py:20-37 (create_annotation) for the frames of a batch: dst[i] = the bytes of src[i] followed by extra[i]
+// (the lines of the inserted objects), written to dst[i].tmp and renamed.  A null dst[i] is skipped, a null extra[i] adds
+// nothing.  One frame per thread at a time (a Python loop of 4 096 frames took 0.3 s of a 0.6 s file-to-file run).
+int r3d_host_append_text_files(const char *const *src, const char *const *dst, const char *const *extra, int32_t n,
+                               int32_t threads) {
+  if (!src || !dst || !extra || n < 0) return r3d::fail(R3D_E_ARG, "host_append_text_files: null pointer or count");
+  if (n == 0) return R3D_OK;
+  if (threads < 1) threads = 1;
+  if (threads > n) threads = n;
+  std::vector<std::string> err(threads);
+  auto work = [&](int t) {
+    std::string text;
+    for (int i = t; i < n; i += threads) {
+      if (!dst[i]) continue;
+      if (!src[i]) {
+        err[t] = "host_append_text_files: a frame without its source file";
+        return;
+      }
+      text.clear();
+      bool ok = true;
+      {
+        const int fd = ::open(src[i], O_RDONLY);
+        ok = fd >= 0;
+        char buf[4096];
+        while (ok) {
+          const ssize_t got = ::read(fd, buf, sizeof buf);
+          if (got < 0 && errno == EINTR) continue;
+          if (got < 0) ok = false;
+          if (got <= 0) break;
+          text.append(buf, (size_t)got);
+        }
+        if (fd >= 0) ::close(fd);
+      }
+      if (ok && extra[i]) text += extra[i];
+      if (ok) ok = commit_file(dst[i], text.data(), text.size());
+      if (!ok) {
+        err[t] = std::string("host_append_text_files: ") + src[i] + " -> " + dst[i] + " (" + std::strerror(errno) + ")";
+        return;
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+  work(0);
+  for (auto &th : pool) th.join();
+  for (int t = 0; t < threads; ++t)
+    if (!err[t].empty()) return r3d::fail(R3D_E_ARG, err[t].c_str());
+  return R3D_OK;
+}
+
 }  // extern "C"

@@ -19,6 +19,7 @@ has no fallback).
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 import queue
 import threading
@@ -254,11 +255,15 @@ class AugmentPipeline:
             names = [frames[i].name for i in chunk] + [None] * (B - len(chunk))
             path = lambda sub, ext: [None if n is None else os.path.join(base, sub, f"{n}.{ext}") for n in names]
             if label_2_for:                                        # object detection: label_2/{f}.txt first (OD tools/datasets.py:81-84)
-                from .Real3DAug.tools.datasets import create_annotation
                 os.makedirs(os.path.join(base, "label_2"), exist_ok=True)
-                for i, acc in zip(chunk, accepted):
-                    src, lines = label_2_for(i, acc)
-                    create_annotation(src, os.path.join(base, "label_2", f"{frames[i].name}.txt"), lines)
+                # (create_annotation for the whole batch by native threads: 4 096 frames in a Python loop were 0.3 s of 0.6)
+                what = [label_2_for(i, acc) for i, acc in zip(chunk, accepted)]
+                n2 = len(what)
+                src = (C.c_char_p * n2)(*[os.fsencode(w[0]) for w in what])
+                dst = (C.c_char_p * n2)(*[os.fsencode(os.path.join(base, "label_2", f"{frames[i].name}.txt")) for i in chunk])
+                extra = (C.c_char_p * n2)(*["".join(w[1]).encode() for w in what])
+                from . import _lib
+                _lib.check(_lib.load().r3d_host_append_text_files(src, dst, extra, n2, min(16, n2)), "r3d_host_append_text_files")
             # straight from the lane's buffers, by native threads: the lane is not submitted again before this returns
             aug.write_files(aug.current_lane, path("velodyne", "bin"), path("labels", "label") if self.write_labels else None,
                             path("check", "bin"))

@@ -168,3 +168,37 @@ def test_delta_writer_writes_what_merge_and_write_do(pkg, tmp_path, check_cols):
     assert lib.r3d_host_write_delta_frames(nowhere, None, None, B, P(in_x), P(in_l), cap, P(alive), chunks, P(tail_x), P(tail_l),
                                            tail_stride, P(counts), check_cols, None, 2) < 0
     assert b"no/dir" in lib.r3d_last_error()
+
+
+def test_native_label_2_writer_equals_create_annotation(pkg, tmp_path):
+    """r3d_host_append_text_files = OD tools/datasets.py:20-37 for a batch: the frame's label_2 file followed by the lines of
+    the inserted objects (the mirror's create_annotation is the reference for the bytes)."""
+    import os
+    lib = pkg._lib.load()
+    from importlib import import_module
+    ds = import_module("pcl-augmentation_amd.Real3DAug.tools.datasets")
+    n = 37
+    srcs, lines = [], []
+    for i in range(n):
+        p = tmp_path / f"src_{i}.txt"
+        p.write_text("".join(f"Car 0.00 0 -1.57 {j}.0 156.40 629.75 189.25 2.85 2.63 12.34 0.47 1.49 69.44 -1.56\n" for j in range(i % 5)))
+        srcs.append(str(p))
+        lines.append([f"Pedestrian 0 0 0 0 0 0 0 1.7 0.6 0.6 {i}.5 1.0 2.0 0.1\n"] * (i % 3))
+    (tmp_path / "a").mkdir(), (tmp_path / "b").mkdir()
+    for i in range(n):
+        ds.create_annotation(srcs[i], str(tmp_path / "a" / f"{i}.txt"), lines[i])
+    dst = [None if i == 5 else str(tmp_path / "b" / f"{i}.txt") for i in range(n)]
+    enc = lambda xs: (C.c_char_p * n)(*[None if x is None else os.fsencode(x) for x in xs])
+    extra = (C.c_char_p * n)(*[None if i == 7 else "".join(lines[i]).encode() for i in range(n)])
+    pkg._lib.check(lib.r3d_host_append_text_files(enc(srcs), enc(dst), extra, n, 4), "append")
+    for i in range(n):
+        if i == 5:
+            assert not (tmp_path / "b" / "5.txt").exists()
+            continue
+        want = (tmp_path / "a" / f"{i}.txt").read_bytes() if i != 7 else open(srcs[i], "rb").read()
+        assert (tmp_path / "b" / f"{i}.txt").read_bytes() == want
+    assert not list((tmp_path / "b").glob("*.tmp"))
+    # a source that does not exist: an error, not a silent skip
+    bad = list(srcs)
+    bad[3] = str(tmp_path / "nothing.txt")
+    assert lib.r3d_host_append_text_files(enc(bad), enc(dst), extra, n, 4) != 0
