@@ -292,6 +292,38 @@ def test_fast_projection_equals_reference_formula(P, synth):
     assert np.array_equal(pix[1][0][0, :len(sc)], sc[:, 8].astype(np.int32))
 
 
+def test_projection_deals_ragged_scenes_out(P, synth):
+    """k_project's workgroups deal the 512-point units of ALL scenes out among themselves: more scenes than one block scan
+    holds (> 1 024), empty scenes, scenes shorter than a wave / a unit, unit boundaries -- the pixel ids, the far counts and
+    the status words must be those of the reference formula (the diagnostic projection) for every scene."""
+    rng = np.random.default_rng(17)
+    base, lab = synth.make_scene(73, 32, 700)
+    sizes = [0, 1, 2, 63, 64, 65, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4097, len(base)]
+    B = 1100
+    scenes = []
+    for s in range(B):
+        n = sizes[s % len(sizes)] if s % 3 else int(rng.integers(0, 1500))
+        start = int(rng.integers(0, len(base) - n + 1))
+        scenes.append((base[start:start + n], lab[start:start + n]))
+    cap = len(base) + 64
+    pix = []
+    for exact in (True, False):
+        b = P.SceneBatch(B, cap, 64, exact_projection=exact)
+        b.load(scenes)
+        b.begin()
+        st = b.status.cpu().numpy()
+        pix.append((b.pixel_ids(), st, b.n_far.cpu().numpy()))
+        del b
+    # (a slice of one ring has next to no elevation range: both projections flag the same scenes)
+    assert np.array_equal(pix[0][1], pix[1][1])
+    fine = pix[1][1] == 0
+    assert fine.sum() > 0.6 * B and fine[[s for s in range(B) if len(scenes[s][0]) == len(base)]].all()
+    for s, (x, _) in enumerate(scenes):
+        if fine[s]:
+            assert np.array_equal(pix[0][0][s, :len(x)], pix[1][0][s, :len(x)]), s
+    assert np.array_equal(pix[0][2], pix[1][2])
+
+
 def test_screened_bounds_equal_numpy(P, synth):
     """k_bounds screens in float32 against a sampled pre-pass and evaluates z/r exactly only where a point can
     be an extreme: the elevation bounds must be those of the plain formula (insertion.py:74-79) whatever the
