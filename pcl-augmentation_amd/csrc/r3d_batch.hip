@@ -308,6 +308,12 @@ constexpr int kVirtAreaCap = 4096;           // pixels of a chunk's box that cou
 #ifndef R3D_PROJECT_WAVES
 #define R3D_PROJECT_WAVES
 #endif
+#ifndef R3D_PROJECT_LOAD_AUX          // cache policy bits of the point loads / the pixel-id stores (2: non-temporal).  Same box,
+#define R3D_PROJECT_LOAD_AUX 2        // one call: 0 / 0 127.0 us, loads 2: 124.8, stores 2: 136.0, both: 127.0 per 256 scenes
+#endif
+#ifndef R3D_PROJECT_STORE_AUX
+#define R3D_PROJECT_STORE_AUX 0
+#endif
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ int box_area_capped(unsigned long long packed, int cols) {
   const int r0 = (int)(packed & 0xFFFF), r1 = (int)((packed >> 16) & 0xFFFF), c0 = (int)((packed >> 32) & 0xFFFF), c1 = (int)((packed >> 48) & 0xFFFF);
@@ -417,7 +423,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
 #ifdef R3D_EXP_L2
     auto fetch = [&](int round) { return __builtin_amdgcn_raw_buffer_load_b96(seg_xyzi, lane_off, (round & 7) * 1024, 0); };
 #else
-    auto fetch = [&](int round) { return __builtin_amdgcn_raw_buffer_load_b96(seg_xyzi, lane_off, round * 1024, 0); };
+    auto fetch = [&](int round) { return __builtin_amdgcn_raw_buffer_load_b96(seg_xyzi, lane_off, round * 1024, R3D_PROJECT_LOAD_AUX); };
 #endif
     // One round: 256 points, one per lane.  round_any: the general form (lanes past the scene's end, float64 points, the
     // diagnostic mode).
@@ -455,7 +461,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
             if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
             else flags |= R3D_S_FAR_OVERFLOW;
           }
-          __builtin_amdgcn_raw_buffer_store_b32((unsigned int)p, seg_pix, lane_off >> 2, (round0 + k) * 256, 0);
+          __builtin_amdgcn_raw_buffer_store_b32((unsigned int)p, seg_pix, lane_off >> 2, (round0 + k) * 256, R3D_PROJECT_STORE_AUX);
         } else {
           queue[atomicAdd(&w.n_slow[s], 1)] = (uint32_t)i;
         }
@@ -546,7 +552,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
       unsigned long long packed, placed_mask = ~0ull;
       if (ok_mask == ~0ull) {
 #ifndef R3D_EXP_NOSTORE
-        __builtin_amdgcn_raw_buffer_store_b32((unsigned int)p, seg_pix, lane_off >> 2, (round0 + k) * 256, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned int)p, seg_pix, lane_off >> 2, (round0 + k) * 256, R3D_PROJECT_STORE_AUX);
 #endif
       } else {                                                 // some lane undecided in float32, or r near / above 500
         bool ok = __builtin_amdgcn_inverse_ballot_w64(ok_mask), far = false;
@@ -561,7 +567,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
             if (f < R3D_FAR_CAP) b.far_pix[(int64_t)s * R3D_FAR_CAP + f] = p;
             else flags |= R3D_S_FAR_OVERFLOW;
           }
-          __builtin_amdgcn_raw_buffer_store_b32((unsigned int)p, seg_pix, lane_off >> 2, (round0 + k) * 256, 0);
+          __builtin_amdgcn_raw_buffer_store_b32((unsigned int)p, seg_pix, lane_off >> 2, (round0 + k) * 256, R3D_PROJECT_STORE_AUX);
         } else {
           queue[atomicAdd(&w.n_slow[s], 1)] = (uint32_t)(t0 + k * 64 + lane);
         }
