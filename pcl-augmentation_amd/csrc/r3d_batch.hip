@@ -335,7 +335,10 @@ __device__ __forceinline__ int box_area_capped(unsigned long long packed, int co
 //     rounds are requested together, a unit ahead of their use (one descriptor per segment, the round's offset in the
 //     scalar operand, past the segment's end zeros).
 constexpr int kSegCap = 256;                  // units of a workgroup's range looked at per pass (segments <= units)
-constexpr int kProjNT = 1024;                 // one workgroup per CU: its sixteen waves share the work of the CU's range
+#ifndef R3D_PROJECT_NT
+#define R3D_PROJECT_NT 1024
+#endif
+constexpr int kProjNT = R3D_PROJECT_NT;       // 1 024: one workgroup per CU, its sixteen waves share the work of the CU's range
 constexpr int kUnit = 64 * kPerThread;        // points a wave takes at a time: eight rounds of 64 consecutive points
 __global__ void __launch_bounds__(kProjNT) R3D_PROJECT_WAVES
 k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_count, BatchWs w, int chunks) {
