@@ -298,8 +298,11 @@ int r3d_batch_debug_counters(const r3d_batch_t *b, int32_t *host_out16, int32_t 
  * order of every output are untouched.  R3D_VIRTUAL_ORDER=0 / 2 in the environment: never / every scene; bit 1024 of
  * `reserved`: every scene of this batch (tests).  The look costs a begin four small launches (~20 us per 256 scenes); a caller
  * who knows that its clouds come in a file order says so with R3D_B_FILE_ORDER in `reserved` and saves them -- a cloud that
- * does not keep the promise costs time (every insert then walks the whole cloud), never results.  The Python mirror
- * (SceneBatch) sets the bit by itself once a batch has come through without an unordered scene, and looks again now and then.
+ * does not keep the promise costs time (every insert then walks the whole cloud), never results.  The bit belongs to the
+ * batch from one r3d_batch_begin to the next: finish / export_delta / export_rows skip the launch that puts the alive bits of
+ * re-numbered scenes back into slab order when it is set, so it must not be set between a begin that looked and its finish.
+ * The Python mirror (SceneBatch) sets the bit by itself, at begin, once a batch has come through without an unordered scene,
+ * and looks again now and then.
  *
  * r3d_batch_export_pix: the pixel id of every point of every scene, in the order of the slabs, as the reference numbers
  * it (row * cols + column, insertion.py:116; `pix` itself holds (row << 16) | column in the internal numbering). */

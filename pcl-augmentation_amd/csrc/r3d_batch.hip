@@ -1197,6 +1197,19 @@ static int project_grid(const r3d_batch_t &b) {
   return (int)(most < resident ? (most > 0 ? most : 1) : resident);
 }
 
+// Can a scene of this batch be in virtual order?  R3D_VIRTUAL_ORDER: 0 never, 1 (default) the scenes whose chunk boxes say
+// that their points come in no file order, 2 all.  Bit 2048 of `reserved` (R3D_B_FILE_ORDER): the caller says that the clouds
+// come in a LiDAR file order -- nothing is looked at, nothing sorted (a cloud that does not keep the promise costs time, not
+// results), and the calls that would put alive bits back into slab order (finish, export_delta, export_rows) skip that
+// launch: the bit has to be the same from a begin to the next.  0: no.
+static int virtual_order_mode(const r3d_batch_t &b) {
+  static const int mode = [] {
+    const char *v = getenv("R3D_VIRTUAL_ORDER");
+    return v && *v ? atoi(v) : 1;
+  }();
+  return mode && (!(b.reserved & R3D_B_FILE_ORDER) || mode == 2 || (b.reserved & kDbgVirtual)) ? mode : 0;
+}
+
 // bounds -> tables -> project for the scenes of (list, count); rows = block rows of the launches.
 static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_t *list,
                             const int32_t *count, int rows, hipStream_t st, int slow_blocks = 4) {
@@ -1210,14 +1223,8 @@ static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_
   hipLaunchKernelGGL(k_project_slow, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_fix_boxes, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w, chunks_of(b));
   {
-    // R3D_VIRTUAL_ORDER: 0 never, 1 (default) the scenes whose chunk boxes say that their points come in no file order, 2 all
-    static const int mode = [] {
-      const char *v = getenv("R3D_VIRTUAL_ORDER");
-      return v && *v ? atoi(v) : 1;
-    }();
-    // bit 2048 of `reserved` (R3D_B_FILE_ORDER): the caller says that the clouds come in a LiDAR file order -- nothing is
-    // looked at, nothing sorted (a cloud that does not keep the promise costs time, not results)
-    if (mode && (!(b.reserved & R3D_B_FILE_ORDER) || mode == 2 || (b.reserved & kDbgVirtual))) {
+    const int mode = virtual_order_mode(b);
+    if (mode) {
       VirtShape v;
       v.mode = mode;
       v.cshift = 6;                                            // bands of 64 columns, groups of rows: at most kVirtBins bins
@@ -1249,11 +1256,11 @@ static int launch_compact(const r3d_batch_t &b, const BatchWs &w, const int32_t 
   // non-temporal loads and stores: nothing of the cloud is read again before r3d_batch_begin overwrites the state
   // (scenes in virtual order: their alive bits back in slab order first; a block of the others returns at once)
   if (rows4) {
-    hipLaunchKernelGGL((k_unvirtual<true>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b));
+    if (virtual_order_mode(b)) hipLaunchKernelGGL((k_unvirtual<true>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b));
     if (tiles >= kPrefixMinTiles) hipLaunchKernelGGL((k_tile_prefix<true>), dim3(1, rows), dim3(1024), 0, st, b, list, count, w, tiles);
     hipLaunchKernelGGL((k_alive_write<true, false>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b), rows4, n_rows);
   } else {
-    hipLaunchKernelGGL((k_unvirtual<false>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b));
+    if (virtual_order_mode(b)) hipLaunchKernelGGL((k_unvirtual<false>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b));
     if (tiles >= kPrefixMinTiles) hipLaunchKernelGGL((k_tile_prefix<false>), dim3(1, rows), dim3(1024), 0, st, b, list, count, w, tiles);
     hipLaunchKernelGGL((k_alive_write<false, true>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b), rows4, n_rows);
   }
@@ -1373,8 +1380,9 @@ int r3d_batch_export_delta(const r3d_batch_t *b, uint64_t *alive, float *tail_xy
   if (rc != R3D_OK) return rc;
   if (!alive || !tail_xyzi || !tail_label || !counts || tail_stride <= 0) return fail(R3D_E_ARG, "batch_export_delta: null output or stride");
   BatchWs w = carve_batch(*b, b->workspace);
-  hipLaunchKernelGGL((k_unvirtual<false>), dim3(tiles_of(*b), b->B), dim3(kPT), 0, (hipStream_t)stream, *b, w.all_list, w.all_count, w,
-                     tiles_of(*b), chunks_of(*b));
+  if (virtual_order_mode(*b))
+    hipLaunchKernelGGL((k_unvirtual<false>), dim3(tiles_of(*b), b->B), dim3(kPT), 0, (hipStream_t)stream, *b, w.all_list, w.all_count, w,
+                       tiles_of(*b), chunks_of(*b));
   hipLaunchKernelGGL(k_export_delta, dim3(8, b->B), dim3(256), 0, (hipStream_t)stream, *b, w, chunks_of(*b),
                      reinterpret_cast<unsigned long long *>(alive), tail_xyzi, tail_label, tail_stride, counts);
   R3D_LAUNCHED("k_export_delta");
