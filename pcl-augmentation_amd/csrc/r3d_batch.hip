@@ -1155,7 +1155,7 @@ int check_batch(const r3d_batch_t *b) {
     return fail(R3D_E_ARG, "batch: null array");
   if (b->cols % 32 != 0)
     return fail(R3D_E_ARG, "batch: cols must be a multiple of 32 (row-aligned bit images)");
-  if (((size_t)(b->cols + 1) + b->rows + 2) * 2 * sizeof(float) > 64 * 1024)
+  if (((size_t)(b->cols + 1) + b->rows + 2) * 2 * sizeof(float) > 60 * 1024)          // (+ 4 KB of its own: 64 KB per workgroup)
     return fail(R3D_E_ARG, "batch: range image too large for the projection kernel's LDS edge tables");
   if ((int64_t)b->rows * b->cols >= (1 << 24))
     return fail(R3D_E_ARG, "batch: range image of 2^24 pixels or more");

@@ -324,6 +324,22 @@ def test_projection_deals_ragged_scenes_out(P, synth):
     assert np.array_equal(pix[0][2], pix[1][2])
 
 
+def test_projection_on_the_widest_range_image(P, synth):
+    """The column edge table of k_project lives in LDS: the widest image the batch accepts (7 616 columns beside 16 rows)
+    must launch and give the reference formula's pixel ids; one column more is an argument error, not a failed launch."""
+    xyzi, label = synth.make_scene(74, 16, 900)
+    pix = []
+    for exact in (True, False):
+        b = P.SceneBatch(2, len(xyzi) + 64, 64, rows=16, cols=7616, exact_projection=exact)
+        b.load([(xyzi, label), (xyzi[::-1].copy(), label[::-1].copy())])
+        b.begin()
+        assert (b.status.cpu().numpy() == 0).all()
+        pix.append(b.pixel_ids())
+    assert np.array_equal(pix[0], pix[1])
+    with pytest.raises(Exception):
+        P.SceneBatch(1, len(xyzi) + 64, 64, rows=64, cols=7680)
+
+
 def test_screened_bounds_equal_numpy(P, synth):
     """k_bounds screens in float32 against a sampled pre-pass and evaluates z/r exactly only where a point can
     be an extreme: the elevation bounds must be those of the plain formula (insertion.py:74-79) whatever the
