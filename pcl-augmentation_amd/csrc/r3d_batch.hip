@@ -355,7 +355,7 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
   const float row_top = (float)(b.rows - 1), col_top = (float)(b.cols - 1);
   // a launch of up to kProjNT scenes (the usual one): a scene per thread, one scan, nothing read twice
   const bool few = cnt <= kProjNT;
-  int my_s = 0, my_n = 0, my_pre = 0, all_tiles;
+  int my_s = 0, my_n = 0, my_pre = 0, all_units;
   {
     int mine = 0;
     if (few) {
@@ -363,15 +363,15 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
     } else {
       for (int e = threadIdx.x; e < cnt; e += kProjNT) mine += (b.n_total[list[e]] + kUnit - 1) / kUnit;
     }
-    my_pre = block_escan_i32(mine, s_scan, all_tiles);
+    my_pre = block_escan_i32(mine, s_scan, all_units);
   }
-  const int lo = (int)((long long)blockIdx.x * all_tiles / gridDim.x);
-  const int hi = (int)((long long)(blockIdx.x + 1) * all_tiles / gridDim.x);
+  const int lo = (int)((long long)blockIdx.x * all_units / gridDim.x);
+  const int hi = (int)((long long)(blockIdx.x + 1) * all_units / gridDim.x);
   for (int sub = lo; sub < hi; sub += kSegCap) {
   const int sub_hi = sub + kSegCap < hi ? sub + kSegCap : hi;
   if (threadIdx.x == 0) s_nseg = 0;
   __syncthreads();
-  auto offer = [&](int s_e, int n_e, int pre) {               // the part of a scene's tiles [pre, pre + t) inside [sub, sub_hi)
+  auto offer = [&](int s_e, int n_e, int pre) {               // the part of a scene's units [pre, pre + t) inside [sub, sub_hi)
     const int t = (n_e + kUnit - 1) / kUnit;
     const int a = pre > sub ? pre : sub, z = pre + t < sub_hi ? pre + t : sub_hi;
     if (a < z) {
@@ -395,14 +395,14 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
   const int n_seg = __builtin_amdgcn_readfirstlane(s_nseg);
   for (int g = 0; g < n_seg; ++g) {
     const int s = __builtin_amdgcn_readfirstlane(s_seg[4 * g + 0]), n = __builtin_amdgcn_readfirstlane(s_seg[4 * g + 1]);
-    const int tile_lo = __builtin_amdgcn_readfirstlane(s_seg[4 * g + 2]), tile_hi = __builtin_amdgcn_readfirstlane(s_seg[4 * g + 3]);
+    const int unit_lo = __builtin_amdgcn_readfirstlane(s_seg[4 * g + 2]), unit_hi = __builtin_amdgcn_readfirstlane(s_seg[4 * g + 3]);
     const int n_head = b.n_head[s];
     __syncthreads();                                       // previous scene's row table is no longer read
     {
       const float2 *rq = reinterpret_cast<const float2 *>(w.row_qf) + (int64_t)s * (b.rows + 2);
       for (int e = threadIdx.x; e < b.rows; e += kProjNT)      // (+-0.9999: the screen's pole test, folded into the limits)
         s_row[e] = make_float2(fminf(rq[e == 0 ? 0 : e + 1].x, 0.9999f), fmaxf(rq[e + 2].y, -0.9999f));
-      if (threadIdx.x == 0) s_next = tile_lo;                  // the segment's units, taken by the waves one at a time
+      if (threadIdx.x == 0) s_next = unit_lo;                  // the segment's units, taken by the waves one at a time
     }
     __syncthreads();
     Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
@@ -417,18 +417,18 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
     int flags = 0, area = 0;
     // unconfirmed points are queued for k_project_slow
     const float *scene_xyzi = b.xyzi + (int64_t)s * b.cap * 4;   // (the slab holds the float32 rounding of float64 points)
-    const int first = tile_lo * kUnit, left = n - first, span = (tile_hi - tile_lo) * kUnit;
+    const int first = unit_lo * kUnit, left = n - first, span = (unit_hi - unit_lo) * kUnit;
     const __amdgpu_buffer_rsrc_t seg_xyzi = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(scene_xyzi + (int64_t)first * 4), 0, (left < span ? left : span) * 16, 0x00020000);
     const __amdgpu_buffer_rsrc_t seg_pix = __builtin_amdgcn_make_buffer_rsrc(
         b.pix + (int64_t)s * b.cap + first, 0, (left < span ? left : span) * 4, 0x00020000);
-    // (past the segment's end the loads return zeros: the rounds requested ahead at its last tile)
+    // (past the segment's end the loads return zeros: the rounds requested ahead at its last unit)
 #ifdef R3D_EXP_L2
     auto fetch = [&](int round) { return __builtin_amdgcn_raw_buffer_load_b96(seg_xyzi, lane_off, (round & 7) * 1024, 0); };
 #else
     auto fetch = [&](int round) { return __builtin_amdgcn_raw_buffer_load_b96(seg_xyzi, lane_off, round * 1024, R3D_PROJECT_LOAD_AUX); };
 #endif
-    // One round: 256 points, one per lane.  round_any: the general form (lanes past the scene's end, float64 points, the
+    // One round of a wave: 64 consecutive points, one per lane.  round_any: the general form (lanes past the scene's end, float64 points, the
     // diagnostic mode).
     auto round_any = [&](const int t0, const int round0, const int k, const u32x3 pt) {
       const int i = t0 + k * 64 + lane;
@@ -611,16 +611,16 @@ k_project(r3d_batch_t b, const int32_t *list, const int32_t *count, int known_co
       return __builtin_amdgcn_readfirstlane(u);
     };
     int unit = claim();
-    if (unit < tile_hi) {
+    if (unit < unit_hi) {
       u32x3 cur[kPerThread], nxt[kPerThread];
 #pragma unroll
-      for (int k = 0; k < kPerThread; ++k) cur[k] = fetch((unit - tile_lo) * kPerThread + k);
-      while (unit < tile_hi) {
+      for (int k = 0; k < kPerThread; ++k) cur[k] = fetch((unit - unit_lo) * kPerThread + k);
+      while (unit < unit_hi) {
         const int unit_next = claim();
         // (past the segment's end the loads return zeros)
 #pragma unroll
-        for (int k = 0; k < kPerThread; ++k) nxt[k] = fetch((unit_next - tile_lo) * kPerThread + k);
-        const int t0 = unit * kUnit, round0 = (unit - tile_lo) * kPerThread;
+        for (int k = 0; k < kPerThread; ++k) nxt[k] = fetch((unit_next - unit_lo) * kPerThread + k);
+        const int t0 = unit * kUnit, round0 = (unit - unit_lo) * kPerThread;
         if (plain && t0 + kUnit <= n) {
 #pragma unroll
           for (int k = 0; k < kPerThread; ++k) round_whole(t0, round0, k, cur[k]);
