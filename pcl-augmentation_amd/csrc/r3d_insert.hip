@@ -2146,6 +2146,9 @@ __device__ __forceinline__ int run_pair(const r3d_batch_t &b, const ChainSlots &
         ++attempts;
         if (need_sample) {
           rc = (b.reserved & kDbgDefer) ? kNoFit : I.sample_phase();
+#ifdef R3D_EXP_SAMPLE_TWICE                                    // (how much of a pair's sample phase shows in the launch?)
+          if (rc == kOk) rc = I.sample_phase();
+#endif
           sample_ok = rc == kOk;
           // The scene may have moved on while the sample was prepared: build on the freshest state, so that fewer
           // slots remain that can invalidate the evaluation (a big pair that has to evaluate twice is the tail
