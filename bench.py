@@ -213,18 +213,17 @@ def extra_legs(pkg, torch, args, all_of_them):
     """The objects beside the headline that run on this GPU: placement_search, e2e, placed, e2e_files (config C5 has its own
     child process).  `all_of_them`: the default line; else only the ones asked for by flag."""
     out = {}
-    if args.placement > 0 or all_of_them:
-        out["placement_search"] = placement_leg(pkg, torch, args.placement or 64, not args.no_cpu_baseline, CONFIGS["C2"]["kinds"])
-    if args.e2e > 0 or all_of_them:
-        e2e = importlib.import_module("tools.e2e_pipeline")
-        out["e2e"] = e2e.measure(pkg, n_frames=args.e2e or 4096)
-    if all_of_them or args.placed:
-        # the placement search in the loop (SURVEY.md par.8 f-1 + the hot path): search -> candidates -> merge per insert slot
-        try:
-            out["placed"] = importlib.import_module("tools.bench_placed").measure(pkg, B=args.placed or 256, K=len(CONFIGS["C2"]["kinds"]),
-                                                                               reps=4, lanes=3)
-        except Exception as e:
-            out["placed"] = {"error": repr(e)[:300]}
+
+    def give_back():
+        """A leg's batches, lanes and pinned staging go back before the next one starts: with the `placed` leg's three lanes
+        (and their pinned slabs) still cached in this process, the first file leg wrote its files at 6.5-8 thousand frames/s
+        where it reaches 12 in a fresh process."""
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        if hasattr(torch._C, "_host_emptyCache"):
+            torch._C._host_emptyCache()
+
     if all_of_them or args.e2e_files:
         # file to file, the shapes of configs C3 (object detection, label_2) and C4 (SemanticKITTI sweep), files on tmpfs
         e2e = importlib.import_module("tools.e2e_pipeline")
@@ -235,6 +234,21 @@ def extra_legs(pkg, torch, args, all_of_them):
                                                             check=0 if args.no_cpu_baseline else 2)
             except Exception as e:                             # the headline must not depend on this leg
                 out["e2e_files"][shape] = {"error": repr(e)[:300]}
+            give_back()
+    if args.placement > 0 or all_of_them:
+        out["placement_search"] = placement_leg(pkg, torch, args.placement or 64, not args.no_cpu_baseline, CONFIGS["C2"]["kinds"])
+        give_back()
+    if args.e2e > 0 or all_of_them:
+        e2e = importlib.import_module("tools.e2e_pipeline")
+        out["e2e"] = e2e.measure(pkg, n_frames=args.e2e or 4096)
+        give_back()
+    if all_of_them or args.placed:
+        # the placement search in the loop (SURVEY.md par.8 f-1 + the hot path): search -> candidates -> merge per insert slot
+        try:
+            out["placed"] = importlib.import_module("tools.bench_placed").measure(pkg, B=args.placed or 256, K=len(CONFIGS["C2"]["kinds"]),
+                                                                               reps=4, lanes=3)
+        except Exception as e:
+            out["placed"] = {"error": repr(e)[:300]}
     return out
 
 
