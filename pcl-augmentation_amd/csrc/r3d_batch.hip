@@ -1193,7 +1193,11 @@ static int project_grid(const r3d_batch_t &b) {
     }
     resident = it->second;
   }
-  const long long most = (long long)b.B * ((b.cap + kUnit - 1) / kUnit);
+  // (a small batch: no more workgroups than have a unit for every wave -- but one per scene when the scenes are that short:
+  // a workgroup's segments follow one another)
+  const long long units = (long long)b.B * ((b.cap + kUnit - 1) / kUnit);
+  long long most = (units + kProjNT / 64 - 1) / (kProjNT / 64);
+  if (most < b.B) most = b.B < units ? b.B : units;
   return (int)(most < resident ? (most > 0 ? most : 1) : resident);
 }
 
