@@ -938,40 +938,108 @@ k_virt_finish(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
 
 // A scene in virtual order: its alive bits back in slab order (what the compaction, the delta and the float64 rows are made
 // from), and the living points per 2048-point tile of the slabs.  One block per tile; the other scenes are left alone.
+// Two launches: every original point alive (the appended ones keep their own bits: they are numbered alike in both orders),
+// then the dead points of the virtual order clear their bit in slab order -- a few per cent of the points, found by walking
+// the alive words once.  (Looked up the other way round, every point through inv[], the kernel took 0.10 ms per 256 scenes.)
 template <bool ROWS4>
 __global__ void __launch_bounds__(kPT)
-k_unvirtual(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles, int chunks) {
-  __shared__ int s_cnt;
+k_unvirtual_all(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles, int chunks) {
   const int cnt = *count;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     const int s = list[li];
     const int n_virt = w.n_virt[s];
     if (!n_virt) continue;
-    const int n = b.n_total[s], t0 = blockIdx.x * kTile;
-    if (t0 >= n) continue;
+    const int n = b.n_total[s];
     const bool shadow = ROWS4 && w.shadow_valid[s] != 0;     // (what k_alive_write<ROWS4> shows)
     const unsigned long long *alive = (shadow ? w.alive_shadow : w.alive) + (int64_t)s * chunks;
-    const uint32_t *inv = w.inv + (int64_t)s * b.cap;
-    __syncthreads();
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    int living = 0;
-    for (int c = (t0 >> 6) + wave; c < ((t0 + kTile) >> 6) && (c << 6) < n; c += kPT / 64) {
-      const int i = (c << 6) + lane;
-      bool on = false;
-      if (i < n) {
-        const int j = i < n_virt ? (int)inv[i] : i;
-        on = (alive[j >> 6] >> (j & 63)) & 1ull;
+    for (int c0 = blockIdx.x * kPT; (c0 << 6) < n; c0 += gridDim.x * kPT) {
+      const int c = c0 + (int)threadIdx.x, lo = c << 6;
+      if (lo < n) {
+        const unsigned long long in_scene = n - lo >= 64 ? ~0ull : (1ull << (n - lo)) - 1ull;
+        const unsigned long long orig = lo >= n_virt ? 0ull : (n_virt - lo >= 64 ? ~0ull : (1ull << (n_virt - lo)) - 1ull);
+        const unsigned long long word = (orig | (orig != ~0ull ? alive[c] & ~orig : 0ull)) & in_scene;
+        w.alive_o[(int64_t)s * chunks + c] = word;
       }
-      const unsigned long long word = __ballot(on);
-      if (lane == 0) w.alive_o[(int64_t)s * chunks + c] = word;
-      living += __popcll(word);
     }
-    if (lane == 0 && living) atomicAdd(&s_cnt, living);
-    __syncthreads();
-    if (threadIdx.x == 0) w.tile_o[(int64_t)s * tiles + blockIdx.x] = s_cnt;
   }
+}
+
+template <bool ROWS4>
+__global__ void __launch_bounds__(kPT)
+k_unvirtual_dead(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles, int chunks) {
+  const int cnt = *count;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    const int s = list[li];
+    const int n_virt = w.n_virt[s];
+    if (!n_virt) continue;
+    const bool shadow = ROWS4 && w.shadow_valid[s] != 0;
+    const unsigned long long *alive = (shadow ? w.alive_shadow : w.alive) + (int64_t)s * chunks;
+    const uint32_t *perm = w.perm + (int64_t)s * b.cap;
+    // a word of the virtual order per lane; the dead points of the wave's 64 words are listed in LDS (their place among the
+    // wave's 4 096 points, by the lanes' prefix sums), then taken 64 at a time, one per lane: one trip to perm[] per 64 dead
+    // points (walked lane by lane, or word by word, the trips followed one another: 71 / 56 us per 256 scenes)
+    __shared__ uint16_t s_dead[kPT / 64][4096];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c0 = blockIdx.x * kPT + (int)(threadIdx.x & ~63); (c0 << 6) < n_virt; c0 += gridDim.x * kPT) {
+      const int c = c0 + lane, lo = c << 6;
+      unsigned long long dead = 0ull;
+      if (lo < n_virt) {
+        const unsigned long long valid = n_virt - lo >= 64 ? ~0ull : (1ull << (n_virt - lo)) - 1ull;
+        dead = ~alive[c] & valid;
+      }
+      const int mine = __popcll(dead);
+      const int incl = wave_iscan_i32(mine), total = wave_last_i32(incl);
+      if (!total) continue;
+      int at = incl - mine;
+      while (dead) {
+        const int bit = __ffsll((long long)dead) - 1;
+        dead &= dead - 1;
+        s_dead[wave][at++] = (uint16_t)((lane << 6) | bit);
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int e = lane; e < total; e += 64) {
+        const uint32_t i = perm[(c0 << 6) + (int)s_dead[wave][e]];
+        atomicAnd(&w.alive_o[(int64_t)s * chunks + (i >> 6)], ~(1ull << (i & 63)));
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// ... and the living points per 2 048-point tile of the slabs, from the finished words (a count kept by the dead points
+// themselves was one more atomic each).
+__global__ void __launch_bounds__(kPT)
+k_unvirtual_tiles(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles, int chunks) {
+  static_assert(kTile == 32 * 64, "a tile is 32 alive words");
+  const int cnt = *count;
+  for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
+    const int s = list[li];
+    if (!w.n_virt[s]) continue;
+    const int n = b.n_total[s];
+    for (int c = blockIdx.x * kPT + (int)threadIdx.x; ((c & ~63) << 6) < n; c += gridDim.x * kPT) {
+      int living = (c << 6) < n ? __popcll(w.alive_o[(int64_t)s * chunks + c]) : 0;
+      living += __shfl_xor(living, 1, 64);                     // the 32 words of a tile: half a wave
+      living += __shfl_xor(living, 2, 64);
+      living += __shfl_xor(living, 4, 64);
+      living += __shfl_xor(living, 8, 64);
+      living += __shfl_xor(living, 16, 64);
+      if ((threadIdx.x & 31) == 0 && (c >> 5) < tiles && ((int64_t)(c >> 5) * kTile) < n) w.tile_o[(int64_t)s * tiles + (c >> 5)] = living;
+    }
+  }
+}
+
+static void launch_unvirtual(const r3d_batch_t &b, const BatchWs &w, const int32_t *list, const int32_t *count, int rows, bool rows4,
+                             hipStream_t st) {
+  const int tiles = tiles_of(b), chunks = chunks_of(b);
+  const dim3 g_all((chunks + kPT - 1) / kPT, rows), g_dead((chunks + kPT - 1) / kPT, rows);
+  if (rows4) {
+    hipLaunchKernelGGL((k_unvirtual_all<true>), g_all, dim3(kPT), 0, st, b, list, count, w, tiles, chunks);
+    hipLaunchKernelGGL((k_unvirtual_dead<true>), g_dead, dim3(kPT), 0, st, b, list, count, w, tiles, chunks);
+  } else {
+    hipLaunchKernelGGL((k_unvirtual_all<false>), g_all, dim3(kPT), 0, st, b, list, count, w, tiles, chunks);
+    hipLaunchKernelGGL((k_unvirtual_dead<false>), g_dead, dim3(kPT), 0, st, b, list, count, w, tiles, chunks);
+  }
+  hipLaunchKernelGGL(k_unvirtual_tiles, g_all, dim3(kPT), 0, st, b, list, count, w, tiles, chunks);
 }
 
 // Clouds of many tiles (config C5: 489 per scan): the living points in front of every tile, once per scene, instead of every
@@ -1313,11 +1381,11 @@ static int launch_compact(const r3d_batch_t &b, const BatchWs &w, const int32_t 
   // non-temporal loads and stores: nothing of the cloud is read again before r3d_batch_begin overwrites the state
   // (scenes in virtual order: their alive bits back in slab order first; a block of the others returns at once)
   if (rows4) {
-    if (virtual_order_mode(b)) hipLaunchKernelGGL((k_unvirtual<true>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b));
+    if (virtual_order_mode(b)) launch_unvirtual(b, w, list, count, rows, true, st);
     if (tiles >= kPrefixMinTiles) hipLaunchKernelGGL((k_tile_prefix<true>), dim3(1, rows), dim3(1024), 0, st, b, list, count, w, tiles);
     hipLaunchKernelGGL((k_alive_write<true, false>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b), rows4, n_rows);
   } else {
-    if (virtual_order_mode(b)) hipLaunchKernelGGL((k_unvirtual<false>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b));
+    if (virtual_order_mode(b)) launch_unvirtual(b, w, list, count, rows, false, st);
     if (tiles >= kPrefixMinTiles) hipLaunchKernelGGL((k_tile_prefix<false>), dim3(1, rows), dim3(1024), 0, st, b, list, count, w, tiles);
     hipLaunchKernelGGL((k_alive_write<false, true>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b), rows4, n_rows);
   }
@@ -1438,8 +1506,7 @@ int r3d_batch_export_delta(const r3d_batch_t *b, uint64_t *alive, float *tail_xy
   if (!alive || !tail_xyzi || !tail_label || !counts || tail_stride <= 0) return fail(R3D_E_ARG, "batch_export_delta: null output or stride");
   BatchWs w = carve_batch(*b, b->workspace);
   if (virtual_order_mode(*b))
-    hipLaunchKernelGGL((k_unvirtual<false>), dim3(tiles_of(*b), b->B), dim3(kPT), 0, (hipStream_t)stream, *b, w.all_list, w.all_count, w,
-                       tiles_of(*b), chunks_of(*b));
+    launch_unvirtual(*b, w, w.all_list, w.all_count, b->B, false, (hipStream_t)stream);
   hipLaunchKernelGGL(k_export_delta, dim3(8, b->B), dim3(256), 0, (hipStream_t)stream, *b, w, chunks_of(*b),
                      reinterpret_cast<unsigned long long *>(alive), tail_xyzi, tail_label, tail_stride, counts);
   R3D_LAUNCHED("k_export_delta");
