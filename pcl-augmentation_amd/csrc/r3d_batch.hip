@@ -1357,10 +1357,10 @@ static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_
       hipLaunchKernelGGL(k_virt_hist, dim3(v.nblk, rows), dim3(kPT), 0, st, b, list, count, w, v);
       hipLaunchKernelGGL(k_virt_scan, dim3(1, rows), dim3(kVirtScanNT), 0, st, b, list, count, w, v);
       {
-        static const size_t lds = (size_t)kVirtBlock * sizeof(uint2) + 3 * kVirtBins * sizeof(uint32_t);
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_virt_scatter),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (attr != hipSuccess) return fail(R3D_E_HIP, "k_virt_scatter: dynamic LDS");
+        const size_t lds = (size_t)kVirtBlock * sizeof(uint2) + 3 * kVirtBins * sizeof(uint32_t);
+        // (per device, every call: the attribute belongs to the current device's copy of the kernel)
+        R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_virt_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
         hipLaunchKernelGGL(k_virt_scatter, dim3(v.nblk, rows), dim3(kPT), lds, st, b, list, count, w, v);
       }
       hipLaunchKernelGGL(k_virt_finish, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w, chunks_of(b));
