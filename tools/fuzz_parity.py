@@ -96,7 +96,9 @@ def main():
         B = int(rng.choice([1, 2, 3, 6, 9]))
         cases = [make_case(synth, rng, rows, cols) for _ in range(B)]
         want = pool.map_async(oracle_case, [(rows, cols) + c for c in cases])
-        debug = int(rng.choice([0, 0, 0, 64, 2, 128]))        # the default launch, every speculative evaluation verified, no speculation, kill masks without hits
+        # the default launch | every speculative evaluation verified | no speculation | kill masks without hits | every scene in
+        # virtual order (the counting sort at begin, the way back to slab order at finish)
+        debug = int(rng.choice([0, 0, 0, 64, 2, 128, 1024, 1024]))
         try:
             res, acc = pkg.augment_batch([(c[0], c[1]) for c in cases], [c[2] for c in cases], [c[3] for c in cases],
                                          rows=rows, cols=cols, debug=debug)
