@@ -99,20 +99,33 @@ __device__ __forceinline__ void exact_q(const r3d_batch_t &b, int s, int i, int 
 // One wave per 2048-point tile reads the tile's first row (64 points: one row in 32); a workgroup (4 tiles)
 // leaves one pair of atomics.  (Per-wave atomics serialise: 15 000 waves on 2 x 32 addresses took 0.13 ms in
 // config C5; a few workgroups per scene looping over the tiles are latency-bound, 0.024 ms.)
+constexpr int kSampleHeads = 8;            // tiles whose first 64 points one wave of k_bounds_sample looks at
 __global__ void __launch_bounds__(kPT)
 k_bounds_sample(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w) {
+  // the first 64 points of every tile; a wave takes kSampleHeads tiles and has their loads under way together (one tile per
+  // wave was a round trip per workgroup: 31 000 workgroups of config C5's batch took 0.09 ms over 8 M points)
   __shared__ unsigned long long s_min[kPT / 64], s_max[kPT / 64];
   int cnt = *count;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
     int n = b.n_total[s], n_head = b.n_head[s];
-    if ((int)blockIdx.x * (kPT / 64) * kTile >= n) continue;
+    if ((int64_t)blockIdx.x * (kPT / 64) * kSampleHeads * kTile >= n) continue;
     const float4 *src = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
     unsigned long long lmin = ~0ull, lmax = 0ull;
     int bad = 0;
-    const int i = (blockIdx.x * (kPT / 64) + wave) * kTile + lane;
-    if (i < n) exact_q(b, s, i, n_head, src[i], lmin, lmax, bad);
+    const int64_t first = ((int64_t)blockIdx.x * (kPT / 64) + wave) * kSampleHeads * kTile + lane;
+    float4 pt[kSampleHeads];
+#pragma unroll
+    for (int u = 0; u < kSampleHeads; ++u) {
+      const int64_t i = first + (int64_t)u * kTile;
+      pt[u] = src[i < n ? i : (n > 0 ? n - 1 : 0)];
+    }
+#pragma unroll
+    for (int u = 0; u < kSampleHeads; ++u) {
+      const int64_t i = first + (int64_t)u * kTile;
+      if (i < n) exact_q(b, s, (int)i, n_head, pt[u], lmin, lmax, bad);
+    }
     lmin = wave_min_u64(lmin);
     lmax = wave_max_u64(lmax);
     if (lane == 0) {
@@ -1333,7 +1346,8 @@ static int virtual_order_mode(const r3d_batch_t &b) {
 static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_t *list,
                             const int32_t *count, int rows, hipStream_t st, int slow_blocks = 4) {
   int tiles = tiles_of(b);
-  hipLaunchKernelGGL(k_bounds_sample, dim3((tiles + kPT / 64 - 1) / (kPT / 64), rows), dim3(kPT), 0, st, b, list, count, w);
+  hipLaunchKernelGGL(k_bounds_sample, dim3((tiles + kSampleHeads * (kPT / 64) - 1) / (kSampleHeads * (kPT / 64)), rows), dim3(kPT), 0, st, b,
+                     list, count, w);
   hipLaunchKernelGGL(k_bounds, dim3(tiles, rows), dim3(kPT), 0, st, b, list, count, w);
   hipLaunchKernelGGL(k_prepare, dim3(1, rows), dim3(kPT), 0, st, b, list, count, w, tiles);
   // (known_count: the list is all_list of a batch that has just begun -- its count is B, no need to wait for the word)

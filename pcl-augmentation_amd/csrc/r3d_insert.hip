@@ -2490,11 +2490,14 @@ __global__ void k_chain_init(r3d_batch_t b, BatchWs w, ChainSlots slots, int nk,
     *w.pool_head = 0ull;
     for (int q = 0; q < 16; ++q) w.queue_next[q] = 0;
     long long rows_of[kMaxChain], sum = 0;
-    for (int k = 0; k < nk; ++k) {
-      w.slot_order[k] = k;
-      rows_of[k] = slots.sample_off[k][b.B];
-      sum += rows_of[k];
-    }
+    for (int k = 0; k < nk; ++k) w.slot_order[k] = k;
+    // (the slots' sizes only for the option that uses them: fifty dependent loads of config C5's launch were 25 of this
+    // kernel's 30 us)
+    if (order_mode == 1 && nk <= 8)
+      for (int k = 0; k < nk; ++k) {
+        rows_of[k] = slots.sample_off[k][b.B];
+        sum += rows_of[k];
+      }
     if (order_mode == 1 && nk <= 8)
       for (int k = 1; k < nk; ++k) {
         if (rows_of[k] * 10 * nk < 18 * sum) continue;         // not a heavy slot
