@@ -1353,8 +1353,10 @@ static int launch_reproject(const r3d_batch_t &b, const BatchWs &w, const int32_
   // (known_count: the list is all_list of a batch that has just begun -- its count is B, no need to wait for the word)
   hipLaunchKernelGGL(k_project, dim3(project_grid(b)), dim3(kProjNT), project_lds_bytes(b), st, b, list, count,
                      list == w.all_list ? b.B : -1, w, chunks_of(b));
+  // (the queue of a scene grows with its size: a 1M-point scan on 448 x 2880 leaves ~600 chunks to k_fix_boxes, one wave each)
+  const int fix_blocks = slow_blocks > tiles / 32 ? slow_blocks : tiles / 32;
   hipLaunchKernelGGL(k_project_slow, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w);
-  hipLaunchKernelGGL(k_fix_boxes, dim3(slow_blocks, rows), dim3(kPT), 0, st, b, list, count, w, chunks_of(b));
+  hipLaunchKernelGGL(k_fix_boxes, dim3(fix_blocks, rows), dim3(kPT), 0, st, b, list, count, w, chunks_of(b));
   {
     const int mode = virtual_order_mode(b);
     if (mode) {
