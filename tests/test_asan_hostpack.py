@@ -1,4 +1,5 @@
-"""CPU: the host half of the streamed driver (r3d_hostpack.cpp: r3d_host_pack_frames, r3d_host_merge_frames, r3d_host_write_delta_frames) built with
+"""CPU: the host half of the streamed driver (r3d_hostpack.cpp: r3d_host_pack_frames, r3d_host_merge_frames, r3d_host_write_delta_frames,
+r3d_host_append_text_files) built with
 g++ -fsanitize=address,undefined and driven through ctypes the way streaming.py does, edge cases included (empty
 frames, counts at chunk boundaries, refused arguments).  GPU sanitizers are not available on the pool; this covers
 the native host code of the path."""
@@ -77,6 +78,21 @@ DRIVER = textwrap.dedent("""
                     assert os.path.getsize(os.path.join(d, f"{s}.check")) == int(n_tail[s]) * cols * 4
             assert lib.r3d_host_write_delta_frames(enc("bin"), None, None, B, sx.ctypes.data, sl.ctypes.data, cap, alive_d.ctypes.data, chunks,
                                                    tx.ctypes.data, tl.ctypes.data, tail, bad.ctypes.data, 5, None, 2) < 0
+            # the label_2 writer: sources of 0 .. 9 000 bytes (several read buffers), extra lines or none, a skipped frame
+            lib.r3d_host_append_text_files.argtypes = [P, P, P, C.c_int32, C.c_int32]
+            lib.r3d_host_append_text_files.restype = C.c_int
+            nfr = 9
+            body = ["Car 0.00 0 -1.57 599.41 156.40 629.75 189.25 2.85 2.63 12.34 0.47 1.49 69.44 -1.56\\n" * (i * 13) for i in range(nfr)]
+            for i in range(nfr):
+                open(os.path.join(d, f"src{i}.txt"), "w").write(body[i])
+            extra = [None if i == 2 else ("Pedestrian 0 0 0 0 0 0 0 1.7 0.6 0.6 1.5 1.0 2.0 0.1\\n" * (i % 3)).encode() for i in range(nfr)]
+            srcs = (C.c_char_p * nfr)(*[os.path.join(d, f"src{i}.txt").encode() for i in range(nfr)])
+            dsts = (C.c_char_p * nfr)(*[None if i == 4 else os.path.join(d, f"dst{i}.txt").encode() for i in range(nfr)])
+            assert lib.r3d_host_append_text_files(srcs, dsts, (C.c_char_p * nfr)(*extra), nfr, 4) == 0
+            for i in range(nfr):
+                if i != 4:
+                    assert open(os.path.join(d, f"dst{i}.txt"), "rb").read() == body[i].encode() + (extra[i] or b"")
+            assert not os.path.exists(os.path.join(d, "dst4.txt"))
     print("asan driver ok")
 """)
 
