@@ -41,6 +41,8 @@ __global__ void k_begin_init(r3d_batch_t b, const int32_t *n_points, BatchWs w, 
   b.n_out[s] = 0;
   w.all_list[s] = s;
   w.shadow_valid[s] = 0;
+  w.img_valid[s] = 0;
+  w.img_dirty[s] = 0;
   w.n_virt[s] = 0;
   w.box_area[s] = 0;
   w.qkeys[2 * s + 0] = ~0ull;   // running min of z/r
@@ -1472,6 +1474,10 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream) {
       break;
     case R3D_K_ALIVE_WRITE:
       return launch_compact(*b, w, w.all_list, w.all_count, b->B, st);
+    case R3D_K_IMAGE_CLEAR:
+      return launch_image_clear(*b, w, st);
+    case R3D_K_IMAGE_BUILD:
+      return launch_image_build(*b, w, st);
     default:
       return fail(R3D_E_ARG, "batch_launch_one: unknown kernel id");
   }

@@ -31,6 +31,7 @@ constexpr int kMaxChain = 64;        // insert slots of one k_insert_chain launc
 constexpr int kRecInts = 16;         // int32 words of a published slot record
 constexpr int kParkInts = 32;        // int32 words of the header a parked pair leaves (r3d_insert.hip)
 constexpr int kEntry = 32;           // bytes of a chunk-list entry of the insert kernels (r3d_insert.hip)
+constexpr int kHoldCap = 16;         // pixels of bound-holding points the image route keeps per scene (r3d_image.hip)
 
 struct BatchWs {
   unsigned long long *qkeys;    // [B][2] ordered keys of min / max of z/r
@@ -74,6 +75,16 @@ struct BatchWs {
                                 // of the pairs whose window exceeds a workgroup's LDS
   unsigned long long *pool_head; // [1] bytes handed out in the running launch
   int32_t *queue_next;          // [16] the running k_insert_chain's work queues: next pair of XCD x's queue in [x] (all pairs: [0])
+  // ---- the image route (r3d_image.hip): a persistent raw range image per scene ----
+  unsigned long long *img;      // [B*npix] minimum SQUARED depth (float64 bits of x*x + y*y + z*z) over the LIVING points of
+                                // every pixel (insertion.py:118-125; the root is monotone), R3D_SENT = nobody there
+  uint16_t *kstep;              // [B*npix] step of the latest accepted insert that made the pixel visible (0: none): a point
+                                // is dead iff its pixel's step exceeds its birth step (insertion.py:470-473 per pixel)
+  uint32_t *occ;                // [B*rows*cols/32] occupancy bits of img (the label image of insertion.py:119-120)
+  int32_t *img_valid;           // [B] 1: img / kstep / occ / hold_pix describe the scene as it stands
+  int32_t *img_dirty;           // [B] 1: kstep holds kills the alive words do not show yet (k_apply_kills)
+  int32_t *hold_pix;            // [B*kHoldCap] pixels of the living points that hold an elevation bound (z/r == q_ext)
+  int32_t *n_hold;              // [B] how many (more than kHoldCap: any occupied pixel of the first / last row counts)
   int32_t *dbg;                 // [64] diagnostic counters of the insert kernels (r3d_batch_debug_counters: the first 16;
                                 // [16..31]: what a diagnostic build notes about the first failed check, `reset` bit 1 asks for them;
                                 // [32..63]: round 5's counters, `reset` bit 2)
@@ -156,12 +167,25 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.tile_pool = c.take<unsigned char>((size_t)w.pool_bytes);
   w.pool_head = c.take<unsigned long long>(1);
   w.queue_next = c.take<int32_t>(16);
+  {
+    const size_t npix = (size_t)b.rows * b.cols;
+    w.img = c.take<unsigned long long>((size_t)b.B * npix);
+    w.kstep = c.take<uint16_t>((size_t)b.B * npix);
+    w.occ = c.take<uint32_t>((size_t)b.B * (npix / 32));
+    w.img_valid = c.take<int32_t>((size_t)b.B);
+    w.img_dirty = c.take<int32_t>((size_t)b.B);
+    w.hold_pix = c.take<int32_t>((size_t)b.B * kHoldCap);
+    w.n_hold = c.take<int32_t>((size_t)b.B);
+  }
   w.dbg = c.take<int32_t>(64);
   w.total = c.off;
   return w;
 }
 
 int check_batch(const r3d_batch_t *b);
+// r3d_image.hip (the image route of the insert step)
+int launch_image_clear(const r3d_batch_t &b, const BatchWs &w, hipStream_t st);
+int launch_image_build(const r3d_batch_t &b, const BatchWs &w, hipStream_t st);
 
 #ifdef __HIPCC__
 // ---- cloud access ---------------------------------------------------------------------------
