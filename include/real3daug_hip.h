@@ -271,8 +271,6 @@ int r3d_batch_adopt_rejected(const r3d_batch_t *b, const int32_t *active, void *
 #define R3D_K_PREPARE 2       /* k_prepare: bounds from the extremes, row-edge table, living points per tile */
 #define R3D_K_PROJECT 3       /* k_project: pixel id of every point (insertion.py:74-76, :104-116) */
 #define R3D_K_ALIVE_WRITE 5   /* k_alive_write: survivors, original order, into out_xyzi / out_label */
-#define R3D_K_IMAGE_CLEAR 6   /* k_image_clear: the range images of the image route emptied (scenes whose image is not valid) */
-#define R3D_K_IMAGE_BUILD 7   /* k_image_build: min squared depth per pixel over the living points (insertion.py:118-125) */
 int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream);
 
 /* Diagnostic: the 16 counters the insert kernels keep in the workspace since r3d_batch_create (or the last

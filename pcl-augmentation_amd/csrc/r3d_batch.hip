@@ -41,8 +41,9 @@ __global__ void k_begin_init(r3d_batch_t b, const int32_t *n_points, BatchWs w, 
   b.n_out[s] = 0;
   w.all_list[s] = s;
   w.shadow_valid[s] = 0;
+#ifdef R3D_EXP_IMAGE
   w.img_valid[s] = 0;
-  w.img_dirty[s] = 0;
+#endif
   w.n_virt[s] = 0;
   w.box_area[s] = 0;
   w.qkeys[2 * s + 0] = ~0ull;   // running min of z/r
@@ -1474,10 +1475,14 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream) {
       break;
     case R3D_K_ALIVE_WRITE:
       return launch_compact(*b, w, w.all_list, w.all_count, b->B, st);
-    case R3D_K_IMAGE_CLEAR:
+#ifdef R3D_EXP_IMAGE
+    case 6:
       return launch_image_clear(*b, w, st);
-    case R3D_K_IMAGE_BUILD:
+    case 7:
       return launch_image_build(*b, w, st);
+    case 8:
+      return launch_image_bands(*b, w, st);
+#endif
     default:
       return fail(R3D_E_ARG, "batch_launch_one: unknown kernel id");
   }

@@ -75,7 +75,8 @@ struct BatchWs {
                                 // of the pairs whose window exceeds a workgroup's LDS
   unsigned long long *pool_head; // [1] bytes handed out in the running launch
   int32_t *queue_next;          // [16] the running k_insert_chain's work queues: next pair of XCD x's queue in [x] (all pairs: [0])
-  // ---- the image route (r3d_image.hip): a persistent raw range image per scene ----
+#ifdef R3D_EXP_IMAGE
+  // ---- experiment (r3d_image.hip, -DR3D_EXP_IMAGE only): a persistent raw range image per scene ----
   unsigned long long *img;      // [B*npix] minimum SQUARED depth (float64 bits of x*x + y*y + z*z) over the LIVING points of
                                 // every pixel (insertion.py:118-125; the root is monotone), R3D_SENT = nobody there
   uint16_t *kstep;              // [B*npix] step of the latest accepted insert that made the pixel visible (0: none): a point
@@ -85,6 +86,9 @@ struct BatchWs {
   int32_t *img_dirty;           // [B] 1: kstep holds kills the alive words do not show yet (k_apply_kills)
   int32_t *hold_pix;            // [B*kHoldCap] pixels of the living points that hold an elevation bound (z/r == q_ext)
   int32_t *n_hold;              // [B] how many (more than kHoldCap: any occupied pixel of the first / last row counts)
+  uint8_t *band_fall;           // [B*rows] k_image_bands: this row band of the scene listed more chunks than its workgroup holds --
+  int32_t *n_fall;              // [B] ... how many of the scene's bands: their points go through k_image_build's global atomics
+#endif
   int32_t *dbg;                 // [64] diagnostic counters of the insert kernels (r3d_batch_debug_counters: the first 16;
                                 // [16..31]: what a diagnostic build notes about the first failed check, `reset` bit 1 asks for them;
                                 // [32..63]: round 5's counters, `reset` bit 2)
@@ -167,6 +171,7 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.tile_pool = c.take<unsigned char>((size_t)w.pool_bytes);
   w.pool_head = c.take<unsigned long long>(1);
   w.queue_next = c.take<int32_t>(16);
+#ifdef R3D_EXP_IMAGE
   {
     const size_t npix = (size_t)b.rows * b.cols;
     w.img = c.take<unsigned long long>((size_t)b.B * npix);
@@ -176,16 +181,22 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
     w.img_dirty = c.take<int32_t>((size_t)b.B);
     w.hold_pix = c.take<int32_t>((size_t)b.B * kHoldCap);
     w.n_hold = c.take<int32_t>((size_t)b.B);
+    w.band_fall = c.take<uint8_t>((size_t)b.B * b.rows);
+    w.n_fall = c.take<int32_t>((size_t)b.B);
   }
+#endif
   w.dbg = c.take<int32_t>(64);
   w.total = c.off;
   return w;
 }
 
 int check_batch(const r3d_batch_t *b);
-// r3d_image.hip (the image route of the insert step)
+#ifdef R3D_EXP_IMAGE
+// r3d_image.hip: round 6's experiment, a persistent raw range image per scene (tools/image_exp/image_build.sh, profiles/r06_image_build.md)
 int launch_image_clear(const r3d_batch_t &b, const BatchWs &w, hipStream_t st);
 int launch_image_build(const r3d_batch_t &b, const BatchWs &w, hipStream_t st);
+int launch_image_bands(const r3d_batch_t &b, const BatchWs &w, hipStream_t st);
+#endif
 
 #ifdef __HIPCC__
 // ---- cloud access ---------------------------------------------------------------------------

@@ -8,16 +8,16 @@
 set -e
 name=$1; shift
 cd "$(dirname "$0")/../pcl-augmentation_amd/csrc"
-SRCS="r3d_level1.hip r3d_batch.hip r3d_insert.hip r3d_image.hip r3d_places.hip r3d_richmap.hip r3d_hostpack.cpp"
+SRCS="r3d_level1.hip r3d_batch.hip r3d_insert.hip r3d_places.hip r3d_richmap.hip r3d_hostpack.cpp"
 HDRS="r3d_device.hpp r3d_host.hpp r3d_batch.hpp r3d_insert_core.hpp ../../include/real3daug_hip.h"
 HASH=$(cat $SRCS $HDRS | sha256sum | cut -c1-16)
 T=$(mktemp -d)
 trap 'rm -rf "$T"' EXIT
 FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wno-unused-function -Wno-pass-failed"
 pids=()
-for f in r3d_level1 r3d_batch r3d_insert r3d_image r3d_places r3d_richmap; do
+for f in r3d_level1 r3d_batch r3d_insert r3d_places r3d_richmap; do
   extra=()
-  { [ $f = r3d_insert ] || [ $f = r3d_image ]; } && extra=(-mllvm -disable-machine-licm)
+  [ $f = r3d_insert ] && extra=(-mllvm -disable-machine-licm)
   [ $f = r3d_level1 ] && extra=("-DR3D_SRC_HASH=\"$HASH\"")
   hipcc $FLAGS "$@" "${extra[@]}" -c $f.hip -o $T/$f.o &
   pids+=($!)
