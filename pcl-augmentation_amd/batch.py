@@ -458,6 +458,7 @@ class SceneBatch:
         pairs, listed = int(out[32]), int(out[33])
         d.update(pairs_committed_by_their_evaluator=pairs, parked_with_record=int(out[34]), parked_unevaluated=int(out[35]),
                  committed_from_record=int(out[36]), scenes_in_sorted_order=int(out[37]),
+                 sparse_tiles=int(out[38]), sparse_tiles_beyond_the_lds=int(out[39]),
                  chunks_listed_per_pair=round(listed / pairs, 1) if pairs else None)
         return d
 

@@ -40,6 +40,8 @@ constexpr int kDbgNoHits = 128;      // the kill masks from the pixel ids in glo
 constexpr int kDbgCount = 4096;      // count per pair (D_PAIRS .. D_TAKEOVER_COMMIT): two to four atomics of every pair on the same few
                                      // addresses, on the chain's critical path -- only when somebody wants to read them (bench.py's
                                      // insert_paths step, the tests)
+constexpr int kDbgSparse = 16384;    // every pair's depth tile as a sparse tile (gather_sparse), whatever its size
+constexpr int kDbgNoSparse = 32768;  // never: a tile beyond the LDS goes to the pool (rounds 3-5)
 constexpr int kDbgVerify = 64;       // a speculative evaluation that is about to be committed is done again, now after its
                                      // predecessors, and compared (visible count, accept, visible pixels, kill masks):
                                      // counters D_VERIFY_RUNS / D_VERIFY_MISMATCH (tests/test_gpu_batch.py soaks on them)
@@ -207,7 +209,8 @@ enum { D_POOL_FULL = 0, D_TILE_POOLED, D_EVAL_TWICE, D_VERIFY_RUNS, D_VERIFY_MIS
        // round 5, [32 ..]: pairs committed from their own evaluation and the chunks they listed; pairs left to whoever finishes
        // their predecessors -- with a record of the evaluation / as they came --; parked pairs committed from their record
        D_PAIRS = 32, D_CHUNKS_LISTED, D_PARKED, D_PARKED_RAW, D_TAKEOVER_COMMIT,
-       D_VIRTUAL /* scenes put into virtual order at step 0: counted by k_virt_scan, r3d_batch.hip */ };
+       D_VIRTUAL /* scenes put into virtual order at step 0: counted by k_virt_scan, r3d_batch.hip */,
+       D_SPARSE /* round 6: evaluations on a sparse tile */, D_SPARSE_NOFIT /* ... that it could not hold either */ };
 static_assert(D_VIRTUAL == kCntVirtual, "the counter r3d_batch.hip writes");
 constexpr int kDbgInts = 64;
 
@@ -266,6 +269,14 @@ struct Ins {
   bool intile;                            // the gather leaves, in every list entry's kill field, which of its points lie inside the tile
   bool flat;                              // gather_flat does the gather
   bool lazy_root;                         // the pooled tile keeps squared depths (tile_key)
+  // the SPARSE tile (round 6): a window whose dense tile exceeds the LDS keeps only the pixels the evaluation reads --
+  // candidates the scene occupies, occupied neighbours of the candidates that are holes of the scene: bits in N, their
+  // number before every window word in s_nrank, one depth each in s_ctile -- in LDS, instead of every pixel in the pool
+  bool sparse;
+  WinImage N;
+  uint32_t *s_nrank;
+  unsigned long long *s_ctile;
+  int nneed;
   bool accept;
   bool cull_only;             // min_points < 0: the state a REJECTED candidate leaves (see commit)
   FastDiv by_W;
@@ -285,7 +296,8 @@ struct Ins {
     g_cand = nullptr;
     s_hit = nullptr;
     hit_cap = 0;
-    intile = flat = lazy_root = false;
+    intile = flat = lazy_root = sparse = false;
+    nneed = 0;
     pool_off = -1;
     g_list = force_glist_ ? w.glist + ((int64_t)s + 1) * chunks * kEntry : nullptr;   // entries grow down from the area's end
   }
@@ -375,6 +387,16 @@ struct Ins {
     const unsigned long long k2 = g_dtile[dl];
     if (NT != 1024) return k2;                              // (only the shape for large range images meets such tiles)
     return !lazy_root || k2 == R3D_SENT ? k2 : depth_key(sqrt(key_depth(k2)));
+  }
+
+  // the sparse tile: depth of window pixel lp (-1: outside), R3D_SENT where the tile keeps none (nobody there, or a
+  // pixel the evaluation does not read)
+  __device__ __forceinline__ unsigned long long ctile_key(int lp) const {
+    const int wd = lp >= 0 ? lp >> 5 : 0;
+    const uint32_t nw = N.w[wd], rk = s_nrank[wd], bit = 1u << (lp & 31);
+    const bool has = lp >= 0 && (nw & bit);
+    const unsigned long long key = s_ctile[has ? (int)rk + __popc(nw & (bit - 1u)) : 0];
+    return has ? key : R3D_SENT;
   }
 
   // LDS layout of a pair: header | out-of-bounds bits | window pixel per point | sorted order | occupancy, closed,
@@ -1043,35 +1065,293 @@ struct Ins {
   // A word outside the window reads as 0; a row or column outside the IMAGE does not take part (no
   // contribution to the dilation, no constraint on the erosion).
   __device__ __forceinline__ void closing(const WinImage &src, WinImage &tmp, WinImage &dst) {
-    for (int pass = 0; pass < 2; ++pass) {
-      const uint32_t *from = pass == 0 ? src.w : tmp.w;
-      uint32_t *to = pass == 0 ? tmp.w : dst.w;
-      for (int e = tid; e < ww; e += NT) {
-        int k, r = win.r_lo + win.by_njw.div(e, k);
-        const int j = k < win.nj0 ? win.jl0 + k : win.jl1 + (k - win.nj0);
-        const bool has_l = k > 0 && k != win.nj0, has_r = k < win.njw - 1 && k != win.nj0 - 1;
-        // what stands in for a neighbour word that is not in the window: nothing, except beyond the image's
-        // first / last column during the erosion
-        const uint32_t l_out = pass && j == 0 ? 1u : 0u, r_out = pass && j == wpr - 1 ? 0x80000000u : 0u;
-        uint32_t acc = pass ? 0xFFFFFFFFu : 0u;
+    morph(src.w, tmp.w, 0);
+    morph(tmp.w, dst.w, 1);
+  }
+  // pass 0: dilation, pass 1: erosion with the 5-row x 3-column element; ends with a barrier
+  __device__ __forceinline__ void morph(const uint32_t *from, uint32_t *to, const int pass) {
+    for (int e = tid; e < ww; e += NT) {
+      int k, r = win.r_lo + win.by_njw.div(e, k);
+      const int j = k < win.nj0 ? win.jl0 + k : win.jl1 + (k - win.nj0);
+      const bool has_l = k > 0 && k != win.nj0, has_r = k < win.njw - 1 && k != win.nj0 - 1;
+      // what stands in for a neighbour word that is not in the window: nothing, except beyond the image's
+      // first / last column during the erosion
+      const uint32_t l_out = pass && j == 0 ? 1u : 0u, r_out = pass && j == wpr - 1 ? 0x80000000u : 0u;
+      uint32_t acc = pass ? 0xFFFFFFFFu : 0u;
 #pragma unroll
-        for (int dr = -2; dr <= 2; ++dr) {
-          const int rr = r + dr;
-          if (rr < 0 || rr >= rows) continue;
-          uint32_t c = 0u, l = l_out, rw = r_out;
-          if (rr >= win.r_lo && rr <= win.r_hi) {
-            const int q = e + dr * win.njw;
-            c = from[q];
-            if (has_l) l = from[q - 1] >> 31;
-            if (has_r) rw = from[q + 1] << 31;
-          }
-          if (pass) acc &= c & ((c << 1) | l) & ((c >> 1) | rw);
-          else acc |= c | (c << 1) | l | (c >> 1) | rw;
+      for (int dr = -2; dr <= 2; ++dr) {
+        const int rr = r + dr;
+        if (rr < 0 || rr >= rows) continue;
+        uint32_t c = 0u, l = l_out, rw = r_out;
+        if (rr >= win.r_lo && rr <= win.r_hi) {
+          const int q = e + dr * win.njw;
+          c = from[q];
+          if (has_l) l = from[q - 1] >> 31;
+          if (has_r) rw = from[q + 1] << 31;
         }
-        to[e] = acc;
+        if (pass) acc &= c & ((c << 1) | l) & ((c >> 1) | rw);
+        else acc |= c | (c << 1) | l | (c >> 1) | rw;
       }
+      to[e] = acc;
+    }
+    __syncthreads();
+  }
+
+  // -- 9. visibility on the candidates: smoothed sample depth < smoothed scene depth (:461-467).  `nc` candidates in s_cand /
+  // g_cand; the scene's depths from the band in LDS / the pool (bt), or -- SP -- from the sparse tile.  Visible pixels: bits
+  // in T; their count, box and the rebase flag in the header.
+  template <bool SP>
+  __device__ __forceinline__ void evaluate(int nc) {
+    WinImage &vis = T;
+    const int W = dt.W;
+    const int half = cols >> 1;
+    int v_n = 0, v_rmin = 0x7FFFFFFF, v_rmax = -1, v_cmin0 = 0x7FFFFFFF, v_cmax0 = -1, v_cmin1 = 0x7FFFFFFF, v_cmax1 = -1;
+    for (int ci = tid; ci < nc; ci += NT) {
+      int lp = (int)(g_cand ? g_cand[ci] : s_cand[ci]);
+      int r, c;
+      win.row_word(lp >> 5, r, c);
+      c = (c << 5) + (lp & 31);
+      double sd = R3D_EMPTY_DEPTH, cd = R3D_EMPTY_DEPTH;
+      const bool a = A.get_local(lp), d = D.get_local(lp);
+      const bool c_hole = !d && E.get_local(lp);
+      // A candidate lies at least 4 rows / 2 columns inside the window unless the image ends there, so the
+      // neighbours of its 5 x 3 footprint are plain offsets in the window-local and tile-local numbering
+      // (rows `rstride` resp. W apart); what leaves the image counts as empty.
+      const int rstride = win.njw << 5, dl0 = SP ? 0 : bt.index(r, c);
+      if (a) sd = key_depth(sample_key(lp));
+      if (d) cd = key_depth(SP ? ctile_key(lp) : (dl0 < 0 ? R3D_SENT : tile_key(dl0)));
+      // hole means (closing.py:44-57): the 15 neighbour keys are gathered first, one image at a time
+      // (one register array, every load issued before the first is used), then summed in the reference's order
+      if (!a) {                                            // a candidate is closed: a hole of the sample
+        unsigned long long v[15];
+#pragma unroll
+        for (int dr = -2; dr <= 2; ++dr)
+#pragma unroll
+          for (int dc = -1; dc <= 1; ++dc) {
+            int rr = r + dr, cc = c + dc;
+            const bool in = rr >= 0 && rr < rows && cc >= 0 && cc < cols;
+            int lq = lp + dr * rstride + dc;
+            v[(dr + 2) * 3 + (dc + 1)] = sample_key(in && (unsigned)lq < (unsigned)(ww << 5) ? lq : -1);
+          }
+        sd = mean_of_keys(v);
+      }
+      if (c_hole) {
+        unsigned long long v[15];
+#pragma unroll
+        for (int dr = -2; dr <= 2; ++dr)
+#pragma unroll
+          for (int dc = -1; dc <= 1; ++dc) {
+            int rr = r + dr, cc = c + dc;
+            const bool in = rr >= 0 && rr < rows && cc >= 0 && cc < cols;
+            if (SP) {                                      // (the window's numbering, as for the sample's holes above)
+              int lq = lp + dr * rstride + dc;
+              v[(dr + 2) * 3 + (dc + 1)] = ctile_key(in && (unsigned)lq < (unsigned)(ww << 5) ? lq : -1);
+            } else {
+              int dq = dl0 + dr * W + dc;
+              const bool ok = in && dl0 >= 0 && (unsigned)dq < (unsigned)bt.npx;
+              unsigned long long key = tile_key(ok ? dq : 0);
+              v[(dr + 2) * 3 + (dc + 1)] = ok ? key : R3D_SENT;
+            }
+          }
+        cd = mean_of_keys(v);
+      }
+      if (sd < cd) {
+        vis.set_local(lp);
+        v_rmin = r < v_rmin ? r : v_rmin;
+        v_rmax = r > v_rmax ? r : v_rmax;
+        if (c < half) {
+          v_cmin0 = c < v_cmin0 ? c : v_cmin0;
+          v_cmax0 = c > v_cmax0 ? c : v_cmax0;
+        } else {
+          v_cmin1 = c < v_cmin1 ? c : v_cmin1;
+          v_cmax1 = c > v_cmax1 ? c : v_cmax1;
+        }
+        if (a) {                                           // its sample points are visible (:474)
+          int rk = rank_of(lp);
+          int p0 = s_start[rk], p1 = s_start[rk + 1];
+          v_n += p1 - p0;
+          for (int p = p0; p < p1; ++p) {
+            int j = s_F[p];
+            if (!cull_only && ((s_oob[j >> 5] >> (j & 31)) & 1u)) atomicOr(&H[H_REBASE], 1);   // bounds move: new extreme elevation
+          }
+        }
+      }
+    }
+    v_n = wave_sum_i32(v_n);
+    v_rmin = wave_min_i32(v_rmin); v_rmax = wave_max_i32(v_rmax);
+    v_cmin0 = wave_min_i32(v_cmin0); v_cmax0 = wave_max_i32(v_cmax0);
+    v_cmin1 = wave_min_i32(v_cmin1); v_cmax1 = wave_max_i32(v_cmax1);
+    if ((tid & 63) == 0 && v_rmax >= 0) {
+      atomicAdd(&H[H_NVIS], v_n);
+      atomicMin(&H[H_VRMIN], v_rmin);
+      atomicMax(&H[H_VRMAX], v_rmax);
+      atomicMin(&H[H_VCMIN0], v_cmin0);
+      atomicMax(&H[H_VCMAX0], v_cmax0);
+      atomicMin(&H[H_VCMIN1], v_cmin1);
+      atomicMax(&H[H_VCMAX1], v_cmax1);
+    }
+  }
+
+  // ---- the sparse tile (round 6) ----------------------------------------------------------------------------------------
+  // A window whose dense depth tile exceeds the LDS (a car a few metres away: 15 000 pixels on the reference's grid, 100 000
+  // on 448 x 2880) used to get its tile in the launch's pool in global memory: cleared pixel by pixel, filled with global
+  // atomics -- 37-47 G/s on this part, profiles/r06_image_build.md --, square-rooted pixel by pixel, read through L2; for an
+  // evaluation that reads a few thousand of those pixels.  Now: pass 1 over the listed chunks sets the scene's occupancy bits
+  // (pixel ids only); the closing says where the scene has holes; the pixels the evaluation can read are the candidates
+  // the scene occupies and the occupied 5 x 3 neighbours of the candidates that are holes of the scene (bits N, ranked);
+  // pass 2 fetches coordinates for the points in THOSE pixels only and min-reduces them in LDS, one slot per needed pixel.
+  //
+  // Pass 1: occupancy bits of the tile's pixels, and per listed chunk which of its living points lie inside the tile.
+  __device__ __forceinline__ void gather_bits() {
+    constexpr int kU = 8;
+    const uint32_t *pixs = reinterpret_cast<const uint32_t *>(b.pix) + (int64_t)s * b.cap;
+    const int nitems = nlist << 6;
+    const int lane = tid & 63;
+    for (int e00 = 0; e00 < nitems; e00 += kU * NT) {
+      int idx[kU];
+      uint32_t p[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int e = e00 + u * NT + tid;
+        idx[u] = -1;
+        if (e < nitems && ((l_alive(e >> 6) >> (e & 63)) & 1ull)) idx[u] = (int)(l_chunk(e >> 6) << 6) + (e & 63);
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) p[u] = idx[u] >= 0 && CHK(idx[u] < n_base && idx[u] < b.cap, 0) ? pixs[idx[u]] : 0u;
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int e = e00 + u * NT + tid;
+        int dl = -1, lp = -1;
+        if (idx[u] >= 0) place_rc(p[u], dl, lp);
+        if (POOL && planes_pooled) or_bits_by_runs(D, dl >= 0 ? lp : -1);
+        else if (dl >= 0) D.set_local(lp);
+        const unsigned long long msk = __ballot(dl >= 0);
+        if (lane == 0 && e < nitems) set_kill(e >> 6, msk);    // (wave-uniform: the listed items come in 64s)
+      }
+    }
+  }
+  // Pass 2: the in-tile points (the masks pass 1 left) whose pixel the evaluation reads, min-reduced on the squared depth.
+  __device__ __forceinline__ void gather_needed() {
+    constexpr int kU = 4;
+    const int n_head = uni(b.n_head[s]), n_virt = uni(w.n_virt[s]);
+    const uint32_t *pixs = reinterpret_cast<const uint32_t *>(b.pix) + (int64_t)s * b.cap;
+    const float4 *xyzi = reinterpret_cast<const float4 *>(b.xyzi) + (int64_t)s * b.cap;
+    const int nitems = nlist << 6;
+    for (int e00 = 0; e00 < nitems; e00 += kU * NT) {
+      int idx[kU], slot[kU];
+      uint32_t p[kU];
+      float4 f[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int e = e00 + u * NT + tid;
+        idx[u] = -1;
+        if (e < nitems && ((l_kill(e >> 6) >> (e & 63)) & 1ull)) idx[u] = (int)(l_chunk(e >> 6) << 6) + (e & 63);
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) p[u] = idx[u] >= 0 ? pixs[idx[u]] : 0u;
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        slot[u] = -1;
+        if (idx[u] < 0) continue;
+        int dl, lp;
+        place_rc(p[u], dl, lp);
+        if (dl < 0) continue;
+        const uint32_t nw = N.w[lp >> 5], bit = 1u << (lp & 31);
+        if (nw & bit) slot[u] = (int)s_nrank[lp >> 5] + __popc(nw & (bit - 1u));
+      }
+      if (n_virt)                                              // (virtual order: the point of the slabs behind the listed number)
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+          if (slot[u] >= 0) idx[u] = orig_of(w, b, s, n_virt, idx[u]);
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        f[u] = make_float4(1.f, 0.f, 0.f, 0.f);
+        if (slot[u] >= 0 && idx[u] < n_head) f[u] = xyzi[idx[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (slot[u] < 0 || !CHK(slot[u] < nneed, 1)) continue;
+        double x = (double)f[u].x, y = (double)f[u].y, z = (double)f[u].z;
+        if (idx[u] >= n_head) load_point(b, s, idx[u], n_head, x, y, z);   // an inserted point: float64, from the log
+        atomicMin(&s_ctile[slot[u]], depth_key(x * x + y * y + z * z));
+      }
+    }
+  }
+  // The scene side of an evaluation on a sparse tile, from the chunk list to the visible bits (steps 7-9 of scene_phase):
+  // kOk; kNoFit when the room between `carve` and `list_start` does not hold it (nothing is lost: the caller goes on with
+  // the dense routes); kStale.  On kOk `band_end` is where the tile ends.
+  template <class Stale>
+  __device__ __forceinline__ int scene_sparse(int carve, int list_start, bool serial, int &band_end, Stale &&stale) {
+    const int cand_bytes = (ncand * 4 + 7) & ~7, img_bytes = (2 * ww * 4 + 7) & ~7;
+    if ((int64_t)carve + cand_bytes + img_bytes + 256 > list_start) return kNoFit;
+    g_dtile = nullptr;
+    g_cand = nullptr;
+    s_cand = reinterpret_cast<uint32_t *>(smem + carve);
+    N.w = reinterpret_cast<uint32_t *>(smem + carve + cand_bytes);
+    s_nrank = N.w + ww;
+    const int tile_at = carve + cand_bytes + img_bytes;
+    bt = dt;                                                   // (one band: the whole window)
+    if (tid == 0) H[H_FILL] = H[H_CARRY] = 0;
+    for (int e = tid; e < ww; e += NT) D.w[e] = 0u;
+    __syncthreads();
+    for (int e = tid; e < ww; e += NT) {                       // the candidates: where the sample is closed
+      uint32_t bits = Cs.w[e];
+      if (!bits) continue;
+      int pos = atomicAdd(&H[H_FILL], __popc(bits));
+      while (bits) {
+        const int bit = __ffs(bits) - 1;
+        bits &= bits - 1;
+        s_cand[pos++] = (uint32_t)((e << 5) + bit);
+      }
+    }
+    STAMP(26);
+    gather_bits();
+    __syncthreads();
+    const int nc = uni(H[H_FILL]);
+    if (!serial && stale()) return kStale;
+    closing(D, T, E);
+    // holes of the scene among the candidates -> T; what the evaluation reads -> N
+    for (int e = tid; e < ww; e += NT) T.w[e] = Cs.w[e] & ~D.w[e] & E.w[e];
+    __syncthreads();
+    morph(T.w, N.w, 0);
+    for (int e = tid; e < ww; e += NT) N.w[e] = (N.w[e] | Cs.w[e]) & D.w[e];
+    __syncthreads();
+    for (int base = 0; base < ww; base += NT) {                // needed pixels before every window word
+      const int e = base + tid;
+      const int c = e < ww ? __popc(N.w[e]) : 0;
+      int tot;
+      const int ex = block_escan_i32(c, scan, tot);
+      const int carry0 = H[H_CARRY];
+      if (e < ww) s_nrank[e] = (uint32_t)(carry0 + ex);
+      __syncthreads();
+      if (tid == 0) H[H_CARRY] = carry0 + tot;
       __syncthreads();
     }
+    nneed = uni(H[H_CARRY]);
+    __syncthreads();                                           // (every wave has read the carry: see sample_phase)
+    if ((int64_t)tile_at + (int64_t)nneed * 8 > list_start) {
+      if (tid == 0) atomicAdd(&w.dbg[D_SPARSE_NOFIT], 1);
+      return kNoFit;
+    }
+    band_end = tile_at + nneed * 8;
+    s_ctile = reinterpret_cast<unsigned long long *>(smem + tile_at);
+    for (int i = tid; i < nneed; i += NT) s_ctile[i] = R3D_SENT;
+    for (int e = tid; e < ww; e += NT) T.w[e] = 0u;            // from here on: the visible pixels
+    __syncthreads();
+    gather_needed();
+    __syncthreads();
+    STAMP(27);                                                 // (both passes over the listed chunks, the scene's closing between them)
+    for (int i = tid; i < nneed; i += NT) {                    // minima of the squared depth -> depths
+      const unsigned long long k2 = s_ctile[i];
+      if (k2 != R3D_SENT) s_ctile[i] = depth_key(sqrt(key_depth(k2)));
+    }
+    __syncthreads();
+    STAMP(8);
+    STAMP(9);
+    if (tid == 0) atomicAdd(&w.dbg[D_SPARSE], 1);
+    evaluate<true>(nc);
+    __syncthreads();
+    return kOk;
   }
 
   // ================================================================================================
@@ -1175,12 +1455,23 @@ struct Ins {
     const int cr0 = uni(H[H_RMIN]) - 2 < 0 ? 0 : uni(H[H_RMIN]) - 2;
     const int cr1 = uni(H[H_RMAX]) + 2 > rows - 1 ? rows - 1 : uni(H[H_RMAX]) + 2;
     bool single = !(b.reserved & (kDbgBands | kDbgPoolTile)) && (int64_t)ncand * 4 + (int64_t)dt.npx * 8 + 8 <= band_bytes;
-    // a window that does not fit the LDS: its tile and candidate list in a piece of the global pool (one
-    // band, the evaluation reads the tile through L2); in row bands in LDS only when the pool is exhausted
+    // a window that does not fit the LDS: a sparse tile (round 6: only the pixels the evaluation reads, in LDS); when even
+    // that does not fit, its tile and candidate list in a piece of the global pool (one band, the evaluation reads the
+    // tile through L2); in row bands in LDS only when the pool is exhausted
     g_dtile = nullptr;
     g_cand = nullptr;
+    sparse = false;
+    int sparse_end = 0;
+    if ((b.reserved & kDbgSparse) || (!single && !(b.reserved & (kDbgBands | kDbgPoolTile | kDbgNoSparse)))) {
+      if (!serial && stale()) return kStale;
+      STAMP(7);
+      const int rs = scene_sparse(carve, list_start, serial, sparse_end, stale);
+      if (rs == kStale) return kStale;
+      sparse = rs == kOk;
+      if (sparse) single = true;
+    }
     // (round 5, measured on config C5: such tiles in row bands in LDS instead -- 30.1 against 5.07 ms per launch)
-    if (!single && !(b.reserved & (kDbgBands | kDbgNoPoolTile)) && pool_off != -2) {
+    if (!sparse && !single && !(b.reserved & (kDbgBands | kDbgNoPoolTile)) && pool_off != -2) {
       if (pool_off == -1) {
         pool_off = pool_take((((long long)dt.npx * 8 + 255) & ~255ll) + (long long)ncand * 4);
         if (pool_off < 0) pool_off = -2;
@@ -1207,7 +1498,7 @@ struct Ins {
     uint16_t *s_kl = nullptr;
     int kl_room = 0;
     if (single) {
-      const int band_end = g_dtile ? carve : (((carve + ncand * 4 + 7) & ~7) + dt.npx * 8);
+      const int band_end = sparse ? sparse_end : (g_dtile ? carve : (((carve + ncand * 4 + 7) & ~7) + dt.npx * 8));
       const int kl_bytes = nlist <= 0xFFFF ? (nlist * 2 + 7) & ~7 : 0;
       if (band_end + kl_bytes <= list_start && kl_bytes) {
         s_kl = reinterpret_cast<uint16_t *>(smem + list_start - kl_bytes);
@@ -1215,21 +1506,21 @@ struct Ins {
       }
       const int hit_bytes = list_start - (s_kl ? kl_bytes : 0) - band_end;
       // (tile and window pixel of a hit share a word: fewer than 65 536 of either)
-      if (NT <= 512 && hit_bytes >= 512 && (ww << 5) < 0xFFFF && dt.npx < 0xFFFF && !(b.reserved & kDbgNoHits)) {
+      if (!sparse && NT <= 512 && hit_bytes >= 512 && (ww << 5) < 0xFFFF && dt.npx < 0xFFFF && !(b.reserved & kDbgNoHits)) {
         s_hit = reinterpret_cast<uint2 *>(smem + band_end);
         hit_cap = hit_bytes >> 3;
       }
     }
-    flat = NT <= 512 && single && (ww << 5) < 0xFFFF && dt.npx < 0xFFFF;
+    flat = !sparse && NT <= 512 && single && (ww << 5) < 0xFFFF && dt.npx < 0xFFFF;
     if (tid == 0) {
       H[H_NHIT] = 0;
       H[H_HITEND] = 0x7FFFFFFF;
     }
 
-    if (!serial && stale()) return kStale;
-    STAMP(7);
+    if (!sparse && !serial && stale()) return kStale;
+    if (!sparse) STAMP(7);
     WinImage &vis = T;
-    for (int a0 = cr0; a0 <= cr1; a0 += per) {
+    for (int a0 = cr0; a0 <= cr1 && !sparse; a0 += per) {
       const int a1 = a0 + per - 1 > cr1 ? cr1 : a0 + per - 1;
       // -- 7. this band of the scene's range image, from the living points -----------------------------
       bt = dt;
@@ -1316,89 +1607,7 @@ struct Ins {
       }
 
       // -- 9. visibility on the candidates: smoothed sample depth < smoothed scene depth (:461-467) ----
-      {
-        const int half = cols >> 1;
-        int v_n = 0, v_rmin = 0x7FFFFFFF, v_rmax = -1, v_cmin0 = 0x7FFFFFFF, v_cmax0 = -1, v_cmin1 = 0x7FFFFFFF, v_cmax1 = -1;
-        for (int ci = tid; ci < nc; ci += NT) {
-          int lp = (int)(g_cand ? g_cand[ci] : s_cand[ci]);
-          int r, c;
-          win.row_word(lp >> 5, r, c);
-          c = (c << 5) + (lp & 31);
-          double sd = R3D_EMPTY_DEPTH, cd = R3D_EMPTY_DEPTH;
-          const bool a = A.get_local(lp), d = D.get_local(lp);
-          const bool c_hole = !d && E.get_local(lp);
-          // A candidate lies at least 4 rows / 2 columns inside the window unless the image ends there, so the
-          // neighbours of its 5 x 3 footprint are plain offsets in the window-local and tile-local numbering
-          // (rows `rstride` resp. W apart); what leaves the image counts as empty.
-          const int rstride = win.njw << 5, dl0 = bt.index(r, c);
-          if (a) sd = key_depth(sample_key(lp));
-          if (d) cd = key_depth(dl0 < 0 ? R3D_SENT : tile_key(dl0));
-          // hole means (closing.py:44-57): the 15 neighbour keys are gathered first, one image at a time
-          // (one register array, every load issued before the first is used), then summed in the reference's order
-          if (!a) {                                            // a candidate is closed: a hole of the sample
-            unsigned long long v[15];
-#pragma unroll
-            for (int dr = -2; dr <= 2; ++dr)
-#pragma unroll
-              for (int dc = -1; dc <= 1; ++dc) {
-                int rr = r + dr, cc = c + dc;
-                const bool in = rr >= 0 && rr < rows && cc >= 0 && cc < cols;
-                int lq = lp + dr * rstride + dc;
-                v[(dr + 2) * 3 + (dc + 1)] = sample_key(in && (unsigned)lq < (unsigned)(ww << 5) ? lq : -1);
-              }
-            sd = mean_of_keys(v);
-          }
-          if (c_hole) {
-            unsigned long long v[15];
-#pragma unroll
-            for (int dr = -2; dr <= 2; ++dr)
-#pragma unroll
-              for (int dc = -1; dc <= 1; ++dc) {
-                int rr = r + dr, cc = c + dc;
-                const bool in = rr >= 0 && rr < rows && cc >= 0 && cc < cols;
-                int dq = dl0 + dr * W + dc;
-                const bool ok = in && dl0 >= 0 && (unsigned)dq < (unsigned)bt.npx;
-                unsigned long long key = tile_key(ok ? dq : 0);
-                v[(dr + 2) * 3 + (dc + 1)] = ok ? key : R3D_SENT;
-              }
-            cd = mean_of_keys(v);
-          }
-          if (sd < cd) {
-            vis.set_local(lp);
-            v_rmin = r < v_rmin ? r : v_rmin;
-            v_rmax = r > v_rmax ? r : v_rmax;
-            if (c < half) {
-              v_cmin0 = c < v_cmin0 ? c : v_cmin0;
-              v_cmax0 = c > v_cmax0 ? c : v_cmax0;
-            } else {
-              v_cmin1 = c < v_cmin1 ? c : v_cmin1;
-              v_cmax1 = c > v_cmax1 ? c : v_cmax1;
-            }
-            if (a) {                                           // its sample points are visible (:474)
-              int rk = rank_of(lp);
-              int p0 = s_start[rk], p1 = s_start[rk + 1];
-              v_n += p1 - p0;
-              for (int p = p0; p < p1; ++p) {
-                int j = s_F[p];
-                if (!cull_only && ((s_oob[j >> 5] >> (j & 31)) & 1u)) atomicOr(&H[H_REBASE], 1);   // bounds move: new extreme elevation
-              }
-            }
-          }
-        }
-        v_n = wave_sum_i32(v_n);
-        v_rmin = wave_min_i32(v_rmin); v_rmax = wave_max_i32(v_rmax);
-        v_cmin0 = wave_min_i32(v_cmin0); v_cmax0 = wave_max_i32(v_cmax0);
-        v_cmin1 = wave_min_i32(v_cmin1); v_cmax1 = wave_max_i32(v_cmax1);
-        if ((tid & 63) == 0 && v_rmax >= 0) {
-          atomicAdd(&H[H_NVIS], v_n);
-          atomicMin(&H[H_VRMIN], v_rmin);
-          atomicMax(&H[H_VRMAX], v_rmax);
-          atomicMin(&H[H_VCMIN0], v_cmin0);
-          atomicMax(&H[H_VCMAX0], v_cmax0);
-          atomicMin(&H[H_VCMIN1], v_cmin1);
-          atomicMax(&H[H_VCMAX1], v_cmax1);
-        }
-      }
+      evaluate<false>(nc);
       __syncthreads();
     }
 

@@ -664,7 +664,8 @@ def test_rejected_candidate_state_equals_the_reference(P, name):
             assert np.allclose(batch.bounds.cpu().numpy()[0], [max_el, min_el], rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("debug", [2, 4, 8, 6, 32, 64, 96, 128, 160, 132, 256, 260, 288, 264])
+@pytest.mark.parametrize("debug", [2, 4, 8, 6, 32, 64, 96, 128, 160, 132, 256, 260, 288, 264,
+                                   16384, 16384 | 2, 16384 | 64, 16384 | 8, 16384 | 256, 32768])
 def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
     """The insert kernel's other routes, forced with the descriptor's diagnostic bits: 2 = never speculate (every slot
     waits for its predecessor first), 4 = the window's depth tile built and evaluated in bands of at most 3 candidate
@@ -672,7 +673,9 @@ def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
     per scene), 128 = the kill masks from the pixel ids in global memory (no hits kept in LDS), 64 = every speculative
     evaluation done again after its predecessors and compared (alone and with pooled tiles), 256 = the chunk list through
     super-boxes as on clouds of 260 000 points and more (alone, with bands, pooled tiles, k_insert_big); all must give the bytes of
-    the oracle chain, through insert_many and slot by slot, and the comparison of bit 64 must never differ."""
+    the oracle chain, through insert_many and slot by slot, and the comparison of bit 64 must never differ.  Round 6:
+    16384 = every pair's depth tile as a SPARSE tile (only the pixels the evaluation reads, gather_bits / gather_needed; alone,
+    never speculating, verified, in k_insert_big, through super-boxes), 32768 = never (tiles beyond the LDS in the pool)."""
     import torch
     cases = [_random_case(synth, 11), _random_case(synth, 12, 32, 900, shuffle=True), _random_case(synth, 13, 64, 500)]
     xyzi, label = synth.make_scene(14, 48, 700)
@@ -694,6 +697,7 @@ def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
         res = batch.results()
         cnt = batch.debug_counters()
         assert cnt["verify_mismatch"] == 0 and ((debug & 64) == 0 or not many or cnt["verify_runs"] > 0), cnt
+        assert (cnt["sparse_tiles"] > 0) == bool(debug & 16384) or not (debug & (16384 | 32768)), cnt
         for i, c in enumerate(cases):
             vb, lb, cb, oacc = _oracle_chain(*c)
             assert [0 if acc[k, i] else -1 for k in range(K)] == oacc

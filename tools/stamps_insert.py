@@ -119,7 +119,9 @@ last = np.unravel_index(np.argmax(raw[:, :, 15]), raw[:, :, 15].shape)[1]
 print(f"the scene whose chain ends last (scene {last}):")
 for k in range(K):
     r = st[k, last]
-    ph = ", ".join(f"{n.split(' ')[0]} {(r[z] - r[a]) / 100.0:.1f}" for n, (a, z) in zip(names, edges))
+    # (a stamp that was never set -- a pair committed from its parked record has no evaluation stamps of its own -- prints as "-")
+    ph = ", ".join(f"{n.split(' ')[0]} " + (f"{(r[z] - r[a]) / 100.0:.1f}" if raw[k, last, z] > 0 and raw[k, last, a] > 0 and r[z] >= r[a] else "-")
+                   for n, (a, z) in zip(names, edges))
     print(f"  slot {k} ({KINDS[k]}): start {(r[0] - t0) / 100.0:.1f} end {(r[15] - t0) / 100.0:.1f} attempts {attempts[k, last]} words {ww[k, last]} chunks {nlist[k, last]} tile px {(info[k, last] >> 48) << 4} | {ph}")
 ends = (raw[K - 1, :, 15] - t0) / 100.0
 print("end of the scenes' chains, us after launch: p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(ends, [50, 90, 99, 100])))
