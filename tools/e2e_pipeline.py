@@ -113,7 +113,7 @@ def measure_run(pkg, n_frames=512, B=64, where=None):
         shutil.rmtree(root, ignore_errors=True)
 
 
-def measure_files(pkg, shape="C3", n_frames=4096, B=256, where=None, check=2, io_threads=16):
+def measure_files(pkg, shape="C3", n_frames=4096, B=256, where=None, check=2, io_threads=16, segment=4096):
     """File to file, the shapes of BASELINE.json's configs C3 and C4, with the files on tmpfs (what the software does when
     the file system is memory; the box's disk is measure_disk's business):
 
@@ -124,7 +124,10 @@ def measure_files(pkg, shape="C3", n_frames=4096, B=256, where=None, check=2, io
         share of the sweep; one rank here).
 
     64 distinct frames, hard-linked to n_frames names (the generator and 2.4 MB of tmpfs per frame are not what is
-    measured).  `check` frames of the timed run are compared byte for byte with the oracle."""
+    measured).  `check` frames of the timed run, spread evenly over it, are compared byte for byte with the oracle.  The run
+    is made in segments of `segment` frames: what a segment has written is deleted again (untimed; the checked frames stay)
+    before the next starts, so that BASELINE's full sizes -- 10 000 frames (C3), 23 201 (C4): 25 / 58 GB of output -- need
+    no more tmpfs than one segment."""
     synth = pkg.synth
     kinds = synth.CONFIG_INSERTS[shape]
     od = shape == "C3"
@@ -169,11 +172,31 @@ def measure_files(pkg, shape="C3", n_frames=4096, B=256, where=None, check=2, io
 
         run(frames[:B], f"{root}/warm")                                                                   # warm-up
         shutil.rmtree(f"{root}/warm")
-        st = run(frames, f"{root}/out")
+        n_check = min(check, n_frames)
+        checked = sorted({int(round(k * (n_frames - 1) / max(n_check - 1, 1))) for k in range(n_check)})
+        keep = {f"{i:06d}" for i in checked}
+        st, segments = None, 0
+        for lo in range(0, n_frames, segment):
+            one = run(frames[lo:lo + segment], f"{root}/out")
+            segments += 1
+            if st is None:
+                st = dict(one)
+            else:
+                for k, v in one.items():
+                    if k.startswith("t_") or k == "written":
+                        st[k] = st.get(k, 0) + v
+            if lo + segment < n_frames:                          # make room (not timed); the frames to be checked stay
+                for sub in ("velodyne", "labels", "check", "label_2", "added_objects"):
+                    d = f"{root}/out/run/{sub}"
+                    if os.path.isdir(d):
+                        for e in os.scandir(d):
+                            if e.name.split(".")[0] not in keep:
+                                os.unlink(e.path)
+        st["frames_per_s"] = st["written"] / st["t_total"] if st.get("t_total") else st["frames_per_s"]
         # a sample of the written files against the oracle (labels collapsed for the object-detection flavour)
         from oracle import real3d_oracle as O
         same = 0
-        for i in range(min(check, n_frames)):
+        for i in checked:
             xyzi, label = synth.make_scene(i % n_distinct)
             if od:
                 label = np.where(label == 40, 40, 1).astype(np.uint32)
@@ -192,7 +215,8 @@ def measure_files(pkg, shape="C3", n_frames=4096, B=256, where=None, check=2, io
                 "frames_per_s_without_lane_setup": round(st["written"] / steady, 1) if steady > 0 else None,
                 "flavour": "object detection: velodyne + check (4 columns) + label_2" if od else "SemanticKITTI: velodyne + labels + check",
                 "through": "AugmentPipeline.run_streamed(label_2_for=...)" if od else "run_sharded_files (rank 0 of 1)",
-                "directory": where or tempfile.gettempdir(), "files_equal_to_oracle": f"{same} of {min(check, n_frames)} checked",
+                "directory": where or tempfile.gettempdir(), "files_equal_to_oracle": f"{same} of {len(checked)} checked",
+                "segments": segments,
                 "seconds": {k[2:]: round(v, 3) for k, v in st.items() if k.startswith("t_")}}
     finally:
         shutil.rmtree(root, ignore_errors=True)
