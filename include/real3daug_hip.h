@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define R3D_VERSION 0x00020004   /* 2.4: R3D_MAX_SAMPLE 65 535; R3D_B_FILE_ORDER, r3d_batch_export_pix, r3d_batch_point_order (clouds in no
+#define R3D_VERSION 0x00020005   /* 2.5: r3d_batch_begin_xyz, r3d_host_pack_frames_xyz, r3d_host_read_frames_xyz (12 bytes per point over the link in delta mode);
+                                  * 2.4: R3D_MAX_SAMPLE 65 535; R3D_B_FILE_ORDER, r3d_batch_export_pix, r3d_batch_point_order (clouds in no
                                   * file order are numbered anew internally); r3d_host_write_delta_frames, r3d_host_append_text_files; r3d_batch_debug_counters
                                   * holds 64 values; R3D_S_CHAIN_TIMEOUT now means "a scene's chain was left unfinished" (no slot
                                   * waits for another any more); the workspace of a batch grew (r3d_batch_workspace_bytes);
@@ -202,6 +203,14 @@ int r3d_batch_create(const r3d_batch_t *b, void *stream);
  * point and resets all per-scene state.  (The min-reduce of :118-125 is done per insert, on the
  * window of the range image that the insert can see -- DESIGN.md par.3.) */
 int r3d_batch_begin(const r3d_batch_t *b, const int32_t *n_points, void *stream);
+
+/* Step 0 from x y z alone (12 bytes per point instead of the 16 of a velodyne row + 4 of a label): xyz3 = device float
+ * [B][cap][3], n_points[s] rows used.  For a caller that still holds the frames on the host and takes the batch's DELTA
+ * (r3d_batch_export_delta + r3d_host_merge_frames / r3d_host_write_delta_frames): nothing on the device reads a frame
+ * point's intensity or label before the compaction, which such a caller does not run.  The slab b->xyzi is filled from
+ * xyz3 with intensity 0, b->label is left as it is: r3d_batch_finish and r3d_batch_export_rows' label column are NOT
+ * valid after this begin (the inserted points carry their own intensity and label as always). */
+int r3d_batch_begin_xyz(const r3d_batch_t *b, const float *xyz3, const int32_t *n_points, void *stream);
 
 /* Step 0 for clouds whose coordinates are genuine float64 (the Waymo flavour: tools/datasets.py:240-262 hands
  * the driver x y z intensity label as float64 after subtracting the LiDAR offset).  rows5: device double
@@ -460,6 +469,12 @@ int r3d_od_maps(const float *xyzi, const uint32_t *label, int64_t n, int32_t roa
  * ===================================================================================== */
 int r3d_host_pack_frames(const float *const *xyzi, const uint32_t *const *label, const int32_t *n_points, int32_t B,
                          int64_t cap, float *dst_xyzi, uint32_t *dst_label, int32_t collapse_keep, int32_t threads);
+/* The same, and x y z of every point once more, 12 bytes per point, into dst_xyz3 [B][cap][3] (NULL: not wanted): what a
+ * caller in delta mode uploads (r3d_batch_begin_xyz) -- the intensities and labels of the frames stay on the host, where the
+ * files are written from the staging slab (r3d_host_write_delta_frames, r3d_host_merge_frames). */
+int r3d_host_pack_frames_xyz(const float *const *xyzi, const uint32_t *const *label, const int32_t *n_points, int32_t B,
+                             int64_t cap, float *dst_xyzi, uint32_t *dst_label, float *dst_xyz3, int32_t collapse_keep,
+                             int32_t threads);
 
 /* The delta of a batch instead of its merged clouds, for a caller that still holds the frames on the host (the
  * streamed file-to-file driver): alive [B][chunks] uint64 -- bit i of word c = point 64 c + i of the scene survives
@@ -490,6 +505,9 @@ int r3d_host_merge_frames(const float *in_xyzi, const uint32_t *in_label, int64_
  * renamed, check last; a NULL velodyne path skips the frame.  Errors (R3D_E_ARG) name the file in r3d_last_error(). */
 int r3d_host_read_frames(const char *const *velodyne_paths, const char *const *label_paths, int32_t B, int64_t cap, float *dst_xyzi,
                          uint32_t *dst_label, int32_t *n_points, int32_t collapse_keep, int32_t threads);
+int r3d_host_read_frames_xyz(const char *const *velodyne_paths, const char *const *label_paths, int32_t B, int64_t cap, float *dst_xyzi,
+                             uint32_t *dst_label, float *dst_xyz3 /* [B][cap][3], nullable: see r3d_host_pack_frames_xyz */,
+                             int32_t *n_points, int32_t collapse_keep, int32_t threads);
 int r3d_host_write_frames(const char *const *velodyne_paths, const char *const *label_paths, const char *const *check_paths, int32_t B,
                           const float *xyzi, const uint32_t *label, int64_t cap, const int32_t *n_out, const float *check,
                           int64_t check_stride, int32_t check_cols, const int32_t *n_check, int32_t threads);

@@ -102,6 +102,7 @@ _SIGNATURES = {
     "r3d_batch_create": (C.c_int, [C.POINTER(BatchDesc), _P]),
     "r3d_batch_begin": (C.c_int, [C.POINTER(BatchDesc), _P, _P]),
     "r3d_batch_begin_f64": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P]),
+    "r3d_batch_begin_xyz": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P]),
     "r3d_batch_insert": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "r3d_batch_finish": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int32, _P]),
     "r3d_batch_launch_one": (C.c_int, [C.POINTER(BatchDesc), C.c_int32, _P]),
@@ -124,6 +125,8 @@ _SIGNATURES = {
     "r3d_places_chunk_ranges": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P]),
     "r3d_host_pack_frames": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, _P, _P, C.c_int32, C.c_int32]),
     "r3d_host_read_frames": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P, C.c_int32, C.c_int32]),
+    "r3d_host_pack_frames_xyz": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P, C.c_int32, C.c_int32]),
+    "r3d_host_read_frames_xyz": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P, _P, C.c_int32, C.c_int32]),
     "r3d_host_write_frames": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P, C.c_int32]),
     "r3d_host_write_delta_frames": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int32, _P,
                                               C.c_int32]),

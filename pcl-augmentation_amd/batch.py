@@ -269,10 +269,23 @@ class SceneBatch:
     @_lib.on_own_device
     def begin(self):
         self.step = 0
+        self._xyz_only = False
         self._rebegin = self.begin                      # how run_inserts' time-out fallback starts the batch again
         self._order_bit()
         _lib.check(self.lib.r3d_batch_begin(C.byref(self.desc), C.c_void_p(self.n_points.data_ptr()),
                                             _lib.stream_ptr()), "r3d_batch_begin")
+
+    @_lib.on_own_device
+    def begin_xyz(self, xyz3):
+        """Step 0 from x y z alone: ``xyz3`` = device tensor [B, cap, 3] float32 (12 bytes per point over the link instead of
+        the 16 of a velodyne row), ``n_points`` already set.  For delta mode only -- the frames' intensities and labels stay on
+        the host, ``finish`` / ``download_views`` refuse (``r3d_batch_begin_xyz``)."""
+        self.step = 0
+        self._rebegin = lambda: self.begin_xyz(xyz3)
+        self._xyz_only = True
+        self._order_bit()
+        _lib.check(self.lib.r3d_batch_begin_xyz(C.byref(self.desc), C.c_void_p(xyz3.data_ptr()), C.c_void_p(self.n_points.data_ptr()),
+                                                _lib.stream_ptr()), "r3d_batch_begin_xyz")
 
     @_lib.on_own_device
     def begin_f64(self, scenes5):
@@ -301,6 +314,7 @@ class SceneBatch:
         """Step 0 from the float64 rows already on the device (``begin_f64``, and again from the time-out fallback of
         ``run_inserts``: the rows and counts are untouched by the inserts)."""
         self.step = 0
+        self._xyz_only = False
         self._rebegin = self._begin_rows5
         self._order_bit()
         self.n_points.copy_(self.torch.from_numpy(self.n_frame))
@@ -421,6 +435,8 @@ class SceneBatch:
     @_lib.on_own_device
     def finish(self, check_cols=5):
         torch = self.torch
+        if getattr(self, "_xyz_only", False):
+            raise _lib.R3DError("finish after begin_xyz: the frames' intensities and labels are not on the device (take the delta)")
         if check_cols:
             # rows beyond n_log[s] are never read: the buffer is kept between calls
             if getattr(self, "_check_buf", None) is None or self._check_buf.shape[2] != check_cols:

@@ -73,6 +73,25 @@ k_load_f64(r3d_batch_t b, const double *__restrict__ rows5, const int32_t *n_poi
   }
 }
 
+// r3d_batch_begin_xyz: x y z rows of 12 bytes -> the float4 slab every kernel reads (intensity 0).  Four points per thread:
+// three 16-byte loads, four 16-byte stores.
+__global__ void __launch_bounds__(kPT)
+k_expand_xyz(r3d_batch_t b, const float *__restrict__ xyz3, const int32_t *n_points) {
+  const int s = blockIdx.y;
+  const int n = n_points[s];
+  if (n < 0 || n > b.cap) return;                              // k_begin_init flags the scene
+  const float4 *src = reinterpret_cast<const float4 *>(xyz3 + (int64_t)s * b.cap * 3);
+  float4 *dst = reinterpret_cast<float4 *>(b.xyzi) + (int64_t)s * b.cap;
+  const int groups = (n + 3) >> 2;                             // (cap is a multiple of 4 points: the last group stays inside the slab)
+  for (int g = blockIdx.x * kPT + threadIdx.x; g < groups; g += gridDim.x * kPT) {
+    const float4 a = src[3 * g], c = src[3 * g + 1], e = src[3 * g + 2];
+    dst[4 * g + 0] = make_float4(a.x, a.y, a.z, 0.f);
+    dst[4 * g + 1] = make_float4(a.w, c.x, c.y, 0.f);
+    dst[4 * g + 2] = make_float4(c.z, c.w, e.x, 0.f);
+    dst[4 * g + 3] = make_float4(e.y, e.z, e.w, 0.f);
+  }
+}
+
 // elevation = acos(z/r) is monotone in q = z/r, so the bounds of insertion.py:78-79 are acos of
 // the extreme q: reduce q here (sqrt + divide per point), take acos twice per scene afterwards.
 //
@@ -1440,6 +1459,20 @@ int r3d_batch_begin(const r3d_batch_t *b, const int32_t *n_points, void *stream)
   if (!n_points) return fail(R3D_E_ARG, "batch_begin: null n_points");
   hipStream_t st = (hipStream_t)stream;
   BatchWs w = carve_batch(*b, b->workspace);
+  hipLaunchKernelGGL(k_begin_init, dim3((b->B + 255) / 256), dim3(256), 0, st, *b, n_points, w, false);
+  return launch_reproject(*b, w, w.all_list, w.all_count, b->B, st);
+}
+
+int r3d_batch_begin_xyz(const r3d_batch_t *b, const float *xyz3, const int32_t *n_points, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  if (!n_points || !xyz3) return fail(R3D_E_ARG, "batch_begin_xyz: null xyz3 or n_points");
+  if (b->cap % 4 != 0) return fail(R3D_E_ARG, "batch_begin_xyz: cap must be a multiple of 4 points");
+  if (((uintptr_t)xyz3 & 15) != 0) return fail(R3D_E_ARG, "batch_begin_xyz: xyz3 must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  BatchWs w = carve_batch(*b, b->workspace);
+  int gx = (int)((b->cap / 4 + kPT * 4 - 1) / (kPT * 4));
+  hipLaunchKernelGGL(k_expand_xyz, dim3(gx < 1 ? 1 : gx, b->B), dim3(kPT), 0, st, *b, xyz3, n_points);
   hipLaunchKernelGGL(k_begin_init, dim3((b->B + 255) / 256), dim3(256), 0, st, *b, n_points, w, false);
   return launch_reproject(*b, w, w.all_list, w.all_count, b->B, st);
 }

@@ -66,12 +66,43 @@ inline void stream_labels(uint32_t *dst, const uint32_t *src, int64_t n, int32_t
   for (; i < n; ++i) dst[i] = one(src[i]);
 }
 
+// dst3[i] = x y z of src4[i] (rows of x y z intensity), 12 bytes per point: what the device needs of a frame in delta mode
+// (r3d_batch_begin_xyz).  Four points per step: 64 bytes in, 48 out, streaming stores (dst3 16-byte aligned).
+inline void stream_xyz(float *dst3, const float *src4, int64_t n) {
+  int64_t i = 0;
+  if (((uintptr_t)dst3 & 15) == 0)
+    for (; i + 4 <= n; i += 4) {
+      const __m128 a = _mm_loadu_ps(src4 + 4 * i), b = _mm_loadu_ps(src4 + 4 * i + 4), c = _mm_loadu_ps(src4 + 4 * i + 8),
+                   d = _mm_loadu_ps(src4 + 4 * i + 12);
+      const __m128 ab = _mm_shuffle_ps(a, b, _MM_SHUFFLE(0, 0, 2, 2));      // z0 z0 x1 x1
+      const __m128 cd = _mm_shuffle_ps(c, d, _MM_SHUFFLE(0, 0, 2, 2));      // z2 z2 x3 x3
+      _mm_stream_ps(dst3 + 3 * i, _mm_shuffle_ps(a, ab, _MM_SHUFFLE(2, 0, 1, 0)));        // x0 y0 z0 x1
+      _mm_stream_ps(dst3 + 3 * i + 4, _mm_shuffle_ps(b, c, _MM_SHUFFLE(1, 0, 2, 1)));     // y1 z1 x2 y2
+      _mm_stream_ps(dst3 + 3 * i + 8, _mm_shuffle_ps(cd, d, _MM_SHUFFLE(2, 1, 2, 0)));    // z2 x3 y3 z3
+    }
+  for (; i < n; ++i) {
+    dst3[3 * i + 0] = src4[4 * i + 0];
+    dst3[3 * i + 1] = src4[4 * i + 1];
+    dst3[3 * i + 2] = src4[4 * i + 2];
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
 int r3d_host_pack_frames(const float *const *xyzi, const uint32_t *const *label, const int32_t *n_points, int32_t B,
                          int64_t cap, float *dst_xyzi, uint32_t *dst_label, int32_t collapse_keep, int32_t threads) {
+  return r3d_host_pack_frames_xyz(xyzi, label, n_points, B, cap, dst_xyzi, dst_label, nullptr, collapse_keep, threads);
+}
+
+int r3d_host_read_frames(const char *const *velodyne_paths, const char *const *label_paths, int32_t B, int64_t cap, float *dst_xyzi,
+                         uint32_t *dst_label, int32_t *n_points, int32_t collapse_keep, int32_t threads) {
+  return r3d_host_read_frames_xyz(velodyne_paths, label_paths, B, cap, dst_xyzi, dst_label, nullptr, n_points, collapse_keep, threads);
+}
+
+int r3d_host_pack_frames_xyz(const float *const *xyzi, const uint32_t *const *label, const int32_t *n_points, int32_t B,
+                             int64_t cap, float *dst_xyzi, uint32_t *dst_label, float *dst_xyz3, int32_t collapse_keep, int32_t threads) {
   if (!xyzi || !label || !n_points || !dst_xyzi || !dst_label || B <= 0 || cap <= 0)
     return r3d::fail(R3D_E_ARG, "host_pack_frames: null pointer or non-positive shape");
   for (int s = 0; s < B; ++s)
@@ -83,6 +114,7 @@ int r3d_host_pack_frames(const float *const *xyzi, const uint32_t *const *label,
     for (int s = t; s < B; s += threads) {
       const int64_t n = n_points[s];
       stream_copy(dst_xyzi + (int64_t)s * cap * 4, xyzi[s], (size_t)n * 4 * sizeof(float));
+      if (dst_xyz3) stream_xyz(dst_xyz3 + (int64_t)s * cap * 3, xyzi[s], n);
       stream_labels(dst_label + (int64_t)s * cap, label[s], n, collapse_keep);
     }
     _mm_sfence();
@@ -215,8 +247,8 @@ bool commit_file(const char *path, const void *data, size_t bytes) {
 // velodyne/{f}.bin (float32 rows of 4) and labels/{f}.label (uint32) of B frames, the way the reference's __getitem__
 // reads them (SS tools/datasets.py:51-56), straight into the staging slabs r3d_host_pack_frames fills: dst_xyzi [B][cap][4],
 // dst_label [B][cap] (masked with 0xFFFF or collapsed, see there), n_points [B].  label_paths may be NULL (all labels 0).
-int r3d_host_read_frames(const char *const *velodyne_paths, const char *const *label_paths, int32_t B, int64_t cap, float *dst_xyzi,
-                         uint32_t *dst_label, int32_t *n_points, int32_t collapse_keep, int32_t threads) {
+int r3d_host_read_frames_xyz(const char *const *velodyne_paths, const char *const *label_paths, int32_t B, int64_t cap, float *dst_xyzi,
+                             uint32_t *dst_label, float *dst_xyz3, int32_t *n_points, int32_t collapse_keep, int32_t threads) {
   if (!velodyne_paths || !dst_xyzi || !dst_label || !n_points || B <= 0 || cap <= 0)
     return r3d::fail(R3D_E_ARG, "host_read_frames: null pointer or non-positive shape");
   if (threads < 1) threads = 1;
@@ -239,6 +271,7 @@ int r3d_host_read_frames(const char *const *velodyne_paths, const char *const *l
       }
       bool ok = read_all(fd, dst_xyzi + (int64_t)s * cap * 4, (size_t)n * 16);
       ::close(fd);
+      if (ok && dst_xyz3) stream_xyz(dst_xyz3 + (int64_t)s * cap * 3, dst_xyzi + (int64_t)s * cap * 4, n);
       uint32_t *dl = dst_label + (int64_t)s * cap;
       if (ok && label_paths && label_paths[s]) {
         int fl = ::open(label_paths[s], O_RDONLY);

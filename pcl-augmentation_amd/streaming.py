@@ -35,7 +35,7 @@ _SUM_COUNTERS = {} if _os.environ.get("R3D_SUM_COUNTERS") else None      # diagn
 
 
 class _Lane:
-    def __init__(self, B, cap, log_cap, K, sample_rows, rows, cols, device, check_cols, delta):
+    def __init__(self, B, cap, log_cap, K, sample_rows, rows, cols, device, check_cols, delta, xyz_upload=False):
         torch = _lib.require_gpu()
         self.torch = torch
         self.bt = SceneBatch(B, cap, log_cap, rows=rows, cols=cols, device=device)
@@ -57,6 +57,10 @@ class _Lane:
             self.out_counts = pin((5, B), torch.int32)                  # n_out, n_log, status, rebases, points numbered anew
             self.out_acc = pin((max(K, 1), B), torch.int32)
             if delta:
+                # xyz_upload: what crosses the link of a frame is x y z alone, 12 bytes per point (r3d_batch_begin_xyz) -- the
+                # host packer writes them beside the full rows, which stay on the host for the merge / the file writers
+                self.in_xyz3 = pin((B, cap, 3), torch.float32) if xyz_upload else None
+                self.d_xyz3 = torch.empty((B, cap, 3), dtype=torch.float32, device=device) if xyz_upload else None
                 # the delta on the device and in pinned memory; the merged results in plain host memory
                 self.d_alive = torch.zeros((B, self.chunks), dtype=torch.int64, device=device)
                 self.d_tail_xyzi = torch.zeros((B, log_cap, 4), dtype=torch.float32, device=device)
@@ -90,17 +94,21 @@ class _Lane:
 
 class StreamedAugmenter:
     def __init__(self, B, n_max, grow, n_slots, sample_rows, lanes=3, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN,
-                 device="cuda:0", check_cols=5, collapse_keep=-1, pack_threads=16, delta=True):
+                 device="cuda:0", check_cols=5, collapse_keep=-1, pack_threads=16, delta=True, xyz_upload=False):
         """B frames per batch, at most n_max points per frame, `grow` inserted points per frame in all
         (sum over the slots), n_slots insert slots, at most sample_rows sample points per slot and batch."""
         self.lib = _lib.load()
         self.B, self.K = int(B), int(n_slots)
         self.collapse_keep, self.pack_threads, self.delta = int(collapse_keep), int(pack_threads), bool(delta)
+        # delta mode: upload x y z alone (12 bytes per point instead of 16).  Off by default: on the boxes measured the streamed
+        # legs are bound by the HOST's memory traffic, not by the link, and the second staging slab adds 1.4 MB of stores per
+        # frame for 0.5 MB less over the link (round 6: 17.8 -> 14.2 thousand frames/s; DESIGN.md par.4b)
+        self.xyz_upload = bool(xyz_upload) and self.delta
         self.check_cols = int(check_cols)
         import os
         self.copy_streams = max(1, min(4, int(os.environ.get("R3D_COPY_STREAMS", "1"))))
         self.lanes = [_Lane(B, n_max + grow, max(grow, 1), self.K, max(int(sample_rows), 1), rows, cols, device, self.check_cols,
-                            self.delta) for _ in range(lanes)]
+                            self.delta, self.xyz_upload) for _ in range(lanes)]
         self.device = device
         # delta mode: False = `collect` leaves the merged clouds unmade (results come back as None) for a caller that only
         # writes files -- `write_files` then writes them straight from the lane's pinned input and the delta, run by run of
@@ -132,8 +140,9 @@ class StreamedAugmenter:
         pl = (C.c_void_p * B)(*[l.ctypes.data for l in ls])
         import time
         t0 = time.perf_counter()
-        _lib.check(self.lib.r3d_host_pack_frames(px, pl, n.ctypes.data, B, bt.cap, ln.in_xyzi.data_ptr(), ln.in_label.data_ptr(),
-                                                 self.collapse_keep, self.pack_threads), "r3d_host_pack_frames")
+        _lib.check(self.lib.r3d_host_pack_frames_xyz(px, pl, n.ctypes.data, B, bt.cap, ln.in_xyzi.data_ptr(), ln.in_label.data_ptr(),
+                                                     ln.in_xyz3.data_ptr() if self.xyz_upload else None, self.collapse_keep,
+                                                     self.pack_threads), "r3d_host_pack_frames_xyz")
         ln.in_n.numpy()[:] = n
         self.times["read_or_pack"] += time.perf_counter() - t0
         return self._enqueue(lane_no, inserts, min_points, tag)
@@ -149,8 +158,9 @@ class StreamedAugmenter:
         pl = enc(label_files) if label_files is not None else None
         import time
         t0 = time.perf_counter()
-        _lib.check(self.lib.r3d_host_read_frames(pv, pl, B, ln.bt.cap, ln.in_xyzi.data_ptr(), ln.in_label.data_ptr(),
-                                                 ln.in_n.data_ptr(), self.collapse_keep, self.pack_threads), "r3d_host_read_frames")
+        _lib.check(self.lib.r3d_host_read_frames_xyz(pv, pl, B, ln.bt.cap, ln.in_xyzi.data_ptr(), ln.in_label.data_ptr(),
+                                                     ln.in_xyz3.data_ptr() if self.xyz_upload else None, ln.in_n.data_ptr(),
+                                                     self.collapse_keep, self.pack_threads), "r3d_host_read_frames_xyz")
         self.times["read_or_pack"] += time.perf_counter() - t0
         return self._enqueue(lane_no, inserts, min_points, tag)
 
@@ -211,12 +221,18 @@ class StreamedAugmenter:
                         continue
                     cs.wait_event(ev)
                     with torch.cuda.stream(cs):
-                        bt.xyzi[lo:hi].copy_(ln.in_xyzi[lo:hi], non_blocking=True)
+                        if self.xyz_upload:
+                            ln.d_xyz3[lo:hi].copy_(ln.in_xyz3[lo:hi], non_blocking=True)
+                        else:
+                            bt.xyzi[lo:hi].copy_(ln.in_xyzi[lo:hi], non_blocking=True)
                         if not self.delta:
                             bt.label[lo:hi].copy_(ln.in_label[lo:hi], non_blocking=True)
                     ln.stream.wait_stream(cs)
             else:
-                bt.xyzi.copy_(ln.in_xyzi, non_blocking=True)     # whole slabs: one contiguous copy each
+                if self.xyz_upload:
+                    ln.d_xyz3.copy_(ln.in_xyz3, non_blocking=True)   # x y z only: 12 bytes per point
+                else:
+                    bt.xyzi.copy_(ln.in_xyzi, non_blocking=True)     # whole slabs: one contiguous copy each
                 if not self.delta:
                     # the frames' labels are read by r3d_batch_finish only: in delta mode they stay on the host,
                     # where the merge takes them from the staging slab (the device holds the inserted points' labels)
@@ -229,8 +245,11 @@ class StreamedAugmenter:
                 self.bytes_h2d += m * 40
             ln.d_off.copy_(ln.in_off, non_blocking=True)
             ln.d_need.copy_(ln.in_need, non_blocking=True)
-            self.bytes_h2d += B * bt.cap * (16 if self.delta else 20)
-            bt.begin()
+            self.bytes_h2d += B * bt.cap * (12 if self.xyz_upload else (16 if self.delta else 20))
+            if self.xyz_upload:
+                bt.begin_xyz(ln.d_xyz3)
+            else:
+                bt.begin()
             if K:
                 _, acc = bt.insert_many_device([(ln.d_rows[k], ln.d_off[k]) for k in range(K)], [ln.d_need[k] for k in range(K)])
                 ln.out_acc.copy_(acc, non_blocking=True)

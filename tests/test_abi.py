@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = pkg._lib.load()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.r3d_version() == 0x00020004
+    assert lib.r3d_version() == 0x00020005
     assert lib.r3d_build_info().decode().startswith("sources ")
     assert isinstance(lib.r3d_last_error(), bytes)
 

@@ -980,10 +980,20 @@ def test_delta_download_equals_finish(P, synth):
     grow = sum(max(len(c[2][k][0]) for c in cases) for k in range(3))
     for check_cols in (5, 4):
         outs = []
-        for delta in (False, True):
+        for delta in (False, True, "xyz"):
             batch = P.SceneBatch(B, max(len(c[0]) for c in cases) + grow, grow)
             batch.load([(c[0], c[1]) for c in cases])
-            batch.begin()
+            if delta == "xyz":
+                # round 6: step 0 from x y z alone, 12 bytes per point over the link (r3d_batch_begin_xyz); the slab's
+                # intensities and labels are wiped first -- nothing on the device may depend on them in delta mode
+                xyz3 = batch.xyzi[:, :, :3].contiguous()
+                batch.xyzi.fill_(float("nan"))
+                batch.label.fill_(-1)
+                batch.begin_xyz(xyz3)
+                with pytest.raises(P._lib.R3DError):
+                    batch.finish(check_cols)
+            else:
+                batch.begin()
             batch.run_inserts([c[2] for c in cases], [c[3] for c in cases])
             if delta:
                 ox, ol, ck, n_out, n_log = batch.download_delta_views(check_cols)
@@ -992,8 +1002,8 @@ def test_delta_download_equals_finish(P, synth):
                 ox, ol, ck, n_out, n_log = batch.download_views()
             outs.append([(ox[s, :n_out[s]].copy(), ol[s, :n_out[s]].copy(), ck[s, :n_log[s]].copy()) for s in range(B)])
         for s in range(B):
-            for a, b in zip(outs[0][s], outs[1][s]):
-                assert a.tobytes() == b.tobytes(), (check_cols, s)
+            for a, b, c in zip(outs[0][s], outs[1][s], outs[2][s]):
+                assert a.tobytes() == b.tobytes() == c.tobytes(), (check_cols, s)
         if check_cols == 5:
             for s, c in enumerate(cases):
                 vb, lb, cb, _ = _oracle_chain(c[0], c[1] & 0xFFFF, c[2], c[3])

@@ -97,8 +97,9 @@ def test_streamed_lanes_and_rows_with_a_shuffled_frame(pkg, synth):
     n_max = max(len(c[0]) for c in cases)
     grow = max(sum(len(slot[0]) for slot in c[2]) for c in cases)
     srows = max(sum(len(c[2][k][0]) for c in cases) for k in range(2))
-    for delta in (True, False):
-        aug = streaming.StreamedAugmenter(len(cases), n_max, grow, 2, srows, lanes=1, delta=delta)
+    for delta, xyz in ((True, False), (False, False), (True, True)):      # (xyz: 12 bytes per point uploaded, r3d_batch_begin_xyz)
+        aug = streaming.StreamedAugmenter(len(cases), n_max, grow, 2, srows, lanes=1, delta=delta, xyz_upload=xyz)
+        assert aug.xyz_upload == xyz
         aug.submit(0, [(c[0], c[1]) for c in cases], [[slot[0] for slot in c[2]] for c in cases], [c[3] for c in cases])
         _, results, accepted = aug.collect(0)
         assert aug.lanes[0].bt.debug_counters()["scenes_in_sorted_order"] == 3

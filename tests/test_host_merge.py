@@ -202,3 +202,46 @@ def test_native_label_2_writer_equals_create_annotation(pkg, tmp_path):
     bad = list(srcs)
     bad[3] = str(tmp_path / "nothing.txt")
     assert lib.r3d_host_append_text_files(enc(bad), enc(dst), extra, n, 4) != 0
+
+
+def test_xyz_packers_equal_numpy(pkg, tmp_path):
+    """r3d_host_pack_frames_xyz / r3d_host_read_frames_xyz: the slabs of r3d_host_pack_frames / r3d_host_read_frames and, beside
+    them, x y z of every point as rows of 12 bytes (what r3d_batch_begin_xyz takes); ragged frames, odd counts, no xyz3 wanted."""
+    import os
+    lib = pkg._lib.load()
+    rng = np.random.default_rng(9)
+    B, cap = 5, 1024
+    ns = [1000, 1, 0, 777, 1024]
+    xs = [rng.random((n, 4), dtype=np.float32) for n in ns]
+    ls = [rng.integers(0, 1 << 20, n).astype(np.uint32) for n in ns]
+    n = np.array(ns, dtype=np.int32)
+    px = (C.c_void_p * B)(*[x.ctypes.data for x in xs])
+    pl = (C.c_void_p * B)(*[l.ctypes.data for l in ls])
+    for want3 in (True, False):
+        dx, dl = np.full((B, cap, 4), -1, dtype=np.float32), np.zeros((B, cap), dtype=np.uint32)
+        d3 = np.full((B, cap, 3), -7, dtype=np.float32)
+        rc = lib.r3d_host_pack_frames_xyz(px, pl, n.ctypes.data, B, cap, dx.ctypes.data, dl.ctypes.data, d3.ctypes.data if want3 else None, -1, 3)
+        assert rc == 0, lib.r3d_last_error()
+        for s in range(B):
+            assert np.array_equal(dx[s, :ns[s]], xs[s]) and np.array_equal(dl[s, :ns[s]], ls[s] & 0xFFFF)
+            if want3:
+                assert np.array_equal(d3[s, :ns[s]], xs[s][:, :3]) and np.all(d3[s, ns[s]:] == -7)
+        if not want3:
+            assert np.all(d3 == -7)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        for s in range(B):
+            xs[s].tofile(f"{s}.bin")
+            ls[s].tofile(f"{s}.label")
+        enc = lambda names: (C.c_char_p * len(names))(*[x.encode() for x in names])
+        dx, dl, d3 = np.zeros((B, cap, 4), dtype=np.float32), np.zeros((B, cap), dtype=np.uint32), np.zeros((B, cap, 3), dtype=np.float32)
+        got = np.zeros(B, dtype=np.int32)
+        rc = lib.r3d_host_read_frames_xyz(enc([f"{s}.bin" for s in range(B)]), enc([f"{s}.label" for s in range(B)]), B, cap,
+                                          dx.ctypes.data, dl.ctypes.data, d3.ctypes.data, got.ctypes.data, -1, 2)
+        assert rc == 0, lib.r3d_last_error()
+        assert list(got) == ns
+        for s in range(B):
+            assert np.array_equal(dx[s, :ns[s]], xs[s]) and np.array_equal(d3[s, :ns[s]], xs[s][:, :3]) and np.array_equal(dl[s, :ns[s]], ls[s] & 0xFFFF)
+    finally:
+        os.chdir(cwd)

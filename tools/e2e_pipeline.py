@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def measure(pkg, n_frames=1024, B=256, lanes=3, pack_threads=16, delta=True, device="cuda:0", before_timed=None):
+def measure(pkg, n_frames=1024, B=256, lanes=3, pack_threads=16, delta=True, device="cuda:0", before_timed=None, xyz_upload=None):
     synth = pkg.synth
     kinds = synth.CONFIG_INSERTS["C2"]
     n_distinct = min(n_frames, B)                     # B distinct frames, cycled: the generator is not what is measured
@@ -35,7 +35,7 @@ def measure(pkg, n_frames=1024, B=256, lanes=3, pack_threads=16, delta=True, dev
     from importlib import import_module
     streaming = import_module("pcl-augmentation_amd.streaming")
     aug = streaming.StreamedAugmenter(B, n_max, grow, len(kinds), srows, lanes=lanes, pack_threads=pack_threads, delta=delta,
-                                      device=device)
+                                      device=device, **({} if xyz_upload is None else {"xyz_upload": xyz_upload}))
     batch = [scenes[s % n_distinct] for s in range(B)], [inserts[s % n_distinct] for s in range(B)]
     n_batches = max(2, n_frames // B)
     got = {"frames": 0, "points": 0}
@@ -47,6 +47,8 @@ def measure(pkg, n_frames=1024, B=256, lanes=3, pack_threads=16, delta=True, dev
     aug.run([(batch[0], batch[1], need, 0)] * 2, consume)           # warm-up: allocations, kernel load, clocks
     got["frames"] = got["points"] = 0
     aug.bytes_h2d = aug.bytes_d2h = 0
+    for k in aug.times:
+        aug.times[k] = 0.0
     if before_timed is not None:
         before_timed()                                                 # (a barrier: the ranks of one host start together)
     t0 = time.perf_counter()
@@ -54,7 +56,8 @@ def measure(pkg, n_frames=1024, B=256, lanes=3, pack_threads=16, delta=True, dev
     dt = time.perf_counter() - t0
     return {"frames_per_s": round(got["frames"] / dt, 1), "frames": got["frames"], "seconds": dt, "batch": B, "lanes": lanes,
             "h2d_GBps": round(aug.bytes_h2d / dt / 1e9, 2), "d2h_GBps": round(aug.bytes_d2h / dt / 1e9, 2),
-            "pack_threads": pack_threads, "delta": delta,
+            "pack_threads": pack_threads, "delta": delta, "bytes_per_point_uploaded": 12 if (delta and aug.xyz_upload) else (16 if delta else 20),
+            "stage_seconds": {k: round(v, 3) for k, v in aug.times.items()},
             "what": "config C2 frames (120k points, 5 inserts) resident in host memory -> native packer -> pinned staging -> "
                     "upload / begin / insert_many / " + ("delta export / download (alive bits + inserted points) -> host merge"
                                                          if delta else "finish / download of the whole clouds") +
