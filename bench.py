@@ -663,7 +663,13 @@ def main():
                        "ms_per_step_one_step_in_flight": round(step_ms_serial, 3),
                        "insert_api": f"r3d_batch_insert x{K}" if args.per_slot_launches else f"r3d_batch_insert_many({K})",
                        "rebases_in_timed_steps": rebases, "settle_steps_in_setup": settle,
-                       "mean_points_out": float(n_out.mean()), "insert_paths_one_step": insert_paths},
+                       "mean_points_out": float(n_out.mean()), "insert_paths_one_step": insert_paths,
+                       # points of ONE step of the timed batch (begin + the inserts) whose pixel the reference formula decided
+                       # with the fractional row / column position within 1e-12 of an integer: where an ULP of arctan2 /
+                       # arccos could move a pixel against the reference (expected 0)
+                       "bin_edge_risk_points": {"scene": insert_paths.get("bin_edge_risk_scene_points"),
+                                                "sample": insert_paths.get("bin_edge_risk_sample_points"),
+                                                "scene_points_projected": int(n_pts)}},
             "roofline": roofline,
             "pipeline_alg_GBps_per_gpu": round(pipe_gbs, 1),
             "pipeline_frac_of_hbm_peak": round(pipe_gbs / HBM_PEAK_GBS, 4),

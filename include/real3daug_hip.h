@@ -295,7 +295,11 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream);
  * values, [32..] are round 5's counters: [32] pairs committed by the workgroup that evaluated them, [33] chunks those pairs
  * listed in all, [34] / [35] pairs whose evaluator found their predecessors still at work and left them -- with a record of
  * the evaluation / as they came -- to the workgroup that finishes slot k - 1 (nobody waits: csrc/r3d_insert.hip), [36] pairs
- * committed from such a record, [37] scenes whose points were put into virtual order at step 0 (below). */
+ * committed from such a record, [37] scenes whose points were put into virtual order at step 0 (below); round 6: [38] evaluations on a
+ * sparse depth tile (a window beyond the LDS keeps only the pixels the evaluation reads), [39] ... that it could not hold either
+ * (pool), [40] / [41] scene / sample points whose pixel the reference formula decided with the fractional row or column position
+ * (insertion.py:104-105 before int()) within 1e-12 of an integer -- where the device library's arctan2 / arccos and NumPy's, an
+ * ULP apart, could truncate to neighbouring bins; every point the verified fast projection cannot confirm is looked at. */
 int r3d_batch_debug_counters(const r3d_batch_t *b, int32_t *host_out16, int32_t reset, void *stream);
 
 /* Point order.  The incremental state of Level 2 is kept per 64 consecutive points (alive word, bounding box of their

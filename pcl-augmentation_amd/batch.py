@@ -28,6 +28,7 @@ class SceneBatch:
     # reads; augment_batch also leaves both on the batch INSTANCE it worked on, which is what holds when several threads run
     # augment_batch at a time (AugmentPipeline.run(lanes > 1): every worker thread has its own batches)
     last_rebases = 0      # rebases counted
+    edge_risk_total = (0, 0)  # points within 1e-12 of a bin edge the batch's kernels have met (scene, sample)
     last_level1 = []      # scenes run once more through the Level-1 kernels (_lib.S_REDO_LEVEL1)
 
     def __init__(self, B, cap, log_cap, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN, device="cuda:0",
@@ -475,6 +476,9 @@ class SceneBatch:
         d.update(pairs_committed_by_their_evaluator=pairs, parked_with_record=int(out[34]), parked_unevaluated=int(out[35]),
                  committed_from_record=int(out[36]), scenes_in_sorted_order=int(out[37]),
                  sparse_tiles=int(out[38]), sparse_tiles_beyond_the_lds=int(out[39]),
+                 # points whose pixel the reference formula decided within 1e-12 of a bin edge (scene points at step 0 /
+                 # rebase, sample points per evaluation): where an ULP of arctan2 / arccos could move a pixel
+                 bin_edge_risk_scene_points=int(out[40]), bin_edge_risk_sample_points=int(out[41]),
                  chunks_listed_per_pair=round(listed / pairs, 1) if pairs else None)
         return d
 
@@ -597,6 +601,10 @@ def augment_batch(scenes, candidates, min_points, rows=_lib.NUMROW, cols=_lib.NU
     accepted = batch.run_inserts(candidates, min_points)
     batch.finish(check_cols)
     batch.last_rebases = SceneBatch.last_rebases = int(batch.rebase.sum().item())
+    # points decided by the reference formula within 1e-12 of a bin edge since this batch object was made (scene, sample):
+    # what tools/fuzz_parity.py reports beside its comparisons
+    cnt = batch.debug_counters(reset=False)
+    batch.edge_risk_total = SceneBatch.edge_risk_total = (cnt["bin_edge_risk_scene_points"], cnt["bin_edge_risk_sample_points"])
     batch.last_level1 = SceneBatch.last_level1 = []
     # A frame beyond the batched kernels' limits -- an insert window that exceeds a CU's LDS (an object a few metres from the
     # sensor on a grid several times the reference's), a sample of more than R3D_MAX_SAMPLE points, more than R3D_FAR_CAP

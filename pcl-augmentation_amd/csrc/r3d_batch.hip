@@ -696,15 +696,16 @@ k_project_slow(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs
     int n_slow = w.n_slow[s], n_head = b.n_head[s];
     Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
     const uint32_t *queue = w.cand + (int64_t)s * w.cand_stride;
-    int flags = 0;
+    int flags = 0, n_risk = 0;
     for (int e = blockIdx.x * kPT + threadIdx.x; e < n_slow; e += gridDim.x * kPT) {
       int i = (int)queue[e];
       double x, y, z;
       load_point(b, s, i, n_head, x, y, z);
       BoxAcc unused;
-      b.pix[(int64_t)s * b.cap + i] = project_point(b, s, bn, x, y, z, flags, unused);
+      b.pix[(int64_t)s * b.cap + i] = project_point(b, s, bn, x, y, z, flags, unused, &n_risk);
     }
     if (flags) atomicOr(&b.status[s], flags);
+    if (n_risk) atomicAdd(&w.dbg[kCntEdgeScene], n_risk);       // (rare: a handful per billion points)
   }
 }
 

@@ -108,6 +108,12 @@ inline int chunks_of(const r3d_batch_t &b) { return (int)((b.cap + 63) / 64); }
 constexpr int kSuperMinChunks = R3D_SUPER_MIN_CHUNKS;
 constexpr int kDbgSuper = 256;
 constexpr int kCntVirtual = 37;      // BatchWs::dbg: scenes put into virtual order at step 0 (D_VIRTUAL of r3d_insert.hip's counters)
+// Round 6, the bin-edge risk counted instead of argued: points whose pixel the reference
+// formula decided with the fractional row or column position within kEdgeRisk of an integer -- where NumPy's arctan2 / arccos
+// and the device library's, which differ within an ULP, could truncate to neighbouring bins.  [40]: scene points (k_project_slow,
+// rebase: everything the verified fast projection could not confirm comes through there), [41]: sample points.
+constexpr int kCntEdgeScene = 40, kCntEdgeSample = 41;
+constexpr double kEdgeRisk = 1e-12;
 inline int supers_of(const r3d_batch_t &b) { return (chunks_of(b) + 63) / 64; }
 #ifdef __HIPCC__
 __host__ __device__
@@ -304,7 +310,7 @@ __device__ __forceinline__ bool box_touches_cols(int cmin, int cmax, int a, int 
 // The reference formula for one point (insertion.py:74-76, :104-116) as a real function call: inlined,
 // the float64 atan2 / acos of the device library raise the register count of every kernel that
 // contains them by ~70 VGPRs.  ok: bit 0 row in range, bit 1 column in range, bit 2 angles finite,
-// bit 3 elevation outside [min_el, max_el].
+// bit 3 elevation outside [min_el, max_el], bit 4 the fractional row or column position within kEdgeRisk of an integer.
 struct SphBin {
   double r;
   int row, col, ok;
@@ -318,14 +324,19 @@ static __device__ __attribute__((noinline)) SphBin spherical_bin(double max_el, 
   o.ok = bin_point(bn, sp.az, sp.el, o.row, o.col);
   if (isfinite(sp.el) && isfinite(sp.az)) o.ok |= 4;
   if (sp.el < min_el || sp.el > max_el) o.ok |= 8;
+  {
+    const double fr = (sp.el - bn.min_el - 0.00001) / bn.d_el, fc = pymod(sp.az, kTwoPi) / bn.d_az;   // insertion.py:104-105 before int()
+    if (fabs(fr - rint(fr)) < kEdgeRisk || fabs(fc - rint(fc)) < kEdgeRisk) o.ok |= 16;
+  }
   return o;
 }
 
 // One scene point under the reference formula: returns its pixel, accumulates the wave's box, the far
 // list and the status flags.
 __device__ __forceinline__ int project_point(const r3d_batch_t &b, int s, const Binning &bn, double x,
-                                             double y, double z, int &flags, BoxAcc &box) {
+                                             double y, double z, int &flags, BoxAcc &box, int *n_risk = nullptr) {
   SphBin sb = spherical_bin(bn.max_el, bn.min_el, bn.rows, bn.cols, x, y, z);
+  if (n_risk && (sb.ok & 16)) ++*n_risk;
   struct { double r; } sp = {sb.r};
   int row = sb.row, col = sb.col, p = 0;
   int ok = sb.ok;
@@ -465,20 +476,21 @@ __device__ __forceinline__ void rebase_scene(const r3d_batch_t &b, const BatchWs
   // (b) re-project the living (insertion.py:74-76, :104-116): pixel ids and chunk boxes -- under the bounds this
   // workgroup has just computed (from LDS: not through a cache that may still hold the old ones)
   Binning bn = make_binning(key_depth(s_min[0]), key_depth(s_max[0]), b.rows, b.cols);
-  int flags = 0;
+  int flags = 0, n_risk = 0;
   for (int i0 = 0; i0 < n; i0 += NT) {
     int i = i0 + tid;
     BoxAcc box;
     if (i < n && alive_bit(w, chunks, s, i)) {
       double x, y, z;
       load_point(b, s, orig_of(w, b, s, n_virt, i), n_head, x, y, z);
-      pix[i] = project_point(b, s, bn, x, y, z, flags, box);
+      pix[i] = project_point(b, s, bn, x, y, z, flags, box, &n_risk);
     }
     unsigned long long packed = box.wave_pack();
     int c0 = i0 + (tid & ~63);
     if ((tid & 63) == 0 && c0 < n) w.chunk_box[(int64_t)s * chunks + (c0 >> 6)] = packed;
   }
   if (flags) atomicOr(&b.status[s], flags);
+  if (n_risk) atomicAdd(&w.dbg[kCntEdgeScene], n_risk);
   phase_sync();
   // ... and the super-boxes over them (a chunk without a living point has left an empty box: rows 0xFFFF .. 0)
   if (supers_on(b, chunks)) {

@@ -608,6 +608,7 @@ struct Ins {
         if (!ok) {
           SphBin sb = spherical_bin(bn.max_el, bn.min_el, rows, cols, x, y, z);
           row = sb.row, col = sb.col, ok = sb.ok;
+          if (ok & 16) atomicAdd(&w.dbg[kCntEdgeSample], 1);        // (within 1e-12 of a bin edge: counted, r3d_batch.hpp)
         }
         if (!(ok & 4)) {
           flags |= R3D_S_NONFINITE;

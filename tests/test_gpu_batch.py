@@ -1008,3 +1008,51 @@ def test_delta_download_equals_finish(P, synth):
             for s, c in enumerate(cases):
                 vb, lb, cb, _ = _oracle_chain(c[0], c[1] & 0xFFFF, c[2], c[3])
                 _check_scene(outs[1][s], vb, lb, cb)
+
+
+def test_points_on_bin_edges_are_counted_and_agree_with_the_oracle(P, synth):
+    """SURVEY.md par.7 / DESIGN.md par.5: NumPy's arctan2 / arccos and the device library's round within an ULP of each
+    other, so a point whose fractional row or column position (insertion.py:104-105 before ``int()``) lies within ~1e-13 of
+    an integer could land in neighbouring pixels on the two sides.  The kernels COUNT the points they decide within 1e-12 of
+    an integer (debug counters 40 / 41).  Planted here: scene points and sample points on the azimuths float32 / float64
+    coordinates hit exactly -- the axes and the diagonals, azimuth + pi = k pi / 4, i.e. column k * cols / 8 on the dot --
+    at several ranges and heights.  They must be counted, and their pixels and the merged bytes must equal the oracle's."""
+    xyzi, label = synth.make_scene(77, 32, 600)
+    extra = []
+    for r in (3.0, 7.5, 20.0, 33.0):
+        for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (1, -1), (-1, 1), (-1, -1)):
+            for dz in (-0.30, -0.12, 0.01):
+                extra.append((r * dx, r * dy, r * dz, 0.5))
+    extra = np.asarray(extra, dtype=np.float32)
+    xyzi = np.vstack([xyzi, extra])
+    label = np.concatenate([label, np.full(len(extra), 50, dtype=np.uint32)])
+    # a sample with points on the same azimuths (genuine float64), in front of the scene
+    smp = synth.make_insert(771, "pedestrian", centre_range=6.0, centre_az=0.0)
+    on_edge = np.array([[6.0, 0.0, -1.0, 0.25, 30.0], [4.0, 4.0, -0.9, 0.25, 30.0], [0.0, 5.5, -1.1, 0.25, 30.0], [-5.0, 5.0, -1.2, 0.25, 30.0]])
+    smp = np.vstack([smp, on_edge])
+    batch = P.SceneBatch(1, len(xyzi) + len(smp) + 64, len(smp) + 64)
+    batch.load([(xyzi, label)])
+    batch.debug_counters(reset=True)
+    batch.begin()
+    pix = batch.pixel_ids()[0, :len(xyzi)]
+    s9 = O.add_space_for_spherical(synth.scene5_from_packed(xyzi, label))
+    s9, max_el, min_el = O.fill_spherical(s9)
+    _, _, s9 = O.geometrical_front_view(s9, O.NUMROW, O.NUMCOLUMN, max_el, min_el)
+    assert np.array_equal(pix, s9[:, 8].astype(np.int64))
+    cols = s9[-len(extra):, 8].astype(np.int64) % O.NUMCOLUMN
+    assert set(cols.tolist()) <= {k * O.NUMCOLUMN // 8 for k in range(8)} | {k * O.NUMCOLUMN // 8 - 1 for k in range(1, 9)}
+    cnt = batch.debug_counters(reset=False)
+    assert cnt["bin_edge_risk_scene_points"] >= len(extra) // 2, cnt       # (how many of them NumPy itself puts within 1e-12: below)
+    # the oracle's own count of such points, by the reference's formula
+    fc = (s9[:, 4] % (2 * np.pi)) / (2 * np.pi / O.NUMCOLUMN)
+    fr = (s9[:, 5] - min_el - 0.00001) / ((max_el - min_el) / O.NUMROW)
+    near = (np.abs(fc - np.rint(fc)) < 1e-12) | (np.abs(fr - np.rint(fr)) < 1e-12)
+    assert near[-len(extra):].sum() >= len(extra) // 2 and abs(int(near.sum()) - cnt["bin_edge_risk_scene_points"]) <= 2, (int(near.sum()), cnt)
+    # ... and through an insert: the sample's edge points are counted, the merged cloud equals the oracle's
+    acc = batch.run_inserts([[[smp]]], [[10]])
+    batch.finish()
+    cnt = batch.debug_counters(reset=False)
+    assert cnt["bin_edge_risk_sample_points"] >= 3, cnt
+    vb, lb, cb, oacc = _oracle_chain(xyzi, label, [[smp]], [10])
+    assert acc[0] == oacc and oacc == [0]
+    _check_scene(batch.results()[0], vb, lb, cb)

@@ -88,6 +88,7 @@ def main():
     pkg = importlib.import_module("pcl-augmentation_amd")
     synth = pkg.synth
     bad, scenes_done, both_raised, t0 = [], 0, 0, time.time()
+    edge_risk, points = [0, 0], [0, 0]      # points within 1e-12 of a bin edge the HIP path met (scene, sample) | points given to it
     pending = []
     for bi in range(n_batches):
         seed = seed0 + bi
@@ -103,6 +104,11 @@ def main():
             res, acc = pkg.augment_batch([(c[0], c[1]) for c in cases], [c[2] for c in cases], [c[3] for c in cases],
                                          rows=rows, cols=cols, debug=debug)
             err = None
+            risk = pkg.SceneBatch.edge_risk_total                     # (a fresh batch per call: the call's own count)
+            edge_risk[0] += risk[0]
+            edge_risk[1] += risk[1]
+            points[0] += sum(len(c[0]) for c in cases)
+            points[1] += sum(len(x) for c in cases for slot in c[2] for x in slot)
         except Exception as e:                                # a status the oracle must explain (e.g. an assert of the reference)
             res, acc, err = None, None, e
         pending.append((seed, rows, cols, debug, cases, res, acc, err, want))
@@ -133,6 +139,8 @@ def main():
     for b in bad:
         print("MISMATCH", b)
     print(f"{scenes_done} scenes in {n_batches} batches: {len(bad)} mismatches; {both_raised} batches in which both sides raised")
+    print(f"bin-edge risk: {edge_risk[0]} of {points[0]} scene points and {edge_risk[1]} of {points[1]} candidate points were decided by the "
+          f"reference formula with the fractional row / column position within 1e-12 of an integer (all of them compared above)")
     sys.exit(1 if bad else 0)
 
 
