@@ -362,6 +362,11 @@ def main():
         cpu_single, cpu_multi, oracle_bytes = cpu_baselines(pkg, cfg, args.config, n_check, budget_s=budget,
                                                             all_cores=budget >= 20.0 and world == 1)
 
+    # N > 1: every rank of the node on its own slice of the host's cores, on its GPU's NUMA node where sysfs says which that is --
+    # before the GPU runtime starts, so that its helper threads and the pinned staging slabs' pages follow (affinity.py)
+    binding = None
+    if world > 1:
+        binding = importlib.import_module("pcl-augmentation_amd.affinity").bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     import torch
     import torch.distributed as dist
     # R3D_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a
@@ -383,7 +388,8 @@ def main():
     distinct = min(args.distinct, B) if args.distinct > 0 else B
     # (the generator is NumPy and releases the interpreter lock: a 1M-point scan takes 0.5 s, 64 of them 8 s on 8 threads)
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=max(1, min(16, len(os.sched_getaffinity(0)) // max(world, 1)))) as gen:
+    gen_threads = len(os.sched_getaffinity(0)) if (binding and binding.get("bound")) else len(os.sched_getaffinity(0)) // max(world, 1)
+    with ThreadPoolExecutor(max_workers=max(1, min(16, gen_threads))) as gen:
         scenes = list(gen.map(lambda s: build_scene(synth, cfg, scene_seed(rank, s)), range(distinct)))
     scenes = [scenes[s % distinct] for s in range(B)]
     inserts = [synth.make_inserts(scene_seed(rank, s), kinds) for s in range(B)]
@@ -530,7 +536,8 @@ def main():
     if world > 1 and not args.no_extra_legs and args.config == "C2":
         e2e = importlib.import_module("tools.e2e_pipeline")
         cores = len(os.sched_getaffinity(0))
-        threads = max(1, min(16, cores // world))
+        # (bound: the mask already is this rank's slice of the host)
+        threads = max(1, min(16, cores if (binding and binding.get("bound")) else cores // world))
         for bt, _, _ in lanes[1:]:
             bt.ws = None                                            # the resident lanes' pools are not needed any more
         del lanes[1:]
@@ -542,7 +549,7 @@ def main():
         dist.all_reduce(f, op=dist.ReduceOp.SUM)
         e2e_all = {"frames_per_s_all_ranks": round(float(f.item()) / float(t.item()), 1), "frames": int(f.item()),
                    "slowest_rank_seconds": round(float(t.item()), 3), "rank0_frames_per_s": mine["frames_per_s"],
-                   "pack_threads_per_rank": threads, "host_cores_visible": cores, "ranks": world,
+                   "pack_threads_per_rank": threads, "host_cores_visible": cores, "ranks": world, "rank0_core_binding": binding,
                    "what": "every rank streams its own frames host memory -> GPU -> host memory at the same time "
                            "(tools/e2e_pipeline.measure, delta download); the ranks share the host"}
 

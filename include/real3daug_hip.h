@@ -14,7 +14,9 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All calls are
  *     asynchronous and stream-ordered; none of them allocates, frees or synchronises, so a call
  *     sequence can be captured into a hipGraph.
- *   - The library owns no device memory and keeps no state besides a thread-local error string.
+ *   - The library owns no device memory and keeps no state besides a thread-local error string, caches of device
+ *     attributes (resident workgroups per kernel shape) and the placement search's helper streams (r3d_places_release).
+ *     It reads no environment variable: every switch is a bit of a descriptor.
  *     Scratch is a caller-provided workspace (size from the *_workspace_bytes queries).
  *   - Return value: R3D_OK or a negative R3D_E_* (bad argument, HIP launch error).  Conditions the
  *     reference reports with `assert` / exceptions while iterating over points are accumulated
@@ -63,11 +65,15 @@ extern "C" {
 #define R3D_S_FAR_OVERFLOW 32     /* batched path: more than R3D_FAR_CAP pixels beyond 500 m */
 #define R3D_S_CHAIN_TIMEOUT 128   /* r3d_batch_insert_many: the chain of the scene's slots was left unfinished (a slot never
                                      published; the name is round 2's, when slots waited for each other against a clock) */
+#define R3D_S_ORDER_PROMISE 256   /* R3D_B_FILE_ORDER was set for r3d_batch_finish / export_delta / export_rows of a batch whose
+                                     r3d_batch_begin had looked at the point order and numbered this scene anew: the scene's
+                                     results are not valid (the bit belongs to the batch from one begin to the next) */
 #define R3D_S_WINDOW_TOO_LARGE 64 /* batched path: the bit images of the insert's window of the range image plus the
                                      sample's per-point arrays exceed one CU's LDS (a sample that covers more
                                      than ~200 000 pixels) */
 
 #define R3D_B_FILE_ORDER 2048     /* r3d_batch_t.reserved: the clouds come in a LiDAR file order (see r3d_batch_export_pix below) */
+#define R3D_B_SLOT_LAUNCHES 65536 /* r3d_batch_t.reserved: r3d_batch_insert_many makes one launch per slot (no chain inside a kernel) */
 #define R3D_MAX_SAMPLE 65535      /* points per insert candidate in the batched path (16-bit indices into the sample; round 4:
                                      8 192).  A candidate whose per-point arrays exceed a chain workgroup's LDS goes to
                                      k_insert_big, one that exceeds a whole CU's comes back as R3D_S_WINDOW_TOO_LARGE; the
@@ -254,8 +260,8 @@ int r3d_batch_finish(const r3d_batch_t *b, float *check, int32_t check_cols, voi
  * r3d_batch_insert (active may be null, or hold nulls); slot k runs as step first_step + k.  Same
  * results as n_slots calls of r3d_batch_insert.  The hand-off between the slots of a scene is an
  * agent-scope release / acquire and does not depend on where the workgroups run; the waits are
- * bounded (R3D_S_CHAIN_TIMEOUT: the scene's later slots were not run, its results are not valid),
- * and the environment variable R3D_NO_CHAIN=1 selects one launch per slot unconditionally. */
+ * bounded (R3D_S_CHAIN_TIMEOUT: the scene's later slots were not run, its results are not valid);
+ * R3D_B_SLOT_LAUNCHES in `reserved` selects one launch per slot unconditionally. */
 int r3d_batch_insert_many(const r3d_batch_t *b, int32_t n_slots, const double *const *samples5,
                           const int64_t *const *sample_off, const int32_t *const *min_points,
                           const int32_t *const *active, int32_t first_step, int32_t *const *n_visible,
@@ -308,12 +314,12 @@ int r3d_batch_debug_counters(const r3d_batch_t *b, int32_t *host_out16, int32_t 
  * reference does not care about the order (insertion.py:100-127 loops over the points as they come), and neither do the
  * results here: r3d_batch_begin looks at the boxes it has just built and, for a scene whose mean box exceeds 1 024 pixels (and
  * that has 4 096 points or more), numbers the points anew by (row, band of 64 columns) -- internally: slabs, log and the
- * order of every output are untouched.  R3D_VIRTUAL_ORDER=0 / 2 in the environment: never / every scene; bit 1024 of
- * `reserved`: every scene of this batch (tests).  The look costs a begin four small launches (~20 us per 256 scenes); a caller
+ * order of every output are untouched.  Bit 1024 of `reserved`: every scene of this batch (tests).  The look costs a begin four small launches (~20 us per 256 scenes); a caller
  * who knows that its clouds come in a file order says so with R3D_B_FILE_ORDER in `reserved` and saves them -- a cloud that
  * does not keep the promise costs time (every insert then walks the whole cloud), never results.  The bit belongs to the
  * batch from one r3d_batch_begin to the next: finish / export_delta / export_rows skip the launch that puts the alive bits of
- * re-numbered scenes back into slab order when it is set, so it must not be set between a begin that looked and its finish.
+ * re-numbered scenes back into slab order when it is set, so it must not be set between a begin that looked and its finish
+ * (a scene that was numbered anew comes back flagged R3D_S_ORDER_PROMISE if it is).
  * The Python mirror (SceneBatch) sets the bit by itself, at begin, once a batch has come through without an unordered scene,
  * and looks again now and then.
  *
@@ -407,6 +413,12 @@ int r3d_places_chunk_ranges(const double *rows, int64_t n, int32_t ld, float *ra
  * and quaternion of every possible placement, same order; cand = for placement ordinal j in
  * [first_cand, first_cand + cand_cap) the m x 5 cloud at cand + cand_off + (j - first_cand)*cand_stride
  * (deepcopy(sample_pcl), :258-264); status int32 [Q] (R3D_PS_*). */
+/* The one thing the library keeps between calls besides the thread-local error string (and caches of device attributes): a
+ * helper stream with two events per (device, caller's stream) on which r3d_find_possible_places runs its orientation chain
+ * beside the point passes, made on first use.  r3d_places_release() waits for them, destroys them and forgets them (call it
+ * when no r3d_find_possible_places is in flight; the next call makes them again). */
+int r3d_places_release(void);
+
 int r3d_find_possible_places(const r3d_place_query_t *queries, int32_t n_queries, int64_t max_n_scene,
                              int64_t max_n_orig, int32_t max_m, int32_t max_boxes, const double *radius_sq,
                              int32_t n_radii, uint8_t *flags, int32_t *n_possible, int32_t *rot_out,

@@ -10,7 +10,7 @@ The directory name contains a hyphen, so import it with
 ``importlib.import_module("pcl-augmentation_amd")`` (or through ``pcl_augmentation_amd.py`` at
 the repository root).
 """
-from . import _lib, synth  # noqa: F401
+from . import _lib, affinity, synth  # noqa: F401
 from ._lib import R3DError  # noqa: F401
 from .batch import SceneBatch, augment_batch, run_sharded, shard_indices  # noqa: F401
 from . import Real3DAug  # noqa: F401
@@ -20,4 +20,4 @@ from .places import PlaceScene, find_places  # noqa: F401
 from .placed import PlacedInserter  # noqa: F401
 from .rich_map import build_rich_map  # noqa: F401
 
-__all__ = ["SceneBatch", "augment_batch", "run_sharded", "shard_indices", "AugmentPipeline", "Frame", "run_sharded_files", "Real3DAug", "synth", "R3DError", "places", "PlaceScene", "find_places", "PlacedInserter", "build_rich_map"]
+__all__ = ["SceneBatch", "augment_batch", "run_sharded", "shard_indices", "AugmentPipeline", "Frame", "run_sharded_files", "Real3DAug", "synth", "R3DError", "places", "PlaceScene", "find_places", "PlacedInserter", "build_rich_map", "affinity"]

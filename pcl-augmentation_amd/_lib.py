@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("R3D_LIB") or os.path.join(_HERE, "libreal3daug_hip.so
 R3D_OK = 0
 S_NONFINITE, S_ROW_RANGE, S_COL_RANGE, S_SAMPLE_TOO_LARGE, S_CAPACITY, S_FAR_OVERFLOW, S_WINDOW_TOO_LARGE = 1, 2, 4, 8, 16, 32, 64
 S_CHAIN_TIMEOUT = 128
+S_ORDER_PROMISE = 256
 # limits of the batched kernels that the reference does not have (insertion.py:455-482 takes a sample of any size and any
 # number of returns beyond 500 m): a frame flagged with one of these -- and with nothing else -- is run once more, alone,
 # through the Level-1 kernels by every mirror that drives Level 2 (batch.augment_batch, streaming.StreamedAugmenter)
@@ -29,12 +30,14 @@ STATUS_TEXT = {
     S_FAR_OVERFLOW: "more than R3D_FAR_CAP pixels deeper than 500 m (Level 2 only; the mirrors redo such a frame through Level 1)",
     S_WINDOW_TOO_LARGE: "the insert's window of the range image and the sample's arrays do not fit one CU's LDS",
     S_CHAIN_TIMEOUT: "insert_many: the chain of a scene's slots was left unfinished",
+    S_ORDER_PROMISE: "R3D_B_FILE_ORDER was set between a begin that numbered this scene's points anew and its finish / export",
 }
 K_BOUNDS, K_PREPARE, K_PROJECT, K_ALIVE_WRITE = 1, 2, 3, 5
 NUMROW, NUMCOLUMN = 112, 1440
 MAX_SAMPLE = 65535
 FAR_CAP = 1024
 B_FILE_ORDER = 2048      # r3d_batch_t.reserved: the clouds come in a LiDAR file order (no look at the chunk boxes, no virtual order)
+B_SLOT_LAUNCHES = 65536  # r3d_batch_t.reserved: r3d_batch_insert_many makes one launch per slot (no chain inside a kernel)
 MAX_CHAIN = 64           # insert slots one launch of the chain kernel takes (kMaxChain in csrc/r3d_batch.hpp); insert_many splits longer lists
 
 
@@ -113,6 +116,7 @@ _SIGNATURES = {
     "r3d_batch_point_order": (C.c_int, [C.POINTER(BatchDesc), _P, _P]),
     "r3d_batch_adopt_rejected": (C.c_int, [C.POINTER(BatchDesc), _P, _P]),
     "r3d_places_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "r3d_places_release": (C.c_int, []),
     "r3d_cut_boxes_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "r3d_cut_boxes": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int64,
                                 _P, C.c_size_t, _P]),

@@ -87,7 +87,9 @@ class SceneBatch:
         # `debug`: further diagnostic bits (2 / 4 / 8 / 16 / 32 / 128: force the insert kernel's other routes; 64: verify every
         # speculative evaluation, csrc/r3d_insert.hip)
         import os
-        debug = int(debug) | int(os.environ.get("R3D_DEBUG_BITS", "0"))   # (diagnostics: the same bits for every batch of the process)
+        # (diagnostics: the same bits for every batch of the process -- read HERE, by the Python mirror; the library itself
+        # reads no environment variable)
+        debug = int(debug) | int(os.environ.get("R3D_DEBUG_BITS", "0"))
         d.B, d.rows, d.cols, d.reserved, d.cap, d.log_cap = B, rows, cols, (1 if exact_projection else 0) | int(debug), cap, log_cap
         for name in ("xyzi", "label", "pix", "n_head", "n_total", "tail_ref", "log5", "log_birth", "n_log",
                      "bounds", "far_pix", "n_far", "rebase",
@@ -546,7 +548,7 @@ class SceneBatch:
                 bad = int((self.status & _lib.S_CHAIN_TIMEOUT).sum().item())
             if bad:
                 raise _lib.R3DError("r3d_batch_insert_many could not order the slots of a scene on this device "
-                                    "(status R3D_S_CHAIN_TIMEOUT); set R3D_NO_CHAIN=1 to insert slot by slot")
+                                    "(status R3D_S_CHAIN_TIMEOUT); SceneBatch(debug=_lib.B_SLOT_LAUNCHES) inserts slot by slot")
             return [[0 if acc_h[k, s] else -1 for k in range(len(candidates[s]))] for s in range(B)]
         log, keep = [], []
         for k in range(k_max):

@@ -1132,7 +1132,7 @@ constexpr int kWaveChunks = kTile / 64 / (kPT / 64);    // chunks of a tile per 
 template <bool ROWS4, bool NONTEMP>
 __global__ void __launch_bounds__(kPT)
 k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w, int tiles, int chunks,
-              double *rows4, int32_t *n_rows) {
+              double *rows4, int32_t *n_rows, bool slab_order_made) {
   static_assert(kWaveChunks == 8 && kTile / 64 <= 64, "a wave reads its tile's alive words with one load");
   int cnt = *count;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1144,6 +1144,7 @@ k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
     // (r3d_batch_export_rows shows the copy a rejected candidate has left, while there is one: BatchWs::shadow_valid)
     const bool shadow = ROWS4 && w.shadow_valid[s] != 0;
     const bool virt = w.n_virt[s] != 0;                       // (virtual order: the bits k_unvirtual has put back into slab order)
+    if (virt && !slab_order_made && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&b.status[s], R3D_S_ORDER_PROMISE);
     const int32_t *tile_alive = (virt ? w.tile_o : (shadow ? w.tile_shadow : w.tile_alive)) + (int64_t)s * tiles;
     const unsigned long long *alive = (virt ? w.alive_o : (shadow ? w.alive_shadow : w.alive)) + (int64_t)s * chunks;
     int pre = 0;
@@ -1268,7 +1269,7 @@ __global__ void k_pack_log(r3d_batch_t b, float *__restrict__ check, int check_c
 // r3d_batch_export_delta: what a host that still holds the frames needs to write the merged files -- the alive word
 // of every 64-point chunk and the inserted points (float32 rounding + label) in insertion order, at a fixed stride.
 __global__ void k_export_delta(r3d_batch_t b, BatchWs w, int chunks, unsigned long long *alive_out, float *tail_xyzi,
-                               uint32_t *tail_label, int64_t tail_stride, int32_t *counts) {
+                               uint32_t *tail_label, int64_t tail_stride, int32_t *counts, bool slab_order_made) {
   const int s = blockIdx.y;
   const int n_head = b.n_head[s], n_total = b.n_total[s];
   const int n_tail = n_total - n_head;
@@ -1276,6 +1277,7 @@ __global__ void k_export_delta(r3d_batch_t b, BatchWs w, int chunks, unsigned lo
     counts[s] = n_head;
     counts[b.B + s] = n_total;
     if (n_tail > tail_stride) atomicOr(&b.status[s], R3D_S_CAPACITY);
+    if (w.n_virt[s] != 0 && !slab_order_made) atomicOr(&b.status[s], R3D_S_ORDER_PROMISE);
   }
   const int n_words = (n_total + 63) >> 6;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += gridDim.x * blockDim.x) {
@@ -1320,14 +1322,10 @@ static size_t project_lds_bytes(const r3d_batch_t &b) {
 }
 
 // k_project's grid: the workgroups the device holds at once (they deal the tiles out among themselves), but no more than
-// there can be tiles.  R3D_PROJECT_GRID: workgroups per CU instead of what the occupancy query says (experiments).
+// there can be tiles.  (The table below is a cache of a device attribute, per device and LDS size -- not state of a batch.)
 static int project_grid(const r3d_batch_t &b) {
   static std::mutex mu;
   static std::map<std::pair<int, size_t>, int> known;      // (device, LDS bytes) -> resident workgroups
-  static const int per_cu_env = [] {
-    const char *v = getenv("R3D_PROJECT_GRID");
-    return v && atoi(v) > 0 ? atoi(v) : 0;
-  }();
   int dev = 0;
   (void)hipGetDevice(&dev);
   const size_t lds = project_lds_bytes(b);
@@ -1339,7 +1337,6 @@ static int project_grid(const r3d_batch_t &b) {
       int cus = 0, per_cu = 0;
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_project, kProjNT, lds) != hipSuccess || per_cu <= 0) per_cu = 1;
-      if (per_cu_env) per_cu = per_cu_env;
       it = known.emplace(std::make_pair(dev, lds), cus * per_cu).first;
     }
     resident = it->second;
@@ -1352,17 +1349,15 @@ static int project_grid(const r3d_batch_t &b) {
   return (int)(most < resident ? (most > 0 ? most : 1) : resident);
 }
 
-// Can a scene of this batch be in virtual order?  R3D_VIRTUAL_ORDER: 0 never, 1 (default) the scenes whose chunk boxes say
-// that their points come in no file order, 2 all.  Bit 2048 of `reserved` (R3D_B_FILE_ORDER): the caller says that the clouds
-// come in a LiDAR file order -- nothing is looked at, nothing sorted (a cloud that does not keep the promise costs time, not
-// results), and the calls that would put alive bits back into slab order (finish, export_delta, export_rows) skip that
-// launch: the bit has to be the same from a begin to the next.  0: no.
+// Can a scene of this batch be in virtual order?  0: no -- bit 2048 of `reserved` (R3D_B_FILE_ORDER): the caller says that the
+// clouds come in a LiDAR file order, nothing is looked at, nothing sorted (a cloud that does not keep the promise costs time,
+// not results); 1: the scenes whose chunk boxes say that their points come in no file order; 2: all (bit 1024, tests).
+// finish / export_delta / export_rows skip the launches that put alive bits back into slab order when the mode is 0; a scene
+// that IS in virtual order then (the caller set the bit between a begin that looked and its finish) is flagged
+// R3D_S_ORDER_PROMISE by the kernel that would have read the missing bits, instead of writing a wrong cloud silently.
 static int virtual_order_mode(const r3d_batch_t &b) {
-  static const int mode = [] {
-    const char *v = getenv("R3D_VIRTUAL_ORDER");
-    return v && *v ? atoi(v) : 1;
-  }();
-  return mode && (!(b.reserved & R3D_B_FILE_ORDER) || mode == 2 || (b.reserved & kDbgVirtual)) ? mode : 0;
+  if (b.reserved & kDbgVirtual) return 2;
+  return (b.reserved & R3D_B_FILE_ORDER) ? 0 : 1;
 }
 
 // bounds -> tables -> project for the scenes of (list, count); rows = block rows of the launches.
@@ -1422,11 +1417,13 @@ static int launch_compact(const r3d_batch_t &b, const BatchWs &w, const int32_t 
   if (rows4) {
     if (virtual_order_mode(b)) launch_unvirtual(b, w, list, count, rows, true, st);
     if (tiles >= kPrefixMinTiles) hipLaunchKernelGGL((k_tile_prefix<true>), dim3(1, rows), dim3(1024), 0, st, b, list, count, w, tiles);
-    hipLaunchKernelGGL((k_alive_write<true, false>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b), rows4, n_rows);
+    hipLaunchKernelGGL((k_alive_write<true, false>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b), rows4, n_rows,
+                       virtual_order_mode(b) != 0);
   } else {
     if (virtual_order_mode(b)) launch_unvirtual(b, w, list, count, rows, false, st);
     if (tiles >= kPrefixMinTiles) hipLaunchKernelGGL((k_tile_prefix<false>), dim3(1, rows), dim3(1024), 0, st, b, list, count, w, tiles);
-    hipLaunchKernelGGL((k_alive_write<false, true>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b), rows4, n_rows);
+    hipLaunchKernelGGL((k_alive_write<false, true>), grid, blk, 0, st, b, list, count, w, tiles, chunks_of(b), rows4, n_rows,
+                       virtual_order_mode(b) != 0);
   }
   R3D_LAUNCHED("compaction kernel");
   return R3D_OK;
@@ -1566,10 +1563,10 @@ int r3d_batch_export_delta(const r3d_batch_t *b, uint64_t *alive, float *tail_xy
   if (rc != R3D_OK) return rc;
   if (!alive || !tail_xyzi || !tail_label || !counts || tail_stride <= 0) return fail(R3D_E_ARG, "batch_export_delta: null output or stride");
   BatchWs w = carve_batch(*b, b->workspace);
-  if (virtual_order_mode(*b))
-    launch_unvirtual(*b, w, w.all_list, w.all_count, b->B, false, (hipStream_t)stream);
+  if (virtual_order_mode(*b)) launch_unvirtual(*b, w, w.all_list, w.all_count, b->B, false, (hipStream_t)stream);
   hipLaunchKernelGGL(k_export_delta, dim3(8, b->B), dim3(256), 0, (hipStream_t)stream, *b, w, chunks_of(*b),
-                     reinterpret_cast<unsigned long long *>(alive), tail_xyzi, tail_label, tail_stride, counts);
+                     reinterpret_cast<unsigned long long *>(alive), tail_xyzi, tail_label, tail_stride, counts,
+                     virtual_order_mode(*b) != 0);
   R3D_LAUNCHED("k_export_delta");
   return R3D_OK;
 }

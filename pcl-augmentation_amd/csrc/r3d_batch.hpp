@@ -16,8 +16,6 @@
 // into slab order (k_unvirtual: alive_o, tile_o).
 #pragma once
 
-#include <cstdlib>
-
 #include "r3d_device.hpp"
 #include "r3d_host.hpp"
 
@@ -60,7 +58,6 @@ struct BatchWs {
                                 // there, the workgroup that finishes the scene's previous slot "predecessor done" -- whoever
                                 // comes second carries on with the pair (r3d_insert.hip: nobody ever waits)
   int32_t *park_hdr;            // [B*kMaxChain*kParkInts] what a parked pair leaves for the workgroup that commits it
-  int32_t *slot_order;          // [kMaxChain] the order in which the running launch hands out its slots
   int32_t *n_virt;              // [B] > 0: the scene's first n_virt points are in virtual order (see the top of this file)
   int32_t *box_area;            // [B] sum of the areas of the scene's chunk boxes as k_project built them (each capped)
   uint32_t *sort_off;           // [B*sort_blocks*512] per block of 4 096 points and bin: count, then first place (k_virt_hist)
@@ -151,7 +148,6 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   w.recs = c.take<int32_t>((size_t)b.B * kMaxChain * kRecInts);
   w.park = c.take<int32_t>((size_t)b.B * kMaxChain);
   w.park_hdr = c.take<int32_t>((size_t)b.B * kMaxChain * kParkInts);
-  w.slot_order = c.take<int32_t>(kMaxChain);
   w.n_virt = c.take<int32_t>((size_t)b.B);
   w.box_area = c.take<int32_t>((size_t)b.B);
   w.sort_off = c.take<uint32_t>((size_t)b.B * ((b.cap + 4095) / 4096) * 512);
@@ -164,16 +160,11 @@ inline BatchWs carve_batch(const r3d_batch_t &b, void *base) {
   // The launch's pool: depth tiles, candidate lists, chunk lists and scratch images of the pairs whose window exceeds a
   // workgroup's LDS (on the reference's grid a few per cent of the pairs, 10-60 KB each; on a range image several times
   // that size most cars, up to ~1 MB each).  Per scene 1 MB or 16 bytes per point of its slab, between 64 MB and 4 GB per
-  // batch -- R3D_POOL_MB overrides --; an exhausted pool costs time, not results (tiles in row bands, the pair left to
+  // batch; an exhausted pool costs time, not results (tiles in row bands, the pair left to
   // k_insert_big).  Per-lane footprint: INTEGRATION.md.
   const int64_t per_scene = (int64_t)b.cap * 16 > (1 << 20) ? (int64_t)b.cap * 16 : (1 << 20);
   w.pool_bytes = (int64_t)b.B * per_scene;
   w.pool_bytes = w.pool_bytes < (64ll << 20) ? (64ll << 20) : (w.pool_bytes > (4ll << 30) ? (4ll << 30) : w.pool_bytes);
-  static const long long pool_mb = [] {
-    const char *v = getenv("R3D_POOL_MB");
-    return v && atoll(v) > 0 ? atoll(v) : 0ll;
-  }();
-  if (pool_mb) w.pool_bytes = pool_mb << 20;
   w.tile_pool = c.take<unsigned char>((size_t)w.pool_bytes);
   w.pool_head = c.take<unsigned long long>(1);
   w.queue_next = c.take<int32_t>(16);

@@ -35,8 +35,7 @@
 // workgroup that has published slot k - 1 leaves "predecessor done"; whoever finds the other's mark there continues with
 // the pair.  Rounds 2-4 had the evaluator spin on the scene's progress word instead (11-14 % of a pair's time, a whole CU
 // idle on large range images), which also tied liveness to the order in which workgroups are dispatched -- a workgroup could
-// only wait for lower block ids -- and needed a wall-clock time-out; now any order of dispatch is correct, so the launch
-// hands out its heaviest slot first when the chain is short (k_chain_init: slot_order).
+// only wait for lower block ids -- and needed a wall-clock time-out; now any order of dispatch is correct.
 // Memory ordering (cdna_hip_programming.md, Guideline 16; correct for any placement of the workgroups): every storing wave
 // drains (s_waitcnt vmcnt(0)), barrier, ONE lane does the agent-scope release, waits again, then the relaxed agent-scope
 // atomic (progress word, hand-over word); the side that finds the other's mark does ONE agent-scope acquire + wait,
@@ -498,10 +497,10 @@ __device__ __forceinline__ void run_pairs_from(unsigned char *smem, int pair_id)
     asm volatile("" : "+s"(ap));
     const ChainArgs &a = *(const ChainArgs *)ap;
     // B8 > 0: slot-major numbering (every scene's first slot, then every scene's second; a scene's slots on one residue of
-    // the pair id mod 8), the slots in the launch's order (BatchWs::slot_order); B8 == 0: scene-major
-    const int B8 = a.B8, nk = a.nk;
-    k = B8 ? uni(a.w.slot_order[pair_id / B8]) : pair_id % nk;
-    s = B8 ? pair_id % B8 : pair_id / nk;
+    // the pair id mod 8)
+    const int B8 = a.B8;
+    k = pair_id / B8;
+    s = pair_id % B8;
   }
   for (;;) {
     ChainArgsPtr ap = (ChainArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -550,7 +549,7 @@ k_insert_chain(ChainArgs args) {
   }
   int *H = reinterpret_cast<int *>(smem);
   const int queue_mode = args.queue_mode;
-  const int total = (args.B8 ? args.B8 : args.b.B) * args.nk;
+  const int total = args.B8 * args.nk;
   const int home = queue_mode >= 2 ? (int)(blockIdx.x & 7) : 0;
   int turn = 0;                                              // queues this workgroup has found empty
   for (;;) {
@@ -627,43 +626,17 @@ k_insert_big(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w,
   }
 }
 
-// Before a chain launch: progress / hand-over words, the pool, the queues -- and the ORDER in which the launch hands out
-// its slots.  Nobody waits for anybody (see the top of the file), so any order is correct.  A slot much heavier than the
-// others (sample rows >= 1.8 x the mean: the car among pedestrians and cyclists) is handed out up to `kPromote` places
-// earlier: it then evaluates while its predecessors run, is found parked when they are done, and the launch no longer ends
-// with "the slowest car, started after two slots had been through the device, plus what queued behind it" (config C2: the
-// scene with the slowest car ended at 334 us, its car taken at 69 us and evaluated for 206).  Not further: a slot evaluated
-// far ahead of its predecessors conflicts with one of them almost surely and is evaluated again by whoever commits it -- on
-// the scene's critical path.  (Tried: all slots by weight, heaviest first -- slot 0 then starts at 100 us and every chain
-// queues behind it: 0.42 ms per launch against 0.35.)  `order_mode`: 0 keep the caller's order, 1 promote (chains of <= 8 slots).
-constexpr int kPromote = 2;
-__global__ void k_chain_init(r3d_batch_t b, BatchWs w, ChainSlots slots, int nk, int order_mode) {
+// Before a chain launch: progress / hand-over words, the pool, the queues.  The launch hands out its slots in the caller's
+// order.  Nobody waits for anybody (see the top of the file), so any order would be
+// correct; measured on config C2 and dropped: all slots by weight, heaviest first (slot 0 then starts at 100 us and every
+// chain queues behind it: 0.42 ms per launch against 0.35), and a heavy slot up to two places earlier (0.43 ms: the car then
+// evaluates against a state two slots old, a tenth of the cars conflict with one of them and start over).
+__global__ void k_chain_init(r3d_batch_t b, BatchWs w, ChainSlots slots, int nk) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= b.B) return;
   if (s == 0) {
     *w.pool_head = 0ull;
     for (int q = 0; q < 16; ++q) w.queue_next[q] = 0;
-    long long rows_of[kMaxChain], sum = 0;
-    for (int k = 0; k < nk; ++k) w.slot_order[k] = k;
-    // (the slots' sizes only for the option that uses them: fifty dependent loads of config C5's launch were 25 of this
-    // kernel's 30 us)
-    if (order_mode == 1 && nk <= 8)
-      for (int k = 0; k < nk; ++k) {
-        rows_of[k] = slots.sample_off[k][b.B];
-        sum += rows_of[k];
-      }
-    if (order_mode == 1 && nk <= 8)
-      for (int k = 1; k < nk; ++k) {
-        if (rows_of[k] * 10 * nk < 18 * sum) continue;         // not a heavy slot
-        int at = 0;
-        while (w.slot_order[at] != k) ++at;
-        for (int hop = 0; hop < kPromote && at > 0; ++hop, --at) {
-          const int before = w.slot_order[at - 1];
-          if (rows_of[before] * 10 * nk >= 18 * sum) break;    // (heavy slots keep their order among themselves)
-          w.slot_order[at - 1] = k;
-          w.slot_order[at] = before;
-        }
-      }
   }
   w.chain_progress[s] = 0;
   w.n_total0[s] = b.n_total[s];
@@ -671,27 +644,19 @@ __global__ void k_chain_init(r3d_batch_t b, BatchWs w, ChainSlots slots, int nk,
   for (int k = 0; k < nk; ++k) w.park[(int64_t)s * kMaxChain + k] = kParkNone;
 }
 
-constexpr int kSmallNT = 256;
 constexpr int kBigNT = 1024;
 constexpr int kBigLds = 160 * 1024;
-
-static int env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
 
 // Shape of a chain workgroup.  Range images of KITTI's size (112 x 1440): two 512-thread workgroups with 80 KB each per
 // CU (measured on config C2: 256 threads x 40 KB leaves most cars to the pool / k_insert_big, 1024 x 160 KB leaves
 // the CUs to one pair each and no room for the other steps in flight).  Large range images (config C5, 448 x 2880:
 // a car's window is ~16x the pixels): one 1024-thread workgroup with the CU's whole LDS -- 2.5 ms per step against
-// 5.9 ms, nearly every pair then fits the chain kernel.  R3D_INSERT_NT / R3D_INSERT_LDS_KB override.
+// 5.9 ms, nearly every pair then fits the chain kernel (round 6, with sparse tiles: 512 x 80 KB 12.7 ms, 1024 x 80 KB
+// 10.8 ms against 5.0 ms per launch -- the six bit images of a large window alone exceed 80 KB).
 static void chain_shape(const r3d_batch_t &b, int &nt, int &lds) {
-  static const int env_nt = env_int("R3D_INSERT_NT", 0), env_kb = env_int("R3D_INSERT_LDS_KB", 0);
   const bool large = (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN;
-  nt = env_nt ? env_nt : (large ? 1024 : 512);
-  int kb = env_kb ? env_kb : (nt == 1024 ? 160 : 80);
-  kb = kb < 16 ? 16 : (kb > 160 ? 160 : kb);
-  lds = kb * 1024;
+  nt = large ? 1024 : 512;
+  lds = (large ? 160 : 80) * 1024;
 }
 
 template <int NT, bool QUEUE>
@@ -700,7 +665,7 @@ static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlo
   // per device, every call: the attribute belongs to the current device's copy of the kernel
   R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_chain<NT, QUEUE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  const int total = (B8 ? B8 : b.B) * nk;
+  const int total = B8 * nk;
   int grid = total;
   if (QUEUE && queue_mode) {
     // how many workgroups of this shape the device keeps resident: asked once per (device, LDS size) and kernel flavour
@@ -726,8 +691,6 @@ static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlo
   }
   ChainArgs args;
   args.b = b;
-  static const int tile_bands = env_int("R3D_TILE_BANDS", 0);
-  if (tile_bands) args.b.reserved |= kDbgNoPoolTile;
   args.slots = sl;
   args.w = w;
   args.nk = nk, args.first_step = first_step, args.chunks = chunks_of(b), args.lds_cap = lds, args.B8 = B8, args.queue_mode = queue_mode;
@@ -739,15 +702,14 @@ static int launch_chain_q(const r3d_batch_t &b, const BatchWs &w, const ChainSlo
 template <int NT>
 static int launch_chain(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step, int lds,
                         hipStream_t st) {
-  // measured on config C2 (round 2): scene-major numbering is 10-40 % slower (the big pairs of all scenes no longer start together)
-  static const bool scene_major = getenv("R3D_CHAIN_ORDER") && std::string(getenv("R3D_CHAIN_ORDER")) == "scene";
-  const int B8 = scene_major ? 0 : (b.B + 7) & ~7;            // a scene's slots on one residue of the pair id mod 8
-  // R3D_CHAIN_QUEUE: 0 one workgroup per pair; 1 resident workgroups that take pairs off one queue; 2 ... off a queue per
-  // XCD (see k_insert_chain).  Default: 2 on large range images (config C5: 6.4 -> 4.8 ms per 128 scans x 50 slots), 0 otherwise.
-  static const int queue_env = env_int("R3D_CHAIN_QUEUE", -1);
+  // a scene's slots on one residue of the pair id mod 8 (slot-major numbering; measured on config C2, round 2: scene-major
+  // numbering is 10-40 % slower -- the big pairs of all scenes no longer start together)
+  const int B8 = (b.B + 7) & ~7;
+  // queue_mode 0: one workgroup per pair; 1: resident workgroups that take pairs off one queue; 2: ... off a queue per XCD
+  // (see k_insert_chain).  2 on large range images (config C5: 6.4 -> 4.8 ms per 128 scans x 50 slots), 0 otherwise.
   const bool large = (int64_t)b.rows * b.cols >= 4ll * R3D_NUMROW * R3D_NUMCOLUMN;
-  int queue_mode = queue_env >= 0 ? (queue_env > 2 ? 2 : queue_env) : (large ? 2 : 0);
-  if ((scene_major || B8 >= (1 << 20)) && queue_mode >= 2) queue_mode = 1;
+  int queue_mode = large ? 2 : 0;
+  if (B8 >= (1 << 20) && queue_mode >= 2) queue_mode = 1;
   return queue_mode ? launch_chain_q<NT, true>(b, w, sl, nk, first_step, lds, B8, queue_mode, st)
                     : launch_chain_q<NT, false>(b, w, sl, nk, first_step, lds, B8, 0, st);
 }
@@ -755,19 +717,12 @@ static int launch_chain(const r3d_batch_t &b, const BatchWs &w, const ChainSlots
 // One launch of the chain kernel for the slots of `sl`, k_insert_big behind it for what it left (idle otherwise).
 static int launch_slots(const r3d_batch_t &b, const BatchWs &w, const ChainSlots &sl, int nk, int first_step,
                         hipStream_t st) {
-  // R3D_SLOT_ORDER: 0 (default) the slots in the caller's order, 1 a heavy slot up to two places earlier (k_chain_init: measured
-  // on config C2, 0.43 against 0.35 ms per launch -- the car then evaluates against a state two slots old, a tenth of the cars
-  // conflict with one of them and start over, and the launch ends with the slowest of THOSE; the bulk is bound by
-  // workgroup-time either way)
-  static const int order_mode = env_int("R3D_SLOT_ORDER", 0);
   int nt, lds;
   chain_shape(b, nt, lds);
   R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_big<kBigNT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
-  hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, sl, nk, order_mode);
-  int rc = nt == 1024  ? launch_chain<1024>(b, w, sl, nk, first_step, lds, st)
-           : nt == 512 ? launch_chain<512>(b, w, sl, nk, first_step, lds, st)
-                       : launch_chain<kSmallNT>(b, w, sl, nk, first_step, lds, st);
+  hipLaunchKernelGGL(k_chain_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, sl, nk);
+  int rc = nt == 1024 ? launch_chain<1024>(b, w, sl, nk, first_step, lds, st) : launch_chain<512>(b, w, sl, nk, first_step, lds, st);
   if (rc != R3D_OK) return rc;
   hipLaunchKernelGGL(k_insert_big<kBigNT>, dim3(b.B), dim3(kBigNT), kBigLds, st, b, sl, nk, first_step, w,
                      chunks_of(b), kBigLds);
@@ -810,7 +765,7 @@ int r3d_batch_insert_many(const r3d_batch_t *b, int32_t n_slots, const double *c
   for (int k = 0; k < n_slots; ++k)
     if (!samples5[k] || !sample_off[k] || !min_points[k] || !n_visible[k] || !accepted[k])
       return fail(R3D_E_ARG, "batch_insert_many: null pointer in a slot");
-  static const bool no_chain = getenv("R3D_NO_CHAIN") != nullptr;      // escape hatch: always one launch per slot
+  const bool no_chain = (b->reserved & R3D_B_SLOT_LAUNCHES) != 0;       // one launch per slot (no chain inside a kernel)
   BatchWs w = carve_batch(*b, b->workspace);
   const int per = no_chain ? 1 : kMaxChain;
   for (int k0 = 0; k0 < n_slots; k0 += per) {

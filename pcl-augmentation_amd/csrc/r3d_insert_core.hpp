@@ -35,7 +35,7 @@ constexpr int kDbgBands = 4;         // the depth tile in bands of at most 3 can
 constexpr int kDbgDefer = 8;         // every pair is left to k_insert_big
 constexpr int kDbgDropPublish = 16;  // slot 0 of scene 0 does not publish: its successors time out
 constexpr int kDbgPoolTile = 32;     // every pair's depth tile and candidate list in the global pool
-constexpr int kDbgNoPoolTile = 8192; // a depth tile beyond the LDS in row bands in LDS, never in the pool (R3D_TILE_BANDS=1)
+constexpr int kDbgNoPoolTile = 8192; // a depth tile beyond the LDS in row bands in LDS, never in the pool
 constexpr int kDbgNoHits = 128;      // the kill masks from the pixel ids in global memory for every chunk (no hits kept in LDS)
 constexpr int kDbgCount = 4096;      // count per pair (D_PAIRS .. D_TAKEOVER_COMMIT): two to four atomics of every pair on the same few
                                      // addresses, on the chain's critical path -- only when somebody wants to read them (bench.py's

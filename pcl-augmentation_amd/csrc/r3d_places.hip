@@ -1136,25 +1136,20 @@ __global__ __launch_bounds__(kCB) void k_place_sample_chain_large(const r3d_plac
 }  // namespace
 
 // A stream of its own per (device, caller's stream) for k_place_orient, with the two events that tie it to the caller's:
-// made on first use, kept for the life of the process (calls on one stream follow each other in stream order, so the
-// events can be recorded again and again).  nullptr: the environment says no, or the runtime would not make one.
+// made on first use, kept until r3d_places_release() (calls on one stream follow each other in stream order, so the events
+// can be recorded again and again).  nullptr: the runtime would not make one (the chain then runs in line).
 struct SideStream {
   hipStream_t stream;
   hipEvent_t start, done;
 };
+static std::mutex g_side_mu;
+static std::map<std::pair<int, hipStream_t>, SideStream *> g_side;
 static SideStream *side_stream_of(hipStream_t st) {
-  static const bool off = [] {
-    const char *v = getenv("R3D_PLACE_SIDE_STREAM");
-    return v && *v == '0';
-  }();
-  if (off) return nullptr;
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, SideStream *> known;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = known.find({dev, st});
-  if (it != known.end()) return it->second;
+  std::lock_guard<std::mutex> lock(g_side_mu);
+  auto it = g_side.find({dev, st});
+  if (it != g_side.end()) return it->second;
   SideStream *s = new SideStream();
   if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&s->start, hipEventDisableTiming) != hipSuccess ||
@@ -1162,8 +1157,27 @@ static SideStream *side_stream_of(hipStream_t st) {
     delete s;
     s = nullptr;
   }
-  known[{dev, st}] = s;
+  g_side[{dev, st}] = s;
   return s;
+}
+
+extern "C" int r3d_places_release(void) {
+  std::lock_guard<std::mutex> lock(g_side_mu);
+  int now = 0;
+  const bool have_dev = hipGetDevice(&now) == hipSuccess;
+  for (auto &kv : g_side) {
+    SideStream *s = kv.second;
+    if (!s) continue;
+    if (have_dev) (void)hipSetDevice(kv.first.first);
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipEventDestroy(s->start);
+    (void)hipEventDestroy(s->done);
+    (void)hipStreamDestroy(s->stream);
+    delete s;
+  }
+  g_side.clear();
+  if (have_dev) (void)hipSetDevice(now);
+  return R3D_OK;
 }
 
 extern "C" size_t r3d_places_workspace_bytes(int32_t n_queries, int32_t max_boxes) {
@@ -1210,7 +1224,7 @@ extern "C" int r3d_find_possible_places(const r3d_place_query_t *queries, int32_
   R3D_HIP(hipMemsetAsync(w.dmin, 0xFF, qr * sizeof(unsigned long long), st));
   R3D_HIP(hipMemsetAsync(w.hit, 0, (size_t)n_queries * 12 * sizeof(uint32_t), st));
   hipLaunchKernelGGL(k_place_centres, dim3((n_queries + 63) / 64), dim3(64), 0, st, queries, n_queries, w, status);
-  // the orientation chain beside the point passes, on the helper stream that belongs to `st` (R3D_PLACE_SIDE_STREAM=0: in line)
+  // the orientation chain beside the point passes, on the helper stream that belongs to `st` (no helper stream: in line)
   // (calls that share one stream must come from one host thread at a time: the two events of the stream's helper are
   // recorded again by every call)
   SideStream *side = side_stream_of(st);
@@ -1247,8 +1261,8 @@ extern "C" int r3d_find_possible_places(const r3d_place_query_t *queries, int32_
   // distance passes of growing reach (metres); a pass only serves the steps whose minimum the
   // previous one could not settle (nothing found within its reach)
   // (round 5: 0.6 m, then the full reach for the steps still open -- the 1.8 m pass in between cost more than it saved the
-  // last one: 1.80 -> 1.75 ms per 320 queries, 4.10 -> 3.94 per 1 280; R3D_PLACE_TWO_PASS=0 brings it back)
-  static const int two_pass = [] { const char *v = getenv("R3D_PLACE_TWO_PASS"); return v && *v == '0' ? 0 : 1; }();
+  // last one: 1.80 -> 1.75 ms per 320 queries, 4.10 -> 3.94 per 1 280)
+  constexpr int two_pass = 1;
   const double reach_of_pass[3] = {0.6, two_pass ? sqrt(reach_max) : 1.8, sqrt(reach_max)};
   if (pb_orig > 0) {
     double settled = 0.0;

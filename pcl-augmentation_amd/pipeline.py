@@ -185,7 +185,7 @@ class AugmentPipeline:
         finally:
             self.process = saved
 
-    def run_streamed(self, frames, inserts_for, lanes=None, label_2_for=None, pack_threads=16, io_threads=16, delta=True):
+    def run_streamed(self, frames, inserts_for, lanes=None, label_2_for=None, pack_threads=None, io_threads=None, delta=True):
         """Like ``run`` for ONE placement per insert: inserts_for(i) -> (samples, min_points) with
         samples[k] = M x 5 float64 (or None).  Batches go through ``StreamedAugmenter`` lanes: pinned
         buffers, native packing, upload / kernels / download of consecutive batches overlapped; only the delta
@@ -196,6 +196,11 @@ class AugmentPipeline:
         is handed back when its files are on disk, the other lanes keep the GPU busy meanwhile."""
         from concurrent.futures import ThreadPoolExecutor
         from .streaming import StreamedAugmenter
+        # host threads: as many as this process may use, at most 16 (a rank of a multi-GPU node is bound to its slice of the
+        # host's cores first, affinity.bind_rank: eight ranks x sixteen unbound threads is what made the host the bottleneck)
+        fair = max(1, min(16, len(os.sched_getaffinity(0))))
+        pack_threads = fair if pack_threads is None else max(1, int(pack_threads))
+        io_threads = fair if io_threads is None else max(1, int(io_threads))
         if lanes is None:
             # (the environment only stands in for an argument that was not given; read once, before anything is started)
             try:

@@ -69,7 +69,7 @@ class PlacedInserter:
         """samples[s]: M x 5 float64 or None; annos[s]: the sample's box (10 floats) after
         read_label_line; ok_labels[s] / ok_maps[s]: placement labels / map codes of its class;
         flavours[s] (optional): dict with ``flavour`` / ``collide_label`` / ``collide_dz`` for the
-        object-detection rules (``find_spot_od.place_query`` builds them).
+        object-detection rules (``find_spot.od.place_query`` builds them).
         last_try (bool, or one per scene; only with ``reference_rejected_state``): this sample is the last one tried for
         its object -- the reference's while-loop then starts over from the scene as the sample has left it (:373).
         Returns (rotation[s] = accepted rotation number or -1, n_possible[s])."""

@@ -665,7 +665,7 @@ def test_rejected_candidate_state_equals_the_reference(P, name):
 
 
 @pytest.mark.parametrize("debug", [2, 4, 8, 6, 32, 64, 96, 128, 160, 132, 256, 260, 288, 264,
-                                   16384, 16384 | 2, 16384 | 64, 16384 | 8, 16384 | 256, 32768])
+                                   16384, 16384 | 2, 16384 | 64, 16384 | 8, 16384 | 256, 32768, 65536])
 def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
     """The insert kernel's other routes, forced with the descriptor's diagnostic bits: 2 = never speculate (every slot
     waits for its predecessor first), 4 = the window's depth tile built and evaluated in bands of at most 3 candidate
@@ -675,7 +675,8 @@ def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
     super-boxes as on clouds of 260 000 points and more (alone, with bands, pooled tiles, k_insert_big); all must give the bytes of
     the oracle chain, through insert_many and slot by slot, and the comparison of bit 64 must never differ.  Round 6:
     16384 = every pair's depth tile as a SPARSE tile (only the pixels the evaluation reads, gather_bits / gather_needed; alone,
-    never speculating, verified, in k_insert_big, through super-boxes), 32768 = never (tiles beyond the LDS in the pool)."""
+    never speculating, verified, in k_insert_big, through super-boxes), 32768 = never (tiles beyond the LDS in the pool);
+    65536 = R3D_B_SLOT_LAUNCHES, insert_many as one launch per slot."""
     import torch
     cases = [_random_case(synth, 11), _random_case(synth, 12, 32, 900, shuffle=True), _random_case(synth, 13, 64, 500)]
     xyzi, label = synth.make_scene(14, 48, 700)
@@ -729,8 +730,6 @@ def test_chain_timeout_is_reported(P, synth):
     the rounds in which slots waited against a clock), its later slots report nothing, the other scene is untouched by it."""
     import os
     import torch
-    if os.environ.get("R3D_NO_CHAIN"):
-        pytest.skip("R3D_NO_CHAIN: one launch per slot, no chain inside a kernel")
     scenes = [synth.make_scene(50 + s, 32, 500) for s in range(2)]
     ins = [[synth.make_insert(500 + 10 * s + k, "pedestrian", rng_range=(5.0, 15.0)) for k in range(3)] for s in range(2)]
     n = max(len(x) for x, _ in scenes)

@@ -116,3 +116,28 @@ def test_streamed_lanes_and_rows_with_a_shuffled_frame(pkg, synth):
         merged, _, _ = O.augment_scene(s5, c[2], c[3])
         assert n_rows[i] == len(merged)
         assert np.array_equal(rows4[i, :n_rows[i], :3], merged[:, :3]) and np.array_equal(rows4[i, :n_rows[i], 3], merged[:, 7])
+
+
+def test_a_broken_file_order_promise_is_flagged(pkg, synth):
+    """R3D_B_FILE_ORDER belongs to the batch from one begin to the next (include/real3daug_hip.h): set between a begin that
+    numbered a scene's points anew and its finish, the launches that put the alive bits back into slab order are skipped --
+    the scene then comes back flagged R3D_S_ORDER_PROMISE instead of as a wrong cloud."""
+    xyzi, label = synth.make_scene(350, 64, 300, shuffle=True)
+    ins = synth.make_insert(3500, "car", rng_range=(4.0, 10.0))
+    batch = pkg.SceneBatch(1, len(xyzi) + len(ins) + 64, len(ins) + 64, order="any")
+    batch.load([(xyzi, label)])
+    batch.begin()
+    batch.run_inserts([[[ins]]], [[15]])
+    assert batch.debug_counters(reset=False)["scenes_in_sorted_order"] == 1
+    batch.desc.reserved |= pkg._lib.B_FILE_ORDER
+    batch.finish()
+    assert int(batch.status.cpu().numpy()[0]) & pkg._lib.S_ORDER_PROMISE
+    with pytest.raises(ValueError):
+        batch.raise_on_status()
+    # ... the bit left alone: the oracle's bytes
+    batch = pkg.SceneBatch(1, len(xyzi) + len(ins) + 64, len(ins) + 64, order="any")
+    batch.load([(xyzi, label)])
+    batch.begin()
+    acc = batch.run_inserts([[[ins]]], [[15]])
+    batch.finish()
+    _check(batch.results(), acc, [(xyzi, label, [[ins]], [15])])

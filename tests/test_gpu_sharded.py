@@ -92,22 +92,26 @@ def test_sharded_file_driver_two_ranks_one_gpu(synth, tmp_path):
     _check_outputs(synth, frames, tmp_path / "out", "c4", False)
 
 
-def test_bench_command_with_two_ranks():
-    """The command the driver runs on a multi-GPU node -- `bench.py --gpus N`: torchrun child, process-group init, barriers
-    around the timed region, all_reduce(MAX) of the time, the per-rank PCIe-inclusive leg -- with two ranks on this one GPU
-    (R3D_DIST_BACKEND=gloo: RCCL wants one GPU per rank).  One JSON line, n_gpus 2, parity keys present."""
+def test_bench_command_with_four_ranks():
+    """The command the driver runs on a multi-GPU node -- `bench.py --gpus N`: torchrun child, every rank bound to its slice of
+    the host's cores before its GPU runtime starts (affinity.bind_rank), process-group init, barriers around the timed region,
+    all_reduce(MAX) of the time, the PCIe-inclusive leg on every rank at the same time (e2e_all_ranks) -- with four ranks on
+    this one GPU (R3D_DIST_BACKEND=gloo: RCCL wants one GPU per rank).  One JSON line, n_gpus 4, parity keys present."""
     env = {**os.environ, "R3D_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scenes", "64",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--scenes", "64",
                         "--repeats", "2", "--e2e", "256", "--cpu-budget", "3", "--parity-scenes", "2"], capture_output=True, text=True,
                        timeout=900, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     out = lines[0]
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["n_gpus"] == 4 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["scenes_per_gpu"] == 64 and out["repeats"]["regions"] == 2
     assert out["parity_of_overlapped_run"]["lanes_byte_equal_to_lane0"] == 2 and "parity_checked" in out
-    assert out["roofline"]["frac"] > 0 and out["e2e_all_ranks"]["ranks"] == 2 and out["e2e_all_ranks"]["frames_per_s_all_ranks"] > 0
+    assert out["roofline"]["frac"] > 0 and out["e2e_all_ranks"]["ranks"] == 4 and out["e2e_all_ranks"]["frames_per_s_all_ranks"] > 0
+    bound = out["e2e_all_ranks"]["rank0_core_binding"]
+    assert bound["bound"] and 1 <= bound["cores"] <= max(1, bound["cores_of_the_host_share"] // 4 + 1)
+    assert out["e2e_all_ranks"]["pack_threads_per_rank"] == min(16, bound["cores"])
     # every --gpus N line carries the CPU baseline (rank 0 times the oracle before it starts its GPU runtime) and rank 0's
     # batch is compared with the oracle's bytes
     assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["kind"] == "port"

@@ -66,10 +66,12 @@ def main(process=None):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    pkg = importlib.import_module("pcl-augmentation_amd")
+    # every rank on its own slice of the host's cores (its GPU's NUMA node where sysfs tells), before the GPU runtime starts
+    binding = pkg.affinity.bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group("gloo")                       # counters only; the data path has no collective
-    pkg = importlib.import_module("pcl-augmentation_amd")
     names = sorted(os.path.splitext(f)[0] for f in os.listdir(args.velodyne) if f.endswith(".bin"))
     frames = [pkg.Frame(os.path.join(args.velodyne, n + ".bin"), os.path.join(args.labels, n + ".label"), n) for n in names]
 
@@ -89,7 +91,7 @@ def main(process=None):
         dist.all_reduce(tot)
     line = json.dumps({"rank": rank, "world_size": world, "frames": len(frames), "mine": len(st["frame_indices"]),
                        "written": st["written"], "skipped_existing": st["skipped_existing"],
-                       "frames_per_s": round(st.get("frames_per_s", 0.0), 1),
+                       "frames_per_s": round(st.get("frames_per_s", 0.0), 1), "core_binding": binding,
                        "all_ranks": {"written": int(tot[0]), "skipped_existing": int(tot[1]), "inserted": int(tot[2])}})
     sys.stdout.flush()
     os.write(1, (line + "\n").encode())                      # one write: the ranks share the launcher's pipe
