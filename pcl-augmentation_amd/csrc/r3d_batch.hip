@@ -1144,7 +1144,15 @@ k_alive_write(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs 
     // (r3d_batch_export_rows shows the copy a rejected candidate has left, while there is one: BatchWs::shadow_valid)
     const bool shadow = ROWS4 && w.shadow_valid[s] != 0;
     const bool virt = w.n_virt[s] != 0;                       // (virtual order: the bits k_unvirtual has put back into slab order)
-    if (virt && !slab_order_made && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&b.status[s], R3D_S_ORDER_PROMISE);
+    if (virt && !slab_order_made) {
+      // the bits in slab order were never made (alive_o / tile_o hold whatever the last batch left): nothing of this scene
+      // is written -- offsets taken from them would point anywhere -- and the scene is flagged
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicOr(&b.status[s], R3D_S_ORDER_PROMISE);
+        (ROWS4 ? n_rows : b.n_out)[s] = 0;
+      }
+      continue;
+    }
     const int32_t *tile_alive = (virt ? w.tile_o : (shadow ? w.tile_shadow : w.tile_alive)) + (int64_t)s * tiles;
     const unsigned long long *alive = (virt ? w.alive_o : (shadow ? w.alive_shadow : w.alive)) + (int64_t)s * chunks;
     int pre = 0;
