@@ -671,6 +671,11 @@ def main():
                        "insert_api": f"r3d_batch_insert x{K}" if args.per_slot_launches else f"r3d_batch_insert_many({K})",
                        "rebases_in_timed_steps": rebases, "settle_steps_in_setup": settle,
                        "mean_points_out": float(n_out.mean()), "insert_paths_one_step": insert_paths,
+                       # SceneBatch(order="auto"): the first begin of a batch object looks at the point order (four small
+                       # launches, ~20 us per 256 scenes); once a batch has come through without an unordered scene the begins
+                       # carry R3D_B_FILE_ORDER -- the timed begins do -- and every 64th looks again.  `shuffled` pays the look
+                       # and the re-numbering in every timed begin.
+                       "point_order_look": "outside the timed region" if args.order == "ring" else "inside every timed begin",
                        # points of ONE step of the timed batch (begin + the inserts) whose pixel the reference formula decided
                        # with the fractional row / column position within 1e-12 of an integer: where an ULP of arctan2 /
                        # arccos could move a pixel against the reference (expected 0)

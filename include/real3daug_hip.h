@@ -54,6 +54,8 @@ extern "C" {
 #define R3D_E_ARG (-1)        /* null pointer, negative size, unsupported shape */
 #define R3D_E_HIP (-2)        /* a HIP runtime call failed; see r3d_last_error() */
 #define R3D_E_WORKSPACE (-3)  /* workspace smaller than the matching *_workspace_bytes() */
+#define R3D_E_IO (-4)         /* a host file writer / appender could not write: r3d_last_error() names the file that failed and why
+                                 (errno as it was at the failing call); the temporary file is removed */
 
 /* device status bits (OR-ed into *status) */
 #define R3D_S_NONFINITE 1         /* NaN/Inf coordinate or a point at the origin (r = 0: z/r is NaN,
@@ -190,7 +192,9 @@ typedef struct r3d_batch {
   int32_t *n_far;        /* [B] */
   int32_t *rebase;       /* [B] re-projections forced so far because the elevation bounds may have moved */
   int32_t *status;       /* [B] R3D_S_* bits */
-  /* outputs of r3d_batch_finish (also scratch of a rebase) */
+  /* outputs of r3d_batch_finish -- and SCRATCH between finishes: r3d_batch_begin may use out_xyzi / out_label for the sort of
+   * a cloud in no file order (and a diagnostic build for its stamps), a rebase for its passes.  Read the previous batch's
+   * results (or order the reads with an event) before the next r3d_batch_begin is enqueued on another stream. */
   float *out_xyzi;       /* [B*cap][4] */
   uint32_t *out_label;   /* [B*cap] */
   int32_t *n_out;        /* [B] */
@@ -305,7 +309,9 @@ int r3d_batch_launch_one(const r3d_batch_t *b, int32_t which, void *stream);
  * sparse depth tile (a window beyond the LDS keeps only the pixels the evaluation reads), [39] ... that it could not hold either
  * (pool), [40] / [41] scene / sample points whose pixel the reference formula decided with the fractional row or column position
  * (insertion.py:104-105 before int()) within 1e-12 of an integer -- where the device library's arctan2 / arccos and NumPy's, an
- * ULP apart, could truncate to neighbouring bins; every point the verified fast projection cannot confirm is looked at. */
+ * ULP apart, could truncate to neighbouring bins; every point the verified fast projection cannot confirm is looked at;
+ * [42] scenes begun under R3D_B_FILE_ORDER whose chunk boxes say that their points come in no file order (the promise then
+ * costs time: every insert walks the whole cloud). */
 int r3d_batch_debug_counters(const r3d_batch_t *b, int32_t *host_out16, int32_t reset, void *stream);
 
 /* Point order.  The incremental state of Level 2 is kept per 64 consecutive points (alive word, bounding box of their
@@ -518,7 +524,8 @@ int r3d_host_merge_frames(const float *in_xyzi, const uint32_t *in_label, int64_
  * r3d_host_pack_frames (labels masked with 0xFFFF, or collapsed with collapse_keep >= 0; label_paths NULL: labels 0), with
  * n_points [B] = rows of every file.  r3d_host_write_frames = the files save_data stores (SS :80-89, OD :86-93): float32
  * rows of 4, uint32 labels (label_paths NULL or a NULL entry: none), check rows; each under "<path>.tmp" first, then
- * renamed, check last; a NULL velodyne path skips the frame.  Errors (R3D_E_ARG) name the file in r3d_last_error(). */
+ * renamed, check last; a NULL velodyne path skips the frame.  Errors name the file in r3d_last_error(): R3D_E_ARG a file that
+ * is not what a reader expects / counts beyond the buffers, R3D_E_IO a write that failed. */
 int r3d_host_read_frames(const char *const *velodyne_paths, const char *const *label_paths, int32_t B, int64_t cap, float *dst_xyzi,
                          uint32_t *dst_label, int32_t *n_points, int32_t collapse_keep, int32_t threads);
 int r3d_host_read_frames_xyz(const char *const *velodyne_paths, const char *const *label_paths, int32_t B, int64_t cap, float *dst_xyzi,
@@ -541,7 +548,9 @@ int r3d_host_write_delta_frames(const char *const *velodyne_paths, const char *c
 
 /* HOST: object_detection/Real3DAug/tools/datasets.py:20-37 (create_annotation, called by save_data :81-84) for the n frames
  * of a batch: dst[i] = the bytes of the frame's label_2 file src[i] followed by extra[i] (the lines of the inserted objects,
- * one zero-terminated string per frame; NULL adds nothing), written to dst[i].tmp and renamed.  A NULL dst[i] is skipped. */
+ * one zero-terminated string per frame; NULL adds nothing), written to dst[i].tmp and renamed.  A NULL dst[i] is skipped.
+ * The reference opens both files in text mode: "\r\n" and a lone "\r" of the source arrive as "\n" (universal newlines) and
+ * are written as "\n" -- so they are here. */
 int r3d_host_append_text_files(const char *const *src, const char *const *dst, const char *const *extra, int32_t n,
                                int32_t threads);
 

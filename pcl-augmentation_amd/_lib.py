@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("R3D_LIB") or os.path.join(_HERE, "libreal3daug_hip.so")
 
 R3D_OK = 0
+E_ARG, E_HIP, E_WORKSPACE, E_IO = -1, -2, -3, -4
 S_NONFINITE, S_ROW_RANGE, S_COL_RANGE, S_SAMPLE_TOO_LARGE, S_CAPACITY, S_FAR_OVERFLOW, S_WINDOW_TOO_LARGE = 1, 2, 4, 8, 16, 32, 64
 S_CHAIN_TIMEOUT = 128
 S_ORDER_PROMISE = 256

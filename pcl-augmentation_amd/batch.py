@@ -481,6 +481,9 @@ class SceneBatch:
                  # points whose pixel the reference formula decided within 1e-12 of a bin edge (scene points at step 0 /
                  # rebase, sample points per evaluation): where an ULP of arctan2 / arccos could move a pixel
                  bin_edge_risk_scene_points=int(out[40]), bin_edge_risk_sample_points=int(out[41]),
+                 # scenes begun under R3D_B_FILE_ORDER (order="file", or "auto" between two looks) whose chunk boxes say that
+                 # their points come in no file order: every insert of such a scene walks the whole cloud (time, never results)
+                 unordered_scenes_under_file_order_promise=int(out[42]),
                  chunks_listed_per_pair=round(listed / pairs, 1) if pairs else None)
         return d
 

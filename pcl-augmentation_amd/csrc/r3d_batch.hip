@@ -332,6 +332,8 @@ __global__ void k_col_table(r3d_batch_t b, BatchWs w) {
 //         and |z| < 71 * hypot(x, y) away from the poles.
 //   ss must be a normal float32 far from overflow / flush-to-zero (1e-30 < ss < 1e30).
 constexpr int kVirtAreaCap = 4096;           // pixels of a chunk's box that count towards box_area (k_virt_hist)
+constexpr int kVirtMeanArea = 1024;          // pixels: a scene whose mean chunk box exceeds this comes in no file order (k_virt_hist)
+constexpr int kDbgVirtual = 1024;            // r3d_batch_t.reserved: every scene in virtual order (tests)
 // The per-point code, counted in vector instructions (round 4: 141 per 64 points; now 69 on the usual path):
 //   * the points come through a buffer descriptor per segment (base = the segment's first point, records = what is left
 //     of the scene): the lane's offset is a constant, the round's a scalar, past the end reads zeros -- no address arithmetic;
@@ -694,6 +696,10 @@ k_project_slow(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs
   for (int li = blockIdx.y; li < cnt; li += gridDim.y) {
     int s = list[li];
     int n_slow = w.n_slow[s], n_head = b.n_head[s];
+    if ((b.reserved & R3D_B_FILE_ORDER) && !(b.reserved & kDbgVirtual) && blockIdx.x == 0 && threadIdx.x == 0) {
+      const int n = b.n_total[s];                            // (k_project has left the boxes' areas: was the promise kept?)
+      if (n >= 4096 && (long long)w.box_area[s] > (long long)kVirtMeanArea * ((n + 63) >> 6)) atomicAdd(&w.dbg[kCntPromiseBroken], 1);
+    }
     Binning bn = make_binning(b.bounds[2 * s + 0], b.bounds[2 * s + 1], b.rows, b.cols);
     const uint32_t *queue = w.cand + (int64_t)s * w.cand_stride;
     int flags = 0, n_risk = 0;
@@ -774,7 +780,6 @@ k_super_rows(r3d_batch_t b, const int32_t *list, const int32_t *count, BatchWs w
 // a bin is whatever the atomics give: nothing that is computed afterwards depends on it (minima per pixel, kills per pixel,
 // the output in slab order).  (First form, one 1024-thread workgroup per scene with the bins in LDS: 1.42 ms per 256 scenes
 // of 120 000 points -- more than the inserts of config C2 gain.)
-constexpr int kVirtMeanArea = 1024;          // pixels (kVirtAreaCap, the cap per chunk: in front of k_project)
 constexpr int kVirtBins = 512;
 #ifndef R3D_VIRT_PER
 #define R3D_VIRT_PER 32
@@ -782,7 +787,6 @@ constexpr int kVirtBins = 512;
 constexpr int kVirtPer = R3D_VIRT_PER;       // points per thread of the histogram / scatter kernels, taken 16 at a time
 constexpr int kVirtGo = 16;
 constexpr int kVirtBlock = kPT * kVirtPer;   // points per block of the histogram / scatter kernels
-constexpr int kDbgVirtual = 1024;            // r3d_batch_t.reserved: every scene in virtual order (tests)
 struct VirtShape {
   int mode, gh, cshift, nbands, nbins, nblk;
 };

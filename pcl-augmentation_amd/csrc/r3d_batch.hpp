@@ -110,6 +110,10 @@ constexpr int kCntVirtual = 37;      // BatchWs::dbg: scenes put into virtual or
 // and the device library's, which differ within an ULP, could truncate to neighbouring bins.  [40]: scene points (k_project_slow,
 // rebase: everything the verified fast projection could not confirm comes through there), [41]: sample points.
 constexpr int kCntEdgeScene = 40, kCntEdgeSample = 41;
+// [42]: scenes projected under R3D_B_FILE_ORDER whose chunk boxes say that their points come in NO file order (mean box beyond
+// kVirtMeanArea pixels): the promise costs such a scene a walk over the whole cloud per insert, never a result -- counted so
+// that a caller (SceneBatch(order="auto") between two looks) can see it.
+constexpr int kCntPromiseBroken = 42;
 constexpr double kEdgeRisk = 1e-12;
 inline int supers_of(const r3d_batch_t &b) { return (chunks_of(b) + 63) / 64; }
 #ifdef __HIPCC__

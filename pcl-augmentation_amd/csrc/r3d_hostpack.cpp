@@ -224,6 +224,7 @@ bool write_all(int fd, const void *src, size_t bytes) {
   while (bytes) {
     ssize_t put = ::write(fd, p, bytes);
     if (put < 0 && errno == EINTR) continue;
+    if (put == 0) errno = EIO;                                                    // (nothing went out and nothing is said: no progress)
     if (put <= 0) return false;
     p += put;
     bytes -= (size_t)put;
@@ -231,14 +232,37 @@ bool write_all(int fd, const void *src, size_t bytes) {
   return true;
 }
 
+// Which file an I/O call failed on and why: errno is taken AT the failing call (a later close / rename / another thread's
+// call would overwrite it), the temporary file is removed, and the message names the file that failed -- not the frame's
+// first one.
+struct IoErr {
+  std::string path;
+  int err = 0;
+  void note(const std::string &p, int e) {
+    if (path.empty()) path = p, err = e ? e : EIO;
+  }
+  std::string text() const { return path + " (" + std::strerror(err) + ")"; }
+};
+
 // the file whole or absent: path.tmp, then rename (what Real3DAug/tools/datasets.py:_commit does)
-bool commit_file(const char *path, const void *data, size_t bytes) {
-  std::string tmp = std::string(path) + ".tmp";
+bool commit_file(const char *path, const void *data, size_t bytes, IoErr &e) {
+  const std::string tmp = std::string(path) + ".tmp";
   int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
-  if (fd < 0) return false;
+  if (fd < 0) {
+    e.note(tmp, errno);
+    return false;
+  }
   bool ok = write_all(fd, data, bytes);
-  ok = (::close(fd) == 0) && ok;
-  if (ok) ok = ::rename(tmp.c_str(), path) == 0;
+  if (!ok) e.note(tmp, errno);
+  if (::close(fd) != 0) {
+    if (ok) e.note(tmp, errno);
+    ok = false;
+  }
+  if (ok && ::rename(tmp.c_str(), path) != 0) {
+    e.note(path, errno);
+    ok = false;
+  }
+  if (!ok) ::unlink(tmp.c_str());
   return ok;
 }
 
@@ -313,19 +337,23 @@ int r3d_host_write_frames(const char *const *velodyne_paths, const char *const *
   if (threads < 1) threads = 1;
   if (threads > B) threads = B;
   std::vector<std::string> err(threads);
+  std::vector<int> bad_arg(threads, 0);
   auto work = [&](int t) {
     for (int s = t; s < B; s += threads) {
       if (!velodyne_paths[s]) continue;                                            // (a padded slot of the last batch)
       const int64_t n = n_out[s];
-      bool ok = n >= 0 && n <= cap && commit_file(velodyne_paths[s], xyzi + (int64_t)s * cap * 4, (size_t)n * 16);
-      if (ok && label_paths && label_paths[s]) ok = commit_file(label_paths[s], label + (int64_t)s * cap, (size_t)n * 4);
-      if (ok && check_paths && check_paths[s]) {
-        const int64_t m = n_check[s];
-        ok = m >= 0 && m <= check_stride &&
-             commit_file(check_paths[s], check + (int64_t)s * check_stride * check_cols, (size_t)m * check_cols * 4);
+      IoErr e;
+      if (n < 0 || n > cap || (check_paths && check_paths[s] && (n_check[s] < 0 || n_check[s] > check_stride))) {
+        err[t] = std::string("host_write_frames: counts of ") + velodyne_paths[s] + " exceed the buffers";
+        bad_arg[t] = 1;
+        return;
       }
+      bool ok = commit_file(velodyne_paths[s], xyzi + (int64_t)s * cap * 4, (size_t)n * 16, e);
+      if (ok && label_paths && label_paths[s]) ok = commit_file(label_paths[s], label + (int64_t)s * cap, (size_t)n * 4, e);
+      if (ok && check_paths && check_paths[s])
+        ok = commit_file(check_paths[s], check + (int64_t)s * check_stride * check_cols, (size_t)n_check[s] * check_cols * 4, e);
       if (!ok) {
-        err[t] = std::string("host_write_frames: could not write ") + velodyne_paths[s] + " (" + std::strerror(errno) + ")";
+        err[t] = std::string("host_write_frames: could not write ") + e.text();
         return;
       }
     }
@@ -335,7 +363,7 @@ int r3d_host_write_frames(const char *const *velodyne_paths, const char *const *
   work(0);
   for (auto &th : pool) th.join();
   for (int t = 0; t < threads; ++t)
-    if (!err[t].empty()) return r3d::fail(R3D_E_ARG, err[t].c_str());
+    if (!err[t].empty()) return r3d::fail(bad_arg[t] ? R3D_E_ARG : R3D_E_IO, err[t].c_str());
   return R3D_OK;
 }
 
@@ -390,6 +418,8 @@ struct IovFile {
   int fd = -1;
   std::vector<iovec> iov;
   bool ok = true;
+  int err = 0;                       // errno of the writev that failed
+  std::string tmp;
   bool flush() {
     size_t done = 0;
     while (ok && done < iov.size()) {
@@ -402,7 +432,8 @@ struct IovFile {
         done += (size_t)n;
         continue;
       }
-      if (put < 0) {
+      if (put <= 0) {                                                    // (0 with bytes outstanding: no progress, not a retry)
+        err = put < 0 ? errno : EIO;
         ok = false;
         break;
       }
@@ -426,16 +457,25 @@ struct IovFile {
   }
 };
 
-bool open_tmp(const char *path, IovFile &f) {
-  std::string tmp = std::string(path) + ".tmp";
-  f.fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+bool open_tmp(const char *path, IovFile &f, IoErr &e) {
+  f.tmp = std::string(path) + ".tmp";
+  f.fd = ::open(f.tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (f.fd < 0) e.note(f.tmp, errno);
   return f.fd >= 0;
 }
-bool close_commit(const char *path, IovFile &f) {
+bool close_commit(const char *path, IovFile &f, IoErr &e) {
   bool ok = f.flush();
-  ok = (::close(f.fd) == 0) && ok;
+  if (!ok) e.note(f.tmp, f.err);
+  if (::close(f.fd) != 0) {
+    if (ok) e.note(f.tmp, errno);
+    ok = false;
+  }
   f.fd = -1;
-  if (ok) ok = ::rename((std::string(path) + ".tmp").c_str(), path) == 0;
+  if (ok && ::rename(f.tmp.c_str(), path) != 0) {
+    e.note(path, errno);
+    ok = false;
+  }
+  if (!ok) ::unlink(f.tmp.c_str());
   return ok;
 }
 
@@ -471,22 +511,23 @@ int r3d_host_write_delta_frames(const char *const *velodyne_paths, const char *c
       if (n_out) n_out[s] = (int32_t)survivors;
       if (!velodyne_paths[s]) continue;                                            // (a padded slot of the last batch)
       bool ok = true;
+      IoErr e;
       {
         IovFile f;
-        ok = open_tmp(velodyne_paths[s], f);
+        ok = open_tmp(velodyne_paths[s], f, e);
         if (ok) {
           alive_runs(aw, 0, n_head, [&](int64_t i, int64_t n) { f.add(hx + i * 4, (size_t)n * 16); return f.ok; });
           alive_runs(aw, n_head, n_total, [&](int64_t i, int64_t n) { f.add(tx + (i - n_head) * 4, (size_t)n * 16); return f.ok; });
-          ok = close_commit(velodyne_paths[s], f);
+          ok = close_commit(velodyne_paths[s], f, e);
         }
       }
       if (ok && label_paths && label_paths[s]) {
         IovFile f;
-        ok = open_tmp(label_paths[s], f);
+        ok = open_tmp(label_paths[s], f, e);
         if (ok) {
           alive_runs(aw, 0, n_head, [&](int64_t i, int64_t n) { f.add(hl + i, (size_t)n * 4); return f.ok; });
           alive_runs(aw, n_head, n_total, [&](int64_t i, int64_t n) { f.add(tl + (i - n_head), (size_t)n * 4); return f.ok; });
-          ok = close_commit(label_paths[s], f);
+          ok = close_commit(label_paths[s], f, e);
         }
       }
       if (ok && check_paths && check_paths[s]) {
@@ -499,10 +540,10 @@ int r3d_host_write_delta_frames(const char *const *velodyne_paths, const char *c
           }
           data = ck5.data();
         }
-        ok = commit_file(check_paths[s], data, (size_t)n_tail * check_cols * 4);
+        ok = commit_file(check_paths[s], data, (size_t)n_tail * check_cols * 4, e);
       }
       if (!ok) {
-        err[t] = std::string("host_write_delta_frames: could not write ") + velodyne_paths[s] + " (" + std::strerror(errno) + ")";
+        err[t] = std::string("host_write_delta_frames: could not write ") + e.text();
         return;
       }
     }
@@ -512,7 +553,7 @@ int r3d_host_write_delta_frames(const char *const *velodyne_paths, const char *c
   work(0);
   for (auto &th : pool) th.join();
   for (int t = 0; t < threads; ++t)
-    if (!err[t].empty()) return r3d::fail(R3D_E_ARG, err[t].c_str());
+    if (!err[t].empty()) return r3d::fail(R3D_E_IO, err[t].c_str());
   return R3D_OK;
 }
 
@@ -527,33 +568,54 @@ int r3d_host_append_text_files(const char *const *src, const char *const *dst, c
   if (threads < 1) threads = 1;
   if (threads > n) threads = n;
   std::vector<std::string> err(threads);
+  std::vector<int> bad_arg(threads, 0);
   auto work = [&](int t) {
     std::string text;
     for (int i = t; i < n; i += threads) {
       if (!dst[i]) continue;
       if (!src[i]) {
         err[t] = "host_append_text_files: a frame without its source file";
+        bad_arg[t] = 1;
         return;
       }
       text.clear();
       bool ok = true;
+      IoErr e;
       {
         const int fd = ::open(src[i], O_RDONLY);
         ok = fd >= 0;
+        if (!ok) e.note(src[i], errno);
         char buf[4096];
         while (ok) {
           const ssize_t got = ::read(fd, buf, sizeof buf);
           if (got < 0 && errno == EINTR) continue;
-          if (got < 0) ok = false;
+          if (got < 0) {
+            e.note(src[i], errno);
+            ok = false;
+          }
           if (got <= 0) break;
           text.append(buf, (size_t)got);
         }
         if (fd >= 0) ::close(fd);
       }
-      if (ok && extra[i]) text += extra[i];
-      if (ok) ok = commit_file(dst[i], text.data(), text.size());
+      if (ok) {
+        // the reference reads the source in text mode (OD tools/datasets.py:23-27): "\r\n" and a lone "\r" arrive as "\n"
+        // (universal newlines), and are written back as "\n"
+        size_t o = 0;
+        for (size_t k = 0; k < text.size(); ++k) {
+          char c = text[k];
+          if (c == '\r') {
+            if (k + 1 < text.size() && text[k + 1] == '\n') ++k;
+            c = '\n';
+          }
+          text[o++] = c;
+        }
+        text.resize(o);
+        if (extra[i]) text += extra[i];
+        ok = commit_file(dst[i], text.data(), text.size(), e);
+      }
       if (!ok) {
-        err[t] = std::string("host_append_text_files: ") + src[i] + " -> " + dst[i] + " (" + std::strerror(errno) + ")";
+        err[t] = std::string("host_append_text_files: ") + src[i] + " -> " + dst[i] + ": " + e.text();
         return;
       }
     }
@@ -563,7 +625,7 @@ int r3d_host_append_text_files(const char *const *src, const char *const *dst, c
   work(0);
   for (auto &th : pool) th.join();
   for (int t = 0; t < threads; ++t)
-    if (!err[t].empty()) return r3d::fail(R3D_E_ARG, err[t].c_str());
+    if (!err[t].empty()) return r3d::fail(bad_arg[t] ? R3D_E_ARG : R3D_E_IO, err[t].c_str());
   return R3D_OK;
 }
 

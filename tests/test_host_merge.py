@@ -181,7 +181,12 @@ def test_native_label_2_writer_equals_create_annotation(pkg, tmp_path):
     srcs, lines = [], []
     for i in range(n):
         p = tmp_path / f"src_{i}.txt"
-        p.write_text("".join(f"Car 0.00 0 -1.57 {j}.0 156.40 629.75 189.25 2.85 2.63 12.34 0.47 1.49 69.44 -1.56\n" for j in range(i % 5)))
+        # (frames 11 / 12 / 13: CRLF, lone CR and mixed line ends -- the reference opens the file in text mode, where universal
+        # newlines turn all of them into "\n"; the mirror's create_annotation does the same, so must the native writer)
+        eol = {11: "\r\n", 12: "\r"}.get(i, "\n")
+        body = "".join(f"Car 0.00 0 -1.57 {j}.0 156.40 629.75 189.25 2.85 2.63 12.34 0.47 1.49 69.44 -1.56{eol if (i != 13 or j % 2) else chr(10)}"
+                       for j in range(max(i % 5, 3 if i in (11, 12, 13) else 0)))
+        p.write_bytes(body.encode())
         srcs.append(str(p))
         lines.append([f"Pedestrian 0 0 0 0 0 0 0 1.7 0.6 0.6 {i}.5 1.0 2.0 0.1\n"] * (i % 3))
     (tmp_path / "a").mkdir(), (tmp_path / "b").mkdir()
@@ -197,11 +202,19 @@ def test_native_label_2_writer_equals_create_annotation(pkg, tmp_path):
             continue
         want = (tmp_path / "a" / f"{i}.txt").read_bytes() if i != 7 else open(srcs[i], "rb").read()
         assert (tmp_path / "b" / f"{i}.txt").read_bytes() == want
+        if i in (11, 12, 13):
+            assert b"\r" not in want and want.count(b"\n") == 3 + len(lines[i])
     assert not list((tmp_path / "b").glob("*.tmp"))
-    # a source that does not exist: an error, not a silent skip
+    # a source that does not exist: an I/O error that names the file, not a silent skip
     bad = list(srcs)
     bad[3] = str(tmp_path / "nothing.txt")
-    assert lib.r3d_host_append_text_files(enc(bad), enc(dst), extra, n, 4) != 0
+    assert lib.r3d_host_append_text_files(enc(bad), enc(dst), extra, n, 4) == pkg._lib.E_IO
+    assert b"nothing.txt" in lib.r3d_last_error()
+    # a destination that cannot be written (its directory does not exist): R3D_E_IO, the message names THAT file, no .tmp stays
+    gone = list(dst)
+    gone[2] = str(tmp_path / "no_such_dir" / "2.txt")
+    assert lib.r3d_host_append_text_files(enc(srcs), enc(gone), extra, n, 1) == pkg._lib.E_IO
+    assert b"no_such_dir" in lib.r3d_last_error() and not list(tmp_path.glob("**/*.tmp"))
 
 
 def test_xyz_packers_equal_numpy(pkg, tmp_path):
