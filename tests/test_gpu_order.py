@@ -141,3 +141,19 @@ def test_a_broken_file_order_promise_is_flagged(pkg, synth):
     acc = batch.run_inserts([[[ins]]], [[15]])
     batch.finish()
     _check(batch.results(), acc, [(xyzi, label, [[ins]], [15])])
+
+
+def test_an_unordered_scene_under_the_file_order_promise_is_counted(pkg, synth):
+    """order="file" on a shuffled scan: same bytes as always (the promise costs time, never results), and the scene shows in
+    the counter a caller between two looks can read (no diagnostic before)."""
+    xyzi, label = synth.make_scene(351, 64, 300, shuffle=True)
+    ins = synth.make_insert(3510, "cyclist", rng_range=(4.0, 10.0))
+    batch = pkg.SceneBatch(1, len(xyzi) + len(ins) + 64, len(ins) + 64, order="file")
+    batch.load([(xyzi, label)])
+    batch.debug_counters(reset=True)
+    batch.begin()
+    acc = batch.run_inserts([[[ins]]], [[15]])
+    batch.finish()
+    cnt = batch.debug_counters(reset=False)
+    assert cnt["unordered_scenes_under_file_order_promise"] == 1 and cnt["scenes_in_sorted_order"] == 0, cnt
+    _check(batch.results(), acc, [(xyzi, label, [[ins]], [15])])
