@@ -352,7 +352,7 @@ int r3d_batch_point_order(const r3d_batch_t *b, int32_t *virtual_order /* [B], d
  * descriptors live in DEVICE memory, like every array they point to.
  * ===================================================================================== */
 #define R3D_PLACE_ROTATIONS 360       /* find_spot.py:228 */
-#define R3D_PLACE_MAX_OK_LABELS 8
+#define R3D_PLACE_MAX_OK_LABELS 32      /* (round 6: 8 before -- a config may list more placement labels per class than the reference's) */
 #define R3D_PLACE_SURFACE_CAP 128     /* surface points per step whose heights can be summed in order when their sum
                                          depends on the order (never for float32 LiDAR heights of similar size) */
 #define R3D_PLACE_MAX_RADII 64

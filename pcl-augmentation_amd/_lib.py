@@ -70,14 +70,14 @@ class PlaceQuery(C.Structure):
         ("scene_ld", C.c_int32), ("scene_label_col", C.c_int32), ("orig_ld", C.c_int32), ("orig_label_col", C.c_int32),
         ("n_boxes", C.c_int32), ("m", C.c_int32), ("map_rows", C.c_int32), ("map_cols", C.c_int32),
         ("n_ok_labels", C.c_int32), ("cand_cap", C.c_int32),
-        ("ok_labels", C.c_int32 * 8), ("ok_map", C.c_uint64 * 4),
+        ("ok_labels", C.c_int32 * 32), ("ok_map", C.c_uint64 * 4),
         ("anno", C.c_double * 10), ("pose", C.c_double * 8), ("map_move", C.c_double * 2),
         ("cand_off", C.c_int64), ("cand_stride", C.c_int64),
         ("flavour", C.c_int32), ("collide_label", C.c_int32), ("collide_dz", C.c_double),
     ]
 
 
-PLACE_ROTATIONS, PLACE_SURFACE_CAP, PLACE_MAX_OK_LABELS = 360, 128, 8
+PLACE_ROTATIONS, PLACE_SURFACE_CAP, PLACE_MAX_OK_LABELS = 360, 128, 32
 PS_SURFACE_OVERFLOW, PS_NONFINITE = 1, 2
 PQ_POINTWISE_ROTATION, PQ_MAP_NEEDS_POINT, PQ_COLLIDE_LABEL, PQ_COLLIDE_ABOVE = 1, 2, 4, 8
 PF_ON_SURFACE, PF_NEAR_ROAD, PF_SCENE_IN_BOX, PF_SAMPLE_IN_BOX, PF_POSSIBLE = 1, 2, 4, 8, 16

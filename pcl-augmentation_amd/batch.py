@@ -579,6 +579,13 @@ class SceneBatch:
         return accepted
 
 
+def level2_takes(rows, cols):
+    """Does the batched path (Level 2) take this range-image shape?  (check_batch of csrc/r3d_batch.hip.)"""
+    rows, cols = int(rows), int(cols)
+    return (0 < rows <= 65535 and 0 < cols <= 65535 and cols % 32 == 0 and rows * cols < (1 << 24)
+            and ((cols + 1) + rows + 2) * 2 * 4 <= 60 * 1024)
+
+
 def augment_batch(scenes, candidates, min_points, rows=_lib.NUMROW, cols=_lib.NUMCOLUMN, device="cuda:0",
                   check_cols=5, reuse=None, debug=0):
     """Run whole frames through the insert loop on one GPU.
@@ -591,6 +598,14 @@ def augment_batch(scenes, candidates, min_points, rows=_lib.NUMROW, cols=_lib.NU
     calls (keyed by B) instead of being allocated every time.
     """
     B = len(scenes)
+    if not level2_takes(rows, cols):
+        # a range image the batched kernels are not built for (columns that are no multiple of 32: the bit images are rows of
+        # 32-pixel words; 2^24 pixels and more; edge tables beyond the projection kernel's LDS): every frame through the
+        # Level-1 kernels, which have none of these limits -- the reference takes any NUMROW / NUMCOLUMN (insertion.py:22-23)
+        from . import level1
+        out = [level1.augment_scene(x, l, candidates[s], min_points[s], rows, cols, device, check_cols) for s, (x, l) in enumerate(scenes)]
+        SceneBatch.last_rebases, SceneBatch.last_level1 = 0, list(range(B))
+        return [o[0] for o in out], [o[1] for o in out]
     grow = max(sum(max((len(x) for x in slot), default=0) for slot in c) for c in candidates)
     cap = max(len(x) for x, _ in scenes) + grow
     batch = reuse.get(B) if reuse is not None else None

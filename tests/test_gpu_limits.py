@@ -134,3 +134,31 @@ def test_a_status_that_is_an_error_still_raises(pkg, synth):
     cases[1][0][5, 0] = np.nan
     with pytest.raises(ValueError):
         pkg.augment_batch([(c[0], c[1]) for c in cases], [c[2] for c in cases], [c[3] for c in cases])
+
+
+@pytest.mark.parametrize("rows,cols", [(50, 1000), (112, 1441)])
+def test_a_grid_whose_columns_are_no_multiple_of_32(pkg, synth, monkeypatch, rows, cols):
+    """Level 2 keeps its bit images as rows of 32-pixel words (``cols % 32 == 0``); the reference takes any NUMROW / NUMCOLUMN
+    (insertion.py:22-23).  ``augment_batch`` runs such a grid frame by frame through the Level-1 kernels instead of raising
+    (round 6): the oracle's bytes, a rebase included."""
+    from conftest import blob_in_front_of_extreme
+    P = pkg
+    monkeypatch.setattr(O, "NUMROW", rows)
+    monkeypatch.setattr(O, "NUMCOLUMN", cols)
+    assert not P.batch.level2_takes(rows, cols) and P.batch.level2_takes(112, 1440)
+    cases = []
+    for s in range(2):
+        xyzi, label = synth.make_scene(930 + s, 40, 500)
+        ins = [synth.make_insert(9300 + 10 * s + k, kind, rng_range=(4.0, 15.0)) for k, kind in enumerate(["car", "pedestrian", "cyclist"])]
+        slots = [[x] for x in ins]
+        if s == 1:
+            slots = [[blob_in_front_of_extreme(xyzi, "max")]] + slots
+        cases.append((xyzi, label, slots, [15] * len(slots)))
+    res, acc = P.augment_batch([(c[0], c[1]) for c in cases], [c[2] for c in cases], [c[3] for c in cases], rows=rows, cols=cols)
+    assert P.SceneBatch.last_level1 == [0, 1]
+    for c, r, a in zip(cases, res, acc):
+        s5 = np.hstack((c[0].astype(np.float64), (c[1] & 0xFFFF).astype(np.float64)[:, None]))
+        merged, allvis, oacc = O.augment_scene(s5, c[2], c[3])
+        vb, lb, cb = O.save_bytes_semantic(merged, allvis)
+        assert list(a) == list(oacc) and any(x == 0 for x in oacc)
+        assert r[0].tobytes() == vb and r[1].tobytes() == lb and r[2].tobytes() == cb

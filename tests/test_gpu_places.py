@@ -147,6 +147,25 @@ def test_candidate_window_and_flags(P, synth):
     assert np.array_equal(part["clouds"], full["clouds"][2:5])
 
 
+def test_more_than_eight_placement_labels(P, synth):
+    """Round 6: a class may list up to 32 placement labels (8 before: a limit the reference does not have, find_spot.py:218-223
+    concatenates whatever the config lists).  Twenty labels that no point carries around the real ones: the same search."""
+    fs = P.Real3DAug.tools.find_spot
+    c = _random_query(synth, 33, 31, 1)
+    sa = fs.read_label_line(c["line"])
+    ok_map, ok_labels = fs.placement_surfaces(sa, CONFIG)
+    scene = P.PlaceScene(c["scene9"], c["original"], [fs._anno10(fs.read_label_line(l)) for l in c["lines"]], c["rich"],
+                         c["move"], c["T"])
+    q = {"scene": scene, "sample": c["sample"], "anno": fs._anno10(sa), "ok_labels": ok_labels, "ok_map": ok_map}
+    padded = dict(q, ok_labels=[900 + i for i in range(10)] + list(ok_labels) + [950 + i for i in range(10)])
+    assert len(padded["ok_labels"]) > 8
+    a, b = P.find_places([q])[0], P.find_places([padded])[0]
+    assert list(a["rotations"]) == list(b["rotations"]) and len(a["rotations"]) > 0
+    assert np.array_equal(a["clouds"], b["clouds"]) and np.array_equal(a["anno"], b["anno"])
+    with pytest.raises(Exception):
+        P.find_places([dict(q, ok_labels=list(range(40)))])
+
+
 def _run_vs_oracle(P, c):
     fs = P.Real3DAug.tools.find_spot
     sa = fs.read_label_line(c["line"])
