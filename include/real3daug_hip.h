@@ -251,6 +251,21 @@ int r3d_batch_insert(const r3d_batch_t *b, const double *samples5, const int64_t
                      const int32_t *min_points, const int32_t *active, int32_t step,
                      int32_t *n_visible, int32_t *accepted, void *stream);
 
+/* The candidate loop of ONE insert slot (insertion.py:449-545) in one call: candidate j (0 <= j < n_cand, as long as
+ * first_cand + j < n_possible[s]) of scene s is the rows sample_off[s] .. sample_off[s + 1] of the packed sample list at
+ * cand + j * cand_stride (doubles) -- the layout r3d_find_possible_places writes with cand_stride = length of the list.
+ * The candidates of a scene are tried in order, the first whose visible part reaches max(1, min_points[s]) is merged exactly as
+ * r3d_batch_insert would (all of them as step `step`), accepted_at[s] = first_cand + j; a scene that accepts none keeps its
+ * accepted_at[s] (initialise to -1).  n_visible[s] = len(visible_sample) of the last candidate tried.  Scenes with active[s]
+ * == 0 (nullable = all active) or an empty sample are skipped.  replay_last != 0: a scene whose LAST existing candidate
+ * (first_cand + j + 1 == n_possible[s]) is rejected gets that candidate once more as min_points < 0 -- the state the
+ * reference's driver is left with (r3d_batch_insert above, r3d_batch_adopt_rejected).  Same results as one r3d_batch_insert
+ * call per candidate with the "still open" scenes as `active`, without the launches and the host's mask arithmetic between. */
+int r3d_batch_insert_first(const r3d_batch_t *b, const double *cand, int64_t cand_stride, const int64_t *sample_off,
+                           const int32_t *min_points, const int32_t *active, const int32_t *n_possible, int32_t first_cand,
+                           int32_t n_cand, int32_t step, int32_t replay_last, int32_t *n_visible, int32_t *accepted_at,
+                           void *stream);
+
 /* Materialise the merged clouds: out_xyzi / out_label / n_out = bytes of velodyne/{f}.bin and
  * labels/{f}.label (SS tools/datasets.py:72-84).  check (nullable) float32
  * [B*log_cap][check_cols] = check/{f}.bin rows from the log. */

@@ -108,6 +108,8 @@ _SIGNATURES = {
     "r3d_batch_begin_f64": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P]),
     "r3d_batch_begin_xyz": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P]),
     "r3d_batch_insert": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
+    "r3d_batch_insert_first": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int64, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         _P, _P, _P]),
     "r3d_batch_finish": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int32, _P]),
     "r3d_batch_launch_one": (C.c_int, [C.POINTER(BatchDesc), C.c_int32, _P]),
     "r3d_batch_debug_counters": (C.c_int, [C.POINTER(BatchDesc), _P, C.c_int32, _P]),

@@ -363,6 +363,22 @@ class SceneBatch:
         return self.n_visible, self.accepted
 
     @_lib.on_own_device
+    def insert_first_device(self, cand, cand_stride, sample_off, min_points, active, n_possible, first_cand, n_cand, accepted_at,
+                            replay_last=False, new_slot=True):
+        """The candidate loop of one insert slot in one call (``r3d_batch_insert_first``): candidate j of all scenes is the
+        packed sample list at ``cand[j * cand_stride:]`` (float64 tensor, what the placement search writes); per scene the
+        candidates ``first_cand + j < n_possible[s]`` are tried in order until one is accepted -- ``accepted_at[s]`` (int32
+        device tensor, -1 where nothing has been accepted yet) then holds its number.  Returns the n_visible tensor."""
+        if new_slot:
+            self.step += 1
+        _lib.check(self.lib.r3d_batch_insert_first(
+            C.byref(self.desc), C.c_void_p(cand.data_ptr()), int(cand_stride), C.c_void_p(sample_off.data_ptr()),
+            C.c_void_p(min_points.data_ptr()), C.c_void_p(active.data_ptr() if active is not None else 0),
+            C.c_void_p(n_possible.data_ptr()), int(first_cand), int(n_cand), self.step, 1 if replay_last else 0,
+            C.c_void_p(self.n_visible.data_ptr()), C.c_void_p(accepted_at.data_ptr()), _lib.stream_ptr()), "r3d_batch_insert_first")
+        return self.n_visible
+
+    @_lib.on_own_device
     def insert_many_device(self, packed, min_points):
         """Several slots with one candidate each in ONE launch (``r3d_batch_insert_many``): packed =
         list of (samples5, sample_off) device tensors per slot, min_points = list of int32 device
@@ -386,14 +402,12 @@ class SceneBatch:
         """list of (M x 5 float64 | None) per scene -> (samples5, sample_off) device tensors."""
         torch = self.torch
         assert len(samples) == self.B
-        sizes = [0 if smp is None else len(smp) for smp in samples]
         off = np.zeros(self.B + 1, dtype=np.int64)
-        off[1:] = np.cumsum(sizes)
-        rows = np.zeros((max(int(off[-1]), 1), 5), dtype=np.float64)
-        for s, smp in enumerate(samples):
-            if sizes[s]:
-                rows[off[s]:off[s + 1]] = smp
-        return (torch.from_numpy(rows).to(self.device), torch.from_numpy(off).to(self.device))
+        np.cumsum(np.fromiter((0 if smp is None else len(smp) for smp in samples), dtype=np.int64, count=self.B), out=off[1:])
+        parts = [smp for smp in samples if smp is not None and len(smp)]
+        # (one concatenation: a Python loop of 256 slice assignments cost 0.4 ms of a placed slot's 4.5)
+        rows = np.concatenate(parts, axis=0).astype(np.float64, copy=False) if parts else np.zeros((1, 5), dtype=np.float64)
+        return (torch.from_numpy(np.ascontiguousarray(rows)).to(self.device), torch.from_numpy(off).to(self.device))
 
     @_lib.on_own_device
     def insert(self, samples, min_points, active=None, new_slot=True):

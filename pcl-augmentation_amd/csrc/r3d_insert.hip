@@ -626,6 +626,84 @@ k_insert_big(r3d_batch_t b, ChainSlots slots, int nk, int first_step, BatchWs w,
   }
 }
 
+// r3d_batch_insert_first: the candidate loop of ONE insert slot inside a kernel (insertion.py:449-545: the placements of a
+// sample are tried in order, the first whose visible part reaches min_points is merged, `break`).  One workgroup per scene
+// walks its candidates one after the other -- nothing to order between workgroups --: candidate j of scene s is the sample
+// rows [sample_off[s], sample_off[s + 1]) of the packed list at cand + j * cand_stride, what r3d_find_possible_places
+// writes.  Rounds 3-5 made this loop on the host: one r3d_batch_insert launch per candidate (three kernels) and a dozen
+// tensor operations between them for the "still open" masks -- 8 x 15 launches per slot of a batch in which four scenes of
+// five accept their first candidate.  PASS 0: the chain kernel's workgroup shape; a candidate that does not fit its LDS
+// leaves the scene, from that candidate on, to PASS 1 (1024 threads, a CU's whole LDS, lists and images in the pool).
+struct FirstArgs {
+  const double *cand;
+  int64_t cand_stride;                  // doubles between candidate j and j + 1 of the packed lists
+  const int64_t *sample_off;
+  const int32_t *min_points, *active, *n_possible;
+  int32_t first_cand, n_cand, step, replay_last;
+  int32_t *n_visible, *accepted_at;
+};
+__global__ void k_first_init(r3d_batch_t b, BatchWs w, int n_cand) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s == 0) *w.pool_head = 0ull;
+  if (s < b.B) w.defer_from[s] = n_cand;
+}
+template <int NT, bool POOL, int PASS>
+__global__ void __launch_bounds__(NT, NT == 1024 ? R3D_BIG_WAVES : R3D_CHAIN_WAVES)
+k_insert_first(r3d_batch_t b, FirstArgs a, BatchWs w, int chunks, int lds_cap) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int s = (int)blockIdx.x, tid = threadIdx.x;
+  if (a.active && !a.active[s]) return;
+  const int j0 = PASS == 0 ? 0 : w.defer_from[s];
+  const int n_have = a.n_possible[s] - a.first_cand;          // candidates of this window that exist
+  const int64_t off = a.sample_off[s], m64 = a.sample_off[s + 1] - off;
+  if (m64 <= 0) return;
+  if (m64 > kKeyCap) {
+    if (tid == 0 && PASS == 0) atomicOr(&b.status[s], R3D_S_SAMPLE_TOO_LARGE);
+    return;
+  }
+  for (int j = j0; j < a.n_cand && j < n_have; ++j) {
+    Ins<NT, POOL> I(b, w, smem, lds_cap, s, chunks, 0, PASS == 1);
+    I.rows5 = a.cand + (int64_t)j * a.cand_stride + off * 5;
+    I.m = uni((int)m64);
+    I.need = uni(a.min_points[s]);
+    I.cull_only = false;
+    I.step = a.step;
+    int rc = I.sample_phase();
+    if (rc == kOk) rc = I.scene_phase(b.n_total[s], true, [] { return false; });
+    if (rc != kOk) {
+      if (PASS == 0) {
+        if (tid == 0) w.defer_from[s] = j;                    // PASS 1 goes on from here
+      } else if (tid == 0) {
+        atomicOr(&b.status[s], R3D_S_WINDOW_TOO_LARGE);      // not even a whole CU's LDS holds it
+      }
+      return;
+    }
+    int flags, n_after;
+    bool rebase = I.commit(typename Ins<NT, POOL>::FromLds{I}, flags, n_after);
+    const bool accepted = I.accept;
+    if (tid == 0) a.n_visible[s] = I.nvis;
+    if (rebase) {
+      phase_sync();
+      unsigned long long *s_min = reinterpret_cast<unsigned long long *>(smem + kHdrBytes), *s_max = s_min + NT / 64;
+      rebase_scene<NT>(b, w, chunks, s, s_min, s_max);
+    }
+    if (accepted) {
+      if (tid == 0) a.accepted_at[s] = a.first_cand + j;
+      return;
+    }
+    // the sample's LAST candidate, rejected: the reference's driver keeps the scene it has culled for it (insertion.py:
+    // 468-471 ran, the next candidate's restore :453 does not come): the same candidate once more as min_points < 0, into
+    // the batch's shadow (r3d_batch_insert, include/real3daug_hip.h)
+    if (a.replay_last && a.first_cand + j + 1 == a.n_possible[s]) {
+      I.cull_only = true;
+      I.need = -1;
+      rc = I.scene_phase(b.n_total[s], true, [] { return false; });
+      if (rc == kOk) (void)I.commit(typename Ins<NT, POOL>::FromLds{I}, flags, n_after);
+    }
+    phase_sync();
+  }
+}
+
 // Before a chain launch: progress / hand-over words, the pool, the queues.  The launch hands out its slots in the caller's
 // order.  Nobody waits for anybody (see the top of the file), so any order would be
 // correct; measured on config C2 and dropped: all slots by weight, heaviest first (slot 0 then starts at 100 us and every
@@ -730,11 +808,39 @@ static int launch_slots(const r3d_batch_t &b, const BatchWs &w, const ChainSlots
   return R3D_OK;
 }
 
+template <int NT>
+static int launch_first(const r3d_batch_t &b, const BatchWs &w, const FirstArgs &a, int lds, hipStream_t st) {
+  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_first<NT, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  R3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_first<kBigNT, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kBigLds));
+  hipLaunchKernelGGL(k_first_init, dim3((b.B + 255) / 256), dim3(256), 0, st, b, w, (int)a.n_cand);
+  hipLaunchKernelGGL((k_insert_first<NT, false, 0>), dim3(b.B), dim3(NT), lds, st, b, a, w, chunks_of(b), lds);
+  hipLaunchKernelGGL((k_insert_first<kBigNT, true, 1>), dim3(b.B), dim3(kBigNT), kBigLds, st, b, a, w, chunks_of(b), kBigLds);
+  R3D_LAUNCHED("k_insert_first");
+  return R3D_OK;
+}
+
 }  // namespace r3d
 
 using namespace r3d;
 
 extern "C" {
+
+int r3d_batch_insert_first(const r3d_batch_t *b, const double *cand, int64_t cand_stride, const int64_t *sample_off,
+                           const int32_t *min_points, const int32_t *active, const int32_t *n_possible, int32_t first_cand,
+                           int32_t n_cand, int32_t step, int32_t replay_last, int32_t *n_visible, int32_t *accepted_at,
+                           void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  if (!cand || !sample_off || !min_points || !n_possible || !n_visible || !accepted_at || step < 1 || n_cand < 1 || first_cand < 0 ||
+      cand_stride < 0)
+    return fail(R3D_E_ARG, "batch_insert_first: null pointer, step < 1, no candidate or a negative offset");
+  BatchWs w = carve_batch(*b, b->workspace);
+  FirstArgs a{cand, cand_stride, sample_off, min_points, active, n_possible, first_cand, n_cand, step, replay_last, n_visible, accepted_at};
+  int nt, lds;
+  chain_shape(*b, nt, lds);
+  return nt == 1024 ? launch_first<1024>(*b, w, a, lds, (hipStream_t)stream) : launch_first<512>(*b, w, a, lds, (hipStream_t)stream);
+}
 
 int r3d_batch_insert(const r3d_batch_t *b, const double *samples5, const int64_t *sample_off,
                      const int32_t *min_points, const int32_t *active, int32_t step,

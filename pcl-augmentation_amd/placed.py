@@ -41,7 +41,13 @@ class PlacedInserter:
             self.maps = [upload_map(m, batch.device) for m in rich_maps]
         self.moves = [(float(np.asarray(m).reshape(-1)[0]), float(np.asarray(m).reshape(-1)[1])) for m in map_moves]
         self.poses = [np.asarray(p, dtype=np.float64)[:2, :4].reshape(8).copy() for p in poses]
-        self.boxes = [np.asarray(b, dtype=np.float64).reshape(-1, 10) for b in scene_boxes]
+        # the annotated boxes of every scene in one array (rows beyond n_boxes[s] unused): an accepted object's box joins its
+        # scene's rows (insertion.py:535) without a Python loop over the batch
+        bx = [np.asarray(b, dtype=np.float64).reshape(-1, 10) for b in scene_boxes]
+        self.n_boxes = np.array([len(b) for b in bx], dtype=np.int64)
+        self.boxes_h = np.zeros((B, max(8, int(self.n_boxes.max()) + 8), 10))
+        for s in range(B):
+            self.boxes_h[s, :len(bx[s])] = bx[s]
         # original_pcl (insertion.py:360): the clouds as loaded, as packed float64 rows
         # (the counts `load` wrote into the pinned staging, when the batch was loaded that way: no wait for the device)
         pin = getattr(batch, "_pin", None)
@@ -64,6 +70,11 @@ class PlacedInserter:
         self.move_arr = np.array(self.moves, dtype=np.float64)
         self.pose_arr = np.array(self.poses, dtype=np.float64)
         self.n_orig_arr = np.array(self.n_orig, dtype=np.int64)
+
+    @property
+    def boxes(self):
+        """Per scene: its annotated boxes so far (k x 10), the accepted objects' included."""
+        return [self.boxes_h[s, :self.n_boxes[s]] for s in range(self.batch.B)]
 
     def insert_slot(self, samples, annos, ok_labels, ok_maps, min_points, chunk=8, flavours=None, last_try=True):
         """samples[s]: M x 5 float64 or None; annos[s]: the sample's box (10 floats) after
@@ -92,11 +103,8 @@ class PlacedInserter:
         if not who:
             return rotation, n_poss
         # one upload for the boxes of all scenes, one launch for the chunk ranges of all current clouds
-        max_b = max(1, max(len(b) for b in self.boxes))
-        boxes_h = np.zeros((B, max_b, 10))
-        for s in range(B):
-            boxes_h[s, :len(self.boxes[s])] = self.boxes[s]
-        boxes_d = torch.from_numpy(boxes_h).to(batch.device)
+        max_b = max(1, int(self.n_boxes.max()))
+        boxes_d = torch.from_numpy(np.ascontiguousarray(self.boxes_h[:, :max_b])).to(batch.device)
         if self.chunked:
             all_ranges = chunk_ranges(rows.view(B * batch.cap, 4)).view(B, batch.cap // 64, 2)
         in_who = set(who)
@@ -113,7 +121,7 @@ class PlacedInserter:
                 rng_s = all_ranges[s, :(n + 63) // 64]
             else:
                 rng_s = chunk_ranges(rows[s, :n])
-            scene = scene_view(rows[s, :n], self.orig_rows[s, :self.n_orig[s]], boxes_d[s], len(self.boxes[s]), self.maps[s],
+            scene = scene_view(rows[s, :n], self.orig_rows[s, :self.n_orig[s]], boxes_d[s], int(self.n_boxes[s]), self.maps[s],
                                self.moves[s], self.poses[s], rng_s, self.orig_ranges[s])
             queries.append({"scene": scene, "sample": smp_rows[int(smp_off_h[s]):int(smp_off_h[s + 1])], "anno": annos[s],
                             "ok_labels": ok_labels[s], "ok_map": ok_maps[s], **((flavours[s] or {}) if flavours else {})})
@@ -140,26 +148,35 @@ class PlacedInserter:
         d["n_scene"], d["n_orig"] = n_rows_h[w], self.n_orig_arr[w]
         d["scene_ld"] = d["orig_ld"] = 4
         d["scene_label_col"] = d["orig_label_col"] = 3
-        d["n_boxes"] = [len(self.boxes[s]) for s in who]
+        d["n_boxes"] = self.n_boxes[w]
         m = (smp_off_h[w + 1] - smp_off_h[w]).astype(np.int64)
         d["m"] = m
         d["map_rows"], d["map_cols"] = self.map_shape[w, 0], self.map_shape[w, 1]
+        # placement labels / map codes: a handful of distinct (class) combinations per batch -- each is encoded once and
+        # written to all its queries at a time (the per-query loop cost 0.4 ms of a slot on 256 frames)
+        groups = {}
         for qi, s in enumerate(who):
-            ol = ok_labels[s]
+            groups.setdefault((tuple(int(v) for v in ok_labels[s]), tuple(int(v) for v in ok_maps[s])), []).append(qi)
+        for (ol, om), qis in groups.items():
             if len(ol) > _lib.PLACE_MAX_OK_LABELS:
-                raise ValueError("at most 8 placement labels per class")
-            d["n_ok_labels"][qi] = len(ol)
-            d["ok_labels"][qi, :len(ol)] = ol
+                raise ValueError(f"at most {_lib.PLACE_MAX_OK_LABELS} placement labels per class")
             bits = [0, 0, 0, 0]
-            for v in ok_maps[s]:
-                if 0 <= int(v) <= 255:
-                    bits[int(v) >> 6] |= 1 << (int(v) & 63)
-            d["ok_map"][qi] = bits
-            if flavours and flavours[s]:
-                d["flavour"][qi] = flavours[s].get("flavour", 0)
-                d["collide_label"][qi] = flavours[s].get("collide_label", 0)
-                d["collide_dz"][qi] = flavours[s].get("collide_dz", 0.0)
-        d["anno"] = np.array([np.asarray(annos[s], dtype=np.float64)[:10] for s in who])
+            for v in om:
+                if 0 <= v <= 255:
+                    bits[v >> 6] |= 1 << (v & 63)
+            qis = np.asarray(qis, dtype=np.int64)
+            d["n_ok_labels"][qis] = len(ol)
+            lab = np.zeros(_lib.PLACE_MAX_OK_LABELS, dtype=np.int32)
+            lab[:len(ol)] = ol
+            d["ok_labels"][qis] = lab
+            d["ok_map"][qis] = np.array(bits, dtype=np.uint64)
+        if flavours:
+            for qi, s in enumerate(who):
+                if flavours[s]:
+                    d["flavour"][qi] = flavours[s].get("flavour", 0)
+                    d["collide_label"][qi] = flavours[s].get("collide_label", 0)
+                    d["collide_dz"][qi] = flavours[s].get("collide_dz", 0.0)
+        d["anno"] = np.asarray([annos[s] for s in who], dtype=np.float64)[:, :10]
         d["pose"], d["map_move"] = self.pose_arr[w], self.move_arr[w]
         return PlaceBatch({"desc": d, "m": m, "max_boxes": max(1, int(d["n_boxes"].max())), "max_n_scene": int(d["n_scene"].max()),
                            "max_n_orig": int(d["n_orig"].max()), "keep": (rows, boxes_d, all_ranges, smp_rows)},
@@ -179,25 +196,17 @@ class PlacedInserter:
         still_open[who_t] = 1
         accepted_at = torch.full((B,), -1, dtype=torch.int32, device=batch.device)
         first, new_slot = 0, True
+        n_possible = torch.zeros(B, dtype=torch.int32, device=batch.device)
         while True:
             pb.run(first_cand=first)
-            n_possible = torch.zeros(B, dtype=torch.int32, device=batch.device)
             n_possible[who_t] = pb.n_possible
-            for j in range(chunk):
-                active = still_open * (n_possible > first + j).to(torch.int32)
-                nv, acc = batch.insert_device(pb.cand[j * pb.total:], sample_off, need, active, new_slot=new_slot)
-                new_slot = False
-                got = acc * active
-                accepted_at = torch.where(got > 0, torch.full_like(accepted_at, first + j), accepted_at)
-                still_open = still_open * (1 - got)
-                if self.reference_rejected_state:
-                    # the sample's LAST candidate, rejected with a visible part: the driver keeps the scene it has culled
-                    # (the candidate is replayed into the batch's shadow; nothing of the scene changes)
-                    # (also one rejected WITHOUT a visible point: a closing-filled hole of the sample in front of the scene is a
-                    # visible pixel all the same and culls there, insertion.py:467-473)
-                    last_rejected = active * still_open * (n_possible == first + j + 1).to(torch.int32)
-                    batch.insert_device(pb.cand[j * pb.total:], sample_off, torch.full_like(need, -1), last_rejected, new_slot=False)
-            more = bool(((n_possible > first + chunk).to(torch.int32) * still_open).any().item())   # one sync per chunk
+            # the window's candidates of every scene, in rotation order until one is accepted: ONE call (round 6;
+            # r3d_batch_insert_first -- one r3d_batch_insert launch per candidate and the masks between them before)
+            batch.insert_first_device(pb.cand, pb.total, sample_off, need, still_open, n_possible, first, chunk, accepted_at,
+                                      replay_last=self.reference_rejected_state, new_slot=new_slot)
+            new_slot = False
+            still_open = still_open * (accepted_at < 0).to(torch.int32)
+            more = bool(((n_possible > first + chunk).to(torch.int32) * still_open).any().item())   # one sync per window
             if not more:
                 break
             first += chunk
@@ -207,11 +216,21 @@ class PlacedInserter:
         st = pb.status.cpu().numpy()
         if st.any():
             raise ValueError(f"placement search status {st[st != 0][0]} (see R3D_PS_*)")
-        for qi, s in enumerate(who):
-            n_poss[s] = int(n_h[s])
-            j = int(acc_h[s])
-            if j >= 0:
-                rotation[s] = int(rot_h[qi, j])
-                box = np.concatenate([anno_h[qi, j], np.asarray(annos[s], dtype=np.float64)[7:10]])
-                self.boxes[s] = np.vstack([self.boxes[s], box[None, :]])       # insertion.py:535
+        w = np.asarray(who, dtype=np.int64)
+        qi = np.arange(len(w))
+        got = acc_h[w] >= 0
+        j = np.where(got, acc_h[w], 0)
+        rot_w = np.where(got, rot_h[qi, j], -1)
+        for s, r, n in zip(who, rot_w.tolist(), n_h[w].tolist()):
+            rotation[s], n_poss[s] = r, n
+        if got.any():
+            # the accepted objects' boxes join their scenes' annotations (insertion.py:535): centre + quaternion of the
+            # accepted placement, the sample's own extent
+            ws, at = w[got], self.n_boxes[w[got]]
+            if int(at.max()) >= self.boxes_h.shape[1]:
+                self.boxes_h = np.concatenate([self.boxes_h, np.zeros((self.boxes_h.shape[0], 8, 10))], axis=1)
+            ext = np.asarray([annos[s] for s in ws.tolist()], dtype=np.float64)[:, 7:10]
+            self.boxes_h[ws, at, :7] = anno_h[qi[got], j[got]]
+            self.boxes_h[ws, at, 7:] = ext
+            self.n_boxes[ws] += 1
         return rotation, n_poss
