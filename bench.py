@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MIN_POINTS = 20
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 
 CONFIGS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on
@@ -249,7 +249,7 @@ def extra_legs(pkg, torch, args, all_of_them):
         # the placement search in the loop (SURVEY.md par.8 f-1 + the hot path): search -> candidates -> merge per insert slot
         try:
             out["placed"] = importlib.import_module("tools.bench_placed").measure(pkg, B=args.placed or 256, K=len(CONFIGS["C2"]["kinds"]),
-                                                                               reps=4, lanes=3)
+                                                                               reps=4, lanes=4)
         except Exception as e:
             out["placed"] = {"error": repr(e)[:300]}
     return out

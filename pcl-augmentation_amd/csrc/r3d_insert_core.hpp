@@ -1463,7 +1463,9 @@ struct Ins {
     g_cand = nullptr;
     sparse = false;
     int sparse_end = 0;
-    if ((b.reserved & kDbgSparse) || (!single && !(b.reserved & (kDbgBands | kDbgPoolTile | kDbgNoSparse)))) {
+    // (only the shape for large range images carries the sparse tile: on the reference's grid a window beyond the 80 KB of a
+    // 512-thread workgroup is rare -- 31 of 1 280 pairs of config C2 -- and the extra code cost that kernel 4 % of its launch)
+    if (NT == 1024 && ((b.reserved & kDbgSparse) || (!single && !(b.reserved & (kDbgBands | kDbgPoolTile | kDbgNoSparse))))) {
       if (!serial && stale()) return kStale;
       STAMP(7);
       const int rs = scene_sparse(carve, list_start, serial, sparse_end, stale);

@@ -665,7 +665,7 @@ def test_rejected_candidate_state_equals_the_reference(P, name):
 
 
 @pytest.mark.parametrize("debug", [2, 4, 8, 6, 32, 64, 96, 128, 160, 132, 256, 260, 288, 264,
-                                   16384, 16384 | 2, 16384 | 64, 16384 | 8, 16384 | 256, 32768, 65536])
+                                   16384 | 8, 32768, 65536])
 def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
     """The insert kernel's other routes, forced with the descriptor's diagnostic bits: 2 = never speculate (every slot
     waits for its predecessor first), 4 = the window's depth tile built and evaluated in bands of at most 3 candidate
@@ -674,9 +674,10 @@ def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
     evaluation done again after its predecessors and compared (alone and with pooled tiles), 256 = the chunk list through
     super-boxes as on clouds of 260 000 points and more (alone, with bands, pooled tiles, k_insert_big); all must give the bytes of
     the oracle chain, through insert_many and slot by slot, and the comparison of bit 64 must never differ.  Round 6:
-    16384 = every pair's depth tile as a SPARSE tile (only the pixels the evaluation reads, gather_bits / gather_needed; alone,
-    never speculating, verified, in k_insert_big, through super-boxes), 32768 = never (tiles beyond the LDS in the pool);
-    65536 = R3D_B_SLOT_LAUNCHES, insert_many as one launch per slot."""
+    16384 = every pair's depth tile as a SPARSE tile (only the pixels the evaluation reads, gather_bits / gather_needed) -- here
+    in k_insert_big, the 1024-thread shape that carries it; the chain kernel of large range images:
+    test_sparse_tiles_on_a_large_grid --, 32768 = never (tiles beyond the LDS in the pool); 65536 = R3D_B_SLOT_LAUNCHES,
+    insert_many as one launch per slot."""
     import torch
     cases = [_random_case(synth, 11), _random_case(synth, 12, 32, 900, shuffle=True), _random_case(synth, 13, 64, 500)]
     xyzi, label = synth.make_scene(14, 48, 700)
@@ -698,9 +699,44 @@ def test_forced_insert_paths_equal_the_oracle(P, synth, debug):
         res = batch.results()
         cnt = batch.debug_counters()
         assert cnt["verify_mismatch"] == 0 and ((debug & 64) == 0 or not many or cnt["verify_runs"] > 0), cnt
-        assert (cnt["sparse_tiles"] > 0) == bool(debug & 16384) or not (debug & (16384 | 32768)), cnt
+        assert (not (debug & 16384) or cnt["sparse_tiles"] > 0) and (not (debug & 32768) or cnt["sparse_tiles"] == 0), cnt
         for i, c in enumerate(cases):
             vb, lb, cb, oacc = _oracle_chain(*c)
+            assert [0 if acc[k, i] else -1 for k in range(K)] == oacc
+            _check_scene(res[i], vb, lb, cb)
+
+
+@pytest.mark.parametrize("debug", [16384, 16384 | 2, 16384 | 64, 16384 | 256, 32768])
+def test_sparse_tiles_on_a_large_grid(P, synth, monkeypatch, debug):
+    """Round 6: on range images of 4 x the reference's size and more the chain kernel (1024 threads, a CU's whole LDS) keeps a
+    window whose dense depth tile exceeds the LDS as a SPARSE tile -- only the pixels the evaluation reads.  Forced for every
+    pair (16384; never speculating; every speculative evaluation verified; through super-boxes) and switched off (32768) on
+    448 x 2880: the oracle's bytes, through insert_many and slot by slot."""
+    import torch
+    monkeypatch.setattr(O, "NUMROW", 448)
+    monkeypatch.setattr(O, "NUMCOLUMN", 2880)
+    cases = [_random_case(synth, 51), _random_case(synth, 52, 64, 700, shuffle=True)]
+    xyzi, label = synth.make_scene(53, 48, 700)
+    cases.append((xyzi, label, [[blob_in_front_of_extreme(xyzi, "max")]] + cases[0][2][:5], [5] + [20] * 5))
+    B, K = len(cases), 6
+    cap = max(len(c[0]) for c in cases) + sum(max(len(c[2][k][0]) for c in cases) for k in range(K)) + 64
+    for many in (True, False):
+        batch = P.SceneBatch(B, cap, cap, rows=448, cols=2880, debug=debug)
+        batch.load([(c[0], c[1]) for c in cases])
+        batch.begin()
+        packed = [batch.pack_samples([c[2][k][0] for c in cases]) for k in range(K)]
+        needs = [torch.tensor([c[3][k] for c in cases], dtype=torch.int32, device=batch.device) for k in range(K)]
+        if many:
+            _, acc = batch.insert_many_device(packed, needs)
+            acc = acc.cpu().numpy()
+        else:
+            acc = np.stack([batch.insert_device(p[0], p[1], nd)[1].cpu().numpy().copy() for p, nd in zip(packed, needs)])
+        batch.finish()
+        res = batch.results()
+        cnt = batch.debug_counters()
+        assert cnt["verify_mismatch"] == 0 and (cnt["sparse_tiles"] > 0) == bool(debug & 16384), cnt        # (448 x 2880 cases this small fit the LDS densely)
+        for i, c in enumerate(cases):
+            vb, lb, cb, oacc = _oracle_chain(c[0], c[1], [s for s in c[2][:K]], c[3][:K])
             assert [0 if acc[k, i] else -1 for k in range(K)] == oacc
             _check_scene(res[i], vb, lb, cb)
 
