@@ -672,8 +672,8 @@ def run_sharded(n_scenes, process_shard, rank=None, world_size=None, group=None)
     path; the single ``all_gather_object`` at the end only returns results to the caller (a
     production driver writes its own files instead and skips it with ``group=False``).
 
-    ``process_shard`` is the GPU pipeline in production (``augment_batch`` on the rank's device);
-    the CPU tests inject the oracle to prove that the union of shards equals the unsharded run.
+    ``process_shard`` is the caller's per-shard work: ``augment_batch`` on the rank's device, as a rule (this function only
+    deals the scene indices out and gathers what comes back; it runs nothing itself).
     """
     import torch.distributed as dist
     if rank is None:

@@ -14,8 +14,7 @@ writer thread stores the results of batch i-1 while batch i is on the GPU; the d
 (``SceneBatch``) is allocated once and re-used.  ``run`` / ``run_placed`` keep the candidate loop
 (several placements per insert) and use one stream; ``run_streamed`` (one placement per insert) also
 overlaps upload, kernels and download over several lanes with pinned buffers (``streaming.py``).
-``process`` can be injected (the CPU tests pass the oracle there; production uses the HIP path and
-has no fallback).
+The device leg is the HIP path and nothing else: there is no fallback and no parameter that selects another one.
 """
 from __future__ import annotations
 
@@ -48,7 +47,7 @@ def _outputs_exist(output_path, folder, name, write_labels, waymo=False):
 
 class AugmentPipeline:
     def __init__(self, output_path, folder, dataset="semantic", batch_size=64, device="cuda:0",
-                 collapse_labels_to_road=None, resume=True, process=None, reference_rejected_state=False):
+                 collapse_labels_to_road=None, resume=True, reference_rejected_state=False):
         """dataset: "semantic" (SemanticKITTI: labels written, 5-column check file) or "kitti"
         (object detection: labels collapsed to {Road, 1} before use, OD insertion.py:353-355,
         no label file, 4-column check file).
@@ -64,7 +63,7 @@ class AugmentPipeline:
         self.write_labels = dataset == "semantic"
         self.road_label = 40 if collapse_labels_to_road is None and dataset == "kitti" else collapse_labels_to_road
         self.waymo = dataset == "waymo"
-        self.process = process or (self._process_waymo if self.waymo else self._process_hip)
+        self.process = self._process_waymo if self.waymo else self._process_hip      # the device leg of `run`
         self.reference_rejected_state = bool(reference_rejected_state)
         self._batches = {}
         self._lane_batches = threading.local()       # run(lanes > 1): every worker thread keeps its own device batches
@@ -468,16 +467,15 @@ class AugmentPipeline:
 
 
 def run_sharded_files(frames, inserts_for, output_path, folder, rank=None, world_size=None, device=None, dataset="semantic",
-                      batch_size=64, lanes=None, label_2_for=None, process=None, resume=True):
+                      batch_size=64, lanes=None, label_2_for=None, resume=True):
     """BASELINE config C4 ("full sweep, scene-sharded across the GPUs of a node"): rank r of G takes frames r, r + G,
     r + 2G, ... and runs them file to file through its own GPU; no rank talks to another on the data path, every frame
     is written by exactly one rank (the reference shards by letting N copies of the script race for claim files,
     SS insertion.py:339-350; resume is by the existence of a frame's outputs, as there).
 
     inserts_for(i) -> (samples, min_points) of frame i: one placement per insert (``run_streamed``; the Waymo flavour,
-    whose clouds are float64, goes through ``run(lanes=...)``: the same overlap of consecutive batches, whole clouds back).  ``process``
-    (tests only): a CPU stand-in for the GPU leg with ``AugmentPipeline.run``'s signature; it gets one candidate per
-    insert.  Returns this rank's counters; `frames` holds the rank's own frame indices."""
+    whose clouds are float64, goes through ``run(lanes=...)``: the same overlap of consecutive batches, whole clouds back).
+    Returns this rank's counters; `frames` holds the rank's own frame indices."""
     if rank is None or world_size is None:
         import torch.distributed as dist
         rank = dist.get_rank() if dist.is_initialized() else 0
@@ -485,9 +483,9 @@ def run_sharded_files(frames, inserts_for, output_path, folder, rank=None, world
     from .batch import shard_indices
     mine = shard_indices(len(frames), rank, world_size)
     pipe = AugmentPipeline(output_path, folder, dataset=dataset, batch_size=batch_size,
-                           device=device or f"cuda:{rank}", resume=resume, process=process)
+                           device=device or f"cuda:{rank}", resume=resume)
     local = [frames[i] for i in mine]
-    if dataset == "waymo" and process is None:
+    if dataset == "waymo":
         # float64 frames (lidar/{f}.npy, SS tools/datasets.py:239-270): `lanes` batches in flight, each on its own thread,
         # stream and device batch (begin_f64 / results_f64); the float32 delta path below does not carry float64 clouds
         def cands64(j):
@@ -496,13 +494,7 @@ def run_sharded_files(frames, inserts_for, output_path, folder, rank=None, world
         st = pipe.run(local, cands64, lanes=lanes or 3)
         st.update(rank=rank, world_size=world_size, frame_indices=mine)
         return st
-    if process is not None:
-        def cands(j):
-            smp, need = inserts_for(mine[j])
-            return [[x] for x in smp], need
-        st = pipe.run(local, cands, label_2_for=(lambda j, acc: label_2_for(mine[j], acc)) if label_2_for else None)
-    else:
-        st = pipe.run_streamed(local, lambda j: inserts_for(mine[j]), lanes=lanes,
-                               label_2_for=(lambda j, acc: label_2_for(mine[j], acc)) if label_2_for else None)
+    st = pipe.run_streamed(local, lambda j: inserts_for(mine[j]), lanes=lanes,
+                           label_2_for=(lambda j, acc: label_2_for(mine[j], acc)) if label_2_for else None)
     st.update(rank=rank, world_size=world_size, frame_indices=mine)
     return st

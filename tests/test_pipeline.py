@@ -70,8 +70,8 @@ def _check_outputs(synth, frames, out_root, folder, od):
 def test_pipeline_plumbing_with_injected_oracle(pkg, synth, tmp_path, od):
     frames = _make_dataset(synth, tmp_path / "in", 5)
     fr = [pkg.Frame(v, l) for v, l in frames]
-    pipe = pkg.AugmentPipeline(str(tmp_path / "out"), "run0", dataset="kitti" if od else "semantic", batch_size=2,
-                               process=_oracle_process(4 if od else 5))
+    pipe = pkg.AugmentPipeline(str(tmp_path / "out"), "run0", dataset="kitti" if od else "semantic", batch_size=2)
+    pipe.process = _oracle_process(4 if od else 5)          # (the test's stand-in for the device leg: the pipeline has no such parameter)
     stats = pipe.run(fr, lambda i: _candidates(synth, i))
     assert stats["written"] == 5 and stats["skipped_existing"] == 0
     _check_outputs(synth, frames, tmp_path / "out", "run0", od)

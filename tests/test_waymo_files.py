@@ -90,7 +90,8 @@ def _oracle_process(scenes5, candidates, min_points):
 def test_waymo_pipeline_plumbing_with_injected_oracle(pkg, synth, tmp_path):
     files = _dataset(synth, tmp_path / "in", 3)
     fr = [pkg.Frame(f, None, f"{i:06d}") for i, f in enumerate(files)]
-    pipe = pkg.AugmentPipeline(str(tmp_path / "out"), "w", dataset="waymo", batch_size=2, process=_oracle_process)
+    pipe = pkg.AugmentPipeline(str(tmp_path / "out"), "w", dataset="waymo", batch_size=2)
+    pipe.process = _oracle_process                          # (the test's stand-in for the device leg)
     st = pipe.run(fr, lambda i: _inserts(synth, i))
     assert st["written"] == 3
     _check(pkg, synth, files, tmp_path / "out", "w")

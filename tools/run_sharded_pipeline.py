@@ -46,9 +46,7 @@ def load_plan(plan_dir, name):
         return parts, [int(x) for x in z["min_points"]]
 
 
-def main(process=None):
-    """``process``: the per-batch GPU leg of ``run_sharded_files`` (None = the HIP path; the CPU test of the sharding
-    logic, tests/sharded_files_child.py, passes its own stand-in -- this driver knows no other leg)."""
+def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--velodyne", required=True)
@@ -85,7 +83,7 @@ def main(process=None):
     import torch
     n_dev = max(torch.cuda.device_count(), 1)
     st = pkg.run_sharded_files(frames, inserts_for, args.output, args.folder, rank, world, device=f"cuda:{local_rank % n_dev}",
-                               dataset=args.dataset, batch_size=args.batch, lanes=args.lanes, process=process)
+                               dataset=args.dataset, batch_size=args.batch, lanes=args.lanes)
     tot = torch.tensor([st["written"], st["skipped_existing"], st["inserted"]], dtype=torch.int64)
     if world > 1:
         dist.all_reduce(tot)
