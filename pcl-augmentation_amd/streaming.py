@@ -285,13 +285,25 @@ class StreamedAugmenter:
         """Wait for the lane; (tag, results, accepted): results[s] = (xyzi [n,4] float32, label [n] uint32,
         check [m,cols] float32) as VIEWS of the lane's buffers (valid until the lane's next submit),
         accepted[s][k] = 0 (accepted) or -1."""
+        self.wait(lane_no)
+        return self.finish_collect(lane_no)
+
+    def wait(self, lane_no):
+        """The first half of ``collect``: block until the lane's device work and downloads are done (``run`` does this on a
+        thread of its own, so that the host merge of one lane overlaps the wait for the next)."""
         import time
         ln = self.lanes[lane_no]
         assert ln.busy
         t0 = time.perf_counter()
         ln.done.synchronize()
+        self.times["wait_device"] += time.perf_counter() - t0
+
+    def finish_collect(self, lane_no):
+        """The second half of ``collect`` (after ``wait``): status check, host merge, the results' views."""
+        import time
+        ln = self.lanes[lane_no]
+        assert ln.busy
         t1 = time.perf_counter()
-        self.times["wait_device"] += t1 - t0
         counts = ln.out_counts.numpy()
         if _SUM_COUNTERS is not None:                                # R3D_SUM_COUNTERS=1: the insert kernels' diagnostic counters, summed
             for k, v in ln.bt.debug_counters(reset=True).items():
@@ -384,19 +396,36 @@ class StreamedAugmenter:
         for i in range(len(self.lanes)):
             free.put(i)
 
-        # three stages on three threads: this one packs / reads and submits; `drain` waits for the lanes in order and
-        # merges (delta mode); `hand_over` calls consume -- file writing, as a rule -- and gives the lane back.  (Merge
-        # and consume on ONE thread were the bottleneck of the file-to-file legs: 0.28 + 0.33 s per 4 096 frames.)
-        def drain():
+        # four stages on four threads: this one packs / reads and submits; `waiter` waits for the lanes' device work in
+        # order; `drain` checks the status and merges (delta mode); `hand_over` calls consume -- file writing, as a rule --
+        # and gives the lane back.  (Merge and consume on ONE thread were the bottleneck of the file-to-file legs: 0.28 +
+        # 0.33 s per 4 096 frames; round 6: the wait for the device and the merge on one thread were the in-memory leg's,
+        # 0.07 + 0.14 s per 4 096 frames beside 0.17 s of packing and enqueueing.)
+        waited = queue.Queue()
+
+        def waiter():
             while True:
                 lane = submitted.get()
+                if lane is None:
+                    waited.put(None)
+                    return
+                try:
+                    if not errors:
+                        self.wait(lane)
+                except Exception as e:
+                    errors.append(e)
+                waited.put(lane)
+
+        def drain():
+            while True:
+                lane = waited.get()
                 if lane is None:
                     merged.put(None)
                     return
                 got = None
                 try:
                     if not errors:
-                        got = self.collect(lane)
+                        got = self.finish_collect(lane)
                 except Exception as e:                             # surfaces in the submitting thread
                     errors.append(e)
                     self.lanes[lane].busy = False
@@ -418,8 +447,10 @@ class StreamedAugmenter:
                     errors.append(e)
                 free.put(lane)
 
+        th0 = threading.Thread(target=waiter, daemon=True)
         th = threading.Thread(target=drain, daemon=True)
         th2 = threading.Thread(target=hand_over, daemon=True)
+        th0.start()
         th.start()
         th2.start()
         try:
@@ -438,6 +469,7 @@ class StreamedAugmenter:
                 submitted.put(lane)
         finally:
             submitted.put(None)
+            th0.join()
             th.join()
             th2.join()
         if errors:
