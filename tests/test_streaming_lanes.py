@@ -31,15 +31,17 @@ def _stub_augmenter(n_lanes):
         aug.lanes[lane].busy, aug.lanes[lane].tag = True, tag
         return lane
 
-    def collect(lane):
-        ln = aug.lanes[lane]
+    def wait(lane):                           # (the waiter thread of `run`: the lane's device work)
         time.sleep(0.001)
+
+    def finish_collect(lane):                 # (the drain thread: status, merge, the results' views)
+        ln = aug.lanes[lane]
         with aug.lock:
             aug.consuming.add(lane)
-        ln.busy = False                       # as the real collect does, BEFORE consume runs
+        ln.busy = False                       # as the real one does, BEFORE consume runs
         return ln.tag, lane, None
 
-    aug.submit, aug.collect = submit, collect
+    aug.submit, aug.wait, aug.finish_collect = submit, wait, finish_collect
     return aug
 
 
