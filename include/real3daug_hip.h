@@ -347,6 +347,11 @@ int r3d_batch_debug_counters(const r3d_batch_t *b, int32_t *host_out16, int32_t 
  * r3d_batch_export_pix: the pixel id of every point of every scene, in the order of the slabs, as the reference numbers
  * it (row * cols + column, insertion.py:116; `pix` itself holds (row << 16) | column in the internal numbering). */
 int r3d_batch_export_pix(const r3d_batch_t *b, int32_t *pix_ids /* [B*cap] */, void *stream);
+/* r3d_batch_export_alive: the alive word of every 64-point chunk of every scene in the order of the slabs, alive [B][chunks]
+ * (chunks = (cap + 63) / 64; bits beyond a scene's n_total are 0) -- the living points of the cloud r3d_batch_export_rows
+ * shows (the copy a rejected candidate has left while there is one), without the rows: what R3D_PQ_SCENE_SLAB queries of the
+ * placement search read.  Does not change the batch. */
+int r3d_batch_export_alive(const r3d_batch_t *b, uint64_t *alive, void *stream);
 /* r3d_batch_point_order: per scene, how many of its points the last r3d_batch_begin numbered anew (0: the scene keeps the order
  * of its slab), into DEVICE memory -- what a caller that sets R3D_B_FILE_ORDER by itself looks at (SceneBatch does). */
 int r3d_batch_point_order(const r3d_batch_t *b, int32_t *virtual_order /* [B], device */, void *stream);
@@ -391,6 +396,12 @@ int r3d_batch_point_order(const r3d_batch_t *b, int32_t *virtual_order /* [B], d
 #define R3D_PQ_COLLIDE_LABEL 4        /* OD :120-121: scene points of label collide_label collide (SS :92-97: every label
                                          that is not placement surface) */
 #define R3D_PQ_COLLIDE_ABOVE 8        /* OD :123-124 ('Pedestrian'): only points with z >= box bottom + collide_dz */
+#define R3D_PQ_SCENE_SLAB 16          /* the current cloud is given as a scene of a batch (r3d_batch_t) stands in HBM instead of as
+                                         float64 rows: `scene` = its float32 x y z intensity rows (b.xyzi + s*cap*4, cast), n_scene =
+                                         n_total[s], scene_head = n_head[s], scene_label = b.label + s*cap, scene_alive = the scene's
+                                         alive words (r3d_batch_export_alive), scene_tail_ref / scene_log5 = b.tail_ref / b.log5 of the
+                                         scene (the float64 coordinates of inserted points); dead points are skipped.  Saves the
+                                         export of the rows (r3d_batch_export_rows) and their chunk ranges per insert slot */
 
 typedef struct r3d_place_query_t {
   const double *scene;     /* current cloud, n_scene rows of scene_ld doubles: x y z at columns 0-2, the label at
@@ -419,6 +430,12 @@ typedef struct r3d_place_query_t {
   int32_t flavour;         /* R3D_PQ_* bits, 0 = semantic_segmentation */
   int32_t collide_label;
   double collide_dz;
+  /* R3D_PQ_SCENE_SLAB only (else unused): */
+  const uint32_t *scene_label;    /* [n_scene] label words of the scene's points (& 0xFFFF taken here) */
+  const uint64_t *scene_alive;    /* [(n_scene + 63) / 64] bit i of word c: point 64 c + i lives */
+  const int32_t *scene_tail_ref;  /* [n_scene - scene_head] log row of point scene_head + t */
+  const double *scene_log5;       /* rows of 5 doubles: x y z of the inserted points */
+  int64_t scene_head;             /* float32-exact points at the front of the scene */
 } r3d_place_query_t;
 
 size_t r3d_places_workspace_bytes(int32_t n_queries, int32_t max_boxes);

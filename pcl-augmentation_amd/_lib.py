@@ -74,12 +74,14 @@ class PlaceQuery(C.Structure):
         ("anno", C.c_double * 10), ("pose", C.c_double * 8), ("map_move", C.c_double * 2),
         ("cand_off", C.c_int64), ("cand_stride", C.c_int64),
         ("flavour", C.c_int32), ("collide_label", C.c_int32), ("collide_dz", C.c_double),
+        ("scene_label", C.c_void_p), ("scene_alive", C.c_void_p), ("scene_tail_ref", C.c_void_p), ("scene_log5", C.c_void_p),
+        ("scene_head", C.c_int64),
     ]
 
 
 PLACE_ROTATIONS, PLACE_SURFACE_CAP, PLACE_MAX_OK_LABELS = 360, 128, 32
 PS_SURFACE_OVERFLOW, PS_NONFINITE = 1, 2
-PQ_POINTWISE_ROTATION, PQ_MAP_NEEDS_POINT, PQ_COLLIDE_LABEL, PQ_COLLIDE_ABOVE = 1, 2, 4, 8
+PQ_POINTWISE_ROTATION, PQ_MAP_NEEDS_POINT, PQ_COLLIDE_LABEL, PQ_COLLIDE_ABOVE, PQ_SCENE_SLAB = 1, 2, 4, 8, 16
 PF_ON_SURFACE, PF_NEAR_ROAD, PF_SCENE_IN_BOX, PF_SAMPLE_IN_BOX, PF_POSSIBLE = 1, 2, 4, 8, 16
 
 _P = C.c_void_p
@@ -116,6 +118,7 @@ _SIGNATURES = {
     "r3d_batch_insert_many": (C.c_int, [C.POINTER(BatchDesc), C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P]),
     "r3d_batch_export_rows": (C.c_int, [C.POINTER(BatchDesc), _P, _P, _P]),
     "r3d_batch_export_pix": (C.c_int, [C.POINTER(BatchDesc), _P, _P]),
+    "r3d_batch_export_alive": (C.c_int, [C.POINTER(BatchDesc), _P, _P]),
     "r3d_batch_point_order": (C.c_int, [C.POINTER(BatchDesc), _P, _P]),
     "r3d_batch_adopt_rejected": (C.c_int, [C.POINTER(BatchDesc), _P, _P]),
     "r3d_places_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),

@@ -437,6 +437,17 @@ class SceneBatch:
         return self.rows4, self.n_rows
 
     @_lib.on_own_device
+    def export_alive(self):
+        """The alive word of every 64-point chunk of every scene, slab order ([B, chunks] int64 device tensor): the living
+        points of the cloud ``export_rows`` shows, without the rows (``r3d_batch_export_alive``)."""
+        torch = self.torch
+        if getattr(self, "_alive_words", None) is None:
+            self._alive_words = torch.zeros((self.B, (self.cap + 63) // 64), dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.r3d_batch_export_alive(C.byref(self.desc), C.c_void_p(self._alive_words.data_ptr()), _lib.stream_ptr()),
+                   "r3d_batch_export_alive")
+        return self._alive_words
+
+    @_lib.on_own_device
     def adopt_rejected(self, active=None):
         """The copy a rejected candidate has left (``insert`` with ``min_points < 0``) becomes the scene, where there is one
         (and ``active[s]``): what the reference's driver goes on with when no further candidate restores the backup

@@ -1307,6 +1307,22 @@ __global__ void k_export_delta(r3d_batch_t b, BatchWs w, int chunks, unsigned lo
   }
 }
 
+// r3d_batch_export_alive: the alive words in slab order, masked to the scene's count
+__global__ void k_export_alive(r3d_batch_t b, BatchWs w, int chunks, unsigned long long *alive_out, bool slab_order_made) {
+  const int s = blockIdx.y;
+  const int n_total = b.n_total[s];
+  const int n_words = (n_total + 63) >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && w.n_virt[s] != 0 && !slab_order_made) atomicOr(&b.status[s], R3D_S_ORDER_PROMISE);
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += gridDim.x * blockDim.x) {
+    // (the cloud r3d_batch_export_rows shows: the copy a rejected candidate has left while there is one)
+    const unsigned long long *src = w.n_virt[s] ? w.alive_o : (w.shadow_valid[s] ? w.alive_shadow : w.alive);
+    unsigned long long a = c < n_words ? src[(int64_t)s * chunks + c] : 0ull;
+    const int left = n_total - (c << 6);
+    if (left < 64) a = left > 0 ? a & ((1ull << left) - 1ull) : 0ull;
+    alive_out[(int64_t)s * chunks + c] = a;
+  }
+}
+
 int check_batch(const r3d_batch_t *b) {
   if (!b) return fail(R3D_E_ARG, "batch: null descriptor");
   if (b->B <= 0 || b->rows <= 0 || b->cols <= 0 || b->cap <= 0 || b->log_cap <= 0)
@@ -1566,6 +1582,18 @@ int r3d_batch_export_pix(const r3d_batch_t *b, int32_t *pix_ids, void *stream) {
   BatchWs w = carve_batch(*b, b->workspace);
   hipLaunchKernelGGL(k_export_pix, dim3(32, b->B), dim3(256), 0, (hipStream_t)stream, *b, w, pix_ids);
   R3D_LAUNCHED("k_export_pix");
+  return R3D_OK;
+}
+
+int r3d_batch_export_alive(const r3d_batch_t *b, uint64_t *alive, void *stream) {
+  int rc = check_batch(b);
+  if (rc != R3D_OK) return rc;
+  if (!alive) return fail(R3D_E_ARG, "batch_export_alive: null output");
+  BatchWs w = carve_batch(*b, b->workspace);
+  if (virtual_order_mode(*b)) launch_unvirtual(*b, w, w.all_list, w.all_count, b->B, true, (hipStream_t)stream);
+  hipLaunchKernelGGL(k_export_alive, dim3(8, b->B), dim3(256), 0, (hipStream_t)stream, *b, w, chunks_of(*b),
+                     reinterpret_cast<unsigned long long *>(alive), virtual_order_mode(*b) != 0);
+  R3D_LAUNCHED("k_export_alive");
   return R3D_OK;
 }
 

@@ -184,6 +184,34 @@ __device__ __forceinline__ bool inside_box(const double *R, const double *up, co
   return in;
 }
 
+// Diagnostic builds (-DR3D_GUARD, tools/build_flavour.sh guard -DR3D_GUARD): a kernel that is about to follow the pointers of
+// a query descriptor looks at them first; one that cannot be a device address is printed with the head of the descriptor
+// and the workgroup leaves (a descriptor overwritten by a stray store shows up as a line of text, not as a queue abort).
+#ifdef R3D_GUARD
+__device__ __forceinline__ bool odd_pointer(const void *p, bool nullable = false, unsigned long long align = 4) {
+  const unsigned long long a = (unsigned long long)p;
+  if (!a) return !nullable;
+  return a < (1ull << 20) || a >= (1ull << 48) || (a & (align - 1ull));
+}
+__device__ __noinline__ bool odd_query(const r3d_place_query_t *Q, int q, int kernel, bool say) {
+  const r3d_place_query_t &d = Q[q];
+  const bool bad = odd_pointer(d.scene) || odd_pointer(d.orig) || odd_pointer(d.boxes, true) || odd_pointer(d.sample) ||
+                   odd_pointer(d.map, false, 1) || odd_pointer(d.scene_ranges, true) || odd_pointer(d.orig_ranges, true) ||
+                   d.scene_ld != 4 || d.orig_ld != 4 || d.n_scene < 0 || d.n_scene > (1 << 24) || d.n_orig < 0 ||
+                   d.n_orig > (1 << 24) || d.m <= 0 || d.m > 8192 || d.n_boxes < 0 || d.n_boxes > 4096;
+  if (bad && say) {
+    const unsigned long long *u = reinterpret_cast<const unsigned long long *>(&d);
+    printf("R3D_GUARD kernel %d query %d at %p: %016llx %016llx %016llx %016llx %016llx %016llx %016llx | n %lld %lld ld %d %d m %d boxes %d | "
+           "tail %016llx %016llx %016llx\n", kernel, q, (const void *)&d, u[0], u[1], u[2], u[3], u[4], u[5], u[6], (long long)d.n_scene,
+           (long long)d.n_orig, d.scene_ld, d.orig_ld, d.m, d.n_boxes, u[56], u[60], u[62]);
+  }
+  return bad;
+}
+#define R3D_GUARD_QUERY(kernel, say) if (odd_query(Q, q, kernel, say)) return
+#else
+#define R3D_GUARD_QUERY(kernel, say)
+#endif
+
 // ---- k_place_centres / k_place_orient: find_spot.py:52-70 applied 360 times to the annotation -----
 // Two chains that do not depend on each other: the box centre (three fused multiply-adds per step: 5 us for the 360
 // steps) is what the point passes need -- which points can be near which step --, the orientation (matrix, product,
@@ -259,6 +287,7 @@ __global__ void k_place_boxes(const r3d_place_query_t *Q, int nq, int max_boxes,
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nq * max_boxes) return;
   int q = t / max_boxes, j = t % max_boxes;
+  R3D_GUARD_QUERY(__LINE__, j == 0);
   const r3d_place_query_t &qq = Q[q];
   if (j >= qq.n_boxes) return;
   const double *b = qq.boxes + (size_t)j * 10;
@@ -442,6 +471,7 @@ __device__ __forceinline__ void stage_query(r3d_place_query_t &dst, const r3d_pl
 __global__ __launch_bounds__(kPB) void k_place_road_min(const r3d_place_query_t *Q, PlaceWs w, float reach, int mode,
                                                         double resolved_sq) {
   const int q = blockIdx.x, tid = threadIdx.x;        // queries of one scene are neighbours: they share the chunk in L2
+  R3D_GUARD_QUERY(__LINE__, threadIdx.x == 0 && blockIdx.y == 0);
   const int64_t n = Q[q].n_orig, start0 = (int64_t)blockIdx.y * kPointsPerBlock * kTurns;
   if (start0 >= n) return;
   __shared__ r3d_place_query_t qq;
@@ -563,6 +593,7 @@ __device__ __forceinline__ int last_bit_exponent(double v) {
 // which are float32 values of similar size).  The ordered list is kept for the other case.
 __global__ __launch_bounds__(kPB) void k_place_surface_gather(const r3d_place_query_t *Q, PlaceWs w, Radii rad) {
   const int q = blockIdx.x, tid = threadIdx.x;        // queries of one scene are neighbours: they share the chunk in L2
+  R3D_GUARD_QUERY(__LINE__, threadIdx.x == 0 && blockIdx.y == 0);
   const int64_t n = Q[q].n_orig, start0 = (int64_t)blockIdx.y * kPointsPerBlock * kTurns;
   if (start0 >= n) return;
   const double reach_sq = key_depth(w.gather_sq[q]);
@@ -698,6 +729,7 @@ __global__ __launch_bounds__(kPB) void k_place_road_level(const r3d_place_query_
 // ---- k_place_scene_in_box: cut_bounding_box(scene_pcl, sample_anno) minus surface (:91-97) --------
 __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_query_t *Q, PlaceWs w) {
   const int q = blockIdx.x, tid = threadIdx.x;
+  R3D_GUARD_QUERY(__LINE__, threadIdx.x == 0 && blockIdx.y == 0);
   const int64_t n = Q[q].n_scene, start0 = (int64_t)blockIdx.y * kPointsPerBlock * kTurns;
   if (start0 >= n) return;
   __shared__ r3d_place_query_t qq;
@@ -748,7 +780,23 @@ __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_quer
   for (int a = tid >> 6; a < n_chunks; a += kPB / 64) {
     const int64_t i = start + (int64_t)s_chunk[a] * 64 + (tid & 63);
     if (i >= end) continue;
-    const Pt p = load_point(qq.scene, i, qq.scene_ld, qq.scene_label_col);
+    Pt p;
+    if (qq.flavour & R3D_PQ_SCENE_SLAB) {
+      // the scene as it stands in its batch (include/real3daug_hip.h): dead points skipped, float32-exact head points from
+      // the slab, inserted points' float64 coordinates from the log -- what r3d_batch_export_rows would have written
+      if (!((in_global(qq.scene_alive)[i >> 6] >> (i & 63)) & 1ull)) continue;
+      if (i < qq.scene_head) {
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const f4_t f = ((InGlobal<f4_t>)reinterpret_cast<const f4_t *>(qq.scene))[i];
+        p.x = (double)f.x, p.y = (double)f.y, p.z = (double)f.z;
+      } else {
+        InGlobal<double> row = in_global(qq.scene_log5 + (int64_t)in_global(qq.scene_tail_ref)[i - qq.scene_head] * 5);
+        p.x = row[0], p.y = row[1], p.z = row[2];
+      }
+      p.label = (double)(in_global(qq.scene_label)[i] & 0xFFFFu);
+    } else {
+      p = load_point(qq.scene, i, qq.scene_ld, qq.scene_label_col);
+    }
     const double x = p.x, y = p.y, z = p.z;
     if (od_label ? !(p.label == (double)qq.collide_label)         // OD :120-121
                  : label_rank(qq, p.label) >= 0) continue;        // SS :94-95: surface may be inside the box
@@ -823,6 +871,7 @@ __device__ __forceinline__ void sample_chain(ChainLds &lds, const r3d_place_quer
                                              uint8_t *flags, int32_t *n_possible, int32_t *rot_out,
                                              double *anno_out, double *cand, int32_t first_cand, int32_t *status) {
   const int q = blockIdx.x, tid = threadIdx.x;
+  R3D_GUARD_QUERY(__LINE__, threadIdx.x == 0);
   const r3d_place_query_t &qq = Q[q];
   const int m = qq.m;
   uint32_t *s_allowed = lds.allowed;

@@ -11,6 +11,8 @@ candidate j of all scenes as one packed sample list, which is what the insert ca
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
 from . import _lib
@@ -18,7 +20,7 @@ from .places import PlaceBatch, chunk_ranges, scene_view, upload_map
 
 
 class PlacedInserter:
-    def __init__(self, batch, rich_maps, map_moves, poses, scene_boxes, reference_rejected_state=False):
+    def __init__(self, batch, rich_maps, map_moves, poses, scene_boxes, reference_rejected_state=False, scene_slab=True):
         """batch: a SceneBatch after ``begin``.  Per scene: rich map (2D integer codes), its
         ``move`` (first two entries used), the 4 x 4 pose and the annotated boxes (k x 10:
         centre, quaternion xyzw, length, width, height).
@@ -35,7 +37,10 @@ class PlacedInserter:
         assert len(rich_maps) == len(map_moves) == len(poses) == len(scene_boxes) == B
         # (maps of one shape -- the usual case, one map geometry per dataset -- go up as one slab)
         if all(isinstance(m, np.ndarray) and m.dtype == np.uint8 and m.shape == rich_maps[0].shape and m.ndim == 2 for m in rich_maps):
-            slab = torch.from_numpy(np.ascontiguousarray(np.stack(rich_maps))).to(batch.device, non_blocking=True)
+            # (stacked in pinned memory that lives as long as this object: the copy is asynchronous)
+            self._maps_pin = torch.empty((B,) + rich_maps[0].shape, dtype=torch.uint8, pin_memory=True)
+            np.stack(rich_maps, out=self._maps_pin.numpy())
+            slab = self._maps_pin.to(batch.device, non_blocking=True)
             self.maps = [slab[s] for s in range(B)]
         else:
             self.maps = [upload_map(m, batch.device) for m in rich_maps]
@@ -64,6 +69,27 @@ class PlacedInserter:
             self.orig_ranges = [r[s, :(self.n_orig[s] + 63) // 64] for s in range(B)]
         else:
             self.orig_ranges = [chunk_ranges(self.orig_rows[s, :self.n_orig[s]]) for s in range(B)]
+        # Round 6: the search reads the CURRENT cloud of a scene where it stands -- the batch's float32 slab, its labels, the
+        # alive words, the log for inserted points (R3D_PQ_SCENE_SLAB) -- instead of float64 rows exported per slot
+        # (r3d_batch_export_rows + their chunk ranges: 0.66 ms of a slot's 3.8 on 256 frames).  The chunk ranges of the slab:
+        # the original cloud's for whole chunks of frame points (a dead point only leaves its chunk's range wider than
+        # needed), "always in reach" for the chunks that hold inserted points.  Float32 frames only (begin / begin_xyz).
+        n_head_h = batch.n_head.cpu().numpy()
+        self.slab = bool(scene_slab) and self.chunked and bool(np.array_equal(n_head_h, np.asarray(self.n_orig)))
+        if self.slab:
+            first_open = torch.from_numpy((n_head_h // 64).astype(np.int64)).to(batch.device)
+            open_ = torch.arange(batch.cap // 64, device=batch.device)[None, :] >= first_open[:, None]
+            sr = self.orig_ranges_all.clone()
+            sr[..., 0][open_] = 0.0
+            sr[..., 1][open_] = float("inf")
+            self.slab_ranges = sr
+            self.n_head_arr = n_head_h.astype(np.int64)
+            self.n_scene_h = self.n_head_arr.copy()                      # (points of the slab so far: updated with every slot's results)
+        # the slot's staging: one pinned buffer up (made on first use, grows), two small pinned buffers down
+        self._up_size, self._up_pin, self._up_dev, self._up_host = 0, None, None, None
+        self._down_f = torch.empty(B * 11, dtype=torch.float64, pin_memory=True)
+        self._down_i = torch.empty(2 * B, dtype=torch.int32, pin_memory=True)
+        self._arange = torch.arange(B, dtype=torch.int64, device=batch.device)
         # what the descriptors of a slot are packed from, per scene, as arrays (insert_slot fills all queries at once)
         self.map_ptr = np.array([m.data_ptr() for m in self.maps], dtype=np.uint64)
         self.map_shape = np.array([m.shape for m in self.maps], dtype=np.int32)
@@ -93,63 +119,132 @@ class PlacedInserter:
                 self.batch.adopt_rejected(None if act.all() else act)
         return out
 
+    # -- one insert slot --------------------------------------------------------------------------
+    # Round 6: what a slot sends to the device -- descriptors, boxes, the samples' rows, offsets, the masks -- is written into
+    # ONE pinned host buffer and goes up with one copy; what it reads back -- per query the accepted candidate, its rotation
+    # and annotation, the search's status; per scene the batch's status and point count -- is gathered on the device and comes
+    # down with two small copies.  (Before: some 25 copies from / to pageable memory per slot, 5.5 MB of them the
+    # annotations of all 360 steps of every query, each one a blocking call into the runtime's staging path.)
+    def _room(self, nbytes):
+        torch = self.torch
+        if nbytes > self._up_size:
+            self._up_size = int(nbytes * 1.25) + (1 << 20)
+            self._up_pin = torch.empty(self._up_size, dtype=torch.uint8, pin_memory=True)
+            self._up_dev = torch.empty(self._up_size, dtype=torch.uint8, device=self.batch.device)
+            self._up_host = self._up_pin.numpy()
+
     def _insert_slot(self, samples, annos, ok_labels, ok_maps, min_points, chunk, flavours):
         torch, batch = self.torch, self.batch
         B = batch.B
-        rows, n_rows = batch.export_rows()
-        n_rows_h = n_rows.cpu().numpy()
         who = [s for s in range(B) if samples[s] is not None and len(samples[s])]
         rotation, n_poss = [-1] * B, [0] * B
         if not who:
             return rotation, n_poss
-        # one upload for the boxes of all scenes, one launch for the chunk ranges of all current clouds
+        if not self.chunked:
+            return self._insert_slot_unchunked(who, samples, annos, ok_labels, ok_maps, min_points, chunk, flavours, rotation, n_poss)
+        if self.slab:
+            rows, alive, all_ranges = None, batch.export_alive(), self.slab_ranges
+        else:
+            rows, n_rows = batch.export_rows()
+            alive, all_ranges = None, chunk_ranges(rows.view(B * batch.cap, 4)).view(B, batch.cap // 64, 2)
+            self.n_scene_h = n_rows.cpu().numpy().astype(np.int64)
+        w = np.asarray(who, dtype=np.int64)
+        nq, max_b = len(w), max(1, int(self.n_boxes.max()))
+        m = np.fromiter((len(samples[s]) for s in who), dtype=np.int64, count=nq)
+        off = np.zeros(B + 1, dtype=np.int64)
+        sizes = np.zeros(B, dtype=np.int64)
+        sizes[w] = m
+        np.cumsum(sizes, out=off[1:])
+        total_rows = int(off[-1])
+        # the slot's upload: layout (every part starts on a 64-byte boundary), host views, device views
+        desc_size = C.sizeof(_lib.PlaceQuery)
+        at, lay = 0, {}
+        for name, nbytes in (("desc", nq * desc_size), ("boxes", B * max_b * 80), ("off", (B + 1) * 8), ("who", nq * 8), ("need", B * 4),
+                             ("open", B * 4), ("rows", total_rows * 40)):
+            lay[name] = (at, nbytes)
+            at += (nbytes + 63) & ~63
+        self._room(at)
+        host, dev = self._up_host, self._up_dev
+        hv = lambda name, dtype: host[lay[name][0]:lay[name][0] + lay[name][1]].view(dtype)
+        dv = lambda name, dtype: dev[lay[name][0]:lay[name][0] + lay[name][1]].view(dtype)
+        dptr = lambda name: np.uint64(dev.data_ptr() + lay[name][0])
+        hv("boxes", np.float64).reshape(B, max_b, 10)[:] = self.boxes_h[:, :max_b]
+        hv("off", np.int64)[:] = off
+        hv("who", np.int64)[:] = w
+        hv("need", np.int32)[:] = np.asarray(min_points, dtype=np.int32)
+        still = hv("open", np.int32)
+        still[:] = 0
+        still[w] = 1
+        np.concatenate([samples[s] for s in who], axis=0, out=hv("rows", np.float64).reshape(total_rows, 5))
+        d = hv("desc", np.uint8)
+        d[:] = 0
+        d = d.view(np.dtype(_lib.PlaceQuery))
+        self._fill_descriptors(d, who, w, m, off, dptr("boxes"), max_b, dptr("rows"), all_ranges, rows, alive, annos, ok_labels, ok_maps,
+                               flavours, chunk)
+        dev[:at].copy_(self._up_pin[:at], non_blocking=True)
+        pb = PlaceBatch({"desc": d, "d_desc": dv("desc", torch.uint8), "m": m, "max_boxes": max(1, int(d["n_boxes"].max())),
+                         "max_n_scene": int(d["n_scene"].max()), "max_n_orig": int(d["n_orig"].max()),
+                         "keep": (rows, all_ranges, alive, dev)}, cand_cap=chunk, device=batch.device, packed=True)
+        return self._try_candidates(pb, who, chunk, annos, rotation, n_poss, dv("off", torch.int64), dv("need", torch.int32),
+                                    dv("who", torch.int64), dv("open", torch.int32))
+
+    def _insert_slot_unchunked(self, who, samples, annos, ok_labels, ok_maps, min_points, chunk, flavours, rotation, n_poss):
+        """A batch whose stride is no multiple of 64 points (no public constructor makes one): per-query descriptors."""
+        torch, batch = self.torch, self.batch
+        B = batch.B
+        rows, n_rows = batch.export_rows()
+        n_rows_h = n_rows.cpu().numpy()
         max_b = max(1, int(self.n_boxes.max()))
         boxes_d = torch.from_numpy(np.ascontiguousarray(self.boxes_h[:, :max_b])).to(batch.device)
-        if self.chunked:
-            all_ranges = chunk_ranges(rows.view(B * batch.cap, 4)).view(B, batch.cap // 64, 2)
         in_who = set(who)
         smp_rows, smp_off = batch.pack_samples([samples[s] if s in in_who else None for s in range(B)])
         smp_off_h = smp_off.cpu().numpy()
-        if self.chunked:
-            pb = self._pack_slot(who, rows, n_rows_h, boxes_d, max_b, all_ranges, smp_rows, smp_off_h, annos, ok_labels, ok_maps,
-                                 flavours, chunk)
-            return self._try_candidates(pb, who, min_points, chunk, annos, rotation, n_poss)
         queries = []
         for s in who:
             n = int(n_rows_h[s])
-            if self.chunked:
-                rng_s = all_ranges[s, :(n + 63) // 64]
-            else:
-                rng_s = chunk_ranges(rows[s, :n])
             scene = scene_view(rows[s, :n], self.orig_rows[s, :self.n_orig[s]], boxes_d[s], int(self.n_boxes[s]), self.maps[s],
-                               self.moves[s], self.poses[s], rng_s, self.orig_ranges[s])
+                               self.moves[s], self.poses[s], chunk_ranges(rows[s, :n]), self.orig_ranges[s])
             queries.append({"scene": scene, "sample": smp_rows[int(smp_off_h[s]):int(smp_off_h[s + 1])], "anno": annos[s],
                             "ok_labels": ok_labels[s], "ok_map": ok_maps[s], **((flavours[s] or {}) if flavours else {})})
         pb = PlaceBatch(queries, cand_cap=chunk, device=batch.device, packed=True)
         pb.sample_sizes = np.array([q.shape[0] for q in pb.samples], dtype=np.int64)
-        return self._try_candidates(pb, who, min_points, chunk, annos, rotation, n_poss)
+        sizes = np.zeros(B, dtype=np.int64)
+        sizes[who] = pb.sample_sizes
+        off = np.zeros(B + 1, dtype=np.int64)
+        off[1:] = np.cumsum(sizes)
+        still = np.zeros(B, dtype=np.int32)
+        still[who] = 1
+        up = lambda a: torch.from_numpy(a).to(batch.device)
+        return self._try_candidates(pb, who, chunk, annos, rotation, n_poss, up(off), up(np.asarray(min_points, dtype=np.int32)),
+                                    up(np.asarray(who, dtype=np.int64)), up(still))
 
-    def _pack_slot(self, who, rows, n_rows_h, boxes_d, max_b, all_ranges, smp_rows, smp_off_h, annos, ok_labels, ok_maps, flavours,
-                   chunk):
-        """The descriptors of a slot's queries, all fields of all queries at once (the per-query form, ``_fill_query``,
-        spent 8 of an insert slot's 11 ms on 256 frames in ctypes field stores)."""
+    def _fill_descriptors(self, d, who, w, m, off, boxes_ptr, max_b, rows_ptr, all_ranges, rows, alive, annos, ok_labels, ok_maps,
+                          flavours, chunk):
+        """The descriptors of a slot's queries, all fields of all queries at once, written where they are uploaded from (the
+        per-query form, ``_fill_query``, spent 8 of an insert slot's 11 ms on 256 frames in ctypes field stores)."""
         batch = self.batch
-        w = np.asarray(who, dtype=np.int64)
-        nq, cap = len(w), batch.cap
-        d = np.zeros(nq, dtype=np.dtype(_lib.PlaceQuery))
+        cap = batch.cap
         u = w.astype(np.uint64)
-        d["scene"] = np.uint64(rows.data_ptr()) + u * np.uint64(cap * 32)
+        if alive is not None:                                            # the scene where it stands in the batch (R3D_PQ_SCENE_SLAB)
+            d["scene"] = np.uint64(batch.xyzi.data_ptr()) + u * np.uint64(cap * 16)
+            d["scene_label"] = np.uint64(batch.label.data_ptr()) + u * np.uint64(cap * 4)
+            d["scene_alive"] = np.uint64(alive.data_ptr()) + u * np.uint64((cap // 64) * 8)
+            d["scene_tail_ref"] = np.uint64(batch.tail_ref.data_ptr()) + u * np.uint64(batch.log_cap * 4)
+            d["scene_log5"] = np.uint64(batch.log5.data_ptr()) + u * np.uint64(batch.log_cap * 40)
+            d["scene_head"] = self.n_head_arr[w]
+            d["flavour"] = _lib.PQ_SCENE_SLAB
+        else:
+            d["scene"] = np.uint64(rows.data_ptr()) + u * np.uint64(cap * 32)
         d["orig"] = np.uint64(self.orig_rows.data_ptr()) + u * np.uint64(cap * 32)
-        d["boxes"] = np.uint64(boxes_d.data_ptr()) + u * np.uint64(max_b * 80)
-        d["sample"] = np.uint64(smp_rows.data_ptr()) + smp_off_h[w].astype(np.uint64) * np.uint64(40)
+        d["boxes"] = boxes_ptr + u * np.uint64(max_b * 80)
+        d["sample"] = rows_ptr + off[w].astype(np.uint64) * np.uint64(40)
         d["map"] = self.map_ptr[w]
         d["scene_ranges"] = np.uint64(all_ranges.data_ptr()) + u * np.uint64((cap // 64) * 8)
         d["orig_ranges"] = np.uint64(self.orig_ranges_all.data_ptr()) + u * np.uint64((cap // 64) * 8)
-        d["n_scene"], d["n_orig"] = n_rows_h[w], self.n_orig_arr[w]
+        d["n_scene"], d["n_orig"] = self.n_scene_h[w], self.n_orig_arr[w]
         d["scene_ld"] = d["orig_ld"] = 4
         d["scene_label_col"] = d["orig_label_col"] = 3
         d["n_boxes"] = self.n_boxes[w]
-        m = (smp_off_h[w + 1] - smp_off_h[w]).astype(np.int64)
         d["m"] = m
         d["map_rows"], d["map_cols"] = self.map_shape[w, 0], self.map_shape[w, 1]
         # placement labels / map codes: a handful of distinct (class) combinations per batch -- each is encoded once and
@@ -173,27 +268,18 @@ class PlacedInserter:
         if flavours:
             for qi, s in enumerate(who):
                 if flavours[s]:
-                    d["flavour"][qi] = flavours[s].get("flavour", 0)
+                    d["flavour"][qi] |= flavours[s].get("flavour", 0)
                     d["collide_label"][qi] = flavours[s].get("collide_label", 0)
                     d["collide_dz"][qi] = flavours[s].get("collide_dz", 0.0)
         d["anno"] = np.asarray([annos[s] for s in who], dtype=np.float64)[:, :10]
         d["pose"], d["map_move"] = self.pose_arr[w], self.move_arr[w]
-        return PlaceBatch({"desc": d, "m": m, "max_boxes": max(1, int(d["n_boxes"].max())), "max_n_scene": int(d["n_scene"].max()),
-                           "max_n_orig": int(d["n_orig"].max()), "keep": (rows, boxes_d, all_ranges, smp_rows)},
-                          cand_cap=chunk, device=batch.device, packed=True)
+        PlaceBatch.candidate_layout(d, m, chunk)
 
-    def _try_candidates(self, pb, who, min_points, chunk, annos, rotation, n_poss):
+    def _try_candidates(self, pb, who, chunk, annos, rotation, n_poss, sample_off, need, who_t, still_open):
+        """sample_off [B + 1] int64, need [B] int32, who_t [queries] int64, still_open [B] int32 (1 for the scenes of `who`):
+        device tensors."""
         torch, batch = self.torch, self.batch
-        B = batch.B
-        sizes = np.zeros(B, dtype=np.int64)
-        sizes[who] = pb.sample_sizes
-        off = np.zeros(B + 1, dtype=np.int64)
-        off[1:] = np.cumsum(sizes)
-        sample_off = torch.from_numpy(off).to(batch.device)
-        need = torch.from_numpy(np.asarray(min_points, dtype=np.int32)).to(batch.device)
-        who_t = torch.tensor(who, dtype=torch.int64, device=batch.device)
-        still_open = torch.zeros(B, dtype=torch.int32, device=batch.device)
-        still_open[who_t] = 1
+        B, nq = batch.B, len(who)
         accepted_at = torch.full((B,), -1, dtype=torch.int32, device=batch.device)
         first, new_slot = 0, True
         n_possible = torch.zeros(B, dtype=torch.int32, device=batch.device)
@@ -210,18 +296,32 @@ class PlacedInserter:
             if not more:
                 break
             first += chunk
-        acc_h, n_h = accepted_at.cpu().numpy(), n_possible.cpu().numpy()
-        rot_h, anno_h = pb.rot_out.cpu().numpy(), pb.anno_out.cpu().numpy()
-        batch.raise_on_status()
-        st = pb.status.cpu().numpy()
+        # per query: accepted candidate (-1: none), possible placements, the accepted one's rotation number and annotation, the
+        # search's status; per scene: the batch's status and point count -- gathered here, two copies into pinned memory
+        acc_w = accepted_at[who_t]
+        j_t = acc_w.clamp(min=0).to(torch.int64)
+        qi_t = self._arange[:nq]
+        res = torch.empty((nq, 11), dtype=torch.float64, device=batch.device)
+        res[:, 0], res[:, 1], res[:, 2], res[:, 3] = acc_w, n_possible[who_t], pb.rot_out[qi_t, j_t], pb.status
+        res[:, 4:] = pb.anno_out[qi_t, j_t]
+        self._down_f[:nq * 11].copy_(res.view(-1), non_blocking=True)
+        self._down_i.copy_(torch.cat([batch.status, batch.n_total]), non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        res_h = self._down_f[:nq * 11].numpy().reshape(nq, 11)
+        st_b, self.n_total_h = self._down_i[:B].numpy(), self._down_i[B:].numpy().astype(np.int64)
+        if self.slab:
+            self.n_scene_h = self.n_total_h                              # (points of the slab, dead ones included)
+        if batch._looked:
+            batch.raise_on_status()                                      # (the first batch of a stream: its point order is noted)
+        for s in np.nonzero(st_b)[0]:
+            _lib.raise_status(int(st_b[s]), f"scene {s}")
+        st = res_h[:, 3]
         if st.any():
-            raise ValueError(f"placement search status {st[st != 0][0]} (see R3D_PS_*)")
+            raise ValueError(f"placement search status {int(st[st != 0][0])} (see R3D_PS_*)")
         w = np.asarray(who, dtype=np.int64)
-        qi = np.arange(len(w))
-        got = acc_h[w] >= 0
-        j = np.where(got, acc_h[w], 0)
-        rot_w = np.where(got, rot_h[qi, j], -1)
-        for s, r, n in zip(who, rot_w.tolist(), n_h[w].tolist()):
+        got = res_h[:, 0] >= 0
+        rot_w = np.where(got, res_h[:, 2], -1).astype(np.int64)
+        for s, r, n in zip(who, rot_w.tolist(), res_h[:, 1].astype(np.int64).tolist()):
             rotation[s], n_poss[s] = r, n
         if got.any():
             # the accepted objects' boxes join their scenes' annotations (insertion.py:535): centre + quaternion of the
@@ -230,7 +330,7 @@ class PlacedInserter:
             if int(at.max()) >= self.boxes_h.shape[1]:
                 self.boxes_h = np.concatenate([self.boxes_h, np.zeros((self.boxes_h.shape[0], 8, 10))], axis=1)
             ext = np.asarray([annos[s] for s in ws.tolist()], dtype=np.float64)[:, 7:10]
-            self.boxes_h[ws, at, :7] = anno_h[qi[got], j[got]]
+            self.boxes_h[ws, at, :7] = res_h[got, 4:]
             self.boxes_h[ws, at, 7:] = ext
             self.n_boxes[ws] += 1
         return rotation, n_poss

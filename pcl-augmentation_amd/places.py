@@ -187,10 +187,21 @@ class PlaceBatch:
         offs = np.zeros(self.nq, dtype=np.int64)
         offs[1:] = np.cumsum(m[:-1] * 5)
         self.offs = [int(x) for x in offs]
-        desc["cand_cap"], desc["cand_off"], desc["cand_stride"] = self.cand_cap, offs, self.total
         self._keep = a.get("keep")
-        self.d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(self.device)
+        if a.get("d_desc") is not None:                     # uploaded by the caller, candidate_layout() applied
+            self.d_desc = a["d_desc"]
+        else:
+            self.candidate_layout(desc, m, self.cand_cap)
+            self.d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(self.device)
         self._outputs(self.total * self.cand_cap, int(a["max_boxes"]), int(a["max_n_scene"]), int(a["max_n_orig"]), int(m.max()))
+
+    @staticmethod
+    def candidate_layout(desc, m, cand_cap):
+        """cand_cap / cand_off / cand_stride of packed descriptors (candidate j of all queries = one packed sample list)."""
+        m = np.asarray(m, dtype=np.int64)
+        offs = np.zeros(len(m), dtype=np.int64)
+        offs[1:] = np.cumsum(m[:-1] * 5)
+        desc["cand_cap"], desc["cand_off"], desc["cand_stride"] = int(cand_cap), offs, int(m.sum()) * 5
 
     def _outputs(self, cand_off, max_boxes, max_n_scene, max_n_orig, max_m):
         torch = _lib.require_gpu()

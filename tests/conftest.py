@@ -41,3 +41,17 @@ def blob_in_front_of_extreme(xyzi, which="max", n=200, seed=0):
     rng = np.random.default_rng(seed)
     pts = xyz[i] * 0.5 + rng.normal(0.0, 0.01, size=(n, 3))
     return np.column_stack([pts, rng.random(n), np.full(n, 30.0)])
+
+
+def rows_from_alive_words(batch, s):
+    """The float64 rows [x y z label] of scene s put together from what a placement query with R3D_PQ_SCENE_SLAB reads: the
+    float32 slab, the label words, r3d_batch_export_alive's words, the log rows of the inserted points."""
+    n_total, n_head = int(batch.n_total[s]), int(batch.n_head[s])
+    words = batch.export_alive()[s].cpu().numpy().view(np.uint64)
+    bits = np.unpackbits(words.view(np.uint8), bitorder="little").astype(bool)
+    assert not bits[n_total:].any()                                  # (masked to the scene's count)
+    xyz = batch.xyzi[s, :n_total, :3].cpu().numpy().astype(np.float64)
+    ref = batch.tail_ref[s].cpu().numpy()[:n_total - n_head]
+    xyz[n_head:] = batch.log5[s].cpu().numpy()[ref, :3]
+    lab = (batch.label[s, :n_total].cpu().numpy() & 0xFFFF).astype(np.float64)
+    return np.c_[xyz, lab][bits[:n_total]]

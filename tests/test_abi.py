@@ -63,7 +63,7 @@ def test_place_query_matches_header(pkg):
                                  ("int32_t", "int64_t", "uint32_t", "uint8_t", "uint64_t", "float", "double")))
         fields += [re.sub(r"\[.*", "", n.strip(",")) for n in names[first:]]
     assert [f for f, _ in pkg._lib.PlaceQuery._fields_] == fields
-    assert ctypes.sizeof(pkg._lib.PlaceQuery) == 7 * 8 + 2 * 8 + 10 * 4 + 32 * 4 + 4 * 8 + (10 + 8 + 2) * 8 + 2 * 8 + 2 * 4 + 8
+    assert ctypes.sizeof(pkg._lib.PlaceQuery) == 7 * 8 + 2 * 8 + 10 * 4 + 32 * 4 + 4 * 8 + (10 + 8 + 2) * 8 + 2 * 8 + 2 * 4 + 8 + 5 * 8
     assert len(pkg.places.search_radii_sq()) == 49 and pkg.places.search_radii_sq()[0] == 0.1 ** 2
 
 

@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import blob_in_front_of_extreme, load_golden
+from conftest import blob_in_front_of_extreme, load_golden, rows_from_alive_words
 from oracle import real3d_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -645,6 +645,7 @@ def test_rejected_candidate_state_equals_the_reference(P, name):
         rows, n_rows = batch.export_rows()
         r = rows[0, :int(n_rows[0])].cpu().numpy()
         assert np.array_equal(r[:, :3], out9[:, :3]) and np.array_equal(r[:, 3], out9[:, 7])
+        assert np.array_equal(rows_from_alive_words(batch, 0), r)          # (the copy a rejected candidate has left)
         if adopt:
             batch.adopt_rejected()
             merged9, added9 = out9, out9[:0]
@@ -655,6 +656,7 @@ def test_rejected_candidate_state_equals_the_reference(P, name):
         rows, n_rows = batch.export_rows()
         r = rows[0, :int(n_rows[0])].cpu().numpy()
         assert np.array_equal(r[:, :3], merged9[:, :3]) and np.array_equal(r[:, 3], merged9[:, 7])
+        assert np.array_equal(rows_from_alive_words(batch, 0), r)
         batch.finish()
         v, l, c = batch.results()[0]
         assert np.array_equal(v, merged9[:, [0, 1, 2, 6]].astype(np.float32)) and np.array_equal(l, merged9[:, 7].astype(np.uint32))

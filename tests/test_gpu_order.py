@@ -5,7 +5,7 @@ Everything here is compared with the oracle byte for byte."""
 import numpy as np
 import pytest
 
-from conftest import blob_in_front_of_extreme
+from conftest import blob_in_front_of_extreme, rows_from_alive_words
 from oracle import real3d_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -116,6 +116,8 @@ def test_streamed_lanes_and_rows_with_a_shuffled_frame(pkg, synth):
         merged, _, _ = O.augment_scene(s5, c[2], c[3])
         assert n_rows[i] == len(merged)
         assert np.array_equal(rows4[i, :n_rows[i], :3], merged[:, :3]) and np.array_equal(rows4[i, :n_rows[i], 3], merged[:, 7])
+        # ... and the same cloud from the alive words in slab order (r3d_batch_export_alive: what a query with R3D_PQ_SCENE_SLAB reads)
+        assert np.array_equal(rows_from_alive_words(batch, i), rows4[i, :n_rows[i]])
 
 
 def test_a_broken_file_order_promise_is_flagged(pkg, synth):

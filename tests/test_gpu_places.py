@@ -206,9 +206,11 @@ def test_heights_whose_sum_depends_on_the_order(P, synth):
     _run_vs_oracle(P, c)
 
 
-def test_placed_insertion_chain_equals_oracle(P, synth):
+@pytest.mark.parametrize("scene_slab", [True, False])
+def test_placed_insertion_chain_equals_oracle(P, synth, scene_slab):
     """Placement search + occlusion merge for several slots of several scenes, everything on the
-    device, against the reference's sequence restated with the two oracles (insertion.py:371-545)."""
+    device, against the reference's sequence restated with the two oracles (insertion.py:371-545).
+    scene_slab: the search reads the scenes where they stand in the batch (R3D_PQ_SCENE_SLAB) / exported float64 rows."""
     fs = P.Real3DAug.tools.find_spot
     classes = [31, 30, 18, 31]
     needs = [25, 10, 10 ** 6, 25]                   # the third slot can never be accepted: every placement is tried
@@ -252,7 +254,8 @@ def test_placed_insertion_chain_equals_oracle(P, synth):
     batch.load([(c["original"][:, :4].astype(np.float32), c["original"][:, 4].astype(np.uint32)) for c in cases])
     batch.begin()
     ins = P.PlacedInserter(batch, [c["rich"] for c in cases], [c["move"] for c in cases], [c["T"] for c in cases],
-                           [[fs._anno10(fs.read_label_line(l)) for l in c["lines"]] for c in cases])
+                           [[fs._anno10(fs.read_label_line(l)) for l in c["lines"]] for c in cases], scene_slab=scene_slab)
+    assert ins.slab == scene_slab
     got_rots = [[] for _ in cases]
     for k in range(len(classes)):
         annos = [fs.read_label_line(slots[k][s][1]) for s in range(3)]
@@ -269,7 +272,8 @@ def test_placed_insertion_chain_equals_oracle(P, synth):
         assert res[s][0].tobytes() == vb and res[s][1].tobytes() == lb and res[s][2].tobytes() == cb
 
 
-def test_placed_chain_with_the_reference_rejected_candidate_state(P, synth):
+@pytest.mark.parametrize("scene_slab", [True, False])
+def test_placed_chain_with_the_reference_rejected_candidate_state(P, synth, scene_slab):
     """The reference's driver after a sample whose candidates were all rejected: scene_pcl stays bound to the copy the LAST
     rejected candidate has culled (insertion.py:468-471 ran, :526 did not) until the next candidate restores the backup
     (:453).  So the next sample's placement search (:433) sees that copy, and when the sample was the object's last try the
@@ -329,7 +333,9 @@ def test_placed_chain_with_the_reference_rejected_candidate_state(P, synth):
     batch.load([(c["original"][:, :4].astype(np.float32), c["original"][:, 4].astype(np.uint32)) for c in cases])
     batch.begin()
     ins = P.PlacedInserter(batch, [c["rich"] for c in cases], [c["move"] for c in cases], [c["T"] for c in cases],
-                           [[fs._anno10(fs.read_label_line(l)) for l in c["lines"]] for c in cases], reference_rejected_state=True)
+                           [[fs._anno10(fs.read_label_line(l)) for l in c["lines"]] for c in cases], reference_rejected_state=True,
+                           scene_slab=scene_slab)
+    assert ins.slab == scene_slab
     got_rots = [[] for _ in cases]
     for k in range(len(classes)):
         annos = [fs.read_label_line(slots[k][s][1]) for s in range(3)]

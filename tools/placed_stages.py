@@ -1,5 +1,5 @@
-"""Where a PlacedInserter slot's time goes (config C2's placed leg): the steps of PlacedInserter._insert_slot one at a time,
-the stream drained after each: python tools/placed_stages.py [B]"""
+"""Where a PlacedInserter slot's time goes (config C2's placed leg): the device calls of PlacedInserter.insert_slot one at a time,
+the stream drained around each, the rest of the slot as one figure: python tools/placed_stages.py [B] [slab|rows]"""
 import importlib
 import os
 import sys
@@ -34,39 +34,39 @@ places = importlib.import_module("pcl-augmentation_amd.places")
 T = {}
 
 
-def lap(name, t0):
-    torch.cuda.synchronize()
-    T[name] = T.get(name, 0.0) + time.perf_counter() - t0
-    return time.perf_counter()
+def timed(obj, name, label):
+    """obj.name runs between two drains of the stream; its time goes to T[label]."""
+    f = getattr(obj, name)
+
+    def g(*a, **kw):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = f(*a, **kw)
+        torch.cuda.synchronize()
+        T[label] = T.get(label, 0.0) + time.perf_counter() - t0
+        return out
+
+    setattr(obj, name, g)
 
 
+mode = sys.argv[2] if len(sys.argv) > 2 else "slab"
+timed(batch, "export_alive", "export_alive")
+timed(batch, "export_rows", "export_rows")
+timed(places, "chunk_ranges", "chunk_ranges")
+placed.chunk_ranges = places.chunk_ranges
+timed(places.PlaceBatch, "run", "search")
+timed(batch, "insert_first_device", "candidates (insert_first)")
+timed(placed.PlacedInserter, "_fill_descriptors", "descriptors")
 for rep in range(3):
-    T.clear()
     batch.load([(f["xyzi"], f["label"]) for f in frames])
     batch.begin()
-    ins = pkg.PlacedInserter(batch, *info)
+    ins = pkg.PlacedInserter(batch, *info, scene_slab=mode == "slab")
     torch.cuda.synchronize()
+    T.clear()
+    t0 = time.perf_counter()
     for smp, annos, okl, okm in slots:
-        t = time.perf_counter()
-        rows, n_rows = batch.export_rows()
-        n_rows_h = n_rows.cpu().numpy()
-        t = lap("export_rows", t)
-        who = list(range(B))
-        max_b = max(1, int(ins.n_boxes.max()))
-        boxes_d = torch.from_numpy(np.ascontiguousarray(ins.boxes_h[:, :max_b])).to(batch.device)
-        t = lap("boxes", t)
-        all_ranges = places.chunk_ranges(rows.view(B * batch.cap, 4)).view(B, batch.cap // 64, 2)
-        t = lap("chunk_ranges", t)
-        smp_rows, smp_off = batch.pack_samples(smp)
-        smp_off_h = smp_off.cpu().numpy()
-        t = lap("pack_samples", t)
-        pb = ins._pack_slot(who, rows, n_rows_h, boxes_d, max_b, all_ranges, smp_rows, smp_off_h, annos, okl, okm, None, 8)
-        t = lap("pack_slot (descriptors)", t)
-        pb.run(first_cand=0)
-        t = lap("search", t)
-        orig_run = pb.run
-        pb.run = lambda first_cand=0: pb                       # (the search has run: _try_candidates' first window)
-        ins._try_candidates(pb, who, [20] * B, 8, annos, [-1] * B, [0] * B)
-        pb.run = orig_run
-        t = lap("candidates + read-back", t)
-    print({k: round(1e3 * v / len(slots), 3) for k, v in T.items()}, "ms per slot; sum", round(1e3 * sum(T.values()) / len(slots), 2), flush=True)
+        ins.insert_slot(smp, annos, okl, okm, [20] * B)
+    torch.cuda.synchronize()
+    whole = time.perf_counter() - t0
+    T["staging, upload, gather, read-back, host"] = whole - sum(T.values())
+    print(mode, {k: round(1e3 * v / len(slots), 3) for k, v in T.items()}, "ms per slot; sum", round(1e3 * whole / len(slots), 2), flush=True)
