@@ -380,6 +380,10 @@ int r3d_batch_point_order(const r3d_batch_t *b, int32_t *virtual_order /* [B], d
 #define R3D_PS_SURFACE_OVERFLOW 1     /* more than R3D_PLACE_SURFACE_CAP surface points in the search radius AND heights
                                          whose sum depends on the order of addition */
 #define R3D_PS_NONFINITE 2            /* NaN / Inf in the sample, its box or the pose */
+#define R3D_PS_BAD_DESCRIPTOR 4       /* the query's descriptor cannot be followed: a null or misaligned pointer, an address no
+                                         device allocation can have, a negative count, m outside 1..8192, label columns outside
+                                         the row, ...  Looked at on the device before any kernel follows a pointer: the query
+                                         gets no placements (n_possible 0), the other queries of the call are served */
 
 /* flags[q][r-1] bits */
 #define R3D_PF_ON_SURFACE 1           /* :234-248 passed */

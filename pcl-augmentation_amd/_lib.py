@@ -80,7 +80,7 @@ class PlaceQuery(C.Structure):
 
 
 PLACE_ROTATIONS, PLACE_SURFACE_CAP, PLACE_MAX_OK_LABELS = 360, 128, 32
-PS_SURFACE_OVERFLOW, PS_NONFINITE = 1, 2
+PS_SURFACE_OVERFLOW, PS_NONFINITE, PS_BAD_DESCRIPTOR = 1, 2, 4
 PQ_POINTWISE_ROTATION, PQ_MAP_NEEDS_POINT, PQ_COLLIDE_LABEL, PQ_COLLIDE_ABOVE, PQ_SCENE_SLAB = 1, 2, 4, 8, 16
 PF_ON_SURFACE, PF_NEAR_ROAD, PF_SCENE_IN_BOX, PF_SAMPLE_IN_BOX, PF_POSSIBLE = 1, 2, 4, 8, 16
 

@@ -73,6 +73,7 @@ struct PlaceWs {
   unsigned long long *surf;     // [Q][360][kCap] (label rank << 40 | point index)
   uint32_t *hit;                // [Q][12] bit r: a non-surface scene point is inside the box of step r
   unsigned long long *gather_sq;// [Q] largest squared radius any step of the query needs (bits of a double)
+  int32_t *bad;                 // [Q] 1: the descriptor cannot be followed (R3D_PS_BAD_DESCRIPTOR): every kernel leaves the query alone
   double *boxes;                // [Q][max_boxes][kBoxD]
   size_t total;
 };
@@ -97,6 +98,7 @@ PlaceWs carve_places(int32_t nq, int32_t max_boxes, void *base) {
   w.surf = c.take<unsigned long long>(qr * kCap);
   w.hit = c.take<uint32_t>((size_t)nq * 12);
   w.gather_sq = c.take<unsigned long long>((size_t)nq);
+  w.bad = c.take<int32_t>((size_t)nq);
   w.boxes = c.take<double>((size_t)nq * (max_boxes > 0 ? max_boxes : 1) * kBoxD);
   w.total = c.off;
   return w;
@@ -212,6 +214,33 @@ __device__ __noinline__ bool odd_query(const r3d_place_query_t *Q, int q, int ke
 #define R3D_GUARD_QUERY(kernel, say)
 #endif
 
+// What k_place_centres looks at before any kernel follows a descriptor's pointers: a descriptor that was never filled, was
+// filled for another layout of the struct or has been overwritten shows up as R3D_PS_BAD_DESCRIPTOR in the query's status
+// (no placements), not as a fault of the queue.
+__device__ __forceinline__ bool address_ok(const void *p, unsigned long long align, bool may_be_null) {
+  const unsigned long long a = (unsigned long long)p;
+  if (!a) return may_be_null;
+  return a >= 4096ull && a < (1ull << 48) && !(a & (align - 1ull));
+}
+__device__ __forceinline__ bool descriptor_ok(const r3d_place_query_t &d) {
+  bool ok = d.n_scene >= 0 && d.n_orig >= 0 && d.n_scene <= (1ll << 40) && d.n_orig <= (1ll << 40);
+  ok = ok && d.scene_ld >= 3 && d.scene_ld <= 4096 && d.orig_ld >= 3 && d.orig_ld <= 4096;
+  ok = ok && d.scene_label_col >= 0 && d.scene_label_col < d.scene_ld && d.orig_label_col >= 0 && d.orig_label_col < d.orig_ld;
+  ok = ok && d.n_boxes >= 0 && d.m >= 1 && d.m <= kCB * 16 && d.map_rows >= 0 && d.map_cols >= 0;
+  ok = ok && d.n_ok_labels >= 0 && d.n_ok_labels <= R3D_PLACE_MAX_OK_LABELS && d.cand_cap >= 0 && d.cand_off >= 0 && d.cand_stride >= 0;
+  const bool slab = d.flavour & R3D_PQ_SCENE_SLAB;
+  ok = ok && address_ok(d.scene, slab ? 16 : 8, d.n_scene == 0) && address_ok(d.orig, 8, d.n_orig == 0);
+  ok = ok && address_ok(d.boxes, 8, d.n_boxes == 0) && address_ok(d.sample, 8, false);
+  ok = ok && address_ok(d.map, 1, d.map_rows == 0 || d.map_cols == 0);
+  ok = ok && address_ok(d.scene_ranges, 4, true) && address_ok(d.orig_ranges, 4, true);
+  if (slab) {
+    ok = ok && d.scene_head >= 0 && d.scene_head <= d.n_scene;
+    ok = ok && address_ok(d.scene_label, 4, d.n_scene == 0) && address_ok(d.scene_alive, 8, d.n_scene == 0);
+    ok = ok && address_ok(d.scene_tail_ref, 4, d.scene_head == d.n_scene) && address_ok(d.scene_log5, 8, d.scene_head == d.n_scene);
+  }
+  return ok;
+}
+
 // ---- k_place_centres / k_place_orient: find_spot.py:52-70 applied 360 times to the annotation -----
 // Two chains that do not depend on each other: the box centre (three fused multiply-adds per step: 5 us for the 360
 // steps) is what the point passes need -- which points can be near which step --, the orientation (matrix, product,
@@ -225,7 +254,9 @@ __global__ void k_place_centres(const r3d_place_query_t *Q, int nq, PlaceWs w, i
   bool finite = true;
   for (int i = 0; i < 10; ++i) finite = finite && isfinite(qq.anno[i]);
   for (int i = 0; i < 8; ++i) finite = finite && isfinite(qq.pose[i]);
-  status[q] = finite ? 0 : R3D_PS_NONFINITE;
+  const bool followable = descriptor_ok(qq);
+  w.bad[q] = followable ? 0 : 1;
+  status[q] = (finite ? 0 : R3D_PS_NONFINITE) | (followable ? 0 : R3D_PS_BAD_DESCRIPTOR);
   w.gather_sq[q] = 0ull;
   const double Z[9] = {kCos1, -kSin1, 0.0, kSin1, kCos1, 0.0, 0.0, 0.0, 1.0};
   // (eight steps' centres leave together, 64 bytes of a lane's own row at a time: a store per step touched 64 lines per wave
@@ -256,7 +287,7 @@ __global__ void k_place_centres(const r3d_place_query_t *Q, int nq, PlaceWs w, i
 
 __global__ void k_place_orient(const r3d_place_query_t *Q, int nq, PlaceWs w) {
   int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nq) return;
+  if (q >= nq || w.bad[q]) return;
   const r3d_place_query_t &qq = Q[q];
   Quat a{qq.anno[3], qq.anno[4], qq.anno[5], qq.anno[6]};
   const double Z[9] = {kCos1, -kSin1, 0.0, kSin1, kCos1, 0.0, 0.0, 0.0, 1.0};
@@ -287,6 +318,7 @@ __global__ void k_place_boxes(const r3d_place_query_t *Q, int nq, int max_boxes,
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nq * max_boxes) return;
   int q = t / max_boxes, j = t % max_boxes;
+  if (w.bad[q]) return;
   R3D_GUARD_QUERY(__LINE__, j == 0);
   const r3d_place_query_t &qq = Q[q];
   if (j >= qq.n_boxes) return;
@@ -471,6 +503,7 @@ __device__ __forceinline__ void stage_query(r3d_place_query_t &dst, const r3d_pl
 __global__ __launch_bounds__(kPB) void k_place_road_min(const r3d_place_query_t *Q, PlaceWs w, float reach, int mode,
                                                         double resolved_sq) {
   const int q = blockIdx.x, tid = threadIdx.x;        // queries of one scene are neighbours: they share the chunk in L2
+  if (w.bad[q]) return;
   R3D_GUARD_QUERY(__LINE__, threadIdx.x == 0 && blockIdx.y == 0);
   const int64_t n = Q[q].n_orig, start0 = (int64_t)blockIdx.y * kPointsPerBlock * kTurns;
   if (start0 >= n) return;
@@ -593,6 +626,7 @@ __device__ __forceinline__ int last_bit_exponent(double v) {
 // which are float32 values of similar size).  The ordered list is kept for the other case.
 __global__ __launch_bounds__(kPB) void k_place_surface_gather(const r3d_place_query_t *Q, PlaceWs w, Radii rad) {
   const int q = blockIdx.x, tid = threadIdx.x;        // queries of one scene are neighbours: they share the chunk in L2
+  if (w.bad[q]) return;
   R3D_GUARD_QUERY(__LINE__, threadIdx.x == 0 && blockIdx.y == 0);
   const int64_t n = Q[q].n_orig, start0 = (int64_t)blockIdx.y * kPointsPerBlock * kTurns;
   if (start0 >= n) return;
@@ -729,6 +763,7 @@ __global__ __launch_bounds__(kPB) void k_place_road_level(const r3d_place_query_
 // ---- k_place_scene_in_box: cut_bounding_box(scene_pcl, sample_anno) minus surface (:91-97) --------
 __global__ __launch_bounds__(kPB) void k_place_scene_in_box(const r3d_place_query_t *Q, PlaceWs w) {
   const int q = blockIdx.x, tid = threadIdx.x;
+  if (w.bad[q]) return;
   R3D_GUARD_QUERY(__LINE__, threadIdx.x == 0 && blockIdx.y == 0);
   const int64_t n = Q[q].n_scene, start0 = (int64_t)blockIdx.y * kPointsPerBlock * kTurns;
   if (start0 >= n) return;
@@ -1144,6 +1179,10 @@ __global__ __launch_bounds__(kCB) void k_place_sample_chain(const r3d_place_quer
                                                            double *anno_out, double *cand, int32_t first_cand,
                                                            int32_t *status) {
   __shared__ ChainLds lds;
+  if (w.bad[blockIdx.x]) {                                        // (R3D_PS_BAD_DESCRIPTOR: no placements)
+    if (threadIdx.x == 0) n_possible[blockIdx.x] = 0;
+    return;
+  }
   const bool pointwise = Q[blockIdx.x].flavour & R3D_PQ_POINTWISE_ROTATION;
   if (Q[blockIdx.x].m == 1) {                                     // one column: the matrix x vector arithmetic throughout
     sample_chain<1, true, true>(lds, Q, w, max_boxes, flags, n_possible, rot_out, anno_out, cand, first_cand, status);
@@ -1168,6 +1207,10 @@ __global__ __launch_bounds__(kCB) void k_place_sample_chain_large(const r3d_plac
                                                                  int32_t *rot_out, double *anno_out, double *cand,
                                                                  int32_t first_cand, int32_t *status) {
   __shared__ ChainLds lds;
+  if (w.bad[blockIdx.x]) {                                        // (R3D_PS_BAD_DESCRIPTOR: no placements)
+    if (threadIdx.x == 0) n_possible[blockIdx.x] = 0;
+    return;
+  }
   const bool pointwise = Q[blockIdx.x].flavour & R3D_PQ_POINTWISE_ROTATION;
   switch (chain_class(Q[blockIdx.x].m)) {
     case 8:

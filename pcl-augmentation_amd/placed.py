@@ -37,10 +37,13 @@ class PlacedInserter:
         assert len(rich_maps) == len(map_moves) == len(poses) == len(scene_boxes) == B
         # (maps of one shape -- the usual case, one map geometry per dataset -- go up as one slab)
         if all(isinstance(m, np.ndarray) and m.dtype == np.uint8 and m.shape == rich_maps[0].shape and m.ndim == 2 for m in rich_maps):
-            # (stacked in pinned memory that lives as long as this object: the copy is asynchronous)
-            self._maps_pin = torch.empty((B,) + rich_maps[0].shape, dtype=torch.uint8, pin_memory=True)
-            np.stack(rich_maps, out=self._maps_pin.numpy())
-            slab = self._maps_pin.to(batch.device, non_blocking=True)
+            # (stacked in pinned memory that belongs to the batch: the copy is asynchronous, and a lane that runs batch after
+            # batch on one SceneBatch pins its staging once -- pinning and unpinning per batch stalls every lane of the process)
+            shape = (B,) + tuple(rich_maps[0].shape)
+            pin = self._staging("maps", lambda: torch.empty(shape, dtype=torch.uint8, pin_memory=True),
+                                lambda t: tuple(t.shape) == shape)
+            np.stack(rich_maps, out=pin.numpy())
+            slab = pin.to(batch.device, non_blocking=True)
             self.maps = [slab[s] for s in range(B)]
         else:
             self.maps = [upload_map(m, batch.device) for m in rich_maps]
@@ -85,11 +88,10 @@ class PlacedInserter:
             self.slab_ranges = sr
             self.n_head_arr = n_head_h.astype(np.int64)
             self.n_scene_h = self.n_head_arr.copy()                      # (points of the slab so far: updated with every slot's results)
-        # the slot's staging: one pinned buffer up (made on first use, grows), two small pinned buffers down
-        self._up_size, self._up_pin, self._up_dev, self._up_host = 0, None, None, None
-        self._down_f = torch.empty(B * 11, dtype=torch.float64, pin_memory=True)
-        self._down_i = torch.empty(2 * B, dtype=torch.int32, pin_memory=True)
-        self._arange = torch.arange(B, dtype=torch.int64, device=batch.device)
+        # the slot's staging: one pinned buffer up (made on first use, grows), two small pinned buffers down; kept on the batch
+        self._down_f = self._staging("down_f", lambda: torch.empty(B * 11, dtype=torch.float64, pin_memory=True))
+        self._down_i = self._staging("down_i", lambda: torch.empty(2 * B, dtype=torch.int32, pin_memory=True))
+        self._arange = self._staging("arange", lambda: torch.arange(B, dtype=torch.int64, device=batch.device))
         # what the descriptors of a slot are packed from, per scene, as arrays (insert_slot fills all queries at once)
         self.map_ptr = np.array([m.data_ptr() for m in self.maps], dtype=np.uint64)
         self.map_shape = np.array([m.shape for m in self.maps], dtype=np.int32)
@@ -125,13 +127,21 @@ class PlacedInserter:
     # and annotation, the search's status; per scene the batch's status and point count -- is gathered on the device and comes
     # down with two small copies.  (Before: some 25 copies from / to pageable memory per slot, 5.5 MB of them the
     # annotations of all 360 steps of every query, each one a blocking call into the runtime's staging path.)
+    def _staging(self, name, make, fits=lambda t: True):
+        """A staging buffer of this batch by name: made once per SceneBatch (one PlacedInserter works on a batch at a time)."""
+        held = self.batch.__dict__.setdefault("_placed_staging", {})
+        if name not in held or not fits(held[name]):
+            held[name] = make()
+        return held[name]
+
     def _room(self, nbytes):
+        """(pinned host buffer, its NumPy view, device buffer) of at least nbytes for a slot's upload."""
         torch = self.torch
-        if nbytes > self._up_size:
-            self._up_size = int(nbytes * 1.25) + (1 << 20)
-            self._up_pin = torch.empty(self._up_size, dtype=torch.uint8, pin_memory=True)
-            self._up_dev = torch.empty(self._up_size, dtype=torch.uint8, device=self.batch.device)
-            self._up_host = self._up_pin.numpy()
+        size = int(nbytes * 1.25) + (1 << 20)
+        pin = self._staging("up_pin", lambda: torch.empty(size, dtype=torch.uint8, pin_memory=True), lambda t: t.numel() >= nbytes)
+        dev = self._staging("up_dev", lambda: torch.empty(pin.numel(), dtype=torch.uint8, device=self.batch.device),
+                            lambda t: t.numel() >= nbytes)
+        return pin, pin.numpy(), dev
 
     def _insert_slot(self, samples, annos, ok_labels, ok_maps, min_points, chunk, flavours):
         torch, batch = self.torch, self.batch
@@ -163,8 +173,7 @@ class PlacedInserter:
                              ("open", B * 4), ("rows", total_rows * 40)):
             lay[name] = (at, nbytes)
             at += (nbytes + 63) & ~63
-        self._room(at)
-        host, dev = self._up_host, self._up_dev
+        up_pin, host, dev = self._room(at)
         hv = lambda name, dtype: host[lay[name][0]:lay[name][0] + lay[name][1]].view(dtype)
         dv = lambda name, dtype: dev[lay[name][0]:lay[name][0] + lay[name][1]].view(dtype)
         dptr = lambda name: np.uint64(dev.data_ptr() + lay[name][0])
@@ -181,7 +190,7 @@ class PlacedInserter:
         d = d.view(np.dtype(_lib.PlaceQuery))
         self._fill_descriptors(d, who, w, m, off, dptr("boxes"), max_b, dptr("rows"), all_ranges, rows, alive, annos, ok_labels, ok_maps,
                                flavours, chunk)
-        dev[:at].copy_(self._up_pin[:at], non_blocking=True)
+        dev[:at].copy_(up_pin[:at], non_blocking=True)
         pb = PlaceBatch({"desc": d, "d_desc": dv("desc", torch.uint8), "m": m, "max_boxes": max(1, int(d["n_boxes"].max())),
                          "max_n_scene": int(d["n_scene"].max()), "max_n_orig": int(d["n_orig"].max()),
                          "keep": (rows, all_ranges, alive, dev)}, cand_cap=chunk, device=batch.device, packed=True)

@@ -240,6 +240,8 @@ class PlaceBatch:
         anno_h, status_h, cand_h = self.anno_out.cpu().numpy(), self.status.cpu().numpy(), self.cand.cpu().numpy()
         out = []
         for i in range(self.nq):
+            if status_h[i] & _lib.PS_BAD_DESCRIPTOR:
+                raise ValueError(f"query {i}: the descriptor cannot be followed (R3D_PS_BAD_DESCRIPTOR, include/real3daug_hip.h)")
             if status_h[i] & _lib.PS_NONFINITE:
                 raise ValueError(f"query {i}: NaN/Inf in the sample, its box or the pose")
             if status_h[i] & _lib.PS_SURFACE_OVERFLOW:

@@ -147,6 +147,42 @@ def test_candidate_window_and_flags(P, synth):
     assert np.array_equal(part["clouds"], full["clouds"][2:5])
 
 
+def test_a_descriptor_that_cannot_be_followed_is_flagged_not_followed(P, synth):
+    """Descriptors overwritten before the call (a pointer that no allocation can have, a sample size of 0, a row stride
+    smaller than its label column): the device looks before any kernel follows a pointer -- those queries come back with
+    R3D_PS_BAD_DESCRIPTOR and no placements, the other queries of the call are served as without them."""
+    import ctypes as C
+    import torch
+    fs = P.Real3DAug.tools.find_spot
+    queries = []
+    for seed in (41, 42, 43, 44, 45):
+        c = _random_query(synth, seed, 31, 1)
+        sa = fs.read_label_line(c["line"])
+        ok_map, ok_labels = fs.placement_surfaces(sa, CONFIG)
+        scene = P.PlaceScene(c["scene9"], c["original"], [fs._anno10(fs.read_label_line(l)) for l in c["lines"]], c["rich"],
+                             c["move"], c["T"])
+        queries.append({"scene": scene, "sample": c["sample"], "anno": fs._anno10(sa), "ok_labels": ok_labels, "ok_map": ok_map})
+    clean = P.find_places(queries, cand_cap=4)
+    pb = P.places.PlaceBatch(queries, cand_cap=4)
+    size = C.sizeof(P._lib.PlaceQuery)
+    d = pb.d_desc.cpu().numpy().copy().view(np.dtype(P._lib.PlaceQuery))
+    assert d.shape == (5,) and d.itemsize == size
+    d["orig"][0] = np.float64(0.73).view(np.uint64)                 # (a float64 where a pointer belongs)
+    d["m"][2] = 0
+    d["orig_ld"][3] = 3                                              # (the label column 3 lies outside rows of 3)
+    pb.d_desc = torch.from_numpy(d.view(np.uint8).reshape(-1)).to(pb.d_desc.device)
+    pb.run()
+    torch.cuda.synchronize()
+    st, n_poss = pb.status.cpu().numpy(), pb.n_possible.cpu().numpy()
+    assert [int(v) & P._lib.PS_BAD_DESCRIPTOR for v in st] == [4, 0, 4, 4, 0] and n_poss[0] == n_poss[2] == n_poss[3] == 0
+    rot, flags = pb.rot_out.cpu().numpy(), pb.flags.cpu().numpy()
+    for i in (1, 4):
+        assert st[i] == 0 and n_poss[i] == len(clean[i]["rotations"]) > 0
+        assert np.array_equal(rot[i, :n_poss[i]], clean[i]["rotations"]) and np.array_equal(flags[i], clean[i]["flags"])
+    with pytest.raises(ValueError, match="descriptor"):
+        pb.results()
+
+
 def test_more_than_eight_placement_labels(P, synth):
     """Round 6: a class may list up to 32 placement labels (8 before: a limit the reference does not have, find_spot.py:218-223
     concatenates whatever the config lists).  Twenty labels that no point carries around the real ones: the same search."""
@@ -518,6 +554,51 @@ def test_file_to_file_with_placement(P, synth, tmp_path, lanes):
         assert (base / "labels" / f"{i:06d}.label").read_bytes() == lb
         assert (base / "check" / f"{i:06d}.bin").read_bytes() == cb
         assert (base / "added_objects" / f"{i:06d}.txt").read_text() == "".join(lines) and lines
+
+
+@pytest.mark.parametrize("rejected_state", [False, True])
+def test_placed_slots_on_full_size_frames_same_by_both_routes(P, synth, rejected_state):
+    """Config C2's placed leg at full size (120k-point frames, the classes' full samples, five slots): the search on the scene
+    where it stands in the batch (R3D_PQ_SCENE_SLAB: float32 slab + alive words + log rows) and the search on exported
+    float64 rows give the same rotations, counts and merged clouds -- the route-independent property at sizes the oracle
+    chain does not reach in a test; slot 3 asks for more visible points than any candidate has (every window is tried)."""
+    fs = P.Real3DAug.tools.find_spot
+    B, kinds = 6, synth.CONFIG_INSERTS["C2"]
+    config = {"insertion": {"placement": synth.PLACEMENT, "placement_labels": synth.PLACEMENT_LABELS}}
+    frames = [synth.make_place_frame(70 + s) for s in range(B)]
+    slots = []
+    for k in range(5):
+        smp, annos, okl, okm = [], [], [], []
+        for s in range(B):
+            pts, line = synth.make_place_sample(7000 + s * 100 + k, kinds[k % len(kinds)])
+            sa = fs.read_label_line(line)
+            m, l = fs.placement_surfaces(sa, config)
+            smp.append(pts)
+            annos.append(fs._anno10(sa))
+            okl.append(l)
+            okm.append(m)
+        slots.append((smp, annos, okl, okm))
+    needs = [20, 20, 10 ** 6, 20, 20]
+    grow = sum(max(len(x) for x in sl[0]) for sl in slots)
+    n = max(len(f["xyzi"]) for f in frames)
+    got = {}
+    for slab in (True, False):
+        batch = P.SceneBatch(B, n + grow + 64, grow + 64)
+        batch.load([(f["xyzi"], f["label"]) for f in frames])
+        batch.begin()
+        ins = P.PlacedInserter(batch, *[[f[k] for f in frames] for k in ("rich", "move", "pose", "boxes")],
+                               reference_rejected_state=rejected_state, scene_slab=slab)
+        assert ins.slab == slab
+        seen = []
+        for k, (smp, annos, okl, okm) in enumerate(slots):
+            seen.append(ins.insert_slot(smp, annos, okl, okm, [needs[k]] * B))
+        batch.finish()
+        got[slab] = (seen, [tuple(a.tobytes() for a in r) for r in batch.results()], [b.copy() for b in ins.boxes])
+    assert got[True][0] == got[False][0] and got[True][1] == got[False][1]
+    assert all(np.array_equal(a, b) for a, b in zip(got[True][2], got[False][2]))
+    rots = [r for slot in got[True][0] for r in slot[0]]
+    assert sum(r > 0 for r in rots) >= 3 * B and all(r == -1 for r in got[True][0][2][0])
+    assert max(got[True][0][2][1]) > 8                               # (slot 3 went through more than one window of candidates)
 
 
 def test_placed_insertion_object_detection_flavour(P, synth):
