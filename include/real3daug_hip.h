@@ -406,6 +406,11 @@ int r3d_batch_point_order(const r3d_batch_t *b, int32_t *virtual_order /* [B], d
                                          alive words (r3d_batch_export_alive), scene_tail_ref / scene_log5 = b.tail_ref / b.log5 of the
                                          scene (the float64 coordinates of inserted points); dead points are skipped.  Saves the
                                          export of the rows (r3d_batch_export_rows) and their chunk ranges per insert slot */
+#define R3D_PQ_ORIG_SLAB 32           /* the original cloud likewise: `orig` = float32 x y z intensity rows (16 bytes each, e.g. the
+                                         first n_head[s] rows of a batch's scene: they are never moved or changed), orig_label =
+                                         their label words (& 0xFFFF taken here); orig_ld / orig_label_col unused; orig_ranges from
+                                         r3d_places_chunk_ranges_f32.  Same values as the float64 rows [x y z label] of the same
+                                         points, half the bytes, no copy */
 
 typedef struct r3d_place_query_t {
   const double *scene;     /* current cloud, n_scene rows of scene_ld doubles: x y z at columns 0-2, the label at
@@ -440,6 +445,8 @@ typedef struct r3d_place_query_t {
   const int32_t *scene_tail_ref;  /* [n_scene - scene_head] log row of point scene_head + t */
   const double *scene_log5;       /* rows of 5 doubles: x y z of the inserted points */
   int64_t scene_head;             /* float32-exact points at the front of the scene */
+  /* R3D_PQ_ORIG_SLAB only (else unused): */
+  const uint32_t *orig_label;     /* [n_orig] label words of the original cloud's points */
 } r3d_place_query_t;
 
 size_t r3d_places_workspace_bytes(int32_t n_queries, int32_t max_boxes);
@@ -447,6 +454,9 @@ size_t r3d_places_workspace_bytes(int32_t n_queries, int32_t max_boxes);
 /* ranges float [ceil(n/64)][2]: smallest and largest distance from the sensor's z axis among the points of
  * every 64-point chunk of a cloud (rows of ld doubles, x y first). */
 int r3d_places_chunk_ranges(const double *rows, int64_t n, int32_t ld, float *ranges, void *stream);
+/* The same for float32 rows [x y z intensity] of 16 bytes (R3D_PQ_SCENE_SLAB / R3D_PQ_ORIG_SLAB): the ranges of the same
+ * points given as float64 rows, bit for bit. */
+int r3d_places_chunk_ranges_f32(const float *rows4, int64_t n, float *ranges, void *stream);
 
 /* radius_sq (HOST array): radius**2 of the search steps that can still succeed (find_spot.py:121-140:
  * 0.1, 0.1+0.1, ... while the next radius is <= 5), as the caller's interpreter evaluates them.

@@ -76,12 +76,13 @@ class PlaceQuery(C.Structure):
         ("flavour", C.c_int32), ("collide_label", C.c_int32), ("collide_dz", C.c_double),
         ("scene_label", C.c_void_p), ("scene_alive", C.c_void_p), ("scene_tail_ref", C.c_void_p), ("scene_log5", C.c_void_p),
         ("scene_head", C.c_int64),
+        ("orig_label", C.c_void_p),
     ]
 
 
 PLACE_ROTATIONS, PLACE_SURFACE_CAP, PLACE_MAX_OK_LABELS = 360, 128, 32
 PS_SURFACE_OVERFLOW, PS_NONFINITE, PS_BAD_DESCRIPTOR = 1, 2, 4
-PQ_POINTWISE_ROTATION, PQ_MAP_NEEDS_POINT, PQ_COLLIDE_LABEL, PQ_COLLIDE_ABOVE, PQ_SCENE_SLAB = 1, 2, 4, 8, 16
+PQ_POINTWISE_ROTATION, PQ_MAP_NEEDS_POINT, PQ_COLLIDE_LABEL, PQ_COLLIDE_ABOVE, PQ_SCENE_SLAB, PQ_ORIG_SLAB = 1, 2, 4, 8, 16, 32
 PF_ON_SURFACE, PF_NEAR_ROAD, PF_SCENE_IN_BOX, PF_SAMPLE_IN_BOX, PF_POSSIBLE = 1, 2, 4, 8, 16
 
 _P = C.c_void_p
@@ -133,6 +134,7 @@ _SIGNATURES = {
     "r3d_map_finish": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "r3d_od_maps": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "r3d_places_chunk_ranges": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P]),
+    "r3d_places_chunk_ranges_f32": (C.c_int, [_P, C.c_int64, _P, _P]),
     "r3d_host_pack_frames": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, _P, _P, C.c_int32, C.c_int32]),
     "r3d_host_read_frames": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P, C.c_int32, C.c_int32]),
     "r3d_host_pack_frames_xyz": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, _P, _P, _P, C.c_int32, C.c_int32]),

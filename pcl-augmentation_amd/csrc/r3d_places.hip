@@ -224,12 +224,13 @@ __device__ __forceinline__ bool address_ok(const void *p, unsigned long long ali
 }
 __device__ __forceinline__ bool descriptor_ok(const r3d_place_query_t &d) {
   bool ok = d.n_scene >= 0 && d.n_orig >= 0 && d.n_scene <= (1ll << 40) && d.n_orig <= (1ll << 40);
-  ok = ok && d.scene_ld >= 3 && d.scene_ld <= 4096 && d.orig_ld >= 3 && d.orig_ld <= 4096;
-  ok = ok && d.scene_label_col >= 0 && d.scene_label_col < d.scene_ld && d.orig_label_col >= 0 && d.orig_label_col < d.orig_ld;
+  const bool slab = d.flavour & R3D_PQ_SCENE_SLAB, orig_slab = d.flavour & R3D_PQ_ORIG_SLAB;
+  ok = ok && (slab || (d.scene_ld >= 3 && d.scene_ld <= 4096 && d.scene_label_col >= 0 && d.scene_label_col < d.scene_ld));
+  ok = ok && (orig_slab || (d.orig_ld >= 3 && d.orig_ld <= 4096 && d.orig_label_col >= 0 && d.orig_label_col < d.orig_ld));
   ok = ok && d.n_boxes >= 0 && d.m >= 1 && d.m <= kCB * 16 && d.map_rows >= 0 && d.map_cols >= 0;
   ok = ok && d.n_ok_labels >= 0 && d.n_ok_labels <= R3D_PLACE_MAX_OK_LABELS && d.cand_cap >= 0 && d.cand_off >= 0 && d.cand_stride >= 0;
-  const bool slab = d.flavour & R3D_PQ_SCENE_SLAB;
-  ok = ok && address_ok(d.scene, slab ? 16 : 8, d.n_scene == 0) && address_ok(d.orig, 8, d.n_orig == 0);
+  ok = ok && address_ok(d.scene, slab ? 16 : 8, d.n_scene == 0) && address_ok(d.orig, orig_slab ? 16 : 8, d.n_orig == 0);
+  if (orig_slab) ok = ok && address_ok(d.orig_label, 4, d.n_orig == 0);
   ok = ok && address_ok(d.boxes, 8, d.n_boxes == 0) && address_ok(d.sample, 8, false);
   ok = ok && address_ok(d.map, 1, d.map_rows == 0 || d.map_cols == 0);
   ok = ok && address_ok(d.scene_ranges, 4, true) && address_ok(d.orig_ranges, 4, true);
@@ -394,10 +395,30 @@ __device__ __forceinline__ Pt load_point(const double *base, int64_t i, int ld, 
   return p;
 }
 
+// A point of the ORIGINAL cloud: float64 rows, or (R3D_PQ_ORIG_SLAB) float32 rows + label words -- the same values.
+__device__ __forceinline__ Pt load_orig(const r3d_place_query_t &qq, int64_t i) {
+  if (qq.flavour & R3D_PQ_ORIG_SLAB) {
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    const f4_t f = ((InGlobal<f4_t>)reinterpret_cast<const f4_t *>(qq.orig))[i];
+    Pt p;
+    p.x = (double)f.x;
+    p.y = (double)f.y;
+    p.z = (double)f.z;
+    p.label = (double)(in_global(qq.orig_label)[i] & 0xFFFFu);
+    return p;
+  }
+  return load_point(qq.orig, i, qq.orig_ld, qq.orig_label_col);
+}
+__device__ __forceinline__ double load_orig_z(const r3d_place_query_t &qq, int64_t i) {
+  if (qq.flavour & R3D_PQ_ORIG_SLAB) return (double)in_global(reinterpret_cast<const float *>(qq.orig))[i * 4 + 2];
+  return in_global(qq.orig)[i * qq.orig_ld + 2];
+}
+
 // Distance range (from the sensor axis) of every 64-point chunk of a cloud: a scan in its native
 // order (ring by ring) has narrow ranges, and a point pass can skip the chunks that cannot be
 // within reach of the circle the sample moves on.  Rounded outwards; [0, inf) if anything is odd.
-__global__ __launch_bounds__(kPB) void k_chunk_ranges(const double *rows, int64_t n, int ld, float *ranges) {
+template <class T>
+__global__ __launch_bounds__(kPB) void k_chunk_ranges(const T *rows, int64_t n, int ld, float *ranges) {
   const int lane = threadIdx.x & 63;
   const int64_t chunk = (int64_t)blockIdx.x * (kPB / 64) + (threadIdx.x >> 6);
   if (chunk * 64 >= n) return;
@@ -405,7 +426,7 @@ __global__ __launch_bounds__(kPB) void k_chunk_ranges(const double *rows, int64_
   float lo = INFINITY, hi = 0.f;
   bool odd = false;
   if (i < n) {
-    double x = rows[i * ld], y = rows[i * ld + 1];
+    double x = (double)rows[i * ld], y = (double)rows[i * ld + 1];
     float rho = sqrtf((float)(x * x + y * y));
     odd = !isfinite(rho);
     lo = hi = rho;
@@ -544,7 +565,7 @@ __global__ __launch_bounds__(kPB) void k_place_road_min(const r3d_place_query_t 
     for (int a = tid >> 6; a < n_chunks; a += kPB / 64) {         // one 64-point chunk per wave and turn
       const int64_t i = start + (int64_t)s_chunk[a] * 64 + (tid & 63);
       if (i >= end) continue;
-      const Pt p = load_point(qq.orig, i, qq.orig_ld, qq.orig_label_col);
+      const Pt p = load_orig(qq, i);
       const double x = p.x, y = p.y;
       if (!(p.z > -3.0)) continue;                                // :133-134
       if (label_rank(qq, p.label) < 0) continue;                  // :125-131
@@ -662,7 +683,7 @@ __global__ __launch_bounds__(kPB) void k_place_surface_gather(const r3d_place_qu
   for (int a = tid >> 6; a < n_chunks; a += kPB / 64) {
     const int64_t i = start + (int64_t)s_chunk[a] * 64 + (tid & 63);
     if (i >= end) continue;
-    const Pt p = load_point(qq.orig, i, qq.orig_ld, qq.orig_label_col);
+    const Pt p = load_orig(qq, i);
     const double x = p.x, y = p.y;
     if (!(p.z > -3.0)) continue;
     int rank = label_rank(qq, p.label);
@@ -730,8 +751,8 @@ __global__ __launch_bounds__(kPB) void k_place_road_level(const r3d_place_query_
   static_assert(kCap == 128, "two keys per lane");
   const unsigned long long k0 = lane < n ? l[lane] : R3D_SENT, k1 = lane + 64 < n ? l[lane + 64] : R3D_SENT;
   const unsigned long long idx_mask = (1ull << 40) - 1;
-  const double z0 = lane < n ? qq.orig[(int64_t)(k0 & idx_mask) * qq.orig_ld + 2] : 0.0;
-  const double z1 = lane + 64 < n ? qq.orig[(int64_t)(k1 & idx_mask) * qq.orig_ld + 2] : 0.0;
+  const double z0 = lane < n ? load_orig_z(qq, (int64_t)(k0 & idx_mask)) : 0.0;
+  const double z1 = lane + 64 < n ? load_orig_z(qq, (int64_t)(k1 & idx_mask)) : 0.0;
   int r0 = 0, r1 = 0;
   for (int j = 0; j < n; ++j) {                                   // keys are distinct (point indices are)
     unsigned long long kj = j < 64 ? __shfl(k0, j, 64) : __shfl(k1, j - 64, 64);
@@ -1281,8 +1302,18 @@ extern "C" int r3d_places_chunk_ranges(const double *rows, int64_t n, int32_t ld
   if (!rows || !ranges || n < 0 || ld < 2) return fail(R3D_E_ARG, "places_chunk_ranges: bad argument");
   if (n == 0) return R3D_OK;
   int64_t chunks = (n + 63) / 64;
-  hipLaunchKernelGGL(k_chunk_ranges, dim3((unsigned)((chunks + kPB / 64 - 1) / (kPB / 64))), dim3(kPB), 0,
+  hipLaunchKernelGGL(k_chunk_ranges<double>, dim3((unsigned)((chunks + kPB / 64 - 1) / (kPB / 64))), dim3(kPB), 0,
                      static_cast<hipStream_t>(stream), rows, n, (int)ld, ranges);
+  R3D_LAUNCHED("k_chunk_ranges");
+  return R3D_OK;
+}
+
+extern "C" int r3d_places_chunk_ranges_f32(const float *rows4, int64_t n, float *ranges, void *stream) {
+  if (!rows4 || !ranges || n < 0) return fail(R3D_E_ARG, "places_chunk_ranges_f32: bad argument");
+  if (n == 0) return R3D_OK;
+  int64_t chunks = (n + 63) / 64;
+  hipLaunchKernelGGL(k_chunk_ranges<float>, dim3((unsigned)((chunks + kPB / 64 - 1) / (kPB / 64))), dim3(kPB), 0,
+                     static_cast<hipStream_t>(stream), rows4, n, 4, ranges);
   R3D_LAUNCHED("k_chunk_ranges");
   return R3D_OK;
 }

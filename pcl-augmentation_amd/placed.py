@@ -56,30 +56,26 @@ class PlacedInserter:
         self.boxes_h = np.zeros((B, max(8, int(self.n_boxes.max()) + 8), 10))
         for s in range(B):
             self.boxes_h[s, :len(bx[s])] = bx[s]
-        # original_pcl (insertion.py:360): the clouds as loaded, as packed float64 rows
+        # original_pcl (insertion.py:360): the clouds as loaded
         # (the counts `load` wrote into the pinned staging, when the batch was loaded that way: no wait for the device)
         pin = getattr(batch, "_pin", None)
         n0 = pin["n"].numpy() if pin is not None and getattr(batch, "_loaded_from_staging", False) else batch.n_points.cpu().numpy()
         self.n_orig = [int(v) for v in n0]
-        self.orig_rows = torch.cat([batch.xyzi[:, :, :3].to(torch.float64),
-                                    (batch.label.to(torch.int64) & 0xFFFF).to(torch.float64)[:, :, None]], dim=2).contiguous()
         # 64-point chunks of a scene are whole chunks of the slab when its stride is a multiple of 64
         self.chunked = batch.cap % 64 == 0
-        if self.chunked:
-            r = chunk_ranges(self.orig_rows.view(B * batch.cap, 4)).view(B, batch.cap // 64, 2)
-            # (a scene's last chunk may take in rows past its end: its range only gets wider, which is safe)
-            self.orig_ranges_all = r
-            self.orig_ranges = [r[s, :(self.n_orig[s] + 63) // 64] for s in range(B)]
-        else:
-            self.orig_ranges = [chunk_ranges(self.orig_rows[s, :self.n_orig[s]]) for s in range(B)]
         # Round 6: the search reads the CURRENT cloud of a scene where it stands -- the batch's float32 slab, its labels, the
         # alive words, the log for inserted points (R3D_PQ_SCENE_SLAB) -- instead of float64 rows exported per slot
-        # (r3d_batch_export_rows + their chunk ranges: 0.66 ms of a slot's 3.8 on 256 frames).  The chunk ranges of the slab:
-        # the original cloud's for whole chunks of frame points (a dead point only leaves its chunk's range wider than
-        # needed), "always in reach" for the chunks that hold inserted points.  Float32 frames only (begin / begin_xyz).
+        # (r3d_batch_export_rows + their chunk ranges: 0.66 ms of a slot's 3.8 on 256 frames), and the ORIGINAL cloud from the
+        # same slab (R3D_PQ_ORIG_SLAB: its first n_head rows never move or change) instead of a float64 copy per batch (1 GB
+        # on 256 frames).  The chunk ranges of the slab: the original cloud's for whole chunks of frame points (a dead point
+        # only leaves its chunk's range wider than needed), "always in reach" for the chunks that hold inserted points.
+        # Float32 frames only (begin / begin_xyz).
         n_head_h = batch.n_head.cpu().numpy()
         self.slab = bool(scene_slab) and self.chunked and bool(np.array_equal(n_head_h, np.asarray(self.n_orig)))
         if self.slab:
+            self.orig_rows = None
+            # (a scene's last chunk may take in rows past its end: its range only gets wider, which is safe)
+            self.orig_ranges_all = chunk_ranges(batch.xyzi.view(B * batch.cap, 4)).view(B, batch.cap // 64, 2)
             first_open = torch.from_numpy((n_head_h // 64).astype(np.int64)).to(batch.device)
             open_ = torch.arange(batch.cap // 64, device=batch.device)[None, :] >= first_open[:, None]
             sr = self.orig_ranges_all.clone()
@@ -88,6 +84,16 @@ class PlacedInserter:
             self.slab_ranges = sr
             self.n_head_arr = n_head_h.astype(np.int64)
             self.n_scene_h = self.n_head_arr.copy()                      # (points of the slab so far: updated with every slot's results)
+        else:
+            # ... as packed float64 rows [x y z label]
+            self.orig_rows = torch.cat([batch.xyzi[:, :, :3].to(torch.float64),
+                                        (batch.label.to(torch.int64) & 0xFFFF).to(torch.float64)[:, :, None]], dim=2).contiguous()
+            if self.chunked:
+                r = chunk_ranges(self.orig_rows.view(B * batch.cap, 4)).view(B, batch.cap // 64, 2)
+                self.orig_ranges_all = r
+                self.orig_ranges = [r[s, :(self.n_orig[s] + 63) // 64] for s in range(B)]
+            else:
+                self.orig_ranges = [chunk_ranges(self.orig_rows[s, :self.n_orig[s]]) for s in range(B)]
         # the slot's staging: one pinned buffer up (made on first use, grows), two small pinned buffers down; kept on the batch
         self._down_f = self._staging("down_f", lambda: torch.empty(B * 11, dtype=torch.float64, pin_memory=True))
         self._down_i = self._staging("down_i", lambda: torch.empty(2 * B, dtype=torch.int32, pin_memory=True))
@@ -244,7 +250,12 @@ class PlacedInserter:
             d["flavour"] = _lib.PQ_SCENE_SLAB
         else:
             d["scene"] = np.uint64(rows.data_ptr()) + u * np.uint64(cap * 32)
-        d["orig"] = np.uint64(self.orig_rows.data_ptr()) + u * np.uint64(cap * 32)
+        if self.slab:                                                    # the original cloud: the same slab's first rows (R3D_PQ_ORIG_SLAB)
+            d["orig"] = np.uint64(batch.xyzi.data_ptr()) + u * np.uint64(cap * 16)
+            d["orig_label"] = np.uint64(batch.label.data_ptr()) + u * np.uint64(cap * 4)
+            d["flavour"] |= _lib.PQ_ORIG_SLAB
+        else:
+            d["orig"] = np.uint64(self.orig_rows.data_ptr()) + u * np.uint64(cap * 32)
         d["boxes"] = boxes_ptr + u * np.uint64(max_b * 80)
         d["sample"] = rows_ptr + off[w].astype(np.uint64) * np.uint64(40)
         d["map"] = self.map_ptr[w]

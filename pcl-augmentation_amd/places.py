@@ -45,11 +45,16 @@ def chunk_ranges(rows):
 
 
 def _chunk_ranges(rows):
-    """r3d_places_chunk_ranges of a device tensor of rows (x y first): float32 [chunks, 2]."""
+    """r3d_places_chunk_ranges of a device tensor of rows (x y first): float32 [chunks, 2].  float32 rows [n, 4] (a batch's
+    slab): r3d_places_chunk_ranges_f32 -- the same ranges as for the float64 rows of the same points."""
     torch = _lib.require_gpu()
     n = rows.shape[0]
     out = torch.empty(((n + 63) // 64, 2), dtype=torch.float32, device=rows.device)
-    if n:
+    if n and rows.dtype == torch.float32:
+        assert rows.shape[1] == 4 and rows.is_contiguous()
+        _lib.check(_lib.load().r3d_places_chunk_ranges_f32(rows.data_ptr(), n, out.data_ptr(), _lib.stream_ptr()),
+                   "r3d_places_chunk_ranges_f32")
+    elif n:
         _lib.check(_lib.load().r3d_places_chunk_ranges(rows.data_ptr(), n, rows.shape[1], out.data_ptr(),
                                                       _lib.stream_ptr()), "r3d_places_chunk_ranges")
     return out

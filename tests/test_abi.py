@@ -63,7 +63,7 @@ def test_place_query_matches_header(pkg):
                                  ("int32_t", "int64_t", "uint32_t", "uint8_t", "uint64_t", "float", "double")))
         fields += [re.sub(r"\[.*", "", n.strip(",")) for n in names[first:]]
     assert [f for f, _ in pkg._lib.PlaceQuery._fields_] == fields
-    assert ctypes.sizeof(pkg._lib.PlaceQuery) == 7 * 8 + 2 * 8 + 10 * 4 + 32 * 4 + 4 * 8 + (10 + 8 + 2) * 8 + 2 * 8 + 2 * 4 + 8 + 5 * 8
+    assert ctypes.sizeof(pkg._lib.PlaceQuery) == 7 * 8 + 2 * 8 + 10 * 4 + 32 * 4 + 4 * 8 + (10 + 8 + 2) * 8 + 2 * 8 + 2 * 4 + 8 + 5 * 8 + 8
     assert len(pkg.places.search_radii_sq()) == 49 and pkg.places.search_radii_sq()[0] == 0.1 ** 2
 
 
@@ -83,6 +83,7 @@ def test_bad_arguments_are_reported_without_a_gpu(pkg):
     assert lib.r3d_map_bounds(None, 10, None, None, None) == -1
     assert lib.r3d_map_finish(None, 0, None, None, None) == -1
     assert lib.r3d_places_chunk_ranges(None, 10, 4, None, None) == -1
+    assert lib.r3d_places_chunk_ranges_f32(None, 10, None, None) == -1
     assert lib.r3d_batch_insert_many(None, 1, None, None, None, None, 1, None, None, None) == -1
     assert lib.r3d_batch_export_rows(None, None, None, None) == -1
 
