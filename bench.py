@@ -213,6 +213,8 @@ def extra_legs(pkg, torch, args, all_of_them):
     """The objects beside the headline that run on this GPU: placement_search, e2e, placed, e2e_files (config C5 has its own
     child process).  `all_of_them`: the default line; else only the ones asked for by flag."""
     out = {}
+    only = getattr(args, "only_leg", None)
+    want = lambda name, asked: (all_of_them or asked) and only in (None, name)
 
     def give_back():
         """A leg's batches, lanes and pinned staging go back before the next one starts: with the `placed` leg's three lanes
@@ -224,7 +226,7 @@ def extra_legs(pkg, torch, args, all_of_them):
         if hasattr(torch._C, "_host_emptyCache"):
             torch._C._host_emptyCache()
 
-    if all_of_them or args.e2e_files:
+    if want("e2e_files", args.e2e_files):
         # file to file, the shapes of configs C3 (object detection, label_2) and C4 (SemanticKITTI sweep), files on tmpfs
         e2e = importlib.import_module("tools.e2e_pipeline")
         out["e2e_files"] = {}
@@ -238,43 +240,50 @@ def extra_legs(pkg, torch, args, all_of_them):
             except Exception as e:                             # the headline must not depend on this leg
                 out["e2e_files"][shape] = {"error": repr(e)[:300]}
             give_back()
-    if args.placement > 0 or all_of_them:
+    if want("placement_search", args.placement > 0):
         out["placement_search"] = placement_leg(pkg, torch, args.placement or 64, not args.no_cpu_baseline, CONFIGS["C2"]["kinds"])
         give_back()
-    if args.e2e > 0 or all_of_them:
+    if want("e2e", args.e2e > 0):
         e2e = importlib.import_module("tools.e2e_pipeline")
         out["e2e"] = e2e.measure(pkg, n_frames=args.e2e or 4096)
         give_back()
-    if all_of_them or args.placed:
+    if want("placed", args.placed):
         # the placement search in the loop (SURVEY.md par.8 f-1 + the hot path): search -> candidates -> merge per insert slot
         try:
             out["placed"] = importlib.import_module("tools.bench_placed").measure(pkg, B=args.placed or 256, K=len(CONFIGS["C2"]["kinds"]),
-                                                                               reps=4, lanes=4)
+                                                                               reps=8, lanes=4)
         except Exception as e:
             out["placed"] = {"error": repr(e)[:300]}
     return out
 
 
 def extra_legs_in_child(args, all_of_them):
-    """The same in a child process, so that nothing these legs do -- a frame flagged by the device, a fault of the runtime --
-    can take the headline with it: the child's JSON line is merged, or its failure recorded."""
-    cmd = [sys.executable, os.path.abspath(__file__), "--legs-child", "--placement", str(args.placement), "--e2e", str(args.e2e),
-           "--placed", str(args.placed), "--e2e-files", str(args.e2e_files)]
-    if all_of_them:
-        cmd.append("--legs-all")
-    if args.no_cpu_baseline:
-        cmd.append("--no-cpu-baseline")
-    wanted = [k for k, on in (("placement_search", args.placement > 0), ("e2e", args.e2e > 0), ("placed", args.placed > 0),
-                              ("e2e_files", args.e2e_files > 0)) if on or all_of_them]
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        if r.returncode == 0 and lines:
-            return json.loads(lines[-1])
-        why = f"the legs' process ended with code {r.returncode}: " + " | ".join((r.stderr or "").strip().splitlines()[-3:])[-400:]
-    except Exception as e:
-        why = repr(e)[:300]
-    return {k: {"error": why} for k in wanted}
+    """The same, every leg in a child process of its own, so that nothing a leg does -- a frame flagged by the device, a fault
+    of the runtime (DESIGN.md par.9 has two queue aborts of the placed lanes on record) -- can take the headline or another
+    leg with it: the child's JSON line is merged, or its failure recorded."""
+    wanted = [k for k, on in (("e2e_files", args.e2e_files > 0), ("placement_search", args.placement > 0), ("e2e", args.e2e > 0),
+                              ("placed", args.placed > 0)) if on or all_of_them]
+    out = {}
+    for leg in wanted:
+        cmd = [sys.executable, os.path.abspath(__file__), "--legs-child", "--only-leg", leg, "--placement", str(args.placement),
+               "--e2e", str(args.e2e), "--placed", str(args.placed), "--e2e-files", str(args.e2e_files)]
+        if all_of_them:
+            cmd.append("--legs-all")
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and lines:
+                out.update(json.loads(lines[-1]))
+                continue
+            tail = [ln for ln in (r.stderr or "").strip().splitlines() if "amdgpu.ids" not in ln]
+            named = [ln.strip() for ln in tail if "Kernel Name" in ln or "grid=" in ln][:2]
+            why = f"the leg's process ended with code {r.returncode}: " + " | ".join(named + tail[-2:])[-600:]
+        except Exception as e:
+            why = repr(e)[:300]
+        out[leg] = {"error": why}
+    return out
 
 
 def main():
@@ -318,6 +327,7 @@ def main():
     ap.add_argument("--cpu-worker", type=int, nargs=2, metavar=("LO", "HI"), help=argparse.SUPPRESS)
     ap.add_argument("--legs-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--legs-all", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--only-leg", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
         return cpu_worker(args)
