@@ -53,6 +53,7 @@ class SceneBatch:
         torch = self.torch
         cap = (int(cap) + 63) // 64 * 64          # whole 64-point chunks per slab (chunk tables of the placement search)
         self.B, self.cap, self.log_cap, self.rows, self.cols = int(B), int(cap), int(log_cap), int(rows), int(cols)
+        self.placed_staging = {}                   # PlacedInserter's staging buffers (pinned once per batch object, not per inserter)
         dev = self.device
 
         def z(shape, dt):

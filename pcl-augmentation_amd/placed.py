@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .places import PlaceBatch, chunk_ranges, scene_view, upload_map
+from .places import PlaceBatch, chunk_ranges, upload_map
 
 
 class PlacedInserter:
@@ -61,8 +61,8 @@ class PlacedInserter:
         pin = getattr(batch, "_pin", None)
         n0 = pin["n"].numpy() if pin is not None and getattr(batch, "_loaded_from_staging", False) else batch.n_points.cpu().numpy()
         self.n_orig = [int(v) for v in n0]
-        # 64-point chunks of a scene are whole chunks of the slab when its stride is a multiple of 64
-        self.chunked = batch.cap % 64 == 0
+        # (64-point chunks of a scene are whole chunks of the slab: SceneBatch rounds its stride up to a multiple of 64)
+        assert batch.cap % 64 == 0
         # Round 6: the search reads the CURRENT cloud of a scene where it stands -- the batch's float32 slab, its labels, the
         # alive words, the log for inserted points (R3D_PQ_SCENE_SLAB) -- instead of float64 rows exported per slot
         # (r3d_batch_export_rows + their chunk ranges: 0.66 ms of a slot's 3.8 on 256 frames), and the ORIGINAL cloud from the
@@ -71,7 +71,7 @@ class PlacedInserter:
         # only leaves its chunk's range wider than needed), "always in reach" for the chunks that hold inserted points.
         # Float32 frames only (begin / begin_xyz).
         n_head_h = batch.n_head.cpu().numpy()
-        self.slab = bool(scene_slab) and self.chunked and bool(np.array_equal(n_head_h, np.asarray(self.n_orig)))
+        self.slab = bool(scene_slab) and bool(np.array_equal(n_head_h, np.asarray(self.n_orig)))
         if self.slab:
             self.orig_rows = None
             # (a scene's last chunk may take in rows past its end: its range only gets wider, which is safe)
@@ -88,12 +88,7 @@ class PlacedInserter:
             # ... as packed float64 rows [x y z label]
             self.orig_rows = torch.cat([batch.xyzi[:, :, :3].to(torch.float64),
                                         (batch.label.to(torch.int64) & 0xFFFF).to(torch.float64)[:, :, None]], dim=2).contiguous()
-            if self.chunked:
-                r = chunk_ranges(self.orig_rows.view(B * batch.cap, 4)).view(B, batch.cap // 64, 2)
-                self.orig_ranges_all = r
-                self.orig_ranges = [r[s, :(self.n_orig[s] + 63) // 64] for s in range(B)]
-            else:
-                self.orig_ranges = [chunk_ranges(self.orig_rows[s, :self.n_orig[s]]) for s in range(B)]
+            self.orig_ranges_all = chunk_ranges(self.orig_rows.view(B * batch.cap, 4)).view(B, batch.cap // 64, 2)
         # the slot's staging: one pinned buffer up (made on first use, grows), two small pinned buffers down; kept on the batch
         self._down_f = self._staging("down_f", lambda: torch.empty(B * 11, dtype=torch.float64, pin_memory=True))
         self._down_i = self._staging("down_i", lambda: torch.empty(2 * B, dtype=torch.int32, pin_memory=True))
@@ -135,7 +130,7 @@ class PlacedInserter:
     # annotations of all 360 steps of every query, each one a blocking call into the runtime's staging path.)
     def _staging(self, name, make, fits=lambda t: True):
         """A staging buffer of this batch by name: made once per SceneBatch (one PlacedInserter works on a batch at a time)."""
-        held = self.batch.__dict__.setdefault("_placed_staging", {})
+        held = self.batch.placed_staging
         if name not in held or not fits(held[name]):
             held[name] = make()
         return held[name]
@@ -156,8 +151,6 @@ class PlacedInserter:
         rotation, n_poss = [-1] * B, [0] * B
         if not who:
             return rotation, n_poss
-        if not self.chunked:
-            return self._insert_slot_unchunked(who, samples, annos, ok_labels, ok_maps, min_points, chunk, flavours, rotation, n_poss)
         if self.slab:
             rows, alive, all_ranges = None, batch.export_alive(), self.slab_ranges
         else:
@@ -202,36 +195,6 @@ class PlacedInserter:
                          "keep": (rows, all_ranges, alive, dev)}, cand_cap=chunk, device=batch.device, packed=True)
         return self._try_candidates(pb, who, chunk, annos, rotation, n_poss, dv("off", torch.int64), dv("need", torch.int32),
                                     dv("who", torch.int64), dv("open", torch.int32))
-
-    def _insert_slot_unchunked(self, who, samples, annos, ok_labels, ok_maps, min_points, chunk, flavours, rotation, n_poss):
-        """A batch whose stride is no multiple of 64 points (no public constructor makes one): per-query descriptors."""
-        torch, batch = self.torch, self.batch
-        B = batch.B
-        rows, n_rows = batch.export_rows()
-        n_rows_h = n_rows.cpu().numpy()
-        max_b = max(1, int(self.n_boxes.max()))
-        boxes_d = torch.from_numpy(np.ascontiguousarray(self.boxes_h[:, :max_b])).to(batch.device)
-        in_who = set(who)
-        smp_rows, smp_off = batch.pack_samples([samples[s] if s in in_who else None for s in range(B)])
-        smp_off_h = smp_off.cpu().numpy()
-        queries = []
-        for s in who:
-            n = int(n_rows_h[s])
-            scene = scene_view(rows[s, :n], self.orig_rows[s, :self.n_orig[s]], boxes_d[s], int(self.n_boxes[s]), self.maps[s],
-                               self.moves[s], self.poses[s], chunk_ranges(rows[s, :n]), self.orig_ranges[s])
-            queries.append({"scene": scene, "sample": smp_rows[int(smp_off_h[s]):int(smp_off_h[s + 1])], "anno": annos[s],
-                            "ok_labels": ok_labels[s], "ok_map": ok_maps[s], **((flavours[s] or {}) if flavours else {})})
-        pb = PlaceBatch(queries, cand_cap=chunk, device=batch.device, packed=True)
-        pb.sample_sizes = np.array([q.shape[0] for q in pb.samples], dtype=np.int64)
-        sizes = np.zeros(B, dtype=np.int64)
-        sizes[who] = pb.sample_sizes
-        off = np.zeros(B + 1, dtype=np.int64)
-        off[1:] = np.cumsum(sizes)
-        still = np.zeros(B, dtype=np.int32)
-        still[who] = 1
-        up = lambda a: torch.from_numpy(a).to(batch.device)
-        return self._try_candidates(pb, who, chunk, annos, rotation, n_poss, up(off), up(np.asarray(min_points, dtype=np.int32)),
-                                    up(np.asarray(who, dtype=np.int64)), up(still))
 
     def _fill_descriptors(self, d, who, w, m, off, boxes_ptr, max_b, rows_ptr, all_ranges, rows, alive, annos, ok_labels, ok_maps,
                           flavours, chunk):
