@@ -39,6 +39,8 @@ extern "C" {
 #endif
 
 #define R3D_VERSION 0x00020005   /* 2.5: r3d_batch_begin_xyz, r3d_host_pack_frames_xyz, r3d_host_read_frames_xyz (12 bytes per point over the link in delta mode);
+                                  * r3d_batch_insert_first, r3d_batch_export_alive, r3d_places_release, r3d_places_chunk_ranges_f32; r3d_place_query_t grew
+                                  * (32 placement labels; R3D_PQ_SCENE_SLAB / R3D_PQ_ORIG_SLAB and their fields); R3D_PS_BAD_DESCRIPTOR; R3D_E_IO;
                                   * 2.4: R3D_MAX_SAMPLE 65 535; R3D_B_FILE_ORDER, r3d_batch_export_pix, r3d_batch_point_order (clouds in no
                                   * file order are numbered anew internally); r3d_host_write_delta_frames, r3d_host_append_text_files; r3d_batch_debug_counters
                                   * holds 64 values; R3D_S_CHAIN_TIMEOUT now means "a scene's chain was left unfinished" (no slot
